@@ -1,0 +1,241 @@
+/* cc_hip.h — C-ABI of the MI355X (gfx950) continuous-clustering hot path.
+ *
+ * This is the drop-in boundary UNDER the reference's C++ class
+ * continuous_clustering::ContinuousClustering (include/continuous_clustering/clustering/
+ * continuous_clustering.hpp:197-290 of UniBwTAS/continuous_clustering): plain pointers, sizes and
+ * int status codes; no C++ types, no exceptions, no torch types. The C++ class in
+ * continuous_clustering_amd/csrc/continuous_clustering.hpp re-creates the reference API on top of
+ * it (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Vocabulary follows the reference: a *firing* is one vertical set of num_rows laser returns, a
+ * *column* is one range-image column (global column index = int64 that grows forever, local column
+ * = global % ring_buffer_max_columns), a *sensor stream* is what one ContinuousClustering object
+ * consumes. One cc_engine owns `num_streams` independent sensor streams of identical geometry and
+ * configuration on one GPU and advances all of them with batched kernel launches.
+ *
+ * Reference entry point replaced by each function is cited as cc.cpp:<line> =
+ * src/clustering/continuous_clustering.cpp, cc.hpp:<line> = the class header above.
+ */
+#ifndef CC_HIP_H
+#define CC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (the C++ wrapper turns the CC_ERR_* of a stream into the reference's
+ *      std::runtime_error texts, cc.cpp:90-91, :298-299, :337-344, :1052, :1073-1075) ---------- */
+enum
+{
+    CC_OK = 0,
+    CC_ERR_INVALID_ARGUMENT = 1,
+    CC_ERR_HIP = 2,                 /* a HIP runtime call failed; see cc_engine_last_error */
+    CC_ERR_NO_DEVICE = 3,           /* no gfx950 device visible: the product path never falls back to CPU */
+    CC_ERR_FIRING_SIZE = 4,         /* cc.cpp:90-91 */
+    CC_ERR_NO_ROBOT_TRANSFORM = 5,  /* cc.cpp:298-299 */
+    CC_ERR_RING_OVERRUN = 6,        /* cc.cpp:337-344 "This column is not cleared ..." */
+    CC_ERR_BOOKKEEPING = 7,         /* cc.cpp:1052 / :1073-1075 */
+    CC_ERR_CAPACITY = 8,            /* an engine-side pool (unfinished trees, events) is full */
+    CC_ERR_NEGATIVE_COLUMN = 9      /* reference computes a negative global column (undefined behaviour there) */
+};
+
+/* ---- ground / debug label values (cc.hpp:15-22, general.hpp:208-357) ----------------------- */
+enum
+{
+    CC_GP_UNKNOWN = 143,     /* WHITE */
+    CC_GP_GROUND = 54,       /* GREEN */
+    CC_GP_OBSTACLE = 119,    /* RED */
+    CC_GP_EGO_VEHICLE = 85,  /* MAGENTA */
+    CC_GP_FOG = 71,          /* LIGHTGRAY */
+    CC_DBG_GRAY = 53,
+    CC_DBG_ORANGE = 105,
+    CC_DBG_GREEN = 54,
+    CC_DBG_YELLOWGREEN = 146,
+    CC_DBG_YELLOW = 145,
+    CC_DBG_RED = 119,
+    CC_DBG_DARKRED = 32,
+    CC_DBG_VIOLET = 141,
+    CC_DBG_LIGHTGRAY = 71,
+    CC_DBG_WHITE = 143
+};
+
+/* ---- configuration: every field of continuous_clustering::Configuration (cc.hpp:24-87) as
+ *      fixed-width scalars, same names, same defaults (cc_config_default) ----------------------- */
+typedef struct cc_config
+{
+    /* GeneralConfiguration cc.hpp:24-27 */
+    int32_t is_single_threaded;
+    /* ContinuousRangeImageConfiguration cc.hpp:29-34 */
+    int32_t sensor_is_clockwise;
+    int32_t num_columns;
+    int32_t supplement_inclination_angle_for_nan_cells;
+    /* ContinuousGroundSegmentationConfiguration cc.hpp:36-66 */
+    float max_slope;
+    float first_ring_as_ground_max_allowed_z_diff;
+    float first_ring_as_ground_min_allowed_z_diff;
+    float last_ground_point_slope_higher_than;
+    float last_ground_point_distance_smaller_than;
+    float ground_because_close_to_last_certain_ground_max_z_diff;
+    float ground_because_close_to_last_certain_ground_max_dist_diff;
+    float obstacle_because_next_certain_obstacle_max_dist_diff;
+    int32_t use_terrain;
+    float terrain_max_allowed_z_diff;
+    float height_ref_to_maximum_;
+    float height_ref_to_ground_;
+    float length_ref_to_front_end_;
+    float length_ref_to_rear_end_;
+    float width_ref_to_left_mirror_;
+    float width_ref_to_right_mirror_;
+    int32_t fog_filtering_enabled;
+    int32_t fog_filtering_intensity_below; /* uint8_t in the reference */
+    float fog_filtering_distance_below;
+    float fog_filtering_inclination_above;
+    /* ContinuousClusteringConfiguration cc.hpp:68-79 */
+    float max_distance;
+    int32_t max_steps_in_row;
+    int32_t max_steps_in_column;
+    int32_t stop_after_association_enabled;
+    int32_t stop_after_association_min_steps;
+    int32_t ignore_points_in_chessboard_pattern;
+    int32_t ignore_points_with_too_big_inclination_angle_diff;
+    int32_t use_last_point_for_cluster_stamp;
+    int32_t cluster_point_trees_every_nth_column;
+} cc_config;
+
+/* Library defaults of cc.hpp:24-79. */
+void cc_config_default(cc_config* cfg);
+/* The KITTI parameter set of src/tools/kitti_demo.cpp:279-294 (single threaded, 2200 columns,
+ * max_distance 0.5, chessboard off, ego box +-3 / +-1.5 / +0.5 / -1.7). */
+void cc_config_kitti(cc_config* cfg);
+
+/* ---- events: what the reference reports through its two std::function callbacks, in the order
+ *      the single-threaded reference would have invoked them ------------------- */
+enum
+{
+    CC_EV_GROUND_COLUMN = 1, /* finished_column_callback_(a, a, true)           cc.cpp:618-620  */
+    CC_EV_CLUSTER = 2,       /* a finished cluster that received an id           cc.cpp:936-940,
+                                a,b = first/last global column it covers, c = id, d = number of points;
+                                the reference invokes finished_cluster_callback_ iff d > 20 (cc.cpp:1023) */
+    CC_EV_PUBLISH_COLUMNS = 3 /* finished_column_callback_(a, b, false), may be empty (b < a) cc.cpp:1087-1089 */
+};
+
+typedef struct cc_event
+{
+    int32_t type;
+    int32_t stream;
+    int64_t a;
+    int64_t b;
+    uint32_t c;
+    uint32_t d;
+    int64_t column; /* global column whose processing produced the event */
+} cc_event;
+
+/* ---- per-stream scalar state readable by the caller (public members cc.hpp:244-251 plus the
+ *      counters the front-ends derive) --------------------------------------------------------- */
+typedef struct cc_stream_state
+{
+    int32_t num_rows;                          /* num_rows_                       cc.hpp:248 */
+    int32_t num_columns;                       /* num_columns_                    cc.hpp:247 */
+    int32_t ring_buffer_max_columns;           /* ring_buffer_max_columns         cc.hpp:246 */
+    int32_t reset_required;                    /* resetRequired()                 cc.cpp:83-86 */
+    int64_t ring_buffer_start_global_column_index; /* cc.hpp:250 */
+    int64_t ring_buffer_end_global_column_index;   /* cc.hpp:251 */
+    int64_t first_unfinished_global_column_index;  /* srig_first_unfinished_..., columns below are segmented */
+    int64_t first_unpublished_global_column_index; /* sc_first_unpublished_..., columns below are published */
+    uint64_t cluster_counter;                  /* sc_cluster_counter_ (next id)   cc.hpp:274 */
+    uint64_t firings_consumed;                 /* firings inserted since reset */
+    uint64_t cells_published;                  /* num_rows * published columns since reset */
+    uint64_t clusters_finished;                /* clusters that received an id since reset */
+    int32_t error;                             /* CC_OK or CC_ERR_* raised inside a kernel for this stream */
+    int32_t n_unfinished_trees;
+    int64_t error_a;                           /* operands of the reference's error text */
+    int64_t error_b;
+} cc_stream_state;
+
+/* ---- host-side view of range-image columns (the fields of continuous_clustering::Point,
+ *      cc.hpp:126-161, that the algorithm owns). Every pointer may be NULL (field not wanted).
+ *      Arrays are column-major like the reference's range_image_ (cc.cpp:181): element
+ *      [(col - from) * num_rows + row]. ------------------------------------------------------- */
+typedef struct cc_column_view
+{
+    float* x;                        /* Point::xyz (odom frame) */
+    float* y;
+    float* z;
+    float* distance;                 /* Point::distance */
+    float* inclination_angle;        /* Point::inclination_angle (NaN cells supplemented, cc.cpp:364-369) */
+    double* continuous_azimuth_angle;/* Point::continuous_azimuth_angle */
+    int64_t* global_column_index;    /* Point::global_column_index (-1 for never-segmented cleared cells) */
+    int64_t* source_firing;          /* sequence number (since reset) of the firing whose point fills the cell, -1 if empty;
+                                        lets the host attach stamp / firing_index / globally_unique_point_index /
+                                        intensity / azimuth_angle, which never leave the host */
+    uint8_t* ground_point_label;     /* Point::ground_point_label */
+    uint8_t* debug_ground_point_label;
+    uint8_t* is_ignored;             /* Point::is_ignored */
+    uint64_t* id;                    /* Point::id — cluster id, reference numbering (cc.cpp:939), 0 = none */
+    int64_t* tree_root_global_column;/* global column of Point::tree_root_, -1 = none */
+    int32_t* tree_root_row;          /* row of Point::tree_root_ */
+} cc_column_view;
+
+typedef struct cc_engine cc_engine;
+
+/* Create an engine on HIP device `device` for `num_streams` sensor streams with `num_rows` lasers.
+ * Equivalent of constructing num_streams ContinuousClustering objects, setConfiguration(cfg) and
+ * reset(num_rows) (cc.cpp:9-81). Fails with CC_ERR_NO_DEVICE when no GPU is present. */
+int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows, const cc_config* cfg);
+void cc_engine_destroy(cc_engine* e);
+
+/* setConfiguration (cc.cpp:66-81): stores the configuration, recomputes max_distance^2 and raises
+ * reset_required on every stream when is_single_threaded / sensor_is_clockwise / num_columns change. */
+int cc_engine_set_config(cc_engine* e, const cc_config* cfg);
+/* reset(num_rows) (cc.cpp:11-64) for all streams. */
+int cc_engine_reset(cc_engine* e, int num_rows);
+/* setTransformRobotFrameFromSensorFrame (cc.cpp:626-631). tf = 3x4 row-major [R|t] in double;
+ * stream = -1 sets it for all streams. */
+int cc_engine_set_robot_from_sensor(cc_engine* e, int stream, const double tf[12]);
+
+/* addFiring x n for ONE stream from host buffers (cc.cpp:88-93 -> the whole call tree of SURVEY 3.1):
+ *   xyz        n * num_rows * 3 floats  (RawPoint::x,y,z in the sensor frame; NaN x = no return)
+ *   intensity  n * num_rows bytes       (RawPoint::intensity)
+ *   poses      n * 12 doubles           (odom_from_sensor as 3x4 row-major [R|t])
+ * Returns when all n firings have been inserted and every column they finish has been segmented,
+ * associated, checked and published; events are queued in reference order. */
+int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz, const uint8_t* intensity,
+                          const double* poses);
+
+/* Throughput entry: advance ALL streams by n firings each from DEVICE-resident buffers
+ *   d_xyz        [num_streams][n][num_rows][3] float
+ *   d_intensity  [num_streams][n][num_rows]    uint8
+ *   d_poses      [num_streams][n][12]          double
+ * Launches on the engine's HIP stream and returns without synchronising. */
+int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, const uint8_t* d_intensity,
+                                 const double* d_poses);
+/* Block until everything launched so far has finished. */
+int cc_engine_sync(cc_engine* e);
+/* The hipStream_t all engine work is enqueued on (for hipEvent timing by the caller). */
+void* cc_engine_hip_stream(cc_engine* e);
+
+/* Enable / disable event recording (default on for 1 stream, off for >1: throughput mode). */
+int cc_engine_record_events(cc_engine* e, int enable);
+/* Move up to `capacity` queued events of `stream` into `out`; *n = number written. Implies sync. */
+int cc_engine_drain_events(cc_engine* e, int stream, cc_event* out, int64_t capacity, int64_t* n);
+
+int cc_engine_stream_state(cc_engine* e, int stream, cc_stream_state* out);
+/* Copy the columns [from, to] (global indices, inclusive, to - from < ring_buffer_max_columns) of `stream` to host. */
+int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, const cc_column_view* view);
+
+/* Device pointers of the two per-cell OUTPUT planes of a stream's ring buffer (ground label u8,
+ * cluster id u32), indexed [local_column * num_rows + row] — what the label-compare kernels and
+ * bench checksums read without leaving HBM. */
+int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_label, const uint32_t** d_cluster_id);
+
+/* Human-readable text of the last failing call on this engine (never NULL). */
+const char* cc_engine_last_error(cc_engine* e);
+/* Library / build identification, e.g. "continuous_clustering_amd 0.1 gfx950". */
+const char* cc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CC_HIP_H */
