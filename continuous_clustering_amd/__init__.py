@@ -1,0 +1,183 @@
+"""continuous_clustering_amd — MI355X (gfx950) implementation of the per-column hot path of
+UniBwTAS/continuous_clustering behind a C-ABI (include/cc_hip.h).
+
+The product is ``libcc_hip.so`` (hand-written HIP kernels + C-ABI host code, built in-tree by
+``continuous_clustering_amd.build``). This Python module is a thin ctypes host mirror of that ABI used by the
+tests and bench.py; the C++ drop-in class lives in ``csrc/continuous_clustering.hpp``. There is NO CPU
+implementation behind this module: loading fails loudly when the library is missing and engine creation
+fails with CC_ERR_NO_DEVICE when no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import capi
+from .capi import Config
+
+__all__ = ["Config", "Engine", "EngineError", "load_library", "capi", "IDENTITY_TF"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcc_hip.so")
+_lib = None
+
+IDENTITY_TF = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"cc_hip error {code}: {msg}")
+        self.code = code
+
+
+def load_library():
+    """dlopen libcc_hip.so (never builds implicitly, never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -m continuous_clustering_amd.build` "
+                          f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    L.cc_config_default.argtypes = [C.POINTER(Config)]
+    L.cc_config_default.restype = None
+    L.cc_config_kitti.argtypes = [C.POINTER(Config)]
+    L.cc_config_kitti.restype = None
+    L.cc_version.restype = C.c_char_p
+    L.cc_engine_create.argtypes = [C.POINTER(vp), i32, i32, i32, C.POINTER(Config)]
+    L.cc_engine_destroy.argtypes = [vp]
+    L.cc_engine_destroy.restype = None
+    L.cc_engine_set_config.argtypes = [vp, C.POINTER(Config)]
+    L.cc_engine_reset.argtypes = [vp, i32]
+    L.cc_engine_set_robot_from_sensor.argtypes = [vp, i32, vp]
+    L.cc_engine_add_firings.argtypes = [vp, i32, i64, vp, vp, vp]
+    L.cc_engine_add_firings_device.argtypes = [vp, i64, vp, vp, vp]
+    L.cc_engine_sync.argtypes = [vp]
+    L.cc_engine_hip_stream.argtypes = [vp]
+    L.cc_engine_hip_stream.restype = vp
+    L.cc_engine_record_events.argtypes = [vp, i32]
+    L.cc_engine_drain_events.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
+    L.cc_engine_pending_events.argtypes = [vp, i32, C.POINTER(i64)]
+    L.cc_engine_stream_state.argtypes = [vp, i32, C.POINTER(capi.StreamState)]
+    L.cc_engine_read_columns.argtypes = [vp, i32, i64, i64, C.POINTER(capi.ColumnView)]
+    L.cc_engine_output_planes.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.cc_engine_last_error.argtypes = [vp]
+    L.cc_engine_last_error.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    """Device/host pointer of a numpy array, a torch tensor or a raw integer address."""
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return a
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()  # torch tensor
+
+
+class Engine:
+    """``num_streams`` independent sensor streams on one GPU — the Python face of ``cc_engine``.
+
+    Method names mirror the reference class (``ContinuousClustering::reset / setConfiguration / addFiring /
+    setTransformRobotFrameFromSensorFrame / resetRequired``, continuous_clustering.hpp:200-221); firings are
+    passed in batches because one kernel launch advances all streams by a batch.
+    """
+
+    def __init__(self, cfg: Config, num_rows: int, num_streams: int = 1, device: int = 0, robot_from_sensor=IDENTITY_TF):
+        self.L = load_library()
+        self.cfg = cfg.copy()
+        self.num_rows = num_rows
+        self.num_streams = num_streams
+        self.h = C.c_void_p()
+        rc = self.L.cc_engine_create(C.byref(self.h), device, num_streams, num_rows, C.byref(self.cfg))
+        if rc != capi.CC_OK:
+            self.h = None
+            raise EngineError(rc, "cc_engine_create failed" + (" (no MI355X visible)" if rc == capi.CC_ERR_NO_DEVICE else ""))
+        if robot_from_sensor is not None:
+            self.set_robot_from_sensor(robot_from_sensor)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.cc_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != capi.CC_OK:
+            raise EngineError(rc, self.L.cc_engine_last_error(self.h).decode())
+
+    # ---- configuration / lifecycle --------------------------------------------------------------
+    def set_config(self, cfg: Config):
+        self.cfg = cfg.copy()
+        self._check(self.L.cc_engine_set_config(self.h, C.byref(self.cfg)))
+
+    def reset(self, num_rows: int | None = None):
+        if num_rows is not None:
+            self.num_rows = num_rows
+        self._check(self.L.cc_engine_reset(self.h, self.num_rows))
+
+    def set_robot_from_sensor(self, tf12, stream: int = -1):
+        tf = np.ascontiguousarray(tf12, dtype=np.float64).reshape(12)
+        self._check(self.L.cc_engine_set_robot_from_sensor(self.h, stream, tf.ctypes.data))
+
+    def record_events(self, enable: bool):
+        self._check(self.L.cc_engine_record_events(self.h, 1 if enable else 0))
+
+    # ---- data path -------------------------------------------------------------------------------
+    def add_firings(self, xyz, intensity, poses, stream: int = 0) -> int:
+        """Host buffers, one stream. Returns the status code (CC_OK or the reference's error class)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        n = xyz.shape[0]
+        if xyz.shape != (n, self.num_rows, 3) or intensity.shape != (n, self.num_rows) or poses.shape != (n, 12):
+            raise ValueError("firing arrays must be [n, num_rows, 3], [n, num_rows], [n, 12]")
+        return self.L.cc_engine_add_firings(self.h, stream, n, xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
+
+    def add_firings_device(self, n: int, d_xyz, d_intensity, d_poses):
+        """Device-resident buffers laid out [num_streams][n][...]; asynchronous."""
+        self._check(self.L.cc_engine_add_firings_device(self.h, n, _ptr(d_xyz), _ptr(d_intensity), _ptr(d_poses)))
+
+    def sync(self) -> int:
+        return self.L.cc_engine_sync(self.h)
+
+    def hip_stream(self) -> int:
+        return self.L.cc_engine_hip_stream(self.h)
+
+    def last_error(self) -> str:
+        return self.L.cc_engine_last_error(self.h).decode()
+
+    # ---- results ---------------------------------------------------------------------------------
+    def state(self, stream: int = 0) -> dict:
+        s = capi.StreamState()
+        self._check(self.L.cc_engine_stream_state(self.h, stream, C.byref(s)))
+        return capi.state_to_dict(s)
+
+    def drain_events(self, stream: int = 0) -> np.ndarray:
+        n = C.c_int64(0)
+        self._check(self.L.cc_engine_pending_events(self.h, stream, C.byref(n)))
+        out = np.zeros(max(1, n.value), dtype=capi.EVENT_DTYPE)
+        got = C.c_int64(0)
+        self._check(self.L.cc_engine_drain_events(self.h, stream, out.ctypes.data, n.value, C.byref(got)))
+        return out[: got.value]
+
+    def read_columns(self, frm: int, to: int, stream: int = 0, fields=None) -> dict:
+        v, arrays = capi.make_column_view(to - frm + 1, self.num_rows, fields)
+        self._check(self.L.cc_engine_read_columns(self.h, stream, frm, to, C.byref(v)))
+        return arrays
+
+    def output_planes(self, stream: int = 0):
+        g, i = C.c_void_p(), C.c_void_p()
+        self._check(self.L.cc_engine_output_planes(self.h, stream, C.byref(g), C.byref(i)))
+        return g.value, i.value

@@ -1,0 +1,126 @@
+// cc_device.h — device-side data layout of one cc_engine (gfx950).
+//
+// Layout in HBM (DESIGN.md "Data layout"): every per-cell field of the reference's 232-byte AoS
+// `Point` (continuous_clustering.hpp:126-161) that the algorithm owns is its own plane
+// plane[stream][local_column * num_rows + row] — column-major like the reference's range_image_
+// (continuous_clustering.cpp:181) so that a 64-lane wavefront whose lanes are the rows of one
+// column reads and writes 64 consecutive elements. Per-tree state (the fields the reference keeps
+// in the root Point) lives in planes indexed by the root cell. Per-stream scalars live in
+// StreamState.
+#pragma once
+#include <stdint.h>
+
+#include "../../include/cc_hip.h"
+
+namespace ccd
+{
+
+constexpr int WAVE = 64;
+constexpr int MAX_ROWS_PER_LANE = 2; // num_rows <= 128
+
+// Scalar state of one sensor stream: the srig_*/sgps_*/sc_* members of the reference class
+// (continuous_clustering.hpp:244-275) plus engine bookkeeping.
+struct StreamState
+{
+    // continuous range image generation (srig)
+    int64_t prev_rearmost;   // srig_previous_global_column_index_of_rearmost_laser
+    int64_t prev_foremost;   // srig_previous_global_column_index_of_foremost_laser
+    int64_t first_unfinished; // srig_first_unfinished_global_column_index
+    int64_t ring_start;      // ring_buffer_start_global_column_index
+    int64_t ring_end;        // ring_buffer_end_global_column_index
+    int64_t first_column;    // first column ever handed to segmentation since reset (-1 = none)
+    int64_t clear_done;      // columns below are physically cleared (clearing lags ring_start by one batch so that the
+                             // host can still read what a batch published, cc.cpp:1087-1091)
+    int32_t reset_required;
+    int32_t has_robot_tf;
+    double robot_from_sensor[12]; // sgps_ego_robot_frame_from_sensor_frame_
+    // continuous clustering (sc)
+    int64_t first_unpublished; // sc_first_unpublished_global_column_index
+    uint64_t cluster_counter;  // sc_cluster_counter_
+    int32_t n_unfinished;      // size of sc_unfinished_point_trees_
+    int32_t pad0;
+    int64_t min_required;      // min root column over the unfinished trees (valid when n_unfinished > 0)
+    double finish_lower_bound; // lower bound of min over unfinished clusters of max finished_at
+    double last_round_min_az;  // column-min azimuth of the previous tree-combination round (the BFS "visited stamp")
+    // batch bookkeeping
+    int64_t clear_allowed; // ring_start when the current host call began: clearing never passes what the host has seen
+    int64_t seg_begin;  // columns [seg_begin, seg_end) were emitted by the insertion kernel in this batch
+    int64_t seg_end;
+    int64_t acp_next;   // next column the association kernel processes
+    int64_t cursor;     // firings of the current batch already consumed
+    uint64_t firings_consumed;
+    uint64_t cells_published;
+    uint64_t clusters_finished;
+    uint64_t exceed_one_rotation; // how often cc.cpp:913-919 fired
+    uint64_t serial_columns;      // columns that took the exact serial association path
+    uint64_t stamp_alias_rounds;  // rounds whose min azimuth equalled the previous round's
+    // errors raised inside kernels
+    int32_t error;
+    int32_t n_events;
+    int64_t error_a;
+    int64_t error_b;
+};
+
+// All planes of an engine. Index of a cell inside a plane: stream * cells_per_stream + lcol * num_rows + row.
+struct Planes
+{
+    // geometry written by the insertion kernel
+    float* x;
+    float* y;
+    float* z;
+    float* dist;
+    float* incl;
+    double* caz;      // continuous azimuth angle
+    int64_t* gcol;    // per-cell global column index (-1 = cleared)
+    int64_t* src;     // sequence number of the firing that filled the cell
+    uint8_t* inten;
+    float* tab;       // sc_inclination_angles_between_lasers_[row] as of this column
+    // per column [stream][lcol]
+    int32_t* trig;    // batch-relative index of the firing that finished the column (its pose is the job's pose)
+    int64_t* colg;    // global column index of a segmented column
+    double* colminaz; // minimum continuous azimuth over the rows of the column
+    // ground segmentation output
+    uint8_t* ground;
+    uint8_t* debug;
+    uint8_t* ignored;
+    // clustering
+    int32_t* root;    // tree root as cell index (lcol * num_rows + row), -1 = none
+    uint32_t* id;     // OUTPUT plane: cluster id of published cells
+    // per-tree planes, indexed by the root cell
+    double* t_fin;    // finished_at_continuous_azimuth_angle
+    uint32_t* t_width; // cluster_width
+    uint32_t* t_pts;  // tree_num_points
+    int32_t* t_uf;    // union-find parent (cell index of another tree root)
+    uint32_t* t_cid;  // id of the finished cluster the tree belongs to (0 = none / too small)
+    int32_t* t_pos;   // position in the unfinished list
+    uint8_t* t_finished; // belongs_to_finished_cluster
+    // per-stream pools [stream][tree_capacity]
+    int32_t* ulist;   // sc_unfinished_point_trees_ in creation order
+    int32_t* ucomp;   // list position of the representative of each listed tree (scratch of the finish check)
+    unsigned long long* agg_fin; // per cluster (indexed by list position of its representative)
+    long long* agg_min;
+    long long* agg_max;
+    uint32_t* agg_pts;
+    uint32_t* agg_cid;
+    int32_t* agg_first;
+    uint8_t* agg_flag;
+    cc_event* events; // [stream][event_capacity]
+    float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
+};
+
+struct Geometry
+{
+    int32_t num_streams;
+    int32_t num_rows;
+    int32_t num_columns;
+    int32_t ring_cols;       // ring_buffer_max_columns = 10 * num_columns (cc.cpp:17)
+    int64_t cells;           // ring_cols * num_rows
+    int32_t tree_capacity;
+    int32_t event_capacity;
+    float az_width;          // srig_azimuth_width_per_column
+    float max_distance_squared;
+    int32_t record_events;
+    int32_t limit_columns;   // a launch stops consuming firings of a stream once it emitted this many columns
+};
+
+} // namespace ccd

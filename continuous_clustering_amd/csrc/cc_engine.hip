@@ -1,0 +1,738 @@
+// cc_engine.hip — host side of the C-ABI in include/cc_hip.h: HBM allocation, batched launches, D2H views.
+// Compiled by hipcc for gfx950 only; there is no CPU implementation behind this ABI — without a GPU
+// cc_engine_create fails with CC_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "cc_kernels.h"
+
+using namespace ccd;
+
+struct cc_engine
+{
+    int device{0};
+    Geometry g{};
+    cc_config cfg{};
+    Planes P{};
+    StreamState* d_states{nullptr};
+    int* d_remaining{nullptr};
+    int* h_remaining{nullptr}; // pinned
+    hipStream_t stream{nullptr};
+    std::vector<void*> allocations;
+    std::string error;
+    // staging for the single-stream host path
+    float* d_stage_xyz{nullptr};
+    uint8_t* d_stage_int{nullptr};
+    double* d_stage_pose{nullptr};
+    int64_t stage_capacity{0};
+    // staging for cc_engine_read_columns
+    void* d_view{nullptr};
+    size_t view_bytes{0};
+    std::vector<std::vector<cc_event>> pending_events; // per stream, drained from the device after each batch
+    // pending continuation of the last device batch (kernel stopped early for some stream)
+    const float* last_xyz{nullptr};
+    const uint8_t* last_int{nullptr};
+    const double* last_pose{nullptr};
+    int64_t last_n{0};
+    int last_first{0}, last_count{0};
+    bool batch_open{false};
+};
+
+namespace
+{
+
+#define CC_HIP_CHECK(e, call)                                                                                      \
+    do                                                                                                             \
+    {                                                                                                              \
+        hipError_t _err = (call);                                                                                  \
+        if (_err != hipSuccess)                                                                                    \
+        {                                                                                                          \
+            (e)->error = std::string(#call) + ": " + hipGetErrorString(_err);                                      \
+            return CC_ERR_HIP;                                                                                     \
+        }                                                                                                          \
+    } while (0)
+
+template<class T>
+int alloc_plane(cc_engine* e, T** out, size_t count)
+{
+    void* p = nullptr;
+    hipError_t err = hipMalloc(&p, count * sizeof(T));
+    if (err != hipSuccess)
+    {
+        e->error = std::string("hipMalloc: ") + hipGetErrorString(err);
+        return CC_ERR_HIP;
+    }
+    e->allocations.push_back(p);
+    *out = (T*) p;
+    return CC_OK;
+}
+
+int validate(cc_engine* e, const cc_config* cfg, int num_rows, int num_streams)
+{
+    if (!cfg || num_rows < 1 || num_rows > WAVE * MAX_ROWS_PER_LANE || num_streams < 1 || cfg->num_columns < 4 ||
+        cfg->cluster_point_trees_every_nth_column < 1)
+    {
+        if (e)
+            e->error = "invalid argument (num_rows must be 1..128, num_columns >= 4, every_nth_column >= 1)";
+        return CC_ERR_INVALID_ARGUMENT;
+    }
+    return CC_OK;
+}
+
+void fill_geometry(cc_engine* e, int num_rows)
+{
+    Geometry& g = e->g;
+    g.num_rows = num_rows;
+    g.num_columns = e->cfg.num_columns;
+    g.az_width = static_cast<float>((2 * M_PI)) / static_cast<float>(g.num_columns); // cc.cpp:16
+    g.ring_cols = g.num_columns * 10;                                                 // cc.cpp:17
+    g.cells = (int64_t) g.ring_cols * num_rows;
+    g.max_distance_squared = e->cfg.max_distance * e->cfg.max_distance; // cc.cpp:80
+    g.limit_columns = 2 * g.num_columns;
+}
+
+int free_all(cc_engine* e)
+{
+    for (void* p : e->allocations)
+        (void) hipFree(p);
+    e->allocations.clear();
+    e->d_stage_xyz = nullptr;
+    e->d_stage_int = nullptr;
+    e->d_stage_pose = nullptr;
+    e->stage_capacity = 0;
+    e->d_view = nullptr;
+    e->view_bytes = 0;
+    return CC_OK;
+}
+
+int allocate(cc_engine* e)
+{
+    const Geometry& g = e->g;
+    const size_t S = (size_t) g.num_streams;
+    const size_t C = S * (size_t) g.cells;
+    const size_t L = S * (size_t) g.ring_cols;
+    const size_t T = S * (size_t) g.tree_capacity;
+    Planes& P = e->P;
+    int rc = CC_OK;
+#define A(field, count)                                \
+    if ((rc = alloc_plane(e, &P.field, (count))) != 0) \
+        return rc;
+    A(x, C) A(y, C) A(z, C) A(dist, C) A(incl, C) A(caz, C) A(gcol, C) A(src, C) A(inten, C) A(tab, C);
+    A(trig, L) A(colg, L) A(colminaz, L);
+    A(ground, C) A(debug, C) A(ignored, C) A(root, C) A(id, C);
+    A(t_fin, C) A(t_width, C) A(t_pts, C) A(t_uf, C) A(t_cid, C) A(t_pos, C) A(t_finished, C);
+    A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
+    A(events, S * (size_t) g.event_capacity);
+    A(curtab, S * (size_t) g.num_rows);
+#undef A
+    if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
+        return rc;
+    if ((rc = alloc_plane(e, &e->d_remaining, 1)) != 0)
+        return rc;
+    return CC_OK;
+}
+
+// reset(num_rows) of every stream, cc.cpp:11-64. `keep_table`: std::vector::resize keeps the old
+// sc_inclination_angles_between_lasers_ values when the size does not change (cc.cpp:46).
+int reset_state(cc_engine* e, bool keep_table)
+{
+    const Geometry& g = e->g;
+    const size_t S = (size_t) g.num_streams;
+    const size_t C = S * (size_t) g.cells;
+    Planes& P = e->P;
+    // cleared cell: distance = inclination = NaN, global column index = -1 (cc.cpp:1110-1119); 0xFF bytes give both
+    CC_HIP_CHECK(e, hipMemsetAsync(P.dist, 0xFF, C * sizeof(float), e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.incl, 0xFF, C * sizeof(float), e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.gcol, 0xFF, C * sizeof(int64_t), e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.id, 0, C * sizeof(uint32_t), e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.ground, CC_GP_UNKNOWN, C, e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.debug, CC_DBG_WHITE, C, e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.ignored, 0, C, e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.root, 0xFF, C * sizeof(int32_t), e->stream));
+    if (!keep_table)
+        CC_HIP_CHECK(e, hipMemsetAsync(P.curtab, 0xFF, S * (size_t) g.num_rows * sizeof(float), e->stream));
+    std::vector<StreamState> init(S);
+    for (auto& st : init)
+    {
+        memset(&st, 0, sizeof(st));
+        st.prev_rearmost = 0;
+        st.prev_foremost = -1;
+        st.first_unfinished = -1;
+        st.ring_start = -1;
+        st.ring_end = -1;
+        st.first_column = -1;
+        st.clear_done = -1;
+        st.first_unpublished = -1;
+        st.cluster_counter = 1;
+        st.min_required = 0;
+        st.finish_lower_bound = std::numeric_limits<double>::max();
+        st.last_round_min_az = -1.0; // Point::visited_at_continuous_azimuth_angle{-1.} cc.hpp:158
+        st.seg_begin = -1;
+        st.seg_end = -1;
+        st.acp_next = -1;
+    }
+    CC_HIP_CHECK(e, hipMemcpyAsync(e->d_states, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice, e->stream));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    for (auto& v : e->pending_events)
+        v.clear();
+    e->batch_open = false;
+    return CC_OK;
+}
+
+int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int,
+                 const double* d_pose)
+{
+    const Geometry& g = e->g;
+    const int rpl = (g.num_rows + WAVE - 1) / WAVE;
+    // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
+    const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
+    dim3 seg_grid((unsigned) ((max_cols + 63) / 64), (unsigned) count);
+    if (rpl == 1)
+        hipLaunchKernelGGL(cck::k_insert<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
+                           d_int, d_pose, (long long) n, e->d_remaining);
+    else
+        hipLaunchKernelGGL(cck::k_insert<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
+                           d_int, d_pose, (long long) n, e->d_remaining);
+    hipLaunchKernelGGL(cck::k_segment, seg_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_pose,
+                       (long long) n);
+    if (rpl == 1)
+        hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    else
+        hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    CC_HIP_CHECK(e, hipGetLastError());
+    return CC_OK;
+}
+
+// Begin a batch: zero the per-stream firing cursors and the early-stop counter.
+__global__ void k_begin_batch(StreamState* states, int first_stream, int count, int* remaining)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count)
+    {
+        states[first_stream + i].cursor = 0;
+        states[first_stream + i].clear_allowed = states[first_stream + i].ring_start;
+    }
+    if (i == 0)
+        *remaining = 0;
+}
+
+__global__ void k_clear_remaining(int* remaining)
+{
+    *remaining = 0;
+}
+
+__global__ void k_clear_events(StreamState* states, int first_stream, int count)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count)
+        states[first_stream + i].n_events = 0;
+}
+
+int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose)
+{
+    hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, e->stream, e->d_states, first_stream, count,
+                       e->d_remaining);
+    int rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose);
+    if (rc)
+        return rc;
+    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    e->last_xyz = d_xyz;
+    e->last_int = d_int;
+    e->last_pose = d_pose;
+    e->last_n = n;
+    e->last_first = first_stream;
+    e->last_count = count;
+    e->batch_open = true;
+    return CC_OK;
+}
+
+int collect_events(cc_engine* e, int first_stream, int count);
+
+// Wait for the open batch; relaunch while some stream stopped early (limit_columns reached).
+int finish_batch(cc_engine* e)
+{
+    if (!e->batch_open)
+    {
+        CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+        return CC_OK;
+    }
+    while (true)
+    {
+        CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+        if (e->g.record_events)
+        {
+            int rc = collect_events(e, e->last_first, e->last_count);
+            if (rc)
+                return rc;
+        }
+        if (*e->h_remaining == 0)
+            break;
+        hipLaunchKernelGGL(k_clear_remaining, dim3(1), dim3(1), 0, e->stream, e->d_remaining);
+        int rc = launch_batch(e, e->last_first, e->last_count, e->last_n, e->last_xyz, e->last_int, e->last_pose);
+        if (rc)
+            return rc;
+        CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    }
+    e->batch_open = false;
+    return CC_OK;
+}
+
+int collect_events(cc_engine* e, int first_stream, int count)
+{
+    std::vector<StreamState> st(count);
+    CC_HIP_CHECK(e, hipMemcpy(st.data(), e->d_states + first_stream, count * sizeof(StreamState), hipMemcpyDeviceToHost));
+    for (int i = 0; i < count; i++)
+    {
+        int n = st[i].n_events;
+        if (n <= 0)
+            continue;
+        auto& dst = e->pending_events[first_stream + i];
+        size_t old = dst.size();
+        dst.resize(old + n);
+        CC_HIP_CHECK(e, hipMemcpy(dst.data() + old, e->P.events + (size_t) (first_stream + i) * e->g.event_capacity,
+                                  n * sizeof(cc_event), hipMemcpyDeviceToHost));
+    }
+    hipLaunchKernelGGL(k_clear_events, dim3((count + 255) / 256), dim3(256), 0, e->stream, e->d_states, first_stream, count);
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    return CC_OK;
+}
+
+int first_stream_error(cc_engine* e, int first_stream, int count)
+{
+    std::vector<StreamState> st(count);
+    if (hipMemcpy(st.data(), e->d_states + first_stream, count * sizeof(StreamState), hipMemcpyDeviceToHost) != hipSuccess)
+        return CC_ERR_HIP;
+    for (int i = 0; i < count; i++)
+        if (st[i].error)
+        {
+            char buf[256];
+            snprintf(buf, sizeof(buf), "stream %d: kernel-side error %d (%lld, %lld)", first_stream + i, st[i].error,
+                     (long long) st[i].error_a, (long long) st[i].error_b);
+            e->error = buf;
+            return st[i].error;
+        }
+    return CC_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void cc_config_default(cc_config* c)
+{
+    memset(c, 0, sizeof(*c));
+    c->is_single_threaded = 0;
+    c->sensor_is_clockwise = 1;
+    c->num_columns = 1700;
+    c->supplement_inclination_angle_for_nan_cells = 1;
+    c->max_slope = 0.2f;
+    c->first_ring_as_ground_max_allowed_z_diff = 0.4f;
+    c->first_ring_as_ground_min_allowed_z_diff = -0.4f;
+    c->last_ground_point_slope_higher_than = -0.1f;
+    c->last_ground_point_distance_smaller_than = 5.f;
+    c->ground_because_close_to_last_certain_ground_max_z_diff = 0.4f;
+    c->ground_because_close_to_last_certain_ground_max_dist_diff = 2.0f;
+    c->obstacle_because_next_certain_obstacle_max_dist_diff = 0.3f;
+    c->use_terrain = 0;
+    c->terrain_max_allowed_z_diff = 0.4f;
+    c->fog_filtering_enabled = 0;
+    c->fog_filtering_intensity_below = 2;
+    c->fog_filtering_distance_below = 18.f;
+    c->fog_filtering_inclination_above = -0.06f;
+    c->max_distance = 0.7f;
+    c->max_steps_in_row = 20;
+    c->max_steps_in_column = 20;
+    c->stop_after_association_enabled = 1;
+    c->stop_after_association_min_steps = 1;
+    c->ignore_points_in_chessboard_pattern = 1;
+    c->ignore_points_with_too_big_inclination_angle_diff = 1;
+    c->use_last_point_for_cluster_stamp = 0;
+    c->cluster_point_trees_every_nth_column = 1;
+}
+
+void cc_config_kitti(cc_config* c)
+{
+    cc_config_default(c);
+    c->is_single_threaded = 1;
+    c->num_columns = 2200;
+    c->ignore_points_in_chessboard_pattern = 0;
+    c->max_distance = 0.5f;
+    c->height_ref_to_maximum_ = 0.5f;
+    c->height_ref_to_ground_ = -1.7f;
+    c->length_ref_to_front_end_ = 3.f;
+    c->length_ref_to_rear_end_ = -3.f;
+    c->width_ref_to_left_mirror_ = 1.5f;
+    c->width_ref_to_right_mirror_ = -1.5f;
+}
+
+const char* cc_version(void)
+{
+    return "continuous_clustering_amd 0.1 gfx950";
+}
+
+int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows, const cc_config* cfg)
+{
+    if (!out)
+        return CC_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int rc = validate(nullptr, cfg, num_rows, num_streams);
+    if (rc)
+        return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev)
+        return CC_ERR_NO_DEVICE;
+    cc_engine* e = new cc_engine();
+    e->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    {
+        delete e;
+        return CC_ERR_HIP;
+    }
+    e->cfg = *cfg;
+    e->g.num_streams = num_streams;
+    e->g.tree_capacity = 1 << 15;
+    e->g.record_events = num_streams == 1 ? 1 : 0;
+    fill_geometry(e, num_rows);
+    e->g.event_capacity = e->g.record_events ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
+    e->pending_events.resize(num_streams);
+    rc = allocate(e);
+    if (rc == CC_OK && hipHostMalloc((void**) &e->h_remaining, sizeof(int)) != hipSuccess)
+        rc = CC_ERR_HIP;
+    if (rc == CC_OK)
+    {
+        *e->h_remaining = 0;
+        rc = reset_state(e, false);
+    }
+    if (rc != CC_OK)
+    {
+        fprintf(stderr, "cc_engine_create: %s\n", e->error.c_str());
+        free_all(e);
+        if (e->h_remaining)
+            (void) hipHostFree(e->h_remaining);
+        (void) hipStreamDestroy(e->stream);
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return CC_OK;
+}
+
+void cc_engine_destroy(cc_engine* e)
+{
+    if (!e)
+        return;
+    (void) hipSetDevice(e->device);
+    (void) hipStreamSynchronize(e->stream);
+    free_all(e);
+    if (e->h_remaining)
+        (void) hipHostFree(e->h_remaining);
+    (void) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int cc_engine_set_config(cc_engine* e, const cc_config* cfg)
+{
+    if (!e || !cfg)
+        return CC_ERR_INVALID_ARGUMENT;
+    int rc = validate(e, cfg, e->g.num_rows, e->g.num_streams);
+    if (rc)
+        return rc;
+    rc = finish_batch(e);
+    if (rc)
+        return rc;
+    (void) hipSetDevice(e->device);
+    const bool need_reset = (e->cfg.is_single_threaded != 0) != (cfg->is_single_threaded != 0) ||
+                            (e->cfg.sensor_is_clockwise != 0) != (cfg->sensor_is_clockwise != 0) ||
+                            e->cfg.num_columns != cfg->num_columns; // cc.cpp:69-74
+    e->cfg = *cfg;
+    e->g.max_distance_squared = cfg->max_distance * cfg->max_distance; // cc.cpp:80
+    if (need_reset)
+    {
+        // raise reset_required on every stream; geometry keeps the old num_columns until cc_engine_reset (cc.cpp:14)
+        std::vector<StreamState> st(e->g.num_streams);
+        CC_HIP_CHECK(e, hipMemcpy(st.data(), e->d_states, st.size() * sizeof(StreamState), hipMemcpyDeviceToHost));
+        for (auto& s : st)
+            s.reset_required = 1;
+        CC_HIP_CHECK(e, hipMemcpy(e->d_states, st.data(), st.size() * sizeof(StreamState), hipMemcpyHostToDevice));
+    }
+    return CC_OK;
+}
+
+int cc_engine_reset(cc_engine* e, int num_rows)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    int rc = validate(e, &e->cfg, num_rows, e->g.num_streams);
+    if (rc)
+        return rc;
+    (void) hipSetDevice(e->device);
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    e->batch_open = false;
+    const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
+    if (!same_shape)
+    {
+        free_all(e);
+        fill_geometry(e, num_rows);
+        e->g.event_capacity = e->g.record_events ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
+        rc = allocate(e);
+        if (rc)
+            return rc;
+    }
+    else
+        fill_geometry(e, num_rows);
+    return reset_state(e, same_shape);
+}
+
+int cc_engine_set_robot_from_sensor(cc_engine* e, int stream, const double tf[12])
+{
+    if (!e || !tf || stream < -1 || stream >= e->g.num_streams)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    const int first = stream < 0 ? 0 : stream, count = stream < 0 ? e->g.num_streams : 1;
+    std::vector<StreamState> st(count);
+    CC_HIP_CHECK(e, hipMemcpy(st.data(), e->d_states + first, count * sizeof(StreamState), hipMemcpyDeviceToHost));
+    for (auto& s : st)
+    {
+        memcpy(s.robot_from_sensor, tf, 12 * sizeof(double));
+        s.has_robot_tf = 1;
+    }
+    CC_HIP_CHECK(e, hipMemcpy(e->d_states + first, st.data(), count * sizeof(StreamState), hipMemcpyHostToDevice));
+    return CC_OK;
+}
+
+int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz, const uint8_t* intensity, const double* poses)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || n < 0 || (n > 0 && (!xyz || !intensity || !poses)))
+        return CC_ERR_INVALID_ARGUMENT;
+    if (n == 0)
+        return CC_OK;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    const int R = e->g.num_rows;
+    // bound a host batch so that staging stays small and a batch never outruns the clearing front
+    const int64_t max_chunk = std::max<int64_t>(1, 2 * (int64_t) e->g.num_columns);
+    if (e->stage_capacity < std::min(n, max_chunk))
+    {
+        int64_t cap = std::min(n, max_chunk);
+        if (e->d_stage_xyz)
+        {
+            // keep the old blocks in `allocations`; they are released with the engine
+        }
+        if ((rc = alloc_plane(e, &e->d_stage_xyz, (size_t) cap * R * 3)) != 0 || (rc = alloc_plane(e, &e->d_stage_int, (size_t) cap * R)) != 0 ||
+            (rc = alloc_plane(e, &e->d_stage_pose, (size_t) cap * 12)) != 0)
+            return rc;
+        e->stage_capacity = cap;
+    }
+    for (int64_t off = 0; off < n; off += max_chunk)
+    {
+        const int64_t m = std::min(max_chunk, n - off);
+        CC_HIP_CHECK(e, hipMemcpyAsync(e->d_stage_xyz, xyz + (size_t) off * R * 3, (size_t) m * R * 3 * sizeof(float),
+                                       hipMemcpyHostToDevice, e->stream));
+        CC_HIP_CHECK(e, hipMemcpyAsync(e->d_stage_int, intensity + (size_t) off * R, (size_t) m * R, hipMemcpyHostToDevice, e->stream));
+        CC_HIP_CHECK(e, hipMemcpyAsync(e->d_stage_pose, poses + (size_t) off * 12, (size_t) m * 12 * sizeof(double),
+                                       hipMemcpyHostToDevice, e->stream));
+        rc = submit(e, stream, 1, m, e->d_stage_xyz, e->d_stage_int, e->d_stage_pose);
+        if (rc)
+            return rc;
+        rc = finish_batch(e);
+        if (rc)
+            return rc;
+        rc = first_stream_error(e, stream, 1);
+        if (rc)
+            return rc;
+    }
+    return CC_OK;
+}
+
+int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, const uint8_t* d_intensity, const double* d_poses)
+{
+    if (!e || n < 0 || (n > 0 && (!d_xyz || !d_intensity || !d_poses)))
+        return CC_ERR_INVALID_ARGUMENT;
+    if (n == 0)
+        return CC_OK;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e); // the previous batch must have consumed all of its firings
+    if (rc)
+        return rc;
+    return submit(e, 0, e->g.num_streams, n, d_xyz, d_intensity, d_poses);
+}
+
+int cc_engine_sync(cc_engine* e)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    return first_stream_error(e, 0, e->g.num_streams);
+}
+
+void* cc_engine_hip_stream(cc_engine* e)
+{
+    return e ? (void*) e->stream : nullptr;
+}
+
+int cc_engine_record_events(cc_engine* e, int enable)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    const int want = enable ? 1 : 0;
+    if (want == e->g.record_events)
+        return CC_OK;
+    e->g.record_events = want;
+    const int cap = want ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
+    if (cap > e->g.event_capacity)
+    {
+        e->g.event_capacity = cap;
+        rc = alloc_plane(e, &e->P.events, (size_t) e->g.num_streams * cap);
+        if (rc)
+            return rc;
+    }
+    return CC_OK;
+}
+
+int cc_engine_drain_events(cc_engine* e, int stream, cc_event* out, int64_t capacity, int64_t* n)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !n || capacity < 0 || (capacity > 0 && !out))
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    auto& q = e->pending_events[stream];
+    const int64_t k = std::min<int64_t>(capacity, (int64_t) q.size());
+    if (k > 0)
+        memcpy(out, q.data(), (size_t) k * sizeof(cc_event));
+    q.erase(q.begin(), q.begin() + k);
+    *n = k;
+    return CC_OK;
+}
+
+int cc_engine_pending_events(cc_engine* e, int stream, int64_t* n)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !n)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    *n = (int64_t) e->pending_events[stream].size();
+    return CC_OK;
+}
+
+int cc_engine_stream_state(cc_engine* e, int stream, cc_stream_state* out)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !out)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    StreamState st;
+    CC_HIP_CHECK(e, hipMemcpy(&st, e->d_states + stream, sizeof(st), hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof(*out));
+    out->num_rows = e->g.num_rows;
+    out->num_columns = e->g.num_columns;
+    out->ring_buffer_max_columns = e->g.ring_cols;
+    out->reset_required = st.reset_required;
+    out->ring_buffer_start_global_column_index = st.ring_start;
+    out->ring_buffer_end_global_column_index = st.ring_end;
+    out->first_unfinished_global_column_index = st.first_unfinished;
+    out->first_unpublished_global_column_index = st.first_unpublished;
+    out->cluster_counter = st.cluster_counter;
+    out->firings_consumed = st.firings_consumed;
+    out->cells_published = st.cells_published;
+    out->clusters_finished = st.clusters_finished;
+    out->error = st.error;
+    out->n_unfinished_trees = st.n_unfinished;
+    out->error_a = st.error ? st.error_a : (int64_t) st.exceed_one_rotation;
+    out->error_b = st.error ? st.error_b : (int64_t) st.serial_columns;
+    return CC_OK;
+}
+
+int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, const cc_column_view* v)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !v || to < from || to - from >= e->g.ring_cols)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    const size_t n = (size_t) (to - from + 1) * e->g.num_rows;
+    // one staging block: 5 float + 1 double + 3 int64 + 3 u8 + 1 u64 + 1 i32 planes
+    const size_t bytes = n * (5 * 4 + 8 + 3 * 8 + 3 + 8 + 4) + 256;
+    if (e->view_bytes < bytes)
+    {
+        void* p = nullptr;
+        CC_HIP_CHECK(e, hipMalloc(&p, bytes));
+        e->allocations.push_back(p);
+        e->d_view = p;
+        e->view_bytes = bytes;
+    }
+    char* base = (char*) e->d_view;
+    cck::ViewOut o;
+    // 8-byte planes first to keep alignment
+    o.caz = (double*) base;
+    o.gcol = (int64_t*) (base + n * 8);
+    o.src = (int64_t*) (base + n * 16);
+    o.root_gcol = (int64_t*) (base + n * 24);
+    o.id = (uint64_t*) (base + n * 32);
+    char* b4 = base + n * 40;
+    o.x = (float*) b4;
+    o.y = (float*) (b4 + n * 4);
+    o.z = (float*) (b4 + n * 8);
+    o.dist = (float*) (b4 + n * 12);
+    o.incl = (float*) (b4 + n * 16);
+    o.root_row = (int32_t*) (b4 + n * 20);
+    char* b1 = b4 + n * 24;
+    o.ground = (uint8_t*) b1;
+    o.debug = (uint8_t*) (b1 + n);
+    o.ignored = (uint8_t*) (b1 + 2 * n);
+    hipLaunchKernelGGL(cck::k_view, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, e->d_states, stream,
+                       (long long) from, o);
+    CC_HIP_CHECK(e, hipGetLastError());
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+#define COPY(dst, srcp, T)                                                                        \
+    if (v->dst)                                                                                   \
+        CC_HIP_CHECK(e, hipMemcpy(v->dst, srcp, n * sizeof(T), hipMemcpyDeviceToHost));
+    COPY(x, o.x, float) COPY(y, o.y, float) COPY(z, o.z, float) COPY(distance, o.dist, float) COPY(inclination_angle, o.incl, float);
+    COPY(continuous_azimuth_angle, o.caz, double) COPY(global_column_index, o.gcol, int64_t) COPY(source_firing, o.src, int64_t);
+    COPY(ground_point_label, o.ground, uint8_t) COPY(debug_ground_point_label, o.debug, uint8_t) COPY(is_ignored, o.ignored, uint8_t);
+    COPY(id, o.id, uint64_t) COPY(tree_root_global_column, o.root_gcol, int64_t) COPY(tree_root_row, o.root_row, int32_t);
+#undef COPY
+    return CC_OK;
+}
+
+int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_label, const uint32_t** d_cluster_id)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams)
+        return CC_ERR_INVALID_ARGUMENT;
+    if (d_ground_label)
+        *d_ground_label = e->P.ground + (size_t) stream * e->g.cells;
+    if (d_cluster_id)
+        *d_cluster_id = e->P.id + (size_t) stream * e->g.cells;
+    return CC_OK;
+}
+
+const char* cc_engine_last_error(cc_engine* e)
+{
+    return e ? e->error.c_str() : "null engine";
+}
+
+} // extern "C"

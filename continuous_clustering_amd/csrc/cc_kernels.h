@@ -1,0 +1,1325 @@
+// cc_kernels.h — hand-written gfx950 kernels of the continuous-clustering hot path.
+//
+//   k_insert     one wavefront per sensor stream, lanes = rows of a firing (continuous range-image insertion,
+//                continuous_clustering.cpp:105-292) — serial over the firings of a batch, parallel over lasers.
+//   k_segment    one lane per finished column (ground-point segmentation + ignore flags, cc.cpp:294-624) —
+//                parallel over all (stream, column) pairs of the batch.
+//   k_associate  one wavefront per sensor stream, lanes = rows of a column: neighbour window scan + distance test
+//                (cc.cpp:638-835), lock-free atomicCAS union-find over point trees, finished-cluster check and
+//                column publishing / clearing (cc.cpp:837-1145) — serial over the columns of a batch.
+//   k_view       gathers columns of one stream into the host-view layout (cc_engine_read_columns).
+//
+// All floating-point expressions keep the reference's operation order; the translation unit is compiled with
+// -ffp-contract=off (and the pragma below) so that nothing is fused into FMAs the x86 reference does not have.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cc_device.h"
+#include "cc_math.h"
+
+#pragma clang fp contract(off)
+
+namespace cck
+{
+using namespace ccd;
+
+#define CC_PI_F 3.14159274101257324219f  /* static_cast<float>(M_PI) */
+#define CC_2PI_D 6.283185307179586       /* 2 * M_PI */
+
+__device__ __forceinline__ int lane_id()
+{
+    return threadIdx.x & 63;
+}
+
+// static_cast<int>(float) as x86 cvttss2si does it: out of range / NaN -> INT_MIN
+__device__ __forceinline__ int f2i_x86(float v)
+{
+    if (!(v > -2147483904.0f && v < 2147483648.0f))
+        return (int) 0x80000000;
+    return (int) v;
+}
+
+__device__ __forceinline__ long long wave_min_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        long long w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ long long wave_max_i64(long long v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        long long w = __shfl_xor(v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        int w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_min_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        double w = __shfl_xor(v, o);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ unsigned long long lanes_below()
+{
+    return (1ull << lane_id()) - 1ull;
+}
+
+// agent-scope relaxed accesses (bypass the CU's L1): used for every word that is also touched by atomics
+template<class T>
+__device__ __forceinline__ T ld_agent(const T* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void raise_error(StreamState* st, int code, long long a, long long b)
+{
+    if (atomicCAS(&st->error, 0, code) == 0)
+    {
+        st->error_a = a;
+        st->error_b = b;
+    }
+}
+
+// Pointers of one stream (planes offset to the stream's first cell / column / pool slot).
+struct SP
+{
+    float *x, *y, *z, *dist, *incl, *tab;
+    double* caz;
+    int64_t *gcol, *src;
+    uint8_t *inten, *ground, *debug, *ignored;
+    int32_t* trig;
+    int64_t* colg;
+    double* colminaz;
+    int32_t* root;
+    uint32_t* id;
+    double* t_fin;
+    uint32_t *t_width, *t_pts, *t_cid;
+    int32_t *t_uf, *t_pos;
+    uint8_t* t_finished;
+    int32_t *ulist, *ucomp;
+    unsigned long long* agg_fin;
+    long long *agg_min, *agg_max;
+    uint32_t *agg_pts, *agg_cid;
+    int32_t* agg_first;
+    uint8_t* agg_flag;
+    float* curtab;
+    cc_event* events;
+};
+
+__device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, int s)
+{
+    SP p;
+    const size_t co = (size_t) s * (size_t) g.cells;
+    const size_t lo = (size_t) s * (size_t) g.ring_cols;
+    const size_t to = (size_t) s * (size_t) g.tree_capacity;
+    p.x = P.x + co;
+    p.y = P.y + co;
+    p.z = P.z + co;
+    p.dist = P.dist + co;
+    p.incl = P.incl + co;
+    p.tab = P.tab + co;
+    p.caz = P.caz + co;
+    p.gcol = P.gcol + co;
+    p.src = P.src + co;
+    p.inten = P.inten + co;
+    p.ground = P.ground + co;
+    p.debug = P.debug + co;
+    p.ignored = P.ignored + co;
+    p.trig = P.trig + lo;
+    p.colg = P.colg + lo;
+    p.colminaz = P.colminaz + lo;
+    p.root = P.root + co;
+    p.id = P.id + co;
+    p.t_fin = P.t_fin + co;
+    p.t_width = P.t_width + co;
+    p.t_pts = P.t_pts + co;
+    p.t_cid = P.t_cid + co;
+    p.t_uf = P.t_uf + co;
+    p.t_pos = P.t_pos + co;
+    p.t_finished = P.t_finished + co;
+    p.ulist = P.ulist + to;
+    p.ucomp = P.ucomp + to;
+    p.agg_fin = P.agg_fin + to;
+    p.agg_min = P.agg_min + to;
+    p.agg_max = P.agg_max + to;
+    p.agg_pts = P.agg_pts + to;
+    p.agg_cid = P.agg_cid + to;
+    p.agg_first = P.agg_first + to;
+    p.agg_flag = P.agg_flag + to;
+    p.curtab = P.curtab + (size_t) s * g.num_rows;
+    p.events = P.events + (size_t) s * g.event_capacity;
+    return p;
+}
+
+// =====================================================================================================
+// k_insert — continuous_clustering.cpp:105-292
+// grid = (number of streams in this launch), block = 64 (one wavefront per stream)
+// =====================================================================================================
+template<int RPL>
+__global__ __launch_bounds__(64) void k_insert(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+                                               const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
+                                               const double* __restrict__ poses, long long n, int* remaining)
+{
+    const int sl = blockIdx.x;
+    const int s = first_stream + sl;
+    const int lane = lane_id();
+    StreamState* st = &states[s];
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
+
+    long long prev_rear = st->prev_rearmost, prev_fore = st->prev_foremost, first_unf = st->first_unfinished;
+    long long ring_start = st->ring_start, ring_end = st->ring_end, first_unpub = st->first_unpublished;
+    int reset_required = st->reset_required;
+    const long long cursor0 = st->cursor;
+    const long long seq0 = (long long) st->firings_consumed;
+    long long seg_begin = first_unf; // may be -1 until the first firing with columns arrives
+    const long long limit_base = first_unf;
+    unsigned long long negative_cols = 0;
+
+    float tabv[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        int row = k * 64 + lane;
+        tabv[k] = row < R ? p.curtab[row] : 0.f;
+    }
+
+    // clearColumns (cc.cpp:1094-1145) for everything earlier batches released: distance / inclination = NaN,
+    // global column index = -1 are the only cleared fields later stages read.
+    long long clear_done = st->clear_done;
+    if (clear_done >= 0)
+    {
+        const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
+        for (; clear_done < clear_to; clear_done++)
+        {
+            const int clc = (int) (clear_done % RC);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const size_t ci = (size_t) clc * R + row;
+                    p.dist[ci] = __builtin_nanf("");
+                    p.incl[ci] = __builtin_nanf("");
+                    p.gcol[ci] = -1;
+                }
+            }
+        }
+    }
+
+    const float* sx = xyz + (size_t) sl * (size_t) n * R * 3;
+    const uint8_t* si = inten + (size_t) sl * (size_t) n * R;
+    const double* sp = poses + (size_t) sl * (size_t) n * 12;
+
+    long long f = cursor0;
+    for (; f < n; f++)
+    {
+        if (limit_base >= 0 && prev_rear - limit_base >= g.limit_columns)
+            break; // keep the distance between insertion and clearing fronts bounded; host relaunches
+        const double* T = sp + f * 12;
+        const double r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
+        const double r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
+        const double r20 = T[8], r21 = T[9], r22 = T[10], tz = T[11];
+
+        long long rear = 0x7fffffffffffffffll, fore = -1;
+        const long long prev_rot = prev_rear / NC;
+        const int prev_cir = (int) (prev_rear % NC);
+        const int half = NC / 2;
+
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row >= R)
+                continue;
+            const size_t pi = ((size_t) f * R + row) * 3;
+            const float fx = sx[pi + 0], fy = sx[pi + 1], fz = sx[pi + 2];
+            if (fx != fx)
+                continue; // std::isnan(p.x()) cc.cpp:131
+            const double px = fx, py = fy, pz = fz;
+            const double ox = ((r00 * px + r01 * py) + r02 * pz) + tx;
+            const double oy = ((r10 * px + r11 * py) + r12 * pz) + ty;
+            const double oz = ((r20 * px + r21 * py) + r22 * pz) + tz;
+            const double rx = ox - tx, ry = oy - ty, rz = oz - tz;
+
+            const float az = ccm::atan2f_exact(fy, fx);
+            const float inc_az = cfg.sensor_is_clockwise ? -az + CC_PI_F : az + CC_PI_F;
+            const int cir = f2i_x86(inc_az / g.az_width);
+            long long gc = prev_rot * NC + cir;
+            const int cdiff = cir - prev_cir;
+            int rot_off = 0;
+            if (cdiff < -half)
+            {
+                gc += NC;
+                rot_off = 1;
+            }
+            else if (prev_rear > 0 && cdiff > half)
+            {
+                gc -= NC;
+                rot_off = -1;
+            }
+            if (gc < 0)
+            {
+                negative_cols++; // undefined behaviour in the reference (negative vector index); dropped here
+                continue;
+            }
+            int lc = (int) (gc % RC);
+            size_t ci = (size_t) lc * R + row;
+            const double cazv = CC_2PI_D * (double) (prev_rot + rot_off) + (double) inc_az;
+            const float dist = (float) __builtin_sqrt((rx * rx + ry * ry) + rz * rz);
+            float cd = p.dist[ci];
+            if (!(cd != cd) && !(dist != dist))
+            {
+                int nl = lc + 1;
+                if (nl >= RC)
+                    nl -= RC;
+                const size_t ni = (size_t) nl * R + row;
+                const float nd = p.dist[ni];
+                if (nd != nd)
+                {
+                    ci = ni;
+                    lc = nl;
+                    gc++;
+                    cd = nd;
+                }
+            }
+            if (!(cd != cd) && ((dist != dist) || dist >= cd))
+                continue;
+            const bool too_far_behind = first_unf >= 0 && gc < first_unf;
+            if (!too_far_behind)
+            {
+                p.x[ci] = (float) ox;
+                p.y[ci] = (float) oy;
+                p.z[ci] = (float) oz;
+                p.inten[ci] = si[(size_t) f * R + row];
+                p.src[ci] = seq0 + (f - cursor0);
+                p.dist[ci] = dist;
+                p.incl[ci] = ccm::asinf_exact((float) rz / dist);
+                p.caz[ci] = cazv;
+                p.gcol[ci] = gc;
+            }
+            rear = gc < rear ? gc : rear;
+            fore = gc > fore ? gc : fore;
+        }
+        rear = wave_min_i64(rear);
+        fore = wave_max_i64(fore);
+        if (rear == 0x7fffffffffffffffll)
+            rear = -1;
+
+        if (rear >= 0 && fore >= 0)
+        {
+            if ((fore - rear) > NC / 2)
+            {
+                reset_required = 1; // cc.cpp:252-261
+                continue;
+            }
+            if (rear > prev_rear)
+                prev_rear = rear;
+            if (fore > prev_fore)
+                prev_fore = fore;
+        }
+        if (prev_fore < 0)
+            continue;
+        if (ring_start == -1)
+        {
+            ring_start = prev_rear;
+            first_unpub = prev_rear;
+            clear_done = prev_rear;
+        }
+        if (prev_fore > ring_end)
+            ring_end = prev_fore;
+        if (first_unf == -1)
+        {
+            first_unf = prev_rear;
+            if (seg_begin < 0)
+                seg_begin = first_unf;
+            if (lane == 0)
+                st->first_column = first_unf;
+        }
+        // finished columns: remember the firing whose pose the segmentation job carries (cc.cpp:289-291) and
+        // advance the per-row inclination step table (cc.cpp:353-357) in column order
+        while (first_unf < prev_rear)
+        {
+            const int lc = (int) (first_unf % RC);
+            if (lane == 0)
+                p.trig[lc] = (int) f;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row >= R)
+                    continue;
+                const size_t ci = (size_t) lc * R + row;
+                const float cur = p.incl[ci];
+                const float below = row + 1 < R ? p.incl[ci + 1] : 0.f;
+                const float diff = cur - below;
+                if (!(diff != diff))
+                    tabv[k] = diff;
+                p.tab[ci] = tabv[k];
+            }
+            first_unf++;
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        int row = k * 64 + lane;
+        if (row < R)
+            p.curtab[row] = tabv[k];
+    }
+    if (lane == 0)
+    {
+        st->prev_rearmost = prev_rear;
+        st->prev_foremost = prev_fore;
+        st->first_unfinished = first_unf;
+        st->ring_start = ring_start;
+        st->ring_end = ring_end;
+        st->clear_done = clear_done;
+        st->first_unpublished = first_unpub;
+        st->reset_required = reset_required;
+        st->seg_begin = seg_begin;
+        st->seg_end = seg_begin >= 0 ? first_unf : -1;
+        st->acp_next = seg_begin;
+        st->cursor = f;
+        st->firings_consumed = (unsigned long long) (seq0 + (f - cursor0));
+        if (f < n)
+            atomicAdd(remaining, 1);
+    }
+    negative_cols = (unsigned long long) wave_max_i64((long long) negative_cols);
+    if (lane == 0 && negative_cols)
+        st->error_b += (long long) negative_cols;
+}
+
+// =====================================================================================================
+// k_segment — continuous_clustering.cpp:294-624. One lane per column.
+// grid = (tiles of 64 columns, streams in this launch), block = 64
+// =====================================================================================================
+__device__ __forceinline__ float len2(float a, float b)
+{
+    return ccm::sqrt_rn(a * a + b * b);
+}
+
+__global__ __launch_bounds__(64) void k_segment(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+                                                const double* __restrict__ poses, long long n)
+{
+    const int sl = blockIdx.y;
+    const int s = first_stream + sl;
+    StreamState* st = &states[s];
+    const long long seg_begin = st->seg_begin, seg_end = st->seg_end;
+    if (seg_begin < 0)
+        return;
+    const long long gc = seg_begin + (long long) blockIdx.x * 64 + lane_id();
+    if (gc >= seg_end)
+        return;
+    if (!st->has_robot_tf)
+    {
+        raise_error(st, CC_ERR_NO_ROBOT_TRANSFORM, gc, 0);
+        return;
+    }
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    const int lc = (int) (gc % RC);
+    const size_t base = (size_t) lc * R;
+
+    const double* T = poses + ((size_t) sl * (size_t) n + (size_t) p.trig[lc]) * 12;
+    // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301)
+    double ir[9], it[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            ir[i * 3 + j] = T[j * 4 + i];
+    for (int i = 0; i < 3; i++)
+        it[i] = ((-ir[i * 3 + 0]) * T[3] + (-ir[i * 3 + 1]) * T[7]) + (-ir[i * 3 + 2]) * T[11];
+    const double* A = st->robot_from_sensor;
+    double er[9], et[3];
+    for (int i = 0; i < 3; i++)
+    {
+        for (int j = 0; j < 3; j++)
+            er[i * 3 + j] = (A[i * 4 + 0] * ir[0 * 3 + j] + A[i * 4 + 1] * ir[1 * 3 + j]) + A[i * 4 + 2] * ir[2 * 3 + j];
+        et[i] = ((A[i * 4 + 0] * it[0] + A[i * 4 + 1] * it[1]) + A[i * 4 + 2] * it[2]) + A[i * 4 + 3];
+    }
+    const float height_sensor_to_ground = -(float) A[11] + cfg.height_ref_to_ground_;
+    const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
+
+    bool first_obstacle_detected = false, first_point_found = false;
+    float lgx = 0.f, lgy = 0.f, lgz = height_sensor_to_ground;
+    float pvx = 0.f, pvy = 0.f, pvz = 0.f;
+    uint8_t previous_label = 0;
+    double min_az = 1.7976931348623157e308;
+
+    for (int row = R - 1; row >= 0; row--)
+    {
+        const size_t ci = base + row;
+        const long long cg = p.gcol[ci];
+        if (cg != gc && cg != -1)
+        {
+            raise_error(st, CC_ERR_RING_OVERRUN, cg, gc); // cc.cpp:320-345
+            return;
+        }
+        p.gcol[ci] = gc;
+        p.root[ci] = -1;
+        p.id[ci] = 0;
+        const float dist = p.dist[ci];
+        uint8_t ground = CC_GP_UNKNOWN, debug = CC_DBG_WHITE;
+        if (dist != dist)
+        {
+            if (cfg.supplement_inclination_angle_for_nan_cells && row < R - 1)
+                p.incl[ci] = p.incl[ci + 1] + p.tab[ci];
+            const double caz = ((double) gc + 0.5) * (double) g.az_width;
+            p.caz[ci] = caz;
+            if (caz < min_az)
+                min_az = caz;
+            p.ground[ci] = ground;
+            p.debug[ci] = debug;
+            continue;
+        }
+        {
+            const double caz = p.caz[ci];
+            if (caz < min_az)
+                min_az = caz;
+        }
+        const float incl = p.incl[ci];
+        if (cfg.fog_filtering_enabled && p.inten[ci] < (uint8_t) cfg.fog_filtering_intensity_below &&
+            dist < cfg.fog_filtering_distance_below && incl > cfg.fog_filtering_inclination_above)
+        {
+            p.ground[ci] = CC_GP_FOG;
+            p.debug[ci] = CC_DBG_LIGHTGRAY;
+            continue;
+        }
+        const float cx = p.x[ci], cy = p.y[ci], cz = p.z[ci];
+        const double dx = cx, dy = cy, dz = cz;
+        const double ex = ((er[0] * dx + er[1] * dy) + er[2] * dz) + et[0];
+        const double ey = ((er[3] * dx + er[4] * dy) + er[5] * dz) + et[1];
+        const double ez = ((er[6] * dx + er[7] * dy) + er[8] * dz) + et[2];
+        if (ex < cfg.length_ref_to_front_end_ && ex > cfg.length_ref_to_rear_end_ && ey < cfg.width_ref_to_left_mirror_ &&
+            ey > cfg.width_ref_to_right_mirror_ && ez < cfg.height_ref_to_maximum_ && ez > cfg.height_ref_to_ground_)
+        {
+            p.ground[ci] = CC_GP_EGO_VEHICLE;
+            p.debug[ci] = CC_DBG_VIOLET;
+            continue;
+        }
+        const float ux = cx - spx, uy = cy - spy, uz = cz - spz; // current_position_wrt_sensor
+
+        if (!first_point_found)
+        {
+            first_point_found = true;
+            const float h = uz - height_sensor_to_ground;
+            if (h > cfg.first_ring_as_ground_min_allowed_z_diff && h < cfg.first_ring_as_ground_max_allowed_z_diff)
+            {
+                ground = CC_GP_GROUND;
+                debug = CC_DBG_GRAY;
+                lgx = ux;
+                lgy = uy;
+                lgz = uz;
+                first_obstacle_detected = false;
+            }
+            else
+            {
+                ground = CC_GP_OBSTACLE;
+                debug = CC_DBG_ORANGE;
+                first_obstacle_detected = true;
+            }
+            pvx = ux;
+            pvy = uy;
+            pvz = uz;
+            previous_label = debug;
+            p.ground[ci] = ground;
+            p.debug[ci] = debug;
+            continue;
+        }
+
+        const float cur2x = len2(ux, uy), cur2y = uz;
+        const float prv2x = len2(pvx, pvy), prv2y = pvz;
+        const float p2cx = cur2x - prv2x, p2cy = cur2y - prv2y;
+        const float slope_to_prev = p2cy / p2cx;
+        bool flat_prev = ccm::absf(slope_to_prev) < cfg.max_slope && p2cx > 0;
+        flat_prev = flat_prev && (!cfg.use_terrain || p2cx < 5);
+        const float lg2x = len2(lgx, lgy), lg2y = lgz;
+        const float l2cx = cur2x - lg2x, l2cy = cur2y - lg2y;
+        const float slope_to_lg = l2cy / l2cx;
+        const bool flat_lg = ccm::absf(slope_to_lg) < cfg.max_slope && l2cx > 0;
+
+        if (!first_obstacle_detected && flat_prev)
+        {
+            ground = CC_GP_GROUND;
+            debug = CC_DBG_GREEN;
+        }
+        else if (!cfg.use_terrain)
+        {
+            if (first_obstacle_detected && flat_prev && flat_lg)
+            {
+                ground = CC_GP_GROUND;
+                debug = CC_DBG_YELLOWGREEN;
+            }
+            else if (ccm::absf(l2cx) < cfg.ground_because_close_to_last_certain_ground_max_dist_diff &&
+                     ccm::absf(l2cy) < cfg.ground_because_close_to_last_certain_ground_max_z_diff)
+            {
+                ground = CC_GP_GROUND;
+                debug = CC_DBG_YELLOW;
+            }
+        }
+        if (ground != CC_GP_GROUND)
+        {
+            ground = CC_GP_OBSTACLE;
+            debug = CC_DBG_RED;
+            // walk down and flip very close ground points to obstacle (cc.cpp:513-535)
+            int below = row + 1;
+            while (below < R)
+            {
+                const size_t bi = base + below;
+                const uint8_t bg = p.ground[bi], bd = p.debug[bi];
+                const float bx = len2(p.x[bi] - spx, p.y[bi] - spy);
+                if (bd == CC_DBG_YELLOW ||
+                    (bg == CC_GP_GROUND && ccm::absf(cur2x - bx) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
+                {
+                    if (bg == CC_GP_GROUND)
+                    {
+                        p.ground[bi] = CC_GP_OBSTACLE;
+                        p.debug[bi] = CC_DBG_DARKRED;
+                    }
+                    below++;
+                }
+                else
+                    break;
+            }
+        }
+        first_obstacle_detected |= ground == CC_GP_OBSTACLE;
+        if (debug == CC_DBG_GREEN || debug == CC_DBG_YELLOWGREEN)
+        {
+            if (slope_to_prev > cfg.last_ground_point_slope_higher_than &&
+                ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than && previous_label != CC_DBG_YELLOW)
+            {
+                lgx = ux;
+                lgy = uy;
+                lgz = uz;
+            }
+        }
+        pvx = ux;
+        pvy = uy;
+        pvz = uz;
+        previous_label = debug;
+        p.ground[ci] = ground;
+        p.debug[ci] = debug;
+    }
+
+    // ignore flags (cc.cpp:567-616)
+    for (int row = R - 1; row >= 0; row--)
+    {
+        const size_t ci = base + row;
+        const float dist = p.dist[ci];
+        bool ign = false;
+        if (dist != dist)
+            ign = true;
+        else if (p.ground[ci] != CC_GP_OBSTACLE)
+            ign = true;
+        else if ((double) dist < 1. * (double) cfg.max_distance)
+            ign = true;
+        else if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1) &&
+                 ccm::atan2f_exact(cfg.max_distance, dist) < p.tab[ci])
+            ign = true;
+        else if (cfg.ignore_points_in_chessboard_pattern)
+        {
+            const bool column_even = gc % 2 == 0;
+            const bool row_even = row % 2 == 0;
+            if ((column_even && !row_even) || (!column_even && row_even))
+                ign = true;
+        }
+        p.ignored[ci] = ign ? 1 : 0;
+    }
+    p.colg[lc] = gc;
+    p.colminaz[lc] = min_az;
+}
+
+// =====================================================================================================
+// k_associate — continuous_clustering.cpp:638-1145. One wavefront per stream, lanes = rows.
+// =====================================================================================================
+constexpr int LINK_SLOTS = 8;
+
+struct AssocCtx
+{
+    SP p;
+    int R, NC, RC;
+    float az_width, maxd2;
+    int max_steps_in_row, max_steps_in_column, stop_enabled, stop_min_steps;
+};
+
+// lock-free union-find over tree roots (cell indices); every access bypasses L1
+__device__ __forceinline__ int uf_find(int32_t* uf, int a)
+{
+    while (true)
+    {
+        const int pa = ld_agent(&uf[a]);
+        if (pa == a)
+            return a;
+        const int gp = ld_agent(&uf[pa]);
+        if (gp != pa)
+            __hip_atomic_store(&uf[a], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // path halving
+        a = pa;
+    }
+}
+
+__device__ __forceinline__ void uf_union(int32_t* uf, int a, int b)
+{
+    while (true)
+    {
+        a = uf_find(uf, a);
+        b = uf_find(uf, b);
+        if (a == b)
+            return;
+        if (a < b)
+        {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        // hang the larger index under the smaller one
+        if (atomicCAS(&uf[a], a, b) == a)
+            return;
+    }
+}
+
+__device__ __forceinline__ void tree_init(const SP& p, int cell, double fin)
+{
+    p.t_fin[cell] = fin;
+    p.t_width[cell] = 1;
+    p.t_pts[cell] = 1;
+    p.t_uf[cell] = cell;
+    p.t_cid[cell] = 0;
+    p.t_finished[cell] = 0;
+}
+
+// The window scan of traverseFieldOfView (cc.cpp:698-771) for one point.
+//  LIVE = false: record the first passing candidate as `parent` and later passing candidates as link candidates;
+//                no tree state is read (valid when no attach is refused, checked by the caller).
+//  LIVE = true : exact reference semantics with immediate attach / link (single lane, rows in order).
+template<bool LIVE>
+__device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, const long long gc, const int row, const int first_local,
+                                           const float mad, const double pcaz, int& p_root, int& parent, int* links, int& nlinks,
+                                           bool& overflow)
+{
+    const SP& p = c.p;
+    const int R = c.R;
+    const int pi = lc * R + row;
+    const float pincl = p.incl[pi], px = p.x[pi], py = p.y[pi], pz = p.z[pi];
+    int needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
+    needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
+    int oc = lc;
+    bool rooted = LIVE ? (p_root != -1) : false;
+    for (int sb = 0; sb <= needed; sb++)
+    {
+        for (int dir = -1; dir <= 1; dir += 2)
+        {
+            if (dir == 1 && sb == 0)
+                continue;
+            int sv = (dir == 1 || sb == 0) ? 1 : 0;
+            int orow = (dir == 1 || sb == 0) ? row + dir : row;
+            while (orow >= 0 && orow < R && sv <= c.max_steps_in_column)
+            {
+                const int oi = oc * R + orow;
+                const float oincl = p.incl[oi];
+                if (ccm::absf(oincl - pincl) > mad)
+                    break;
+                if (!p.ignored[oi])
+                {
+                    bool consider = true;
+                    int oroot = -1;
+                    if (LIVE)
+                    {
+                        oroot = p.root[oi];
+                        consider = (p_root >= 0 && p_root / R == 0) || oroot != p_root; // cc.cpp:733 incl. its "== 0" quirk
+                    }
+                    if (consider)
+                    {
+                        const float dx = px - p.x[oi], dy = py - p.y[oi], dz = pz - p.z[oi];
+                        if (dx * dx + dy * dy + dz * dz < c.maxd2)
+                        {
+                            if (LIVE)
+                            {
+                                if (p_root == -1)
+                                {
+                                    // associatePointToPointTree cc.cpp:643-673
+                                    const long long rg = p.colg[oroot / R];
+                                    const uint32_t nw = (uint32_t) (gc - rg + 1);
+                                    if (nw <= (uint32_t) c.NC && !p.t_finished[oroot])
+                                    {
+                                        p_root = oroot;
+                                        p.t_width[oroot] = nw;
+                                        const double cand = pcaz + (double) mad;
+                                        const double cur = ld_agent(&p.t_fin[oroot]);
+                                        if (cand > cur)
+                                            __hip_atomic_store(&p.t_fin[oroot], cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                        atomicAdd(&p.t_pts[oroot], 1u);
+                                    }
+                                }
+                                else
+                                {
+                                    // associatePointTreeToPointTree cc.cpp:675-696
+                                    if (!p.t_finished[p_root] && !p.t_finished[oroot] && p_root != oroot)
+                                        uf_union(p.t_uf, p_root, oroot);
+                                }
+                            }
+                            else
+                            {
+                                if (!rooted)
+                                {
+                                    parent = oi;
+                                    rooted = true;
+                                }
+                                else if (nlinks < LINK_SLOTS)
+                                    links[nlinks++] = oi;
+                                else
+                                    overflow = true;
+                            }
+                        }
+                    }
+                }
+                if (LIVE)
+                    rooted = p_root != -1;
+                if (rooted && c.stop_enabled && sv >= c.stop_min_steps)
+                    break;
+                orow += dir;
+                sv++;
+            }
+        }
+        if (rooted && c.stop_enabled && sb >= c.stop_min_steps)
+            break;
+        if (oc == first_local)
+            break;
+        oc--;
+        if (oc < 0)
+            oc += c.RC;
+    }
+}
+
+template<int RPL>
+__global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream)
+{
+    const int s = first_stream + blockIdx.x;
+    const int lane = lane_id();
+    StreamState* st = &states[s];
+    if (st->error != 0 || st->seg_begin < 0)
+        return;
+    AssocCtx c;
+    c.p = stream_ptrs(P, g, s);
+    const SP& p = c.p;
+    const int R = c.R = g.num_rows;
+    const int NC = c.NC = g.num_columns;
+    const int RC = c.RC = g.ring_cols;
+    c.az_width = g.az_width;
+    c.maxd2 = g.max_distance_squared;
+    c.max_steps_in_row = cfg.max_steps_in_row;
+    c.max_steps_in_column = cfg.max_steps_in_column;
+    c.stop_enabled = cfg.stop_after_association_enabled;
+    c.stop_min_steps = cfg.stop_after_association_min_steps;
+    const int nth = cfg.cluster_point_trees_every_nth_column;
+
+    __shared__ int s_parent[WAVE * MAX_ROWS_PER_LANE];
+    __shared__ int s_links[WAVE * MAX_ROWS_PER_LANE][LINK_SLOTS];
+    __shared__ int s_bcast[4];
+    __shared__ double s_bd[2];
+    __shared__ long long s_bl[2];
+
+    long long first_unpub = st->first_unpublished, ring_start = st->ring_start;
+    unsigned long long cluster_counter = st->cluster_counter;
+    int n_unf = st->n_unfinished;
+    long long M = st->min_required;
+    double L = st->finish_lower_bound;
+    double last_min_az = st->last_round_min_az;
+    unsigned long long cells_published = st->cells_published, clusters_finished = st->clusters_finished;
+    unsigned long long exceed = st->exceed_one_rotation, serial_cols = st->serial_columns, alias_rounds = st->stamp_alias_rounds;
+    int n_events = st->n_events;
+    const long long col_end = st->seg_end;
+    int err = 0;
+    long long err_a = 0, err_b = 0;
+
+    auto emit = [&](int type, long long a, long long b, unsigned cc, unsigned dd, long long column)
+    {
+        if (!g.record_events)
+            return;
+        if (lane == 0)
+        {
+            if (n_events < g.event_capacity)
+            {
+                cc_event e;
+                e.type = type;
+                e.stream = s;
+                e.a = a;
+                e.b = b;
+                e.c = cc;
+                e.d = dd;
+                e.column = column;
+                p.events[n_events] = e;
+            }
+        }
+        n_events++;
+    };
+
+    for (long long gc = st->acp_next; gc < col_end && err == 0; gc++)
+    {
+        const int lc = (int) (gc % RC);
+        const int first_local = (int) (first_unpub % RC);
+        emit(CC_EV_GROUND_COLUMN, gc, gc, 0, 0, gc);
+
+        // ------------------------------------------------------------------ association (cc.cpp:773-835)
+        float mad[RPL];
+        double pcaz[RPL];
+        bool active[RPL];
+        int parent[RPL], nlinks[RPL];
+        bool overflow = false;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            active[k] = false;
+            parent[k] = -1;
+            nlinks[k] = 0;
+            mad[k] = 0.f;
+            pcaz[k] = 0.;
+            if (row < R)
+            {
+                const int ci = lc * R + row;
+                if (!p.ignored[ci])
+                {
+                    active[k] = true;
+                    mad[k] = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                    pcaz[k] = p.caz[ci];
+                    int dummy_root = -1;
+                    scan_point<false>(c, lc, gc, row, first_local, mad[k], pcaz[k], dummy_root, parent[k], s_links[row], nlinks[k],
+                                      overflow);
+                }
+                s_parent[row] = active[k] ? parent[k] : -2;
+            }
+        }
+        __syncthreads();
+        // resolve tree roots through same-column parents, then verify that no attach would have been refused
+        int rootc[RPL];
+        bool refused = overflow;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            rootc[k] = -1;
+            if (active[k])
+            {
+                if (parent[k] < 0)
+                    rootc[k] = lc * R + row; // new tree
+                else
+                {
+                    int r = parent[k];
+                    while (true)
+                    {
+                        if (r / R != lc)
+                        {
+                            r = p.root[r];
+                            break;
+                        }
+                        const int pr = s_parent[r - lc * R];
+                        if (pr < 0)
+                            break; // r is a new tree root of this column
+                        r = pr;
+                    }
+                    rootc[k] = r;
+                    if (r < 0)
+                        refused = true; // candidate without tree: impossible for a processed, non-ignored cell
+                    else
+                    {
+                        const long long rg = p.colg[r / R];
+                        const uint32_t nw = (uint32_t) (gc - rg + 1);
+                        if (nw > (uint32_t) NC || p.t_finished[r])
+                            refused = true;
+                    }
+                }
+            }
+        }
+        const bool column_serial = __any(refused);
+
+        if (!column_serial)
+        {
+            // (a) roots + new trees in row order
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                const bool is_new = active[k] && parent[k] < 0;
+                const unsigned long long mask = __ballot(is_new);
+                const int cnt = __popcll(mask);
+                if (n_unf + cnt > g.tree_capacity)
+                {
+                    err = CC_ERR_CAPACITY;
+                    err_a = n_unf + cnt;
+                    break;
+                }
+                if (active[k])
+                    p.root[lc * R + row] = rootc[k];
+                if (is_new)
+                {
+                    const int cell = lc * R + row;
+                    const int pos = n_unf + __popcll(mask & lanes_below());
+                    const double fin = pcaz[k] + (double) mad[k];
+                    tree_init(p, cell, fin);
+                    p.ulist[pos] = cell;
+                    p.t_pos[cell] = pos;
+                    L = fin < L ? fin : L;
+                }
+                if (cnt > 0 && n_unf == 0)
+                    M = gc;
+                n_unf += cnt;
+            }
+            L = wave_min_f64(L);
+            __syncthreads();
+            // (b) attach: root bookkeeping of associatePointToPointTree (cc.cpp:661-671)
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                if (active[k] && parent[k] >= 0)
+                {
+                    const int r = rootc[k];
+                    const long long rg = p.colg[r / R];
+                    p.t_width[r] = (uint32_t) (gc - rg + 1);
+                    const double cand = pcaz[k] + (double) mad[k];
+                    atomicMax((unsigned long long*) &p.t_fin[r], (unsigned long long) __double_as_longlong(cand));
+                    atomicAdd(&p.t_pts[r], 1u);
+                }
+            }
+            __syncthreads();
+            // (c) links between trees (cc.cpp:675-696) as lock-free unions
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (active[k] && parent[k] >= 0)
+                {
+                    const int rp = rootc[k];
+                    for (int j = 0; j < nlinks[k]; j++)
+                    {
+                        const int rq = p.root[s_links[row][j]];
+                        if (rq != rp && rq >= 0 && !p.t_finished[rp] && !p.t_finished[rq])
+                            uf_union(p.t_uf, rp, rq);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        else
+        {
+            // exact serial replay of the column by one lane (rare: >1-rotation clusters, finished trees in reach)
+            serial_cols++;
+            if (lane == 0)
+            {
+                int nn = n_unf;
+                double LL = L;
+                long long MM = M;
+                int e = 0;
+                for (int row = 0; row < R; row++)
+                {
+                    const int ci = lc * R + row;
+                    if (p.ignored[ci])
+                        continue;
+                    const float m = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                    const double caz = p.caz[ci];
+                    int proot = -1, par = -1, nl = 0;
+                    bool ov = false;
+                    scan_point<true>(c, lc, gc, row, first_local, m, caz, proot, par, nullptr, nl, ov);
+                    if (proot == -1)
+                    {
+                        if (nn + 1 > g.tree_capacity)
+                        {
+                            e = CC_ERR_CAPACITY;
+                            break;
+                        }
+                        proot = ci;
+                        const double fin = caz + (double) m;
+                        tree_init(p, ci, fin);
+                        p.ulist[nn] = ci;
+                        p.t_pos[ci] = nn;
+                        if (nn == 0)
+                            MM = gc;
+                        nn++;
+                        LL = fin < LL ? fin : LL;
+                    }
+                    p.root[ci] = proot;
+                }
+                s_bcast[0] = nn;
+                s_bcast[1] = e;
+                s_bd[0] = LL;
+                s_bl[0] = MM;
+            }
+            __syncthreads();
+            n_unf = s_bcast[0];
+            if (s_bcast[1])
+            {
+                err = s_bcast[1];
+                err_a = n_unf;
+            }
+            L = s_bd[0];
+            M = s_bl[0];
+            __syncthreads();
+        }
+        if (err)
+            break;
+
+        // ------------------------------------------------------------------ finished-cluster check (cc.cpp:837-974)
+        if (gc % nth != 0)
+            continue;
+        const double min_az = p.colminaz[lc];
+        long long M_c;
+        if (n_unf == 0)
+            M_c = gc + 1;
+        else if (min_az == last_min_az)
+        {
+            // every older tree still carries the visited stamp of the previous round: none of them
+            // is a BFS start and none is expanded; trees created in this column cannot be finished yet.
+            alias_rounds++;
+            M_c = M;
+        }
+        else if (!(min_az >= L) && !((gc + 1 - M) >= NC))
+            M_c = M; // no cluster can be finished: nothing to scan
+        else
+        {
+            // full pass over the unfinished trees
+            for (int i = lane; i < n_unf; i += 64)
+            {
+                p.agg_fin[i] = 0ull;
+                p.agg_min[i] = 0x7fffffffffffffffll;
+                p.agg_max[i] = 0;
+                p.agg_pts[i] = 0;
+                p.agg_first[i] = 0x7fffffff;
+                p.agg_cid[i] = 0;
+                p.agg_flag[i] = 0;
+            }
+            __syncthreads();
+            for (int i = lane; i < n_unf; i += 64)
+            {
+                const int t = p.ulist[i];
+                const int rep = uf_find(p.t_uf, t);
+                const int j = p.t_pos[rep];
+                p.ucomp[i] = j;
+                const long long tg = p.colg[t / R];
+                atomicMax(&p.agg_fin[j], (unsigned long long) __double_as_longlong(ld_agent(&p.t_fin[t])));
+                atomicMin(&p.agg_min[j], tg);
+                atomicMax(&p.agg_max[j], tg + (long long) p.t_width[t]);
+                atomicAdd(&p.agg_pts[j], ld_agent(&p.t_pts[t]));
+                atomicMin(&p.agg_first[j], i);
+            }
+            __syncthreads();
+            int exceed_local = 0;
+            for (int i = lane; i < n_unf; i += 64)
+            {
+                if (p.ucomp[i] == i)
+                {
+                    const double fin = __longlong_as_double((long long) ld_agent(&p.agg_fin[i]));
+                    const bool unfinished = fin > min_az;
+                    const bool exceeds = (ld_agent(&p.agg_max[i]) - ld_agent(&p.agg_min[i])) >= NC;
+                    if (exceeds)
+                        exceed_local++;
+                    p.agg_flag[i] = (!unfinished || exceeds) ? 1 : 0;
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1)
+                exceed_local += __shfl_xor(exceed_local, o);
+            exceed += exceed_local;
+            __syncthreads();
+            // ids in the order the reference's BFS would discover the clusters: by earliest tree in the list
+            int last_first = -1;
+            while (true)
+            {
+                int best = 0x7fffffff;
+                for (int i = lane; i < n_unf; i += 64)
+                    if (p.ucomp[i] == i && p.agg_flag[i] && ld_agent(&p.agg_pts[i]) > 5u)
+                    {
+                        const int fi = ld_agent(&p.agg_first[i]);
+                        if (fi > last_first && fi < best)
+                            best = fi;
+                    }
+                best = wave_min_i32(best);
+                if (best == 0x7fffffff)
+                    break;
+                // the representative's slot is ucomp[best]
+                const int j = p.ucomp[best];
+                const unsigned cid = (unsigned) cluster_counter;
+                if (lane == 0)
+                    p.agg_cid[j] = cid;
+                emit(CC_EV_CLUSTER, ld_agent(&p.agg_min[j]), ld_agent(&p.agg_max[j]) - 1, cid, ld_agent(&p.agg_pts[j]), gc);
+                cluster_counter++;
+                clusters_finished++;
+                last_first = best;
+            }
+            __syncthreads();
+            // mark trees, minimum required column, stable compaction of the list
+            long long min_all = 0x7fffffffffffffffll, min_surv = 0x7fffffffffffffffll;
+            double L_new = 1.7976931348623157e308;
+            int out = 0;
+            for (int base = 0; base < n_unf; base += 64)
+            {
+                const int i = base + lane;
+                bool surv = false;
+                int t = -1;
+                if (i < n_unf)
+                {
+                    t = p.ulist[i];
+                    const int j = p.ucomp[i];
+                    const long long tg = p.colg[t / R];
+                    min_all = tg < min_all ? tg : min_all;
+                    if (p.agg_flag[j])
+                    {
+                        p.t_finished[t] = 1;
+                        p.t_cid[t] = p.agg_cid[j];
+                    }
+                    else
+                    {
+                        surv = true;
+                        min_surv = tg < min_surv ? tg : min_surv;
+                        if (j == i)
+                        {
+                            const double fin = __longlong_as_double((long long) ld_agent(&p.agg_fin[i]));
+                            L_new = fin < L_new ? fin : L_new;
+                        }
+                    }
+                }
+                const unsigned long long mask = __ballot(surv);
+                if (surv)
+                {
+                    const int np = out + __popcll(mask & lanes_below());
+                    p.ulist[np] = t;
+                    p.t_pos[t] = np;
+                }
+                out += __popcll(mask);
+            }
+            min_all = wave_min_i64(min_all);
+            min_surv = wave_min_i64(min_surv);
+            L = wave_min_f64(L_new);
+            M_c = min_all;
+            M = min_surv;
+            n_unf = out;
+            __syncthreads();
+        }
+        last_min_az = min_az;
+
+        // ------------------------------------------------------------------ publish + clear (cc.cpp:1035-1145)
+        if (M_c < first_unpub)
+        {
+            err = CC_ERR_BOOKKEEPING;
+            err_a = M_c;
+            err_b = first_unpub;
+            break;
+        }
+        const long long old_unpub = first_unpub, old_ring = ring_start;
+        first_unpub = M_c;
+        ring_start = first_unpub - NC > 0 ? first_unpub - NC : 0;
+        emit(CC_EV_PUBLISH_COLUMNS, old_unpub, first_unpub - 1, 0, 0, gc);
+        for (long long pc = old_unpub; pc < first_unpub; pc++)
+        {
+            const int plc = (int) (pc % RC);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const int ci = plc * R + row;
+                    const int r = p.root[ci];
+                    p.id[ci] = r >= 0 ? p.t_cid[r] : 0u;
+                }
+            }
+        }
+        cells_published += (unsigned long long) (first_unpub - old_unpub) * (unsigned long long) R;
+        // physical clearing of [old_ring, ring_start) is deferred to the next k_insert (StreamState::clear_done)
+        (void) old_ring;
+    }
+
+    if (lane == 0)
+    {
+        st->first_unpublished = first_unpub;
+        st->ring_start = ring_start;
+        st->cluster_counter = cluster_counter;
+        st->n_unfinished = n_unf;
+        st->min_required = M;
+        st->finish_lower_bound = L;
+        st->last_round_min_az = last_min_az;
+        st->cells_published = cells_published;
+        st->clusters_finished = clusters_finished;
+        st->exceed_one_rotation = exceed;
+        st->serial_columns = serial_cols;
+        st->stamp_alias_rounds = alias_rounds;
+        st->acp_next = col_end;
+        st->n_events = n_events < g.event_capacity ? n_events : g.event_capacity;
+        if (g.record_events && n_events > g.event_capacity && err == 0)
+        {
+            err = CC_ERR_CAPACITY;
+            err_a = n_events;
+        }
+        if (err)
+            raise_error(st, err, err_a, err_b);
+    }
+}
+
+// =====================================================================================================
+// k_view — host view of columns [from, from + ncols) of one stream (cc_engine_read_columns)
+// grid = ncols, block = 64
+// =====================================================================================================
+struct ViewOut
+{
+    float *x, *y, *z, *dist, *incl;
+    double* caz;
+    int64_t *gcol, *src, *root_gcol;
+    uint8_t *ground, *debug, *ignored;
+    uint64_t* id;
+    int32_t* root_row;
+};
+
+__global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamState* states, int s, long long from, ViewOut o)
+{
+    const StreamState* st = &states[s];
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    const long long gc = from + blockIdx.x;
+    const int lc = (int) (((gc % RC) + RC) % RC);
+    const bool in_ring = st->ring_end >= 0 && gc >= 0 && gc >= st->clear_done && gc <= st->ring_end;
+    const bool segmented = in_ring && st->first_column >= 0 && gc >= st->first_column && gc < st->first_unfinished;
+    for (int row = lane_id(); row < R; row += 64)
+    {
+        const size_t ci = (size_t) lc * R + row;
+        const size_t oi = (size_t) blockIdx.x * R + row;
+        const float nanf_ = __builtin_nanf("");
+        const bool filled = in_ring && (segmented ? true : p.gcol[ci] == gc);
+        const bool has_point = filled && !(p.dist[ci] != p.dist[ci]) && p.gcol[ci] == gc;
+        o.x[oi] = has_point ? p.x[ci] : nanf_;
+        o.y[oi] = has_point ? p.y[ci] : nanf_;
+        o.z[oi] = has_point ? p.z[ci] : nanf_;
+        o.dist[oi] = has_point ? p.dist[ci] : nanf_;
+        o.incl[oi] = (has_point || segmented) ? p.incl[ci] : nanf_;
+        o.caz[oi] = (has_point || segmented) ? p.caz[ci] : __builtin_nan("");
+        o.gcol[oi] = segmented ? gc : (has_point ? gc : -1);
+        o.src[oi] = has_point ? p.src[ci] : -1;
+        o.ground[oi] = segmented ? p.ground[ci] : (uint8_t) CC_GP_UNKNOWN;
+        o.debug[oi] = segmented ? p.debug[ci] : (uint8_t) CC_DBG_WHITE;
+        o.ignored[oi] = segmented ? p.ignored[ci] : 0;
+        const int r = segmented ? p.root[ci] : -1;
+        o.id[oi] = r >= 0 ? (uint64_t) p.t_cid[r] : 0ull;
+        o.root_gcol[oi] = r >= 0 ? p.colg[r / R] : -1;
+        o.root_row[oi] = r >= 0 ? r % R : 0;
+    }
+}
+
+} // namespace cck

@@ -200,7 +200,10 @@ int cc_engine_set_robot_from_sensor(cc_engine* e, int stream, const double tf[12
  *   intensity  n * num_rows bytes       (RawPoint::intensity)
  *   poses      n * 12 doubles           (odom_from_sensor as 3x4 row-major [R|t])
  * Returns when all n firings have been inserted and every column they finish has been segmented,
- * associated, checked and published; events are queued in reference order. */
+ * associated, checked and published; events are queued in reference order.
+ * Columns published during a call stay readable (cc_engine_read_columns) until the next call when
+ * n <= 2 * num_columns; longer calls are split internally and may clear (cc.cpp:1091) what their first
+ * part published. */
 int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz, const uint8_t* intensity,
                           const double* poses);
 
@@ -220,6 +223,9 @@ void* cc_engine_hip_stream(cc_engine* e);
 int cc_engine_record_events(cc_engine* e, int enable);
 /* Move up to `capacity` queued events of `stream` into `out`; *n = number written. Implies sync. */
 int cc_engine_drain_events(cc_engine* e, int stream, cc_event* out, int64_t capacity, int64_t* n);
+
+/* Number of queued events of `stream`. Implies sync. */
+int cc_engine_pending_events(cc_engine* e, int stream, int64_t* n);
 
 int cc_engine_stream_state(cc_engine* e, int stream, cc_stream_state* out);
 /* Copy the columns [from, to] (global indices, inclusive, to - from < ring_buffer_max_columns) of `stream` to host. */

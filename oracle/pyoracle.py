@@ -1,0 +1,135 @@
+"""ctypes wrapper of oracle/libcc_oracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module. It is the checker
+for the HIP path, never part of it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from continuous_clustering_amd import capi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcc_oracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "cc_oracle.cpp")
+    hdr = os.path.join(_HERE, "..", "include", "cc_hip.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "libcc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(capi.Config), C.c_int]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_record.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_config.argtypes = [C.c_void_p, C.POINTER(capi.Config)]
+        L.orc_reset.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_robot_from_sensor.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_add_firings.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_time_firings.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_time_firings.restype = C.c_double
+        L.orc_last_error.restype = C.c_char_p
+        L.orc_last_error.argtypes = [C.c_void_p]
+        L.orc_stream_state.argtypes = [C.c_void_p, C.POINTER(capi.StreamState)]
+        L.orc_num_events.restype = C.c_int64
+        L.orc_num_events.argtypes = [C.c_void_p]
+        L.orc_drain_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        L.orc_read_published.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(capi.ColumnView)]
+        L.orc_published_base.restype = C.c_int64
+        L.orc_published_base.argtypes = [C.c_void_p]
+        L.orc_published_count.restype = C.c_int64
+        L.orc_published_count.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+IDENTITY_TF = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+
+
+class Oracle:
+    """One sensor stream processed by the CPU restatement (single-threaded reference order)."""
+
+    def __init__(self, cfg: capi.Config, num_rows: int, robot_from_sensor=IDENTITY_TF, record: bool = True):
+        self.L = lib()
+        self.cfg = cfg.copy()
+        self.num_rows = num_rows
+        self.h = self.L.orc_create(C.byref(self.cfg), num_rows)
+        if robot_from_sensor is not None:
+            self.set_robot_from_sensor(robot_from_sensor)
+        self.L.orc_record(self.h, 1 if record else 0)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def set_robot_from_sensor(self, tf12):
+        tf = np.ascontiguousarray(tf12, dtype=np.float64).reshape(12)
+        self.L.orc_set_robot_from_sensor(self.h, tf.ctypes.data)
+
+    def reset(self, num_rows=None):
+        self.L.orc_reset(self.h, self.num_rows if num_rows is None else num_rows)
+
+    def set_config(self, cfg: capi.Config):
+        self.cfg = cfg.copy()
+        self.L.orc_set_config(self.h, C.byref(self.cfg))
+
+    def add_firings(self, xyz, intensity, poses) -> int:
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        n = xyz.shape[0]
+        assert xyz.shape == (n, self.num_rows, 3) and intensity.shape == (n, self.num_rows) and poses.shape == (n, 12)
+        return self.L.orc_add_firings(self.h, n, xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
+
+    def time_firings(self, xyz, intensity, poses) -> float:
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        return self.L.orc_time_firings(self.h, xyz.shape[0], xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
+
+    def last_error(self) -> str:
+        return self.L.orc_last_error(self.h).decode()
+
+    def state(self) -> dict:
+        s = capi.StreamState()
+        self.L.orc_stream_state(self.h, C.byref(s))
+        return capi.state_to_dict(s)
+
+    def drain_events(self) -> np.ndarray:
+        n = self.L.orc_num_events(self.h)
+        out = np.zeros(n, dtype=capi.EVENT_DTYPE)
+        got = C.c_int64(0)
+        self.L.orc_drain_events(self.h, out.ctypes.data, n, C.byref(got))
+        return out[: got.value]
+
+    def published_range(self):
+        base = self.L.orc_published_base(self.h)
+        cnt = self.L.orc_published_count(self.h)
+        return base, base + cnt - 1
+
+    def read_published(self, frm: int, to: int, fields=None) -> dict:
+        v, arrays = capi.make_column_view(to - frm + 1, self.num_rows, fields)
+        rc = self.L.orc_read_published(self.h, frm, to, C.byref(v))
+        if rc != 0:
+            raise ValueError(f"orc_read_published({frm},{to}) -> {rc}")
+        return arrays
