@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of the continuous-clustering hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], the throughput configuration of the metric "Mpoints/s clustered (64-beam
+stream)"): 256 concurrent synthetic S64 sensor streams per GPU (64 rows x 2200 columns per rotation, KITTI
+parameters of src/tools/kitti_demo.cpp:279-294, seeded scenes of SURVEY.md 8d, sensor translating at 10 m/s).
+One *step* = one pass of the hot path (insertion -> ground segmentation -> association / union-find ->
+finished-cluster check -> publish) over one batch = one rotation (2200 firings) of every stream. Inputs are
+generated directly in HBM before the timed region. value = published range-image cells per second (NaN cells
+included) over all GPUs, in Mpoints/s. Streams never interact, so ranks share nothing on the data path
+(weak scaling: 256 streams per GPU); the only collective is the gather of per-rank result counts at the end.
+
+The JSON line also carries
+  roofline      dominant kernel vs the 8 TB/s HBM roof: algorithmic bytes per launch (19.5 B per cell at 64 rows,
+                SURVEY 8d) / its average duration measured with HIP events on the engine's stream
+  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference's single-threaded path) timed on this box's
+                host cores on a bounded sample of the same workload: N independent single-threaded instances (mode C)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=256, help="sensor streams per GPU")
+    ap.add_argument("--firings", type=int, default=2200, help="firings per stream per step (2200 = one rotation)")
+    ap.add_argument("--sensor", default="s64", choices=["s64", "s128"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    return ap.parse_args()
+
+
+def gen_inputs(torch, dev, sensor, n_streams, n_firings, n_batches, seed0):
+    """[batch][stream][firing][row][3] etc., generated in HBM. Every stream has its own seeded scene."""
+    from continuous_clustering_amd import synth
+    R = sensor.num_rows
+    xyz = torch.empty((n_batches, n_streams, n_firings, R, 3), dtype=torch.float32, device=dev)
+    inten = torch.empty((n_batches, n_streams, n_firings, R), dtype=torch.uint8, device=dev)
+    poses = torch.empty((n_batches, n_streams, n_firings, 12), dtype=torch.float64, device=dev)
+    for s in range(n_streams):
+        st = synth.make_stream(n_firings * n_batches, seed=seed0 + s, sensor=sensor, motion=synth.Motion.translate(10.0),
+                               start_column=40 if sensor.azimuth_offsets_deg else 0, xp=torch, device=dev, chunk=n_firings)
+        xyz[:, s] = st.xyz.view(n_batches, n_firings, R, 3)
+        inten[:, s] = st.intensity.view(n_batches, n_firings, R)
+        poses[:, s] = st.poses.view(n_batches, n_firings, 12)
+    return xyz, inten, poses
+
+
+def cpu_baseline(cfg, sensor, xyz, inten, poses, n_threads):
+    """Mode C of BASELINE.md 3: n_threads independent single-threaded oracle instances, one stream each."""
+    from oracle.pyoracle import Oracle
+    n_threads = max(1, n_threads)
+    R = sensor.num_rows
+    oracles = [Oracle(cfg, R, record=False) for _ in range(n_threads)]
+    times = [0.0] * n_threads
+
+    def work(i):
+        times[i] = oracles[i].time_firings(xyz[i], inten[i], poses[i])
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    wall = time.perf_counter() - t0
+    cells = sum(o.state()["cells_published"] for o in oracles)
+    single = oracles[0].state()["cells_published"] / times[0] if times[0] > 0 else 0.0
+    return {"value": cells / max(times) / 1e6, "wall_s": wall, "single_core": single / 1e6, "cells": cells}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from continuous_clustering_amd import Engine, capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    sensor = synth.SensorModel.s64() if args.sensor == "s64" else synth.SensorModel.s128()
+    cfg = capi.Config.kitti() if args.sensor == "s64" else capi.Config.vls128()
+    S, F, R = args.streams, args.firings, sensor.num_rows
+    n_batches = args.warmup + args.steps
+    xyz, inten, poses = gen_inputs(torch, dev, sensor, S, F, n_batches, seed0=1234 + rank * S)
+    torch.cuda.synchronize()
+
+    eng = Engine(cfg, R, S, device=local_rank)
+    eng.record_events(False)
+
+    def step(b):
+        eng.add_firings_device(F, xyz[b], inten[b], poses[b])
+
+    for b in range(args.warmup):
+        step(b)
+    rc = eng.sync()
+    if rc != 0:
+        raise SystemExit(f"engine error {rc}: {eng.last_error()}")
+    before = eng.totals()
+    eng.enable_timing(True)
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for b in range(args.warmup, n_batches):
+        step(b)
+    rc = eng.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if rc != 0:
+        raise SystemExit(f"engine error {rc}: {eng.last_error()}")
+    after = eng.totals()
+    ktimes = eng.kernel_times()
+    eng.enable_timing(False)
+
+    cells = after["cells_published"] - before["cells_published"]
+    clusters = after["clusters_finished"] - before["clusters_finished"]
+    # the one exchange step of the path: gather per-rank result counts (RCCL over xGMI), max of the elapsed times
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([cells, clusters, after["serial_columns"]], dtype=torch.int64, device=dev)
+        gathered = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(gathered, cnt)
+        cells = int(sum(int(g[0]) for g in gathered))
+        clusters = int(sum(int(g[1]) for g in gathered))
+
+    out = None
+    if rank == 0:
+        alg_bytes_per_cell = 18.0 + 96.0 / R  # 13 B read + 5 B written per cell + 96 B pose per column
+        batches = max(1, ktimes["batches"])
+        per_kernel = {k: ktimes[k] / batches for k in ("insert_ms", "segment_ms", "associate_ms")}
+        dom = max(per_kernel, key=per_kernel.get)
+        cells_per_launch = float(S * F * R)
+        achieved = cells_per_launch * alg_bytes_per_cell / (per_kernel[dom] * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom.replace("_ms", ""), {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpoints/s clustered (64-beam streams)" if R == 64 else f"Mpoints/s clustered ({R}-beam streams)",
+            "value": cells / elapsed / 1e6,
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{S} concurrent synthetic S{R} sensor streams per GPU ({R} rows x {cfg.num_columns} columns/rotation, "
+                            f"{'KITTI' if R == 64 else 'library-default'} parameters), {F} firings per stream per step, "
+                            f"inputs resident in HBM; BASELINE.json configs[2] shape",
+                "streams_per_gpu": S, "firings_per_step": F, "num_rows": R, "num_columns": cfg.num_columns,
+                "sharding": f"stream-per-wavefront, {world} rank(s) x {S} streams, no data-path collective",
+            },
+            "cells_published": cells,
+            "clusters_finished": clusters,
+            "serial_columns": after["serial_columns"],
+            "kernel_ms_per_step": per_kernel,
+            "roofline": {
+                "bound": "hbm", "kernel": "k_" + dom.replace("_ms", ""), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": cells_per_launch * alg_bytes_per_cell,
+                "note": "path is latency/dependency-bound (serial per-stream column recurrence), not bandwidth-bound",
+            },
+        }
+
+    # ---- single-stream latency (BASELINE.json configs[1] shape): one firing per call through the host API --------
+    if rank == 0 and not args.no_latency:
+        e1 = Engine(cfg, R, 1, device=local_rank)
+        hx = xyz[0, 0].cpu().numpy()
+        hi = inten[0, 0].cpu().numpy()
+        hp = poses[0, 0].cpu().numpy()
+        e1.add_firings(hx[:200], hi[:200], hp[:200])
+        lat = []
+        for k in range(200, min(F, 1400)):
+            t1 = time.perf_counter()
+            e1.add_firings(hx[k:k + 1], hi[k:k + 1], hp[k:k + 1])
+            lat.append(time.perf_counter() - t1)
+        lat = np.array(lat) * 1e6
+        out["latency_us_per_column_single_stream"] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
+                                                      "mode": "1 firing per cc_engine_add_firings call (H2D + 3 kernels + sync)"}
+        e1.close()
+
+    # ---- CPU baseline on this box's host cores ------------------------------------------------------------------
+    if rank == 0 and not args.no_cpu_baseline:
+        ncpu = os.cpu_count() or 1
+        nthreads = args.cpu_threads or min(ncpu, 32, S)
+        nb = min(n_batches, 4)
+        hx = xyz[:nb, :nthreads].permute(1, 0, 2, 3, 4).reshape(nthreads, nb * F, R, 3).cpu().numpy()
+        hi = inten[:nb, :nthreads].permute(1, 0, 2, 3).reshape(nthreads, nb * F, R).cpu().numpy()
+        hp = poses[:nb, :nthreads].permute(1, 0, 2, 3).reshape(nthreads, nb * F, 12).cpu().numpy()
+        cb = cpu_baseline(cfg, sensor, hx, hi, hp, nthreads)
+        out["cpu_baseline"] = {
+            "value": cb["value"], "unit": "Mpoints/s", "cores": nthreads, "kind": "port",
+            "sample": f"{nthreads} of the {S} streams x {nb} rotations ({cb['cells']} published cells), one single-threaded oracle "
+                      f"instance per host thread (BASELINE.md mode C); single instance on 1 core: {cb['single_core']:.2f} Mpoints/s",
+            "host_cpus": ncpu, "wall_s": cb["wall_s"],
+        }
+    elif rank == 0:
+        out["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

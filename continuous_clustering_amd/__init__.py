@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -32,6 +33,26 @@ class EngineError(RuntimeError):
         self.code = code
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64 / libhsa-runtime64. If this module
+    loaded /opt/rocm's copy first and torch its own afterwards, the second runtime would find no GPU. So when a torch
+    wheel is installed, bind to ITS runtime (without importing torch); otherwise the system runtime is used."""
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+            path = os.path.join(libdir, name)
+            if os.path.exists(path):
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def load_library():
     """dlopen libcc_hip.so (never builds implicitly, never falls back)."""
     global _lib
@@ -40,6 +61,7 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -m continuous_clustering_amd.build` "
                           f"(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     L.cc_config_default.argtypes = [C.POINTER(Config)]
@@ -64,6 +86,9 @@ def load_library():
     L.cc_engine_stream_state.argtypes = [vp, i32, C.POINTER(capi.StreamState)]
     L.cc_engine_read_columns.argtypes = [vp, i32, i64, i64, C.POINTER(capi.ColumnView)]
     L.cc_engine_output_planes.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.cc_engine_enable_timing.argtypes = [vp, i32]
+    L.cc_engine_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 3), C.POINTER(C.c_uint64)]
+    L.cc_engine_totals.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.cc_engine_last_error.argtypes = [vp]
     L.cc_engine_last_error.restype = C.c_char_p
     _lib = L
@@ -176,6 +201,21 @@ class Engine:
         v, arrays = capi.make_column_view(to - frm + 1, self.num_rows, fields)
         self._check(self.L.cc_engine_read_columns(self.h, stream, frm, to, C.byref(v)))
         return arrays
+
+    def enable_timing(self, enable: bool = True):
+        self._check(self.L.cc_engine_enable_timing(self.h, 1 if enable else 0))
+
+    def kernel_times(self) -> dict:
+        ms = (C.c_double * 3)()
+        n = C.c_uint64(0)
+        self._check(self.L.cc_engine_kernel_times(self.h, C.byref(ms), C.byref(n)))
+        return {"insert_ms": ms[0], "segment_ms": ms[1], "associate_ms": ms[2], "batches": n.value}
+
+    def totals(self) -> dict:
+        v = [C.c_uint64(0) for _ in range(4)]
+        self._check(self.L.cc_engine_totals(self.h, *[C.byref(x) for x in v]))
+        return {"cells_published": v[0].value, "clusters_finished": v[1].value, "firings_consumed": v[2].value,
+                "serial_columns": v[3].value}
 
     def output_planes(self, stream: int = 0):
         g, i = C.c_void_p(), C.c_void_p()

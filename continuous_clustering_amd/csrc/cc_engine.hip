@@ -42,6 +42,12 @@ struct cc_engine
     int64_t last_n{0};
     int last_first{0}, last_count{0};
     bool batch_open{false};
+    // optional per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
+    bool timing{false};
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used{0};
+    double kernel_ms[3]{0, 0, 0}; // insert, segment, associate
+    uint64_t kernel_launches{0};
 };
 
 namespace
@@ -193,18 +199,39 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
     const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
     dim3 seg_grid((unsigned) ((max_cols + 63) / 64), (unsigned) count);
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (e->timing)
+    {
+        for (int i = 0; i < 4; i++)
+        {
+            if (e->ev_used == e->ev_pool.size())
+            {
+                hipEvent_t x;
+                CC_HIP_CHECK(e, hipEventCreate(&x));
+                e->ev_pool.push_back(x);
+            }
+            ev[i] = e->ev_pool[e->ev_used++];
+        }
+        CC_HIP_CHECK(e, hipEventRecord(ev[0], e->stream));
+    }
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_insert<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                            d_int, d_pose, (long long) n, e->d_remaining);
     else
         hipLaunchKernelGGL(cck::k_insert<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                            d_int, d_pose, (long long) n, e->d_remaining);
+    if (e->timing)
+        CC_HIP_CHECK(e, hipEventRecord(ev[1], e->stream));
     hipLaunchKernelGGL(cck::k_segment, seg_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_pose,
                        (long long) n);
+    if (e->timing)
+        CC_HIP_CHECK(e, hipEventRecord(ev[2], e->stream));
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
     else
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    if (e->timing)
+        CC_HIP_CHECK(e, hipEventRecord(ev[3], e->stream));
     CC_HIP_CHECK(e, hipGetLastError());
     return CC_OK;
 }
@@ -254,6 +281,22 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
 
 int collect_events(cc_engine* e, int first_stream, int count);
 
+int resolve_timing(cc_engine* e)
+{
+    for (size_t i = 0; i + 3 < e->ev_used; i += 4)
+    {
+        for (int k = 0; k < 3; k++)
+        {
+            float ms = 0.f;
+            CC_HIP_CHECK(e, hipEventElapsedTime(&ms, e->ev_pool[i + k], e->ev_pool[i + k + 1]));
+            e->kernel_ms[k] += ms;
+        }
+        e->kernel_launches++;
+    }
+    e->ev_used = 0;
+    return CC_OK;
+}
+
 // Wait for the open batch; relaunch while some stream stopped early (limit_columns reached).
 int finish_batch(cc_engine* e)
 {
@@ -265,6 +308,12 @@ int finish_batch(cc_engine* e)
     while (true)
     {
         CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+        if (e->timing)
+        {
+            int rc = resolve_timing(e);
+            if (rc)
+                return rc;
+        }
         if (e->g.record_events)
         {
             int rc = collect_events(e, e->last_first, e->last_count);
@@ -430,6 +479,8 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipSetDevice(e->device);
     (void) hipStreamSynchronize(e->stream);
     free_all(e);
+    for (hipEvent_t ev : e->ev_pool)
+        (void) hipEventDestroy(ev);
     if (e->h_remaining)
         (void) hipHostFree(e->h_remaining);
     (void) hipStreamDestroy(e->stream);
@@ -727,6 +778,65 @@ int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_l
         *d_ground_label = e->P.ground + (size_t) stream * e->g.cells;
     if (d_cluster_id)
         *d_cluster_id = e->P.id + (size_t) stream * e->g.cells;
+    return CC_OK;
+}
+
+int cc_engine_enable_timing(cc_engine* e, int enable)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    e->timing = enable != 0;
+    e->kernel_ms[0] = e->kernel_ms[1] = e->kernel_ms[2] = 0;
+    e->kernel_launches = 0;
+    return CC_OK;
+}
+
+int cc_engine_kernel_times(cc_engine* e, double ms[3], uint64_t* launches)
+{
+    if (!e || !ms)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    for (int k = 0; k < 3; k++)
+        ms[k] = e->kernel_ms[k];
+    if (launches)
+        *launches = e->kernel_launches;
+    return CC_OK;
+}
+
+int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters_finished, uint64_t* firings_consumed,
+                     uint64_t* serial_columns)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    std::vector<StreamState> st(e->g.num_streams);
+    CC_HIP_CHECK(e, hipMemcpy(st.data(), e->d_states, st.size() * sizeof(StreamState), hipMemcpyDeviceToHost));
+    uint64_t a = 0, b = 0, c = 0, d = 0;
+    for (auto& s : st)
+    {
+        a += s.cells_published;
+        b += s.clusters_finished;
+        c += s.firings_consumed;
+        d += s.serial_columns;
+    }
+    if (cells_published)
+        *cells_published = a;
+    if (clusters_finished)
+        *clusters_finished = b;
+    if (firings_consumed)
+        *firings_consumed = c;
+    if (serial_columns)
+        *serial_columns = d;
     return CC_OK;
 }
 

@@ -1,0 +1,116 @@
+"""Named parity cases shared by the CPU (oracle / golden) and GPU (engine vs oracle) tests.
+
+Every case is (stream, config, robot_from_sensor or None). Streams are small (seconds for the CPU oracle)."""
+from __future__ import annotations
+
+import numpy as np
+
+from continuous_clustering_amd import capi, synth
+from continuous_clustering_amd.synth import Motion, SceneModel, SensorModel
+
+
+def _kitti(num_columns=2200, **over):
+    c = capi.Config.kitti()
+    c.num_columns = num_columns
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def _vls(num_columns=1700, **over):
+    c = capi.Config.vls128()
+    c.num_columns = num_columns
+    for k, v in over.items():
+        setattr(c, k, v)
+    return c
+
+
+def _s64(cols):
+    return SensorModel(num_rows=64, num_columns=cols)
+
+
+def _s128(cols, offsets=True):
+    s = SensorModel.s128(offsets)
+    s.num_columns = cols
+    return s
+
+
+ROBOT_TF_TILTED = np.array([0.9961946980917455, 0.0, 0.08715574274765817, 1.2,
+                            0.0, 1.0, 0.0, 0.1,
+                            -0.08715574274765817, 0.0, 0.9961946980917455, 0.3], dtype=np.float64)
+
+
+def build_case(name: str):
+    if name == "s64_static":
+        return synth.make_stream(720 * 3, seed=1234, sensor=_s64(720)), _kitti(720), None
+    if name == "s64_translate":
+        return synth.make_stream(720 * 3, seed=7, sensor=_s64(720), motion=Motion.translate()), _kitti(720), None
+    if name == "s64_turn":
+        return synth.make_stream(720 * 3, seed=8, sensor=_s64(720), motion=Motion.turn(10.0, 0.6)), _kitti(720), None
+    if name == "s64_full_2200":
+        return synth.make_stream(2200 * 2 + 300, seed=21, motion=Motion.translate()), _kitti(2200), None
+    if name == "s64_forced_finish_ring":
+        # unbroken wall ring: clusters exceed one rotation -> tree-width refusals, finished-root refusals, forced finish
+        sc = SceneModel(n_objects=0, wall_radius=12.0, wall_gaps_deg=())
+        return synth.make_stream(360 * 4, seed=5, sensor=_s64(360), scene=sc), _kitti(360), None
+    if name == "s64_ring_with_objects":
+        sc = SceneModel(n_objects=25, wall_radius=14.0, wall_gaps_deg=(), object_range=(3.0, 11.0))
+        return synth.make_stream(360 * 4, seed=6, sensor=_s64(360), scene=sc, motion=Motion.translate(3.0)), _kitti(360), None
+    if name == "s64_fog_and_ego":
+        sc = SceneModel(n_objects=40, object_range=(1.5, 12.0), object_radius=(0.2, 0.6))
+        cfg = _kitti(720, fog_filtering_enabled=1, fog_filtering_intensity_below=40, fog_filtering_distance_below=18.0,
+                     fog_filtering_inclination_above=-0.2)
+        return synth.make_stream(720 * 2 + 50, seed=9, sensor=_s64(720), scene=sc), cfg, None
+    if name == "s64_counterclockwise":
+        sen = _s64(720)
+        sen.clockwise = False
+        return synth.make_stream(720 * 2 + 50, seed=10, sensor=sen), _kitti(720, sensor_is_clockwise=0), None
+    if name == "s64_every_2nd_column":
+        return synth.make_stream(720 * 2 + 50, seed=11, sensor=_s64(720)), _kitti(720, cluster_point_trees_every_nth_column=2), None
+    if name == "s64_no_early_stop":
+        # stop_after_association disabled: many links per point -> exercises the exact serial association path
+        return synth.make_stream(360 * 2 + 50, seed=12, sensor=_s64(360)), _kitti(360, stop_after_association_enabled=0), None
+    if name == "s64_min_steps_3":
+        return synth.make_stream(720 * 2 + 50, seed=13, sensor=_s64(720)), _kitti(720, stop_after_association_min_steps=3), None
+    if name == "s64_dropouts":
+        sc = SceneModel(dropout=0.35, max_range=40.0)
+        return synth.make_stream(720 * 2 + 50, seed=14, sensor=_s64(720), scene=sc, motion=Motion.translate()), _kitti(720), None
+    if name == "s64_no_supplement_no_incl_ignore":
+        cfg = _kitti(720, supplement_inclination_angle_for_nan_cells=0, ignore_points_with_too_big_inclination_angle_diff=0)
+        return synth.make_stream(720 * 2 + 50, seed=15, sensor=_s64(720), scene=SceneModel(dropout=0.2)), cfg, None
+    if name == "s64_robot_tf_tilted":
+        cfg = _kitti(720)
+        return synth.make_stream(720 * 2 + 50, seed=16, sensor=_s64(720), motion=Motion.turn(8.0, 0.3)), cfg, ROBOT_TF_TILTED
+    if name == "s128_offsets":
+        return synth.make_stream(680 * 3, seed=17, sensor=_s128(680), start_column=20), _vls(680), None
+    if name == "s128_no_offsets_translate":
+        return synth.make_stream(680 * 3, seed=18, sensor=_s128(680, False), motion=Motion.translate()), _vls(680), None
+    if name == "s128_full_1700":
+        return synth.make_stream(1700 * 2 + 200, seed=19, sensor=SensorModel.s128(), start_column=40,
+                                 motion=Motion.translate()), _vls(1700), None
+    if name == "s32_small_sensor":
+        sen = SensorModel(num_rows=32, num_columns=512, incl_top_deg=10.0, incl_bottom_deg=-30.0)
+        return synth.make_stream(512 * 3, seed=20, sensor=sen), _vls(512, max_distance=0.5), None
+    # ---- small variants kept as committed golden fixtures -------------------------------------------------------
+    if name == "g_s64_translate":
+        return synth.make_stream(800, seed=31, sensor=_s64(360), motion=Motion.translate()), _kitti(360), None
+    if name == "g_s64_forced_finish_ring":
+        sc = SceneModel(n_objects=0, wall_radius=12.0, wall_gaps_deg=())
+        return synth.make_stream(240 * 4, seed=32, sensor=_s64(240), scene=sc), _kitti(240), None
+    if name == "g_s128_offsets":
+        return synth.make_stream(816, seed=33, sensor=_s128(340), start_column=12, motion=Motion.turn(6.0, 0.4)), _vls(340), None
+    if name == "g_s64_fog_and_ego":
+        sc = SceneModel(n_objects=40, object_range=(1.5, 12.0), object_radius=(0.2, 0.6), dropout=0.1)
+        cfg = _kitti(360, fog_filtering_enabled=1, fog_filtering_intensity_below=40, fog_filtering_distance_below=18.0,
+                     fog_filtering_inclination_above=-0.2)
+        return synth.make_stream(800, seed=34, sensor=_s64(360), scene=sc), cfg, ROBOT_TF_TILTED
+    raise KeyError(name)
+
+
+ALL_CASES = ["s64_static", "s64_translate", "s64_turn", "s64_full_2200", "s64_forced_finish_ring", "s64_ring_with_objects",
+             "s64_fog_and_ego", "s64_counterclockwise", "s64_every_2nd_column", "s64_no_early_stop", "s64_min_steps_3",
+             "s64_dropouts", "s64_no_supplement_no_incl_ignore", "s64_robot_tf_tilted", "s128_offsets",
+             "s128_no_offsets_translate", "s128_full_1700", "s32_small_sensor"]
+
+# cases stored as golden fixtures under tests/golden/ (inputs + expected outputs)
+GOLDEN_CASES = ["g_s64_translate", "g_s64_forced_finish_ring", "g_s128_offsets", "g_s64_fog_and_ego"]

@@ -1,0 +1,104 @@
+"""GPU: the throughput entry (device-resident inputs, many streams per launch) at and above BASELINE.json sizes,
+checked through size-independent properties and against the oracle on sampled streams."""
+import numpy as np
+import pytest
+
+import cases
+import util
+from continuous_clustering_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_batches(torch, streams, n_batches, F):
+    S = len(streams)
+    R = streams[0].sensor.num_rows
+    xyz = torch.empty((n_batches, S, F, R, 3), dtype=torch.float32, device="cuda")
+    inten = torch.empty((n_batches, S, F, R), dtype=torch.uint8, device="cuda")
+    poses = torch.empty((n_batches, S, F, 12), dtype=torch.float64, device="cuda")
+    for s, st in enumerate(streams):
+        xyz[:, s] = torch.from_numpy(st.xyz[:n_batches * F]).view(n_batches, F, R, 3)
+        inten[:, s] = torch.from_numpy(st.intensity[:n_batches * F]).view(n_batches, F, R)
+        poses[:, s] = torch.from_numpy(st.poses[:n_batches * F]).view(n_batches, F, 12)
+    return xyz, inten, poses
+
+
+def test_multi_stream_device_path_equals_per_stream_oracle(oracle_lib):
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    sen = synth.SensorModel(num_rows=64, num_columns=720)
+    cfg = capi.Config.kitti()
+    cfg.num_columns = 720
+    S, F, NB = 6, 720, 3
+    motions = [synth.Motion.static(), synth.Motion.translate(), synth.Motion.turn()]
+    streams = [synth.make_stream(F * NB, seed=100 + s, sensor=sen, motion=motions[s % 3]) for s in range(S)]
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, 64, S)
+    e.record_events(True)
+    oracles = [Oracle(cfg, 64) for _ in range(S)]
+    for s in range(S):
+        assert oracles[s].add_firings(streams[s].xyz, streams[s].intensity, streams[s].poses) == 0
+    evo = [o.drain_events() for o in oracles]
+    pos = [0] * S
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+        assert e.sync() == 0, e.last_error()
+        for s in range(S):
+            ev = e.drain_events(s)
+            ref = evo[s][pos[s]:pos[s] + len(ev)]
+            assert len(ev) == len(ref)
+            assert (ev["stream"] == s).all()
+            for fld in ("type", "a", "b", "c", "d", "column"):
+                assert np.array_equal(ev[fld], ref[fld]), (s, fld)
+            pos[s] += len(ev)
+            pub = ev[(ev["type"] == capi.EV_PUBLISH_COLUMNS) & (ev["b"] >= ev["a"])]
+            if len(pub):
+                lo, hi = int(pub["a"].min()), int(pub["b"].max())
+                util.compare_columns(oracles[s].read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo)
+    for s in range(S):
+        assert pos[s] == len(evo[s])
+        so, se = oracles[s].state(), e.state(s)
+        for k in util.STATE_FIELDS:
+            assert so[k] == se[k], (s, k)
+
+
+def test_full_size_properties_256_streams():
+    """BASELINE.json configs[2] shape: 256 concurrent 64 x 2200 streams. Properties: every stream publishes, totals add
+    up, replicated inputs give identical per-stream results (determinism across wavefronts), output planes carry only
+    legal labels, and a sampled stream equals the oracle."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    cfg = capi.Config.kitti()
+    S, F, NB = 256, 2200, 2
+    distinct = 4
+    base = [synth.make_stream(F * NB, seed=500 + s, motion=synth.Motion.translate()) for s in range(distinct)]
+    streams = [base[s % distinct] for s in range(S)]
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, 64, S)
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+    assert e.sync() == 0, e.last_error()
+    tot = e.totals()
+    states = [e.state(s) for s in range(S)]
+    assert tot["firings_consumed"] == S * F * NB
+    assert tot["cells_published"] == sum(st["cells_published"] for st in states)
+    assert all(st["cells_published"] > 0.9 * 64 * (F * NB - 400) for st in states)
+    for s in range(distinct, S):
+        for k in util.STATE_FIELDS:
+            assert states[s][k] == states[s % distinct][k], (s, k)
+    # sampled stream vs oracle
+    for s in (0, 3):
+        o = Oracle(cfg, 64)
+        assert o.add_firings(streams[s].xyz, streams[s].intensity, streams[s].poses) == 0
+        so = o.state()
+        for k in util.STATE_FIELDS:
+            assert so[k] == states[s][k], (s, k)
+        # columns still in the ring (not yet cleared) must equal the oracle's published snapshot
+        hi = states[s]["first_unpublished_global_column_index"] - 1
+        lo = hi - 1500
+        for s2 in (s, s + distinct * 7):
+            util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo)
+    g_ptr, id_ptr = e.output_planes(0)
+    assert g_ptr and id_ptr

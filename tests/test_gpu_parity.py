@@ -1,0 +1,81 @@
+"""GPU: the HIP path, called through the C-ABI (libcc_hip.so), against the CPU oracle on the same seeded inputs.
+Bit-exact bar: events (reference callback order), ground / debug labels, ignore flags, geometry bit patterns, tree
+roots, raw cluster ids (and therefore the canonical partition)."""
+import numpy as np
+import pytest
+
+import cases
+import util
+from continuous_clustering_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+CHUNKS = {
+    "s64_static": [720, 1, 33, 500],
+    "s64_translate": [300],
+    "s64_full_2200": [2200],
+    "s128_full_1700": [1700, 3],
+    "s64_forced_finish_ring": [97],
+}
+
+
+@pytest.mark.parametrize("name", cases.ALL_CASES)
+def test_engine_matches_oracle(name, oracle_lib):
+    stream, cfg, tf = cases.build_case(name)
+    summary = util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns]), robot_tf=tf)
+    assert summary["published_columns"] > stream.sensor.num_columns
+    assert summary["clusters"] >= 3
+    es = summary["engine_state"]
+    # (error_a, error_b) double as (clusters exceeding one rotation, serially replayed columns) when there is no error
+    assert es["error_a"] == summary["oracle_state"]["error_a"]
+    if name in ("s64_forced_finish_ring", "s64_no_early_stop"):
+        assert es["error_b"] > 0, "the exact serial association path was expected to run"
+
+
+def test_single_firing_calls(oracle_lib):
+    """addFiring one firing at a time (the reference's calling pattern)."""
+    stream, cfg, tf = cases.build_case("g_s64_translate")
+    util.run_and_compare(stream, cfg, chunks=[1], robot_tf=tf)
+
+
+def test_reset_and_reuse(oracle_lib):
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    stream, cfg, tf = cases.build_case("g_s64_translate")
+    e = Engine(cfg, 64)
+    o = Oracle(cfg, 64)
+    for rep in range(2):
+        assert e.add_firings(stream.xyz[:500], stream.intensity[:500], stream.poses[:500]) == 0
+        assert o.add_firings(stream.xyz[:500], stream.intensity[:500], stream.poses[:500]) == 0
+        ee, eo = e.drain_events(), o.drain_events()
+        assert len(ee) == len(eo) and all(np.array_equal(ee[f], eo[f]) for f in ("type", "a", "b", "c", "d", "column"))
+        e.reset()
+        o.reset()
+        # reset() drops the robot transform (cc.cpp:39): the next segmented column must fail until it is set again
+        assert e.add_firings(stream.xyz[:50], stream.intensity[:50], stream.poses[:50]) == capi.CC_ERR_NO_ROBOT_TRANSFORM
+        assert o.add_firings(stream.xyz[:50], stream.intensity[:50], stream.poses[:50]) == capi.CC_ERR_NO_ROBOT_TRANSFORM
+        e.reset()
+        o.reset()
+        e.set_robot_from_sensor(capi_identity())
+        o.set_robot_from_sensor(capi_identity())
+
+
+def capi_identity():
+    return np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)
+
+
+def test_bad_start_sets_reset_required(oracle_lib):
+    from continuous_clustering_amd import Engine
+    stream, cfg, tf = cases.build_case("g_s64_translate")
+    bad = stream.xyz[:1].copy()
+    bad[0, :32, 1] = np.abs(bad[0, :32, 1]) + 0.1
+    bad[0, 32:, 1] = -np.abs(bad[0, 32:, 1]) - 0.1
+    bad[0, :, 0] = -np.abs(bad[0, :, 0]) - 1.0
+    e = Engine(cfg, 64)
+    assert e.add_firings(bad, stream.intensity[:1], stream.poses[:1]) == 0
+    assert e.state()["reset_required"] == 1  # cc.cpp:252-261
+    cfg2 = cfg.copy()
+    cfg2.num_columns = 400
+    e2 = Engine(cfg, 64)
+    e2.set_config(cfg2)
+    assert e2.state()["reset_required"] == 1  # cc.cpp:73-74
