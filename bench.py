@@ -160,7 +160,7 @@ def main():
     if rank == 0:
         alg_bytes_per_cell = 18.0 + 96.0 / R  # 13 B read + 5 B written per cell + 96 B pose per column
         batches = max(1, ktimes["batches"])
-        per_kernel = {k: ktimes[k] / batches for k in ("insert_ms", "segment_ms", "associate_ms")}
+        per_kernel = {k: v / batches for k, v in ktimes.items() if k.endswith("_ms")}
         dom = max(per_kernel, key=per_kernel.get)
         cells_per_launch = float(S * F * R)
         achieved = cells_per_launch * alg_bytes_per_cell / (per_kernel[dom] * 1e-3) / 1e9

@@ -17,6 +17,9 @@ namespace ccd
 
 constexpr int WAVE = 64;
 constexpr int MAX_ROWS_PER_LANE = 2; // num_rows <= 128
+constexpr int LINK_SLOTS = 4;        // link candidates recorded per point by the static window scan
+constexpr int WIN_COLS = 32;         // columns of tree-slot ids kept in LDS by the association kernel
+constexpr int TREE_SLOTS = 512;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
 
 // Scalar state of one sensor stream: the srig_*/sgps_*/sc_* members of the reference class
 // (continuous_clustering.hpp:244-275) plus engine bookkeeping.
@@ -47,6 +50,10 @@ struct StreamState
     int64_t seg_begin;  // columns [seg_begin, seg_end) were emitted by the insertion kernel in this batch
     int64_t seg_end;
     int64_t acp_next;   // next column the association kernel processes
+    int64_t pub_begin;  // columns [pub_begin, pub_end) were published by the association kernel in this pass
+    int64_t pub_end;
+    int32_t assoc_mode; // 0: tree state in LDS (k_assoc_lds), 1: tree state in global memory (k_associate)
+    int32_t pad1;
     int64_t cursor;     // firings of the current batch already consumed
     uint64_t firings_consumed;
     uint64_t cells_published;
@@ -55,6 +62,7 @@ struct StreamState
     uint64_t serial_columns;      // columns that took the exact serial association path
     uint64_t stamp_alias_rounds;  // rounds whose min azimuth equalled the previous round's
     // errors raised inside kernels
+    uint64_t dbg[8];              // section cycle counters (CC_PROFILE_SECTIONS builds only)
     int32_t error;
     int32_t n_events;
     int64_t error_a;
@@ -105,6 +113,12 @@ struct Planes
     int32_t* agg_first;
     uint8_t* agg_flag;
     cc_event* events; // [stream][event_capacity]
+    // staging written by the static window scan (k_scan), consumed by k_assoc_lds
+    // candidates are coded as (columns back << 8) | row
+    int16_t* sc_parent;  // first accepted candidate, -1 = none, -2 = point is ignored
+    uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS
+    unsigned long long* sc_links; // LINK_SLOTS x 16-bit candidate codes packed into one word per cell
+    double* sc_fin;      // continuous azimuth + max angle diff of the point (its contribution to finished_at)
     float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
 };
 

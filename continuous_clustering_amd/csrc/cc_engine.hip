@@ -46,7 +46,7 @@ struct cc_engine
     bool timing{false};
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used{0};
-    double kernel_ms[3]{0, 0, 0}; // insert, segment, associate
+    double kernel_ms[6]{0, 0, 0, 0, 0, 0}; // insert, segment, scan, assoc_lds, assoc_global, publish
     uint64_t kernel_launches{0};
 };
 
@@ -135,6 +135,7 @@ int allocate(cc_engine* e)
     A(t_fin, C) A(t_width, C) A(t_pts, C) A(t_uf, C) A(t_cid, C) A(t_pos, C) A(t_finished, C);
     A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
     A(events, S * (size_t) g.event_capacity);
+    A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
     A(curtab, S * (size_t) g.num_rows);
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
@@ -182,6 +183,9 @@ int reset_state(cc_engine* e, bool keep_table)
         st.seg_begin = -1;
         st.seg_end = -1;
         st.acp_next = -1;
+        st.pub_begin = -1;
+        st.pub_end = -1;
+        st.assoc_mode = e->cfg.max_steps_in_row > WIN_COLS - 2 ? 1 : 0;
     }
     CC_HIP_CHECK(e, hipMemcpyAsync(e->d_states, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice, e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
@@ -199,10 +203,11 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
     const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
     dim3 seg_grid((unsigned) ((max_cols + 63) / 64), (unsigned) count);
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    constexpr int NK = 6;
+    hipEvent_t ev[NK + 1] = {};
     if (e->timing)
     {
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i <= NK; i++)
         {
             if (e->ev_used == e->ev_pool.size())
             {
@@ -214,24 +219,41 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         }
         CC_HIP_CHECK(e, hipEventRecord(ev[0], e->stream));
     }
+    int k = 0;
+#define CC_MARK()    \
+    if (e->timing) \
+        CC_HIP_CHECK(e, hipEventRecord(ev[++k], e->stream));
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_insert<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                            d_int, d_pose, (long long) n, e->d_remaining);
     else
         hipLaunchKernelGGL(cck::k_insert<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                            d_int, d_pose, (long long) n, e->d_remaining);
-    if (e->timing)
-        CC_HIP_CHECK(e, hipEventRecord(ev[1], e->stream));
+    CC_MARK();
     hipLaunchKernelGGL(cck::k_segment, seg_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_pose,
                        (long long) n);
-    if (e->timing)
-        CC_HIP_CHECK(e, hipEventRecord(ev[2], e->stream));
+    CC_MARK();
+    const dim3 scan_grid(cck::SCAN_BLOCKS, (unsigned) count);
+    if (rpl == 1)
+        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    else
+        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    CC_MARK();
+    if (rpl == 1)
+        hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    else
+        hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    CC_MARK();
+    // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
     else
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
-    if (e->timing)
-        CC_HIP_CHECK(e, hipEventRecord(ev[3], e->stream));
+    CC_MARK();
+    hipLaunchKernelGGL(cck::k_publish, dim3(cck::PUBLISH_BLOCKS, (unsigned) count), dim3(64), 0, e->stream, g, e->P, e->d_states,
+                       first_stream);
+    CC_MARK();
+#undef CC_MARK
     CC_HIP_CHECK(e, hipGetLastError());
     return CC_OK;
 }
@@ -283,9 +305,9 @@ int collect_events(cc_engine* e, int first_stream, int count);
 
 int resolve_timing(cc_engine* e)
 {
-    for (size_t i = 0; i + 3 < e->ev_used; i += 4)
+    for (size_t i = 0; i + 6 < e->ev_used; i += 7)
     {
-        for (int k = 0; k < 3; k++)
+        for (int k = 0; k < 6; k++)
         {
             float ms = 0.f;
             CC_HIP_CHECK(e, hipEventElapsedTime(&ms, e->ev_pool[i + k], e->ev_pool[i + k + 1]));
@@ -503,13 +525,19 @@ int cc_engine_set_config(cc_engine* e, const cc_config* cfg)
                             e->cfg.num_columns != cfg->num_columns; // cc.cpp:69-74
     e->cfg = *cfg;
     e->g.max_distance_squared = cfg->max_distance * cfg->max_distance; // cc.cpp:80
-    if (need_reset)
+    const bool force_global = cfg->max_steps_in_row > WIN_COLS - 2;
+    if (need_reset || force_global)
     {
         // raise reset_required on every stream; geometry keeps the old num_columns until cc_engine_reset (cc.cpp:14)
         std::vector<StreamState> st(e->g.num_streams);
         CC_HIP_CHECK(e, hipMemcpy(st.data(), e->d_states, st.size() * sizeof(StreamState), hipMemcpyDeviceToHost));
         for (auto& s : st)
-            s.reset_required = 1;
+        {
+            if (need_reset)
+                s.reset_required = 1;
+            if (force_global)
+                s.assoc_mode = 1;
+        }
         CC_HIP_CHECK(e, hipMemcpy(e->d_states, st.data(), st.size() * sizeof(StreamState), hipMemcpyHostToDevice));
     }
     return CC_OK;
@@ -790,12 +818,13 @@ int cc_engine_enable_timing(cc_engine* e, int enable)
     if (rc)
         return rc;
     e->timing = enable != 0;
-    e->kernel_ms[0] = e->kernel_ms[1] = e->kernel_ms[2] = 0;
+    for (double& v : e->kernel_ms)
+        v = 0;
     e->kernel_launches = 0;
     return CC_OK;
 }
 
-int cc_engine_kernel_times(cc_engine* e, double ms[3], uint64_t* launches)
+int cc_engine_kernel_times(cc_engine* e, double ms[6], uint64_t* launches)
 {
     if (!e || !ms)
         return CC_ERR_INVALID_ARGUMENT;
@@ -803,7 +832,7 @@ int cc_engine_kernel_times(cc_engine* e, double ms[3], uint64_t* launches)
     int rc = finish_batch(e);
     if (rc)
         return rc;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 6; k++)
         ms[k] = e->kernel_ms[k];
     if (launches)
         *launches = e->kernel_launches;
@@ -837,6 +866,17 @@ int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters
         *firings_consumed = c;
     if (serial_columns)
         *serial_columns = d;
+    return CC_OK;
+}
+
+int cc_engine_debug_counters(cc_engine* e, int stream, uint64_t out[8])
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !out)
+        return CC_ERR_INVALID_ARGUMENT;
+    StreamState st;
+    CC_HIP_CHECK(e, hipMemcpy(&st, e->d_states + stream, sizeof(st), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++)
+        out[i] = st.dbg[i];
     return CC_OK;
 }
 

@@ -172,6 +172,7 @@ struct Oracle
     int64_t published_base{-1};            // gcol of published[0]
     uint64_t firings_consumed{0}, cells_published{0}, clusters_finished{0};
     uint64_t exceed_one_rotation{0};
+    uint64_t max_unfinished{0};
     std::string error;
 
     Cell& at(int64_t lcol, int row)
@@ -720,6 +721,8 @@ struct Oracle
     void combine_trees(int64_t gcol, std::list<Ref>& new_trees, double col_min_az)
     {
         unfinished.splice(unfinished.end(), new_trees);
+        if (unfinished.size() > max_unfinished)
+            max_unfinished = unfinished.size();
         if (gcol % cfg.cluster_point_trees_every_nth_column != 0)
             return;
 
@@ -1010,6 +1013,7 @@ int orc_stream_state(orc_handle* h, cc_stream_state* s)
     s->clusters_finished = o.clusters_finished;
     s->n_unfinished_trees = (int32_t) o.unfinished.size();
     s->error_a = (int64_t) o.exceed_one_rotation;
+    s->error_b = (int64_t) o.max_unfinished;
     return CC_OK;
 }
 
