@@ -19,6 +19,7 @@ constexpr int WAVE = 64;
 constexpr int MAX_ROWS_PER_LANE = 2; // num_rows <= 128
 constexpr int LINK_SLOTS = 4;        // link candidates recorded per point by the static window scan
 constexpr int WIN_COLS = 32;         // columns of tree-slot ids kept in LDS by the association kernel
+constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLOSE = 16;
 constexpr int TREE_SLOTS = 512;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
 
 // Scalar state of one sensor stream: the srig_*/sgps_*/sc_* members of the reference class
@@ -114,6 +115,10 @@ struct Planes
     uint8_t* agg_flag;
     cc_event* events; // [stream][event_capacity]
     // staging written by the static window scan (k_scan), consumed by k_assoc_lds
+    // staging written by k_seg_pre, consumed by k_seg_scan
+    float* sg_x2;       // ||xy|| of the point relative to the sensor (to2dInAzimuthPlane(...).x, cc.hpp:229-232)
+    float* sg_uz;       // z of the point relative to the sensor
+    uint8_t* sg_flags;  // SG_* bits
     // candidates are coded as (columns back << 8) | row
     int16_t* sc_parent;  // first accepted candidate, -1 = none, -2 = point is ignored
     uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS

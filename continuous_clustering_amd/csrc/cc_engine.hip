@@ -136,6 +136,7 @@ int allocate(cc_engine* e)
     A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
     A(events, S * (size_t) g.event_capacity);
     A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
+    A(sg_x2, C) A(sg_uz, C) A(sg_flags, C);
     A(curtab, S * (size_t) g.num_rows);
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
@@ -230,8 +231,16 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         hipLaunchKernelGGL(cck::k_insert<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                            d_int, d_pose, (long long) n, e->d_remaining);
     CC_MARK();
-    hipLaunchKernelGGL(cck::k_segment, seg_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_pose,
-                       (long long) n);
+    if (rpl == 1)
+        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, e->stream, g, e->cfg, e->P,
+                           e->d_states, first_stream, d_pose, (long long) n);
+    else
+        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, e->stream, g, e->cfg, e->P,
+                           e->d_states, first_stream, d_pose, (long long) n);
+    {
+        const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
+        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+    }
     CC_MARK();
     const dim3 scan_grid(cck::SCAN_BLOCKS, (unsigned) count);
     if (rpl == 1)
@@ -472,6 +481,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     fill_geometry(e, num_rows);
     e->g.event_capacity = e->g.record_events ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
     e->pending_events.resize(num_streams);
+    (void) hipFuncSetAttribute((const void*) cck::k_seg_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     rc = allocate(e);
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_remaining, sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;

@@ -136,6 +136,8 @@ struct SP
     uint8_t* sc_nlinks;
     unsigned long long* sc_links;
     double* sc_fin;
+    float *sg_x2, *sg_uz;
+    uint8_t* sg_flags;
 };
 
 __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, int s)
@@ -184,6 +186,9 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.sc_nlinks = P.sc_nlinks + co;
     p.sc_links = P.sc_links + co;
     p.sc_fin = P.sc_fin + co;
+    p.sg_x2 = P.sg_x2 + co;
+    p.sg_uz = P.sg_uz + co;
+    p.sg_flags = P.sg_flags + co;
     return p;
 }
 
@@ -439,234 +444,404 @@ __device__ __forceinline__ float len2(float a, float b)
     return ccm::sqrt_rn(a * a + b * b);
 }
 
-__global__ __launch_bounds__(64) void k_segment(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+// ---- k_seg_pre: everything of the segmentation that does not depend on the rows below. One wavefront per column,
+// lanes = rows (coalesced); blocks stride over the columns of the batch. grid = (SEGPRE_BLOCKS, streams), block = 64.
+constexpr int SEGPRE_BLOCKS = 128;
+
+template<int RPL>
+__global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
                                                 const double* __restrict__ poses, long long n)
 {
     const int sl = blockIdx.y;
     const int s = first_stream + sl;
     StreamState* st = &states[s];
     const long long seg_begin = st->seg_begin, seg_end = st->seg_end;
-    if (seg_begin < 0)
-        return;
-    const long long gc = seg_begin + (long long) blockIdx.x * 64 + lane_id();
-    if (gc >= seg_end)
+    if (seg_begin < 0 || seg_begin >= seg_end)
         return;
     if (!st->has_robot_tf)
     {
-        raise_error(st, CC_ERR_NO_ROBOT_TRANSFORM, gc, 0);
+        if (blockIdx.x == 0 && lane_id() == 0)
+            raise_error(st, CC_ERR_NO_ROBOT_TRANSFORM, seg_begin, 0);
         return;
     }
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    const int lc = (int) (gc % RC);
-    const size_t base = (size_t) lc * R;
-
-    const double* T = poses + ((size_t) sl * (size_t) n + (size_t) p.trig[lc]) * 12;
-    // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301)
-    double ir[9], it[3];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++)
-            ir[i * 3 + j] = T[j * 4 + i];
-    for (int i = 0; i < 3; i++)
-        it[i] = ((-ir[i * 3 + 0]) * T[3] + (-ir[i * 3 + 1]) * T[7]) + (-ir[i * 3 + 2]) * T[11];
+    const int lane = lane_id();
+    __shared__ float s_incl[WAVE * RPL];
+    __shared__ int s_done[WAVE * RPL];
     const double* A = st->robot_from_sensor;
-    double er[9], et[3];
-    for (int i = 0; i < 3; i++)
-    {
-        for (int j = 0; j < 3; j++)
-            er[i * 3 + j] = (A[i * 4 + 0] * ir[0 * 3 + j] + A[i * 4 + 1] * ir[1 * 3 + j]) + A[i * 4 + 2] * ir[2 * 3 + j];
-        et[i] = ((A[i * 4 + 0] * it[0] + A[i * 4 + 1] * it[1]) + A[i * 4 + 2] * it[2]) + A[i * 4 + 3];
-    }
     const float height_sensor_to_ground = -(float) A[11] + cfg.height_ref_to_ground_;
-    const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
+    (void) height_sensor_to_ground;
 
-    bool first_obstacle_detected = false, first_point_found = false;
-    float lgx = 0.f, lgy = 0.f, lgz = height_sensor_to_ground;
-    float pvx = 0.f, pvy = 0.f, pvz = 0.f;
-    uint8_t previous_label = 0;
-    double min_az = 1.7976931348623157e308;
-
-    for (int row = R - 1; row >= 0; row--)
+    for (long long gc = seg_begin + blockIdx.x; gc < seg_end; gc += gridDim.x)
     {
-        const size_t ci = base + row;
-        const long long cg = p.gcol[ci];
-        if (cg != gc && cg != -1)
+        const int lc = (int) (gc % RC);
+        const size_t base = (size_t) lc * R;
+        const double* T = poses + ((size_t) sl * (size_t) n + (size_t) p.trig[lc]) * 12;
+        // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301)
+        double ir[9], it[3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                ir[i * 3 + j] = T[j * 4 + i];
+        for (int i = 0; i < 3; i++)
+            it[i] = ((-ir[i * 3 + 0]) * T[3] + (-ir[i * 3 + 1]) * T[7]) + (-ir[i * 3 + 2]) * T[11];
+        double er[9], et[3];
+        for (int i = 0; i < 3; i++)
         {
-            raise_error(st, CC_ERR_RING_OVERRUN, cg, gc); // cc.cpp:320-345
-            return;
+            for (int j = 0; j < 3; j++)
+                er[i * 3 + j] = (A[i * 4 + 0] * ir[0 * 3 + j] + A[i * 4 + 1] * ir[1 * 3 + j]) + A[i * 4 + 2] * ir[2 * 3 + j];
+            et[i] = ((A[i * 4 + 0] * it[0] + A[i * 4 + 1] * it[1]) + A[i * 4 + 2] * it[2]) + A[i * 4 + 3];
         }
-        p.gcol[ci] = gc;
-        p.root[ci] = -1;
-        p.id[ci] = 0;
-        const float dist = p.dist[ci];
-        uint8_t ground = CC_GP_UNKNOWN, debug = CC_DBG_WHITE;
-        if (dist != dist)
-        {
-            if (cfg.supplement_inclination_angle_for_nan_cells && row < R - 1)
-                p.incl[ci] = p.incl[ci + 1] + p.tab[ci];
-            const double caz = ((double) gc + 0.5) * (double) g.az_width;
-            p.caz[ci] = caz;
-            if (caz < min_az)
-                min_az = caz;
-            p.ground[ci] = ground;
-            p.debug[ci] = debug;
-            continue;
-        }
-        {
-            const double caz = p.caz[ci];
-            if (caz < min_az)
-                min_az = caz;
-        }
-        const float incl = p.incl[ci];
-        if (cfg.fog_filtering_enabled && p.inten[ci] < (uint8_t) cfg.fog_filtering_intensity_below &&
-            dist < cfg.fog_filtering_distance_below && incl > cfg.fog_filtering_inclination_above)
-        {
-            p.ground[ci] = CC_GP_FOG;
-            p.debug[ci] = CC_DBG_LIGHTGRAY;
-            continue;
-        }
-        const float cx = p.x[ci], cy = p.y[ci], cz = p.z[ci];
-        const double dx = cx, dy = cy, dz = cz;
-        const double ex = ((er[0] * dx + er[1] * dy) + er[2] * dz) + et[0];
-        const double ey = ((er[3] * dx + er[4] * dy) + er[5] * dz) + et[1];
-        const double ez = ((er[6] * dx + er[7] * dy) + er[8] * dz) + et[2];
-        if (ex < cfg.length_ref_to_front_end_ && ex > cfg.length_ref_to_rear_end_ && ey < cfg.width_ref_to_left_mirror_ &&
-            ey > cfg.width_ref_to_right_mirror_ && ez < cfg.height_ref_to_maximum_ && ez > cfg.height_ref_to_ground_)
-        {
-            p.ground[ci] = CC_GP_EGO_VEHICLE;
-            p.debug[ci] = CC_DBG_VIOLET;
-            continue;
-        }
-        const float ux = cx - spx, uy = cy - spy, uz = cz - spz; // current_position_wrt_sensor
+        const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
 
-        if (!first_point_found)
+        float dist[RPL], incl[RPL], tabv[RPL];
+        bool isnan_[RPL], overrun = false;
+        double min_az = 1.7976931348623157e308;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
         {
-            first_point_found = true;
-            const float h = uz - height_sensor_to_ground;
-            if (h > cfg.first_ring_as_ground_min_allowed_z_diff && h < cfg.first_ring_as_ground_max_allowed_z_diff)
+            const int row = k * 64 + lane;
+            dist[k] = incl[k] = tabv[k] = 0.f;
+            isnan_[k] = true;
+            if (row < R)
             {
-                ground = CC_GP_GROUND;
-                debug = CC_DBG_GRAY;
-                lgx = ux;
-                lgy = uy;
-                lgz = uz;
-                first_obstacle_detected = false;
+                const size_t ci = base + row;
+                const long long cg = p.gcol[ci];
+                if (cg != gc && cg != -1)
+                    overrun = true; // cc.cpp:320-345
+                dist[k] = p.dist[ci];
+                incl[k] = p.incl[ci];
+                tabv[k] = p.tab[ci];
+                isnan_[k] = dist[k] != dist[k];
+                s_incl[row] = incl[k];
+                s_done[row] = (!isnan_[k] || !cfg.supplement_inclination_angle_for_nan_cells || row == R - 1) ? 1 : 0;
+            }
+        }
+        if (__any(overrun))
+        {
+            if (lane == 0)
+                raise_error(st, CC_ERR_RING_OVERRUN, -2, gc);
+            continue;
+        }
+        // NaN cells: inclination of the cell below (already supplemented) + the per-row step (cc.cpp:364-369); runs of NaN
+        // cells resolve bottom-up, one row per iteration
+        __syncthreads();
+        while (true)
+        {
+            bool pending = false;
+            float nv[RPL];
+            bool upd[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                upd[k] = false;
+                nv[k] = 0.f;
+                if (row < R && !s_done[row])
+                {
+                    if (s_done[row + 1])
+                    {
+                        nv[k] = s_incl[row + 1] + tabv[k];
+                        upd[k] = true;
+                    }
+                    else
+                        pending = true;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (upd[k])
+                {
+                    s_incl[row] = nv[k];
+                    s_done[row] = 1;
+                    incl[k] = nv[k];
+                }
+            }
+            __syncthreads();
+            if (!__any(pending))
+                break;
+        }
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row >= R)
+                continue;
+            const size_t ci = base + row;
+            p.gcol[ci] = gc;
+            p.root[ci] = -1;
+            p.id[ci] = 0;
+            int flags = 0;
+            float x2 = 0.f, uz = 0.f;
+            if (isnan_[k])
+            {
+                flags = SG_NAN;
+                if (cfg.supplement_inclination_angle_for_nan_cells && row < R - 1)
+                    p.incl[ci] = incl[k];
+                const double caz = ((double) gc + 0.5) * (double) g.az_width; // cc.cpp:371-372
+                p.caz[ci] = caz;
+                if (caz < min_az)
+                    min_az = caz;
             }
             else
             {
-                ground = CC_GP_OBSTACLE;
-                debug = CC_DBG_ORANGE;
-                first_obstacle_detected = true;
+                const double caz = p.caz[ci];
+                if (caz < min_az)
+                    min_az = caz;
+                const float cx = p.x[ci], cy = p.y[ci], cz = p.z[ci];
+                if (cfg.fog_filtering_enabled && p.inten[ci] < (uint8_t) cfg.fog_filtering_intensity_below &&
+                    dist[k] < cfg.fog_filtering_distance_below && incl[k] > cfg.fog_filtering_inclination_above)
+                    flags |= SG_FOG;
+                const double dx = cx, dy = cy, dz = cz;
+                const double ex = ((er[0] * dx + er[1] * dy) + er[2] * dz) + et[0];
+                const double ey = ((er[3] * dx + er[4] * dy) + er[5] * dz) + et[1];
+                const double ez = ((er[6] * dx + er[7] * dy) + er[8] * dz) + et[2];
+                if (ex < cfg.length_ref_to_front_end_ && ex > cfg.length_ref_to_rear_end_ && ey < cfg.width_ref_to_left_mirror_ &&
+                    ey > cfg.width_ref_to_right_mirror_ && ez < cfg.height_ref_to_maximum_ && ez > cfg.height_ref_to_ground_)
+                    flags |= SG_EGO;
+                const float ux = cx - spx, uy = cy - spy;
+                uz = cz - spz;
+                x2 = len2(ux, uy);
+                if ((double) dist[k] < 1. * (double) cfg.max_distance)
+                    flags |= SG_TOO_CLOSE;
+                if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1) &&
+                    ccm::atan2f_exact(cfg.max_distance, dist[k]) < tabv[k])
+                    flags |= SG_INCL_IGNORE;
             }
-            pvx = ux;
-            pvy = uy;
-            pvz = uz;
-            previous_label = debug;
-            p.ground[ci] = ground;
-            p.debug[ci] = debug;
-            continue;
+            p.sg_x2[ci] = x2;
+            p.sg_uz[ci] = uz;
+            p.sg_flags[ci] = (uint8_t) flags;
         }
+        min_az = wave_min_f64(min_az);
+        if (lane == 0)
+        {
+            p.colg[lc] = gc;
+            p.colminaz[lc] = min_az;
+        }
+    }
+}
 
-        const float cur2x = len2(ux, uy), cur2y = uz;
-        const float prv2x = len2(pvx, pvy), prv2y = pvz;
-        const float p2cx = cur2x - prv2x, p2cy = cur2y - prv2y;
-        const float slope_to_prev = p2cy / p2cx;
-        bool flat_prev = ccm::absf(slope_to_prev) < cfg.max_slope && p2cx > 0;
-        flat_prev = flat_prev && (!cfg.use_terrain || p2cx < 5);
-        const float lg2x = len2(lgx, lgy), lg2y = lgz;
-        const float l2cx = cur2x - lg2x, l2cy = cur2y - lg2y;
-        const float slope_to_lg = l2cy / l2cx;
-        const bool flat_lg = ccm::absf(slope_to_lg) < cfg.max_slope && l2cx > 0;
+// ---- k_seg_scan: the row-serial part (cc.cpp:306-565 state machine + downward fix-up + ignore flags 567-616).
+// One lane per column on LDS-transposed tiles of 64 columns: global traffic is coalesced (lanes = rows while loading and
+// storing), the bottom-to-top scan of each lane reads conflict-free LDS (odd row pitch).
+// grid = (tiles of 64 columns, streams), block = 64, dynamic LDS = seg_scan_lds_bytes(num_rows).
+__host__ __device__ inline int seg_pitch_f(int R)
+{
+    return R | 1; // odd number of words per column
+}
+__host__ __device__ inline int seg_pitch_b(int R)
+{
+    return ((R + 3) & ~3) + 4; // bytes per column: multiple of 4 whose word count is odd
+}
+__host__ inline size_t seg_scan_lds_bytes(int R)
+{
+    return (size_t) 64 * seg_pitch_f(R) * 4 * 2 + (size_t) 64 * seg_pitch_b(R) * 4;
+}
 
-        if (!first_obstacle_detected && flat_prev)
+__global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream)
+{
+    const int s = first_stream + blockIdx.y;
+    StreamState* st = &states[s];
+    const long long seg_begin = st->seg_begin, seg_end = st->seg_end;
+    if (seg_begin < 0 || st->error != 0)
+        return;
+    const long long tile0 = seg_begin + (long long) blockIdx.x * 64;
+    if (tile0 >= seg_end)
+        return;
+    const int ncols = (int) (seg_end - tile0 < 64 ? seg_end - tile0 : 64);
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    const int lane = lane_id();
+    const int PF = seg_pitch_f(R), PB = seg_pitch_b(R);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* l_x2 = (float*) smem;
+    float* l_uz = l_x2 + 64 * PF;
+    unsigned char* l_flags = (unsigned char*) (l_uz + 64 * PF);
+    unsigned char* l_ground = l_flags + 64 * PB;
+    unsigned char* l_debug = l_ground + 64 * PB;
+    unsigned char* l_ign = l_debug + 64 * PB;
+
+    int lc0 = (int) (tile0 % RC);
+    // load: one coalesced row-run per column
+    {
+        int lc = lc0;
+        for (int c = 0; c < ncols; c++)
         {
-            ground = CC_GP_GROUND;
-            debug = CC_DBG_GREEN;
-        }
-        else if (!cfg.use_terrain)
-        {
-            if (first_obstacle_detected && flat_prev && flat_lg)
+            for (int row = lane; row < R; row += 64)
             {
-                ground = CC_GP_GROUND;
-                debug = CC_DBG_YELLOWGREEN;
+                const size_t ci = (size_t) lc * R + row;
+                l_x2[c * PF + row] = p.sg_x2[ci];
+                l_uz[c * PF + row] = p.sg_uz[ci];
+                l_flags[c * PB + row] = p.sg_flags[ci];
             }
-            else if (ccm::absf(l2cx) < cfg.ground_because_close_to_last_certain_ground_max_dist_diff &&
-                     ccm::absf(l2cy) < cfg.ground_because_close_to_last_certain_ground_max_z_diff)
-            {
-                ground = CC_GP_GROUND;
-                debug = CC_DBG_YELLOW;
-            }
+            lc = lc + 1 == RC ? 0 : lc + 1;
         }
-        if (ground != CC_GP_GROUND)
+    }
+    __syncthreads();
+    if (lane < ncols)
+    {
+        const long long gc = tile0 + lane;
+        const float* x2 = l_x2 + lane * PF;
+        const float* uzp = l_uz + lane * PF;
+        const unsigned char* fl = l_flags + lane * PB;
+        unsigned char* og = l_ground + lane * PB;
+        unsigned char* od = l_debug + lane * PB;
+        unsigned char* oi = l_ign + lane * PB;
+        const float height_sensor_to_ground = -(float) st->robot_from_sensor[11] + cfg.height_ref_to_ground_;
+        bool first_obstacle_detected = false, first_point_found = false;
+        float lg2x = 0.f, lgz = height_sensor_to_ground; // last (quite certain) ground point in the azimuth plane
+        float pv2x = 0.f, pvz = 0.f;
+        unsigned char previous_label = 0;
+        for (int row = R - 1; row >= 0; row--)
         {
-            ground = CC_GP_OBSTACLE;
-            debug = CC_DBG_RED;
-            // walk down and flip very close ground points to obstacle (cc.cpp:513-535)
-            int below = row + 1;
-            while (below < R)
+            const int f = fl[row];
+            unsigned char ground = CC_GP_UNKNOWN, debug = CC_DBG_WHITE;
+            if (f & SG_NAN)
             {
-                const size_t bi = base + below;
-                const uint8_t bg = p.ground[bi], bd = p.debug[bi];
-                const float bx = len2(p.x[bi] - spx, p.y[bi] - spy);
-                if (bd == CC_DBG_YELLOW ||
-                    (bg == CC_GP_GROUND && ccm::absf(cur2x - bx) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
+                og[row] = ground;
+                od[row] = debug;
+                continue;
+            }
+            if (f & SG_FOG)
+            {
+                og[row] = CC_GP_FOG;
+                od[row] = CC_DBG_LIGHTGRAY;
+                continue;
+            }
+            if (f & SG_EGO)
+            {
+                og[row] = CC_GP_EGO_VEHICLE;
+                od[row] = CC_DBG_VIOLET;
+                continue;
+            }
+            const float cur2x = x2[row], cur2y = uzp[row];
+            if (!first_point_found)
+            {
+                first_point_found = true;
+                const float h = cur2y - height_sensor_to_ground;
+                if (h > cfg.first_ring_as_ground_min_allowed_z_diff && h < cfg.first_ring_as_ground_max_allowed_z_diff)
                 {
-                    if (bg == CC_GP_GROUND)
-                    {
-                        p.ground[bi] = CC_GP_OBSTACLE;
-                        p.debug[bi] = CC_DBG_DARKRED;
-                    }
-                    below++;
+                    ground = CC_GP_GROUND;
+                    debug = CC_DBG_GRAY;
+                    lg2x = cur2x;
+                    lgz = cur2y;
+                    first_obstacle_detected = false;
                 }
                 else
-                    break;
+                {
+                    ground = CC_GP_OBSTACLE;
+                    debug = CC_DBG_ORANGE;
+                    first_obstacle_detected = true;
+                }
+                pv2x = cur2x;
+                pvz = cur2y;
+                previous_label = debug;
+                og[row] = ground;
+                od[row] = debug;
+                continue;
             }
-        }
-        first_obstacle_detected |= ground == CC_GP_OBSTACLE;
-        if (debug == CC_DBG_GREEN || debug == CC_DBG_YELLOWGREEN)
-        {
-            if (slope_to_prev > cfg.last_ground_point_slope_higher_than &&
-                ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than && previous_label != CC_DBG_YELLOW)
+            const float p2cx = cur2x - pv2x, p2cy = cur2y - pvz;
+            const float slope_to_prev = p2cy / p2cx;
+            bool flat_prev = ccm::absf(slope_to_prev) < cfg.max_slope && p2cx > 0;
+            flat_prev = flat_prev && (!cfg.use_terrain || p2cx < 5);
+            const float l2cx = cur2x - lg2x, l2cy = cur2y - lgz;
+            const float slope_to_lg = l2cy / l2cx;
+            const bool flat_lg = ccm::absf(slope_to_lg) < cfg.max_slope && l2cx > 0;
+            if (!first_obstacle_detected && flat_prev)
             {
-                lgx = ux;
-                lgy = uy;
-                lgz = uz;
+                ground = CC_GP_GROUND;
+                debug = CC_DBG_GREEN;
             }
+            else if (!cfg.use_terrain)
+            {
+                if (first_obstacle_detected && flat_prev && flat_lg)
+                {
+                    ground = CC_GP_GROUND;
+                    debug = CC_DBG_YELLOWGREEN;
+                }
+                else if (ccm::absf(l2cx) < cfg.ground_because_close_to_last_certain_ground_max_dist_diff &&
+                         ccm::absf(l2cy) < cfg.ground_because_close_to_last_certain_ground_max_z_diff)
+                {
+                    ground = CC_GP_GROUND;
+                    debug = CC_DBG_YELLOW;
+                }
+            }
+            if (ground != CC_GP_GROUND)
+            {
+                ground = CC_GP_OBSTACLE;
+                debug = CC_DBG_RED;
+                int below = row + 1; // cc.cpp:513-535
+                while (below < R)
+                {
+                    const unsigned char bg = og[below], bd = od[below];
+                    if (bd == CC_DBG_YELLOW ||
+                        (bg == CC_GP_GROUND && ccm::absf(cur2x - x2[below]) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
+                    {
+                        if (bg == CC_GP_GROUND)
+                        {
+                            og[below] = CC_GP_OBSTACLE;
+                            od[below] = CC_DBG_DARKRED;
+                        }
+                        below++;
+                    }
+                    else
+                        break;
+                }
+            }
+            first_obstacle_detected |= ground == CC_GP_OBSTACLE;
+            if (debug == CC_DBG_GREEN || debug == CC_DBG_YELLOWGREEN)
+            {
+                if (slope_to_prev > cfg.last_ground_point_slope_higher_than &&
+                    ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than && previous_label != CC_DBG_YELLOW)
+                {
+                    lg2x = cur2x;
+                    lgz = cur2y;
+                }
+            }
+            pv2x = cur2x;
+            pvz = cur2y;
+            previous_label = debug;
+            og[row] = ground;
+            od[row] = debug;
         }
-        pvx = ux;
-        pvy = uy;
-        pvz = uz;
-        previous_label = debug;
-        p.ground[ci] = ground;
-        p.debug[ci] = debug;
-    }
-
-    // ignore flags (cc.cpp:567-616)
-    for (int row = R - 1; row >= 0; row--)
-    {
-        const size_t ci = base + row;
-        const float dist = p.dist[ci];
-        bool ign = false;
-        if (dist != dist)
-            ign = true;
-        else if (p.ground[ci] != CC_GP_OBSTACLE)
-            ign = true;
-        else if ((double) dist < 1. * (double) cfg.max_distance)
-            ign = true;
-        else if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1) &&
-                 ccm::atan2f_exact(cfg.max_distance, dist) < p.tab[ci])
-            ign = true;
-        else if (cfg.ignore_points_in_chessboard_pattern)
+        for (int row = R - 1; row >= 0; row--) // cc.cpp:567-616
         {
-            const bool column_even = gc % 2 == 0;
-            const bool row_even = row % 2 == 0;
-            if ((column_even && !row_even) || (!column_even && row_even))
+            const int f = fl[row];
+            bool ign = false;
+            if (f & SG_NAN)
                 ign = true;
+            else if (og[row] != CC_GP_OBSTACLE)
+                ign = true;
+            else if (f & (SG_TOO_CLOSE | SG_INCL_IGNORE))
+                ign = true;
+            else if (cfg.ignore_points_in_chessboard_pattern)
+            {
+                const bool column_even = gc % 2 == 0;
+                const bool row_even = row % 2 == 0;
+                if ((column_even && !row_even) || (!column_even && row_even))
+                    ign = true;
+            }
+            oi[row] = ign ? 1 : 0;
         }
-        p.ignored[ci] = ign ? 1 : 0;
     }
-    p.colg[lc] = gc;
-    p.colminaz[lc] = min_az;
+    __syncthreads();
+    {
+        int lc = lc0;
+        for (int c = 0; c < ncols; c++)
+        {
+            for (int row = lane; row < R; row += 64)
+            {
+                const size_t ci = (size_t) lc * R + row;
+                p.ground[ci] = l_ground[c * PB + row];
+                p.debug[ci] = l_debug[c * PB + row];
+                p.ignored[ci] = l_ign[c * PB + row];
+            }
+            lc = lc + 1 == RC ? 0 : lc + 1;
+        }
+    }
 }
 
 // =====================================================================================================
