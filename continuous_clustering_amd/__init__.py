@@ -87,7 +87,7 @@ def load_library():
     L.cc_engine_read_columns.argtypes = [vp, i32, i64, i64, C.POINTER(capi.ColumnView)]
     L.cc_engine_output_planes.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.cc_engine_enable_timing.argtypes = [vp, i32]
-    L.cc_engine_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 6), C.POINTER(C.c_uint64)]
+    L.cc_engine_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 7), C.POINTER(C.c_uint64)]
     L.cc_engine_totals.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.cc_engine_last_error.argtypes = [vp]
     L.cc_engine_last_error.restype = C.c_char_p
@@ -206,10 +206,10 @@ class Engine:
         self._check(self.L.cc_engine_enable_timing(self.h, 1 if enable else 0))
 
     def kernel_times(self) -> dict:
-        ms = (C.c_double * 6)()
+        ms = (C.c_double * 7)()
         n = C.c_uint64(0)
         self._check(self.L.cc_engine_kernel_times(self.h, C.byref(ms), C.byref(n)))
-        names = ("insert_ms", "segment_ms", "scan_ms", "assoc_lds_ms", "assoc_global_ms", "publish_ms")
+        names = ("prep_ms", "insert_ms", "segment_ms", "scan_ms", "assoc_lds_ms", "assoc_global_ms", "publish_ms")
         d = {k: ms[i] for i, k in enumerate(names)}
         d["batches"] = n.value
         return d

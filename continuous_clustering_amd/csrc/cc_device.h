@@ -19,6 +19,8 @@ constexpr int WAVE = 64;
 constexpr int MAX_ROWS_PER_LANE = 2; // num_rows <= 128
 constexpr int LINK_SLOTS = 4;        // link candidates recorded per point by the static window scan
 constexpr int WIN_COLS = 32;         // columns of tree-slot ids kept in LDS by the association kernel
+constexpr int PP_SKIP = 0x7fffffff;
+constexpr int INS_WIN = 128;         // columns of `distance` kept in LDS by the insertion kernel
 constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLOSE = 16;
 constexpr int TREE_SLOTS = 512;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
 
@@ -115,6 +117,14 @@ struct Planes
     uint8_t* agg_flag;
     cc_event* events; // [stream][event_capacity]
     // staging written by the static window scan (k_scan), consumed by k_assoc_lds
+    // staging written by k_prep (per input point of the batch: [stream][firing][row]), consumed by k_insert2
+    float* pp_x;
+    float* pp_y;
+    float* pp_z;       // point in the odom frame
+    float* pp_dist;
+    float* pp_incl;
+    float* pp_incaz;   // increasing azimuth angle (cc.cpp:146-148)
+    int32_t* pp_cir;   // column index within the rotation (cc.cpp:151); PP_SKIP = no return
     // staging written by k_seg_pre, consumed by k_seg_scan
     float* sg_x2;       // ||xy|| of the point relative to the sensor (to2dInAzimuthPlane(...).x, cc.hpp:229-232)
     float* sg_uz;       // z of the point relative to the sensor

@@ -31,6 +31,8 @@ struct cc_engine
     uint8_t* d_stage_int{nullptr};
     double* d_stage_pose{nullptr};
     int64_t stage_capacity{0};
+    // staging of k_prep: [streams in launch][n][rows]
+    size_t prep_capacity{0};
     // staging for cc_engine_read_columns
     void* d_view{nullptr};
     size_t view_bytes{0};
@@ -46,7 +48,7 @@ struct cc_engine
     bool timing{false};
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used{0};
-    double kernel_ms[6]{0, 0, 0, 0, 0, 0}; // insert, segment, scan, assoc_lds, assoc_global, publish
+    double kernel_ms[7]{0, 0, 0, 0, 0, 0, 0}; // prep, insert+table, segment, scan, assoc_lds, assoc_global, publish
     uint64_t kernel_launches{0};
 };
 
@@ -114,6 +116,7 @@ int free_all(cc_engine* e)
     e->stage_capacity = 0;
     e->d_view = nullptr;
     e->view_bytes = 0;
+    e->prep_capacity = 0;
     return CC_OK;
 }
 
@@ -196,15 +199,30 @@ int reset_state(cc_engine* e, bool keep_table)
     return CC_OK;
 }
 
+int ensure_prep(cc_engine* e, size_t points)
+{
+    if (e->prep_capacity >= points)
+        return CC_OK;
+    Planes& P = e->P;
+    int rc;
+    // old blocks stay in `allocations` until the engine is destroyed or re-shaped (growth is rare: batch sizes repeat)
+    if ((rc = alloc_plane(e, &P.pp_x, points)) || (rc = alloc_plane(e, &P.pp_y, points)) || (rc = alloc_plane(e, &P.pp_z, points)) ||
+        (rc = alloc_plane(e, &P.pp_dist, points)) || (rc = alloc_plane(e, &P.pp_incl, points)) ||
+        (rc = alloc_plane(e, &P.pp_incaz, points)) || (rc = alloc_plane(e, &P.pp_cir, points)))
+        return rc;
+    e->prep_capacity = points;
+    return CC_OK;
+}
+
 int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int,
-                 const double* d_pose)
+                 const double* d_pose, bool first_pass)
 {
     const Geometry& g = e->g;
     const int rpl = (g.num_rows + WAVE - 1) / WAVE;
     // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
     const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
     dim3 seg_grid((unsigned) ((max_cols + 63) / 64), (unsigned) count);
-    constexpr int NK = 6;
+    constexpr int NK = 7;
     hipEvent_t ev[NK + 1] = {};
     if (e->timing)
     {
@@ -224,12 +242,29 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
 #define CC_MARK()    \
     if (e->timing) \
         CC_HIP_CHECK(e, hipEventRecord(ev[++k], e->stream));
-    if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_insert<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
-                           d_int, d_pose, (long long) n, e->d_remaining);
-    else
-        hipLaunchKernelGGL(cck::k_insert<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
-                           d_int, d_pose, (long long) n, e->d_remaining);
+    const size_t points = (size_t) count * (size_t) n * g.num_rows;
+    if (first_pass) // relaunch passes of the same batch reuse the staged points
+    {
+        int rcp = ensure_prep(e, points);
+        if (rcp)
+            return rcp;
+        hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((points + 255) / 256)), dim3(256), 0, e->stream, g, e->cfg, e->P, d_xyz, d_pose,
+                           (long long) points);
+    }
+    CC_MARK();
+    {
+        const size_t lds = cck::insert2_lds_bytes(g.num_rows);
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, e->stream, g, e->cfg, e->P, e->d_states, first_stream,
+                               d_int, (long long) n, e->d_remaining);
+        else
+            hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, e->stream, g, e->cfg, e->P, e->d_states, first_stream,
+                               d_int, (long long) n, e->d_remaining);
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64), 0, e->stream, g, e->P, e->d_states, first_stream);
+        else
+            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64), 0, e->stream, g, e->P, e->d_states, first_stream);
+    }
     CC_MARK();
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, e->stream, g, e->cfg, e->P,
@@ -296,7 +331,7 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
 {
     hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, e->stream, e->d_states, first_stream, count,
                        e->d_remaining);
-    int rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose);
+    int rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true);
     if (rc)
         return rc;
     CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -314,9 +349,9 @@ int collect_events(cc_engine* e, int first_stream, int count);
 
 int resolve_timing(cc_engine* e)
 {
-    for (size_t i = 0; i + 6 < e->ev_used; i += 7)
+    for (size_t i = 0; i + 7 < e->ev_used; i += 8)
     {
-        for (int k = 0; k < 6; k++)
+        for (int k = 0; k < 7; k++)
         {
             float ms = 0.f;
             CC_HIP_CHECK(e, hipEventElapsedTime(&ms, e->ev_pool[i + k], e->ev_pool[i + k + 1]));
@@ -354,7 +389,7 @@ int finish_batch(cc_engine* e)
         if (*e->h_remaining == 0)
             break;
         hipLaunchKernelGGL(k_clear_remaining, dim3(1), dim3(1), 0, e->stream, e->d_remaining);
-        int rc = launch_batch(e, e->last_first, e->last_count, e->last_n, e->last_xyz, e->last_int, e->last_pose);
+        int rc = launch_batch(e, e->last_first, e->last_count, e->last_n, e->last_xyz, e->last_int, e->last_pose, false);
         if (rc)
             return rc;
         CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -482,6 +517,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     e->g.event_capacity = e->g.record_events ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
     e->pending_events.resize(num_streams);
     (void) hipFuncSetAttribute((const void*) cck::k_seg_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void) hipFuncSetAttribute((const void*) cck::k_insert2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     rc = allocate(e);
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_remaining, sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
@@ -834,7 +871,7 @@ int cc_engine_enable_timing(cc_engine* e, int enable)
     return CC_OK;
 }
 
-int cc_engine_kernel_times(cc_engine* e, double ms[6], uint64_t* launches)
+int cc_engine_kernel_times(cc_engine* e, double ms[7], uint64_t* launches)
 {
     if (!e || !ms)
         return CC_ERR_INVALID_ARGUMENT;
@@ -842,7 +879,7 @@ int cc_engine_kernel_times(cc_engine* e, double ms[6], uint64_t* launches)
     int rc = finish_batch(e);
     if (rc)
         return rc;
-    for (int k = 0; k < 6; k++)
+    for (int k = 0; k < 7; k++)
         ms[k] = e->kernel_ms[k];
     if (launches)
         *launches = e->kernel_launches;

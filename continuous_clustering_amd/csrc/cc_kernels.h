@@ -87,6 +87,23 @@ __device__ __forceinline__ void wave_lds_sync()
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Tell the compiler that a value is wave-uniform (it then lives in SGPRs and drives scalar branches instead of exec-masked
+// "divergent" control flow). Only call with values that really are equal in all active lanes.
+__device__ __forceinline__ int uniform_i32(int v)
+{
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ long long uniform_i64(long long v)
+{
+    const unsigned lo = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (unsigned long long) v);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) ((unsigned long long) v >> 32));
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    return __longlong_as_double(uniform_i64(__double_as_longlong(v)));
+}
+
 __device__ __forceinline__ unsigned long long lanes_below()
 {
     return (1ull << lane_id()) - 1ull;
@@ -442,6 +459,641 @@ __global__ __launch_bounds__(64) void k_insert(Geometry g, cc_config cfg, Planes
 __device__ __forceinline__ float len2(float a, float b)
 {
     return ccm::sqrt_rn(a * a + b * b);
+}
+
+// =====================================================================================================
+// k_prep — the per-point part of insertFiringIntoRangeImage (cc.cpp:127-151, 189, 224-232): rigid transform, range,
+// azimuth -> column within the rotation, inclination. Independent per point, so it runs over all points of the batch
+// in parallel; the serial kernel below only decides where each point lands. grid = points / 256, block = 256.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes P, const float* __restrict__ xyz,
+                                             const double* __restrict__ poses, long long n_points)
+{
+    const long long i = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_points)
+        return;
+    const int R = g.num_rows;
+    const long long firing = i / R; // [stream][firing] flattened
+    const float fx = xyz[i * 3 + 0], fy = xyz[i * 3 + 1], fz = xyz[i * 3 + 2];
+    if (fx != fx)
+    {
+        P.pp_cir[i] = PP_SKIP; // std::isnan(p.x()) cc.cpp:131
+        return;
+    }
+    const double* T = poses + firing * 12;
+    const double px = fx, py = fy, pz = fz;
+    const double tx = T[3], ty = T[7], tz = T[11];
+    const double ox = ((T[0] * px + T[1] * py) + T[2] * pz) + tx;
+    const double oy = ((T[4] * px + T[5] * py) + T[6] * pz) + ty;
+    const double oz = ((T[8] * px + T[9] * py) + T[10] * pz) + tz;
+    const double rx = ox - tx, ry = oy - ty, rz = oz - tz;
+    const float az = ccm::atan2f_exact(fy, fx);
+    const float inc_az = cfg.sensor_is_clockwise ? -az + CC_PI_F : az + CC_PI_F;
+    const float dist = (float) __builtin_sqrt((rx * rx + ry * ry) + rz * rz);
+    P.pp_x[i] = (float) ox;
+    P.pp_y[i] = (float) oy;
+    P.pp_z[i] = (float) oz;
+    P.pp_dist[i] = dist;
+    P.pp_incl[i] = ccm::asinf_exact((float) rz / dist);
+    P.pp_incaz[i] = inc_az;
+    P.pp_cir[i] = f2i_x86(inc_az / g.az_width);
+}
+
+// =====================================================================================================
+// k_insert2 — the serial part of insertFiringIntoRangeImage (cc.cpp:152-292): global column of every return relative to the
+// previous rearmost laser, cell collision rule, rearmost / foremost tracking, emission of finished columns. One wavefront
+// per stream, lanes = rows; the `distance` plane of the INS_WIN columns around the insertion front lives in LDS so that the
+// occupancy tests never wait for HBM.
+// =====================================================================================================
+constexpr int INS_RING = 16; // firings staged in LDS ahead of the consumer wave
+
+__host__ inline size_t insert2_lds_bytes(int R)
+{
+    // distance window + ring of staged firings (7 float/int planes + intensity bytes) + 2 sync words
+    return (size_t) INS_WIN * R * 4 + (size_t) INS_RING * R * (7 * 4 + 4) + 64;
+}
+
+// block = 128: wavefront 0 is the consumer (the serial algorithm), wavefront 1 the loader that streams the staged points
+// of the coming firings from HBM into an LDS ring, so that the consumer never waits for a global load.
+template<int RPL>
+__global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+                                                 const uint8_t* __restrict__ inten, long long n, int* remaining)
+{
+    const int sl = blockIdx.x;
+    const int s = first_stream + sl;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    StreamState* st = &states[s];
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* w_dist = (float*) smem;                       // [INS_WIN][R]
+    float* r_x = w_dist + INS_WIN * R;                   // [INS_RING][R] each
+    float* r_y = r_x + INS_RING * R;
+    float* r_z = r_y + INS_RING * R;
+    float* r_d = r_z + INS_RING * R;
+    float* r_i = r_d + INS_RING * R;
+    float* r_a = r_i + INS_RING * R;
+    int* r_c = (int*) (r_a + INS_RING * R);
+    int* r_t = r_c + INS_RING * R;                       // intensity (one int per cell keeps the stores conflict-free)
+    volatile long long* v_ready = (volatile long long*) (r_t + INS_RING * R); // firings [.., v_ready) are staged
+    volatile long long* v_done = v_ready + 1;            // firings [.., v_done) have been consumed
+    volatile long long* v_stop = v_ready + 2;            // consumer stopped early at this firing (or -1)
+
+    const long long cursor0 = st->cursor;
+    const size_t pbase = (size_t) sl * (size_t) n * R;
+    if (threadIdx.x == 0)
+    {
+        *v_ready = cursor0;
+        *v_done = cursor0;
+        *v_stop = -1;
+    }
+    __syncthreads();
+
+    if (wave == 1)
+    {
+        // ------------------------------------------------------------------ loader
+        const uint8_t* si = inten + pbase;
+        const float *qx = P.pp_x + pbase, *qy = P.pp_y + pbase, *qz = P.pp_z + pbase, *qd = P.pp_dist + pbase, *qi = P.pp_incl + pbase,
+                    *qa = P.pp_incaz + pbase;
+        const int32_t* qc = P.pp_cir + pbase;
+        constexpr int U = 4; // firings in flight per round
+        for (long long f0 = cursor0; f0 < n; f0 += U)
+        {
+            float x[U][RPL], y[U][RPL], z[U][RPL], d[U][RPL], ii[U][RPL], a[U][RPL];
+            int c[U][RPL], t[U][RPL];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    c[u][k] = PP_SKIP;
+                    x[u][k] = y[u][k] = z[u][k] = d[u][k] = ii[u][k] = a[u][k] = 0.f;
+                    t[u][k] = 0;
+                    if (row < R && f0 + u < n)
+                    {
+                        const size_t pi = (size_t) (f0 + u) * R + row;
+                        c[u][k] = qc[pi];
+                        x[u][k] = qx[pi];
+                        y[u][k] = qy[pi];
+                        z[u][k] = qz[pi];
+                        d[u][k] = qd[pi];
+                        ii[u][k] = qi[pi];
+                        a[u][k] = qa[pi];
+                        t[u][k] = si[pi];
+                    }
+                }
+            // wait until the ring has room for these U firings (or the consumer stopped)
+            while (*v_done + INS_RING < f0 + U && *v_stop < 0)
+                __builtin_amdgcn_s_sleep(2);
+            if (*v_stop >= 0)
+                break;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                const int slot = (int) ((f0 + u) % INS_RING);
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    if (row < R)
+                    {
+                        const int o = slot * R + row;
+                        r_c[o] = c[u][k];
+                        r_x[o] = x[u][k];
+                        r_y[o] = y[u][k];
+                        r_z[o] = z[u][k];
+                        r_d[o] = d[u][k];
+                        r_i[o] = ii[u][k];
+                        r_a[o] = a[u][k];
+                        r_t[o] = t[u][k];
+                    }
+                }
+            }
+            wave_lds_sync();
+            if (lane == 0)
+                *v_ready = (f0 + U < n ? f0 + U : n);
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    long long prev_rear = st->prev_rearmost, prev_fore = st->prev_foremost, first_unf = st->first_unfinished;
+    long long ring_start = st->ring_start, ring_end = st->ring_end, first_unpub = st->first_unpublished;
+    int reset_required = st->reset_required;
+    const long long seq0 = (long long) st->firings_consumed;
+    long long seg_begin = first_unf;
+    const long long limit_base = first_unf;
+    unsigned long long negative_cols = 0;
+
+    // deferred clearColumns (cc.cpp:1094-1145) for what earlier calls released
+    long long clear_done = st->clear_done;
+    if (clear_done >= 0)
+    {
+        const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
+        for (; clear_done < clear_to; clear_done++)
+        {
+            const int clc = (int) (clear_done % RC);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const size_t ci = (size_t) clc * R + row;
+                    p.dist[ci] = __builtin_nanf("");
+                    p.incl[ci] = __builtin_nanf("");
+                    p.gcol[ci] = -1;
+                }
+            }
+        }
+    }
+
+    // window = global columns [wbase, wbase + INS_WIN), column gcx at LDS column gcx % INS_WIN
+    long long wbase = -1;
+    auto window_fill = [&](long long from, long long to) // load columns [from, to) from the global distance plane
+    {
+        int lcx = (int) (from % RC);
+        constexpr int B = 16; // columns in flight
+        for (long long g0 = from; g0 < to; g0 += B)
+        {
+            float v[B][RPL];
+            int lcs = lcx;
+#pragma unroll
+            for (int u = 0; u < B; u++)
+            {
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    v[u][k] = 0.f;
+                    if (row < R && g0 + u < to)
+                        v[u][k] = p.dist[(size_t) lcs * R + row];
+                }
+                lcs = lcs + 1 == RC ? 0 : lcs + 1;
+            }
+#pragma unroll
+            for (int u = 0; u < B; u++)
+            {
+                const int wc = (int) ((g0 + u) & (INS_WIN - 1));
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    if (row < R && g0 + u < to)
+                        w_dist[wc * R + row] = v[u][k];
+                }
+            }
+            lcx = lcs;
+        }
+    };
+    auto window_seek = [&](long long need_lo, long long need_hi) // make [need_lo, need_hi] resident if it fits
+    {
+        long long nb = need_lo - 24;
+        if (nb < 0)
+            nb = 0;
+        if (wbase < 0 || nb >= wbase + INS_WIN || nb < wbase)
+        {
+            wbase = nb;
+            window_fill(wbase, wbase + INS_WIN);
+        }
+        else if (need_hi >= wbase + INS_WIN)
+        {
+            window_fill(wbase + INS_WIN, nb + INS_WIN);
+            wbase = nb;
+        }
+        wave_lds_sync();
+    };
+
+    // 64-bit divisions by run-time divisors cost hundreds of cycles each: keep rotation index, column within the rotation
+    // and ring column of the previous rearmost laser incrementally
+    long long prev_rot = prev_rear / NC;
+    int prev_cir = (int) (prev_rear - prev_rot * NC);
+    int rear_lc = (int) (prev_rear % RC);
+    long long tracked_rear = prev_rear;
+#ifdef CC_PROFILE_SECTIONS
+    unsigned long long isec[6] = {0, 0, 0, 0, 0, 0};
+#define CC_ISEC(i) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); isec[i] += _n - ins_work_mark; ins_work_mark = _n; }
+    unsigned long long ins_wait = 0, ins_work = 0, ins_work_mark = 0;
+    const unsigned long long ins_t0 = __builtin_amdgcn_s_memtime();
+#endif
+    long long f = cursor0;
+    for (; f < n; f++)
+    {
+        if (limit_base >= 0 && prev_rear - limit_base >= g.limit_columns)
+            break;
+#ifdef CC_PROFILE_SECTIONS
+        const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
+#endif
+        while (*v_ready <= f)
+            __builtin_amdgcn_s_sleep(1);
+        wave_lds_sync();
+#ifdef CC_PROFILE_SECTIONS
+        const unsigned long long t1_ = __builtin_amdgcn_s_memtime();
+        ins_wait += t1_ - t0_;
+        ins_work_mark = t1_;
+#endif
+        const int slot = (int) (f & (INS_RING - 1));
+        if (tracked_rear != prev_rear)
+        {
+            const long long dlt = prev_rear - tracked_rear;
+            if (dlt > 0 && dlt < NC)
+            {
+                prev_cir += (int) dlt;
+                if (prev_cir >= NC)
+                {
+                    prev_cir -= NC;
+                    prev_rot++;
+                }
+                rear_lc += (int) dlt;
+                if (rear_lc >= RC)
+                    rear_lc -= RC;
+            }
+            else
+            {
+                prev_rot = prev_rear / NC;
+                prev_cir = (int) (prev_rear - prev_rot * NC);
+                rear_lc = (int) (prev_rear % RC);
+            }
+            tracked_rear = prev_rear;
+        }
+        int cir[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            cir[k] = row < R ? r_c[slot * R + row] : PP_SKIP;
+        }
+        const int half = NC / 2;
+        const long long rot_base = prev_rot * NC;
+        // global column of every return (cc.cpp:152-175)
+        long long gcv[RPL];
+        int rot_off[RPL];
+        bool have[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            have[k] = cir[k] != PP_SKIP;
+            gcv[k] = 0;
+            rot_off[k] = 0;
+            if (have[k])
+            {
+                long long gc = rot_base + cir[k];
+                const int cdiff = cir[k] - prev_cir;
+                if (cdiff < -half)
+                {
+                    gc += NC;
+                    rot_off[k] = 1;
+                }
+                else if (prev_rear > 0 && cdiff > half)
+                {
+                    gc -= NC;
+                    rot_off[k] = -1;
+                }
+                if (gc < 0)
+                {
+                    negative_cols++; // undefined behaviour in the reference (negative vector index); dropped here
+                    have[k] = false;
+                }
+                gcv[k] = gc;
+            }
+        }
+#ifdef CC_PROFILE_SECTIONS
+        CC_ISEC(0)
+#endif
+        // wave-wide range of touched columns: few distinct values per firing -> peel them off with ballots
+        long long need_lo = 0x7fffffffffffffffll, need_hi = -1;
+        {
+            bool todo[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+                todo[k] = have[k];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                unsigned long long m = __ballot(todo[k]);
+                while (m)
+                {
+                    const int src = __ffsll((long long) m) - 1;
+                    const long long v = __shfl(gcv[k], src);
+                    need_lo = v < need_lo ? v : need_lo;
+                    need_hi = v > need_hi ? v : need_hi;
+#pragma unroll
+                    for (int k2 = 0; k2 < RPL; k2++)
+                        if (todo[k2] && gcv[k2] == v)
+                            todo[k2] = false;
+                    m = __ballot(todo[k]);
+                }
+            }
+        }
+#ifdef CC_PROFILE_SECTIONS
+        CC_ISEC(1)
+#endif
+        need_lo = uniform_i64(need_lo);
+        need_hi = uniform_i64(need_hi);
+        long long rear = -1, fore = -1;
+        if (need_hi >= 0)
+        {
+            if (wbase < 0 || need_lo < wbase || need_hi + 1 >= wbase + INS_WIN)
+                window_seek(need_lo, need_hi + 1);
+            long long l_rear = 0x7fffffffffffffffll, l_fore = -1;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (!have[k])
+                    continue;
+                long long gc = gcv[k];
+                // ring column: offset from the previous rearmost laser's ring column (|offset| < one rotation < RC)
+                int lc = rear_lc + (int) (gc - prev_rear);
+                if (lc < 0)
+                    lc += RC;
+                else if (lc >= RC)
+                    lc -= RC;
+                const int so = slot * R + row;
+                const float d = r_d[so];
+                const bool res = gc >= wbase && gc + 1 < wbase + INS_WIN; // both candidate columns resident in LDS
+                float cd = res ? w_dist[(int) (gc & (INS_WIN - 1)) * R + row] : p.dist[(size_t) lc * R + row];
+                if (!(cd != cd) && !(d != d)) // cell occupied: try the next column (cc.cpp:188-202)
+                {
+                    const float nd = res ? w_dist[(int) ((gc + 1) & (INS_WIN - 1)) * R + row]
+                                         : p.dist[(size_t) (lc + 1 >= RC ? 0 : lc + 1) * R + row];
+                    if (nd != nd)
+                    {
+                        gc++;
+                        lc = lc + 1 >= RC ? 0 : lc + 1;
+                        cd = nd;
+                    }
+                }
+                if (!(cd != cd) && ((d != d) || d >= cd))
+                    continue; // never overwrite a valid cell by NaN or a farther return (cc.cpp:204-206)
+                const bool too_far_behind = first_unf >= 0 && gc < first_unf;
+                if (!too_far_behind)
+                {
+                    const size_t ci = (size_t) lc * R + row;
+#ifndef CC_EXP_NOSTORE
+                    p.x[ci] = r_x[so];
+                    p.y[ci] = r_y[so];
+                    p.z[ci] = r_z[so];
+                    p.inten[ci] = (uint8_t) r_t[so];
+                    p.src[ci] = seq0 + (f - cursor0);
+                    p.incl[ci] = r_i[so];
+                    p.caz[ci] = CC_2PI_D * (double) (prev_rot + rot_off[k]) + (double) r_a[so];
+                    p.gcol[ci] = gc;
+#endif
+                    p.dist[ci] = d;
+                    if (gc >= wbase && gc < wbase + INS_WIN)
+                        w_dist[(int) (gc & (INS_WIN - 1)) * R + row] = d;
+                }
+                l_rear = gc < l_rear ? gc : l_rear;
+                l_fore = gc > l_fore ? gc : l_fore;
+            }
+#ifdef CC_PROFILE_SECTIONS
+            CC_ISEC(2)
+#endif
+            // rearmost / foremost over the lanes that reached the tracking code: values lie in [need_lo, need_hi + 1]
+            {
+                const int span = (int) (need_hi + 1 - need_lo);
+                int o_lo = l_fore >= 0 ? (int) (l_rear - need_lo) : 0x7fffffff;
+                int o_hi = l_fore >= 0 ? (int) (l_fore - need_lo) : -1;
+                if (span <= 1)
+                {
+                    // KITTI-shaped firings: every return in one column (or its successor)
+                    const unsigned long long lo0 = __ballot(o_lo == 0), hi1 = __ballot(o_hi == 1), any = __ballot(o_hi >= 0);
+                    if (any)
+                    {
+                        rear = need_lo + (lo0 ? 0 : 1);
+                        fore = need_lo + (hi1 ? 1 : 0);
+                    }
+                }
+                else
+                {
+                    o_lo = wave_min_i32(o_lo);
+                    int neg_hi = -o_hi;
+                    neg_hi = wave_min_i32(neg_hi);
+                    o_hi = -neg_hi;
+                    if (o_hi >= 0)
+                    {
+                        rear = need_lo + o_lo;
+                        fore = need_lo + o_hi;
+                    }
+                }
+            }
+        }
+        rear = uniform_i64(rear);
+        fore = uniform_i64(fore);
+        wave_lds_sync();
+        if (lane == 0)
+            *v_done = f + 1;
+#ifdef CC_PROFILE_SECTIONS
+        CC_ISEC(3)
+#endif
+
+        if (rear >= 0 && fore >= 0)
+        {
+            if ((fore - rear) > NC / 2)
+            {
+                reset_required = 1; // cc.cpp:252-261
+                continue;
+            }
+            if (rear > prev_rear)
+                prev_rear = rear;
+            if (fore > prev_fore)
+                prev_fore = fore;
+        }
+        if (prev_fore < 0)
+            continue;
+        if (ring_start == -1)
+        {
+            ring_start = prev_rear;
+            first_unpub = prev_rear;
+            clear_done = prev_rear;
+        }
+        if (prev_fore > ring_end)
+            ring_end = prev_fore;
+        if (first_unf == -1)
+        {
+            first_unf = prev_rear;
+            if (seg_begin < 0)
+                seg_begin = first_unf;
+            if (lane == 0)
+                st->first_column = first_unf;
+        }
+        // finished columns carry the pose of this firing (cc.cpp:289-291)
+        if (first_unf < prev_rear)
+        {
+            if (prev_rear - first_unf < RC)
+            {
+                // ring column of first_unf from the (already updated) rearmost column; tracked_* still describe the old one
+                for (long long c = first_unf + lane; c < prev_rear; c += 64)
+                {
+                    int tl = rear_lc + (int) (c - tracked_rear);
+                    if (tl < 0)
+                        tl += RC;
+                    else if (tl >= RC)
+                        tl -= RC;
+                    p.trig[tl] = (int) f;
+                }
+            }
+            else
+                for (long long c = first_unf + lane; c < prev_rear; c += 64)
+                    p.trig[(int) (c % RC)] = (int) f;
+            first_unf = prev_rear;
+        }
+    }
+    if (lane == 0)
+        *v_stop = f; // releases the loader if it is waiting for ring space
+#ifdef CC_PROFILE_SECTIONS
+    if (lane == 0)
+    {
+        st->dbg[0] += ins_wait;
+        st->dbg[1] += isec[0];
+        st->dbg[2] += isec[1];
+        st->dbg[3] += isec[2];
+        st->dbg[4] += isec[3];
+        st->dbg[5] += __builtin_amdgcn_s_memtime() - ins_t0;
+    }
+#endif
+
+    if (lane == 0)
+    {
+        st->prev_rearmost = prev_rear;
+        st->prev_foremost = prev_fore;
+        st->first_unfinished = first_unf;
+        st->ring_start = ring_start;
+        st->ring_end = ring_end;
+        st->clear_done = clear_done;
+        st->first_unpublished = first_unpub;
+        st->reset_required = reset_required;
+        st->seg_begin = seg_begin;
+        st->seg_end = seg_begin >= 0 ? first_unf : -1;
+        st->acp_next = seg_begin;
+        st->pub_begin = first_unpub;
+        st->pub_end = first_unpub;
+        st->cursor = f;
+        st->firings_consumed = (unsigned long long) (seq0 + (f - cursor0));
+        if (f < n)
+            atomicAdd(remaining, 1);
+    }
+    negative_cols = (unsigned long long) wave_max_i64((long long) negative_cols);
+    if (lane == 0 && negative_cols)
+        st->error_b += (long long) negative_cols;
+}
+
+// =====================================================================================================
+// k_table — sc_inclination_angles_between_lasers_ (cc.cpp:353-357): per row the last non-NaN inclination step over
+// the emitted columns, in column order. One wavefront per stream, lanes = rows; the loads do not depend on each other, so
+// they pipeline. grid = streams, block = 64.
+// =====================================================================================================
+template<int RPL>
+__global__ __launch_bounds__(64) void k_table(Geometry g, Planes P, StreamState* states, int first_stream)
+{
+    const int s = first_stream + blockIdx.x;
+    const int lane = lane_id();
+    StreamState* st = &states[s];
+    const long long seg_begin = st->seg_begin, seg_end = st->seg_end;
+    if (seg_begin < 0 || seg_begin >= seg_end)
+        return;
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    float tabv[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        tabv[k] = row < R ? p.curtab[row] : 0.f;
+    }
+    int lc = (int) (seg_begin % RC);
+    constexpr int U = 8;
+    for (long long c0 = seg_begin; c0 < seg_end; c0 += U)
+    {
+        float cur[U][RPL], below[U][RPL];
+        int lcs[U];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            lcs[u] = lc;
+            lc = lc + 1 == RC ? 0 : lc + 1;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                cur[u][k] = below[u][k] = 0.f;
+                if (row < R && c0 + u < seg_end)
+                {
+                    const size_t ci = (size_t) lcs[u] * R + row;
+                    cur[u][k] = p.incl[ci];
+                    below[u][k] = row + 1 < R ? p.incl[ci + 1] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+        {
+            if (c0 + u >= seg_end)
+                break;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const float diff = cur[u][k] - below[u][k];
+                    if (!(diff != diff))
+                        tabv[k] = diff;
+                    p.tab[(size_t) lcs[u] * R + row] = tabv[k];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        if (row < R)
+            p.curtab[row] = tabv[k];
+    }
 }
 
 // ---- k_seg_pre: everything of the segmentation that does not depend on the rows below. One wavefront per column,
@@ -2297,7 +2949,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     }
 #ifdef CC_PROFILE_SECTIONS
     CC_SEC(7)
-    if (lane == 0)
+    if (lane == 0 && false)
         for (int i = 0; i < 8; i++)
             st->dbg[i] += tsec[i];
 #endif

@@ -17,5 +17,5 @@ tot = np.zeros(8)
 for s in range(0,S,16):
     out = np.zeros(8, dtype=np.uint64); L.cc_engine_debug_counters(e.h, s, out.ctypes.data); tot += out
 tot /= (S/16)
-names = ["init","loop top","issue prefetch","resolve(+wait loads)","apply/links","colminaz load","C+P","ballots(wait data)"]
+names = ["wait ready","gcol calc","ballot peel","window+stores","rear/fore+done","total loop","-","-"]
 for n,v in zip(names,tot): print(f"{n:24s} {v:14.0f} ticks  per column {v/(F*NB):10.1f}")

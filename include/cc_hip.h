@@ -237,10 +237,10 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
 int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_label, const uint32_t** d_cluster_id);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every
- * batch (insert, segment, scan, assoc_lds, assoc_global, publish). enable resets the accumulators;
+ * batch (prep, insert+table, segment, scan, assoc_lds, assoc_global, publish). enable resets the accumulators;
  * cc_engine_kernel_times returns the accumulated milliseconds and the number of batches measured. */
 int cc_engine_enable_timing(cc_engine* e, int enable);
-int cc_engine_kernel_times(cc_engine* e, double ms[6], uint64_t* launches);
+int cc_engine_kernel_times(cc_engine* e, double ms[7], uint64_t* launches);
 /* Sums over all streams (any pointer may be NULL). Implies sync. */
 int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters_finished, uint64_t* firings_consumed,
                      uint64_t* serial_columns);
