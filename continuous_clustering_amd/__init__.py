@@ -86,6 +86,7 @@ def load_library():
     L.cc_engine_stream_state.argtypes = [vp, i32, C.POINTER(capi.StreamState)]
     L.cc_engine_read_columns.argtypes = [vp, i32, i64, i64, C.POINTER(capi.ColumnView)]
     L.cc_engine_output_planes.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
+    L.cc_engine_set_option.argtypes = [vp, C.c_char_p, i64]
     L.cc_engine_enable_timing.argtypes = [vp, i32]
     L.cc_engine_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 7), C.POINTER(C.c_uint64)]
     L.cc_engine_totals.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
@@ -201,6 +202,9 @@ class Engine:
         v, arrays = capi.make_column_view(to - frm + 1, self.num_rows, fields)
         self._check(self.L.cc_engine_read_columns(self.h, stream, frm, to, C.byref(v)))
         return arrays
+
+    def set_option(self, name: str, value: int):
+        self._check(self.L.cc_engine_set_option(self.h, name.encode(), int(value)))
 
     def enable_timing(self, enable: bool = True):
         self._check(self.L.cc_engine_enable_timing(self.h, 1 if enable else 0))

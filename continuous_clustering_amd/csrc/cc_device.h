@@ -9,6 +9,7 @@
 // StreamState.
 #pragma once
 #include <stdint.h>
+#include <hip/hip_runtime.h>
 
 #include "../../include/cc_hip.h"
 
@@ -50,11 +51,16 @@ struct StreamState
     double last_round_min_az;  // column-min azimuth of the previous tree-combination round (the BFS "visited stamp")
     // batch bookkeeping
     int64_t clear_allowed; // ring_start when the current host call began: clearing never passes what the host has seen
-    int64_t seg_begin;  // columns [seg_begin, seg_end) were emitted by the insertion kernel in this batch
-    int64_t seg_end;
-    int64_t acp_next;   // next column the association kernel processes
-    int64_t pub_begin;  // columns [pub_begin, pub_end) were published by the association kernel in this pass
-    int64_t pub_end;
+    // per-batch hand-off from the insertion chain to the segmentation / association chain; two slots because batch b + 1
+    // is inserted (HIP stream 1) while batch b is still segmented and associated (HIP stream 2)
+    struct BatchDesc
+    {
+        int64_t seg_begin; // columns [seg_begin, seg_end) were emitted by the insertion kernel in this batch
+        int64_t seg_end;
+        int64_t acp_next;  // next column the association kernels process
+        int64_t pub_begin; // columns [pub_begin, pub_end) were published while this batch was associated
+        int64_t pub_end;
+    } batch[2];
     int32_t assoc_mode; // 0: tree state in LDS (k_assoc_lds), 1: tree state in global memory (k_associate)
     int32_t pad1;
     int64_t cursor;     // firings of the current batch already consumed
@@ -129,6 +135,9 @@ struct Planes
     float* sg_x2;       // ||xy|| of the point relative to the sensor (to2dInAzimuthPlane(...).x, cc.hpp:229-232)
     float* sg_uz;       // z of the point relative to the sensor
     uint8_t* sg_flags;  // SG_* bits
+    // one 16-byte record per cell for the window scan: {x, y, z, inclination}; x = NaN for ignored cells, so that the
+    // distance test of cc.cpp:638-641 fails for them without a separate is_ignored load
+    float4* sc_rec;
     // candidates are coded as (columns back << 8) | row
     int16_t* sc_parent;  // first accepted candidate, -1 = none, -2 = point is ignored
     uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS
@@ -150,6 +159,8 @@ struct Geometry
     float max_distance_squared;
     int32_t record_events;
     int32_t limit_columns;   // a launch stops consuming firings of a stream once it emitted this many columns
+    int32_t debug_flags;     // experiment switches (cc_engine_set_option "debug_flags"); 0 in production
+    int32_t lds_tree_limit;  // unfinished trees kept in LDS before a stream falls back to the global-memory kernel (<= TREE_SLOTS)
 };
 
 } // namespace ccd

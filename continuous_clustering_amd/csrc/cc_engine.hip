@@ -23,7 +23,12 @@ struct cc_engine
     StreamState* d_states{nullptr};
     int* d_remaining{nullptr};
     int* h_remaining{nullptr}; // pinned
-    hipStream_t stream{nullptr};
+    hipStream_t stream{nullptr};  // insertion chain (and everything else when not pipelined)
+    hipStream_t stream2{nullptr}; // segmentation / association chain of the pipelined throughput path
+    hipEvent_t ev_ins[2]{nullptr, nullptr}, ev_assoc[2]{nullptr, nullptr};
+    uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 1
+    bool pipelined{false};        // last submitted batch used both streams
+    bool assoc_pending[2]{false, false};
     std::vector<void*> allocations;
     std::string error;
     // staging for the single-stream host path
@@ -103,6 +108,8 @@ void fill_geometry(cc_engine* e, int num_rows)
     g.cells = (int64_t) g.ring_cols * num_rows;
     g.max_distance_squared = e->cfg.max_distance * e->cfg.max_distance; // cc.cpp:80
     g.limit_columns = 2 * g.num_columns;
+    if (g.lds_tree_limit <= 0 || g.lds_tree_limit > TREE_SLOTS)
+        g.lds_tree_limit = TREE_SLOTS;
 }
 
 int free_all(cc_engine* e)
@@ -139,7 +146,7 @@ int allocate(cc_engine* e)
     A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
     A(events, S * (size_t) g.event_capacity);
     A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
-    A(sg_x2, C) A(sg_uz, C) A(sg_flags, C);
+    A(sg_x2, C) A(sg_uz, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
@@ -184,11 +191,8 @@ int reset_state(cc_engine* e, bool keep_table)
         st.min_required = 0;
         st.finish_lower_bound = std::numeric_limits<double>::max();
         st.last_round_min_az = -1.0; // Point::visited_at_continuous_azimuth_angle{-1.} cc.hpp:158
-        st.seg_begin = -1;
-        st.seg_end = -1;
-        st.acp_next = -1;
-        st.pub_begin = -1;
-        st.pub_end = -1;
+        for (auto& d : st.batch)
+            d.seg_begin = d.seg_end = d.acp_next = d.pub_begin = d.pub_end = -1;
         st.assoc_mode = e->cfg.max_steps_in_row > WIN_COLS - 2 ? 1 : 0;
     }
     CC_HIP_CHECK(e, hipMemcpyAsync(e->d_states, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice, e->stream));
@@ -196,6 +200,7 @@ int reset_state(cc_engine* e, bool keep_table)
     for (auto& v : e->pending_events)
         v.clear();
     e->batch_open = false;
+    e->assoc_pending[0] = e->assoc_pending[1] = false;
     return CC_OK;
 }
 
@@ -214,8 +219,9 @@ int ensure_prep(cc_engine* e, size_t points)
     return CC_OK;
 }
 
+// One pass over a batch: insertion chain on `si`, segmentation/association chain on `sa` (si == sa when not pipelined).
 int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int,
-                 const double* d_pose, bool first_pass)
+                 const double* d_pose, bool first_pass, int slot, hipStream_t si, hipStream_t sa)
 {
     const Geometry& g = e->g;
     const int rpl = (g.num_rows + WAVE - 1) / WAVE;
@@ -223,10 +229,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
     dim3 seg_grid((unsigned) ((max_cols + 63) / 64), (unsigned) count);
     constexpr int NK = 7;
-    hipEvent_t ev[NK + 1] = {};
+    hipEvent_t ev[NK + 2] = {};
     if (e->timing)
     {
-        for (int i = 0; i <= NK; i++)
+        for (int i = 0; i < NK + 2; i++)
         {
             if (e->ev_used == e->ev_pool.size())
             {
@@ -236,80 +242,94 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             }
             ev[i] = e->ev_pool[e->ev_used++];
         }
-        CC_HIP_CHECK(e, hipEventRecord(ev[0], e->stream));
     }
     int k = 0;
-#define CC_MARK()    \
-    if (e->timing) \
-        CC_HIP_CHECK(e, hipEventRecord(ev[++k], e->stream));
+#define CC_MARK(st_) \
+    if (e->timing)   \
+        CC_HIP_CHECK(e, hipEventRecord(ev[k++], st_));
+    // ---- insertion chain -----------------------------------------------------------------------------------------
+    CC_MARK(si); // ev0
     const size_t points = (size_t) count * (size_t) n * g.num_rows;
     if (first_pass) // relaunch passes of the same batch reuse the staged points
     {
         int rcp = ensure_prep(e, points);
         if (rcp)
             return rcp;
-        hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((points + 255) / 256)), dim3(256), 0, e->stream, g, e->cfg, e->P, d_xyz, d_pose,
+        hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((points + 255) / 256)), dim3(256), 0, si, g, e->cfg, e->P, d_xyz, d_pose,
                            (long long) points);
     }
-    CC_MARK();
+    CC_MARK(si); // ev1: prep
     {
         const size_t lds = cck::insert2_lds_bytes(g.num_rows);
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, e->stream, g, e->cfg, e->P, e->d_states, first_stream,
+            hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, si, g, e->cfg, e->P, e->d_states, first_stream, slot,
                                d_int, (long long) n, e->d_remaining);
         else
-            hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, e->stream, g, e->cfg, e->P, e->d_states, first_stream,
+            hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, si, g, e->cfg, e->P, e->d_states, first_stream, slot,
                                d_int, (long long) n, e->d_remaining);
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64), 0, e->stream, g, e->P, e->d_states, first_stream);
+            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64), 0, si, g, e->P, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64), 0, e->stream, g, e->P, e->d_states, first_stream);
+            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64), 0, si, g, e->P, e->d_states, first_stream, slot);
     }
-    CC_MARK();
+    CC_MARK(si); // ev2: insert + table
+    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
+    if (si != sa)
+    {
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(sa, e->ev_ins[slot], 0));
+    }
+    // ---- segmentation / association chain --------------------------------------------------------------------
+    CC_MARK(sa); // ev3: start of the second chain
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, e->stream, g, e->cfg, e->P,
-                           e->d_states, first_stream, d_pose, (long long) n);
+        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states,
+                           first_stream, slot, d_pose, (long long) n);
     else
-        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, e->stream, g, e->cfg, e->P,
-                           e->d_states, first_stream, d_pose, (long long) n);
+        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states,
+                           first_stream, slot, d_pose, (long long) n);
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
-        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
-    CC_MARK();
+    CC_MARK(sa); // ev4: segment
     const dim3 scan_grid(cck::SCAN_BLOCKS, (unsigned) count);
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
-    CC_MARK();
+        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    CC_MARK(sa); // ev5: scan
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+        hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
-    CC_MARK();
+        hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    CC_MARK(sa); // ev6: assoc_lds
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
+        hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, e->stream, g, e->cfg, e->P, e->d_states, first_stream);
-    CC_MARK();
-    hipLaunchKernelGGL(cck::k_publish, dim3(cck::PUBLISH_BLOCKS, (unsigned) count), dim3(64), 0, e->stream, g, e->P, e->d_states,
-                       first_stream);
-    CC_MARK();
+        hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    CC_MARK(sa); // ev7: assoc_global
+    hipLaunchKernelGGL(cck::k_publish, dim3(cck::PUBLISH_BLOCKS, (unsigned) count), dim3(64), 0, sa, g, e->P, e->d_states, first_stream,
+                       slot);
+    CC_MARK(sa); // ev8: publish
 #undef CC_MARK
+    if (si != sa)
+    {
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_assoc[slot], sa));
+        e->assoc_pending[slot] = true;
+    }
     CC_HIP_CHECK(e, hipGetLastError());
     return CC_OK;
 }
 
-// Begin a batch: zero the per-stream firing cursors and the early-stop counter.
-__global__ void k_begin_batch(StreamState* states, int first_stream, int count, int* remaining)
+// Begin a batch: zero the per-stream firing cursors and the early-stop counter; fix how far clearing may go.
+__global__ void k_begin_batch(StreamState* states, int first_stream, int count, int* remaining, int unlimited_clear)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count)
     {
         states[first_stream + i].cursor = 0;
-        states[first_stream + i].clear_allowed = states[first_stream + i].ring_start;
+        states[first_stream + i].clear_allowed = unlimited_clear ? 0x7fffffffffffffffll : states[first_stream + i].ring_start;
     }
     if (i == 0)
         *remaining = 0;
@@ -327,34 +347,19 @@ __global__ void k_clear_events(StreamState* states, int first_stream, int count)
         states[first_stream + i].n_events = 0;
 }
 
-int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose)
-{
-    hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, e->stream, e->d_states, first_stream, count,
-                       e->d_remaining);
-    int rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true);
-    if (rc)
-        return rc;
-    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    e->last_xyz = d_xyz;
-    e->last_int = d_int;
-    e->last_pose = d_pose;
-    e->last_n = n;
-    e->last_first = first_stream;
-    e->last_count = count;
-    e->batch_open = true;
-    return CC_OK;
-}
-
 int collect_events(cc_engine* e, int first_stream, int count);
 
 int resolve_timing(cc_engine* e)
 {
-    for (size_t i = 0; i + 7 < e->ev_used; i += 8)
+    // 9 events per pass: ev0 | prep | ev1 | insert+table | ev2 ... ev3 | segment | ev4 | scan | ev5 | assoc_lds | ev6 | assoc_global |
+    // ev7 | publish | ev8
+    static const int from[7] = {0, 1, 3, 4, 5, 6, 7};
+    for (size_t i = 0; i + 8 < e->ev_used; i += 9)
     {
         for (int k = 0; k < 7; k++)
         {
             float ms = 0.f;
-            CC_HIP_CHECK(e, hipEventElapsedTime(&ms, e->ev_pool[i + k], e->ev_pool[i + k + 1]));
+            CC_HIP_CHECK(e, hipEventElapsedTime(&ms, e->ev_pool[i + from[k]], e->ev_pool[i + from[k] + 1]));
             e->kernel_ms[k] += ms;
         }
         e->kernel_launches++;
@@ -363,38 +368,81 @@ int resolve_timing(cc_engine* e)
     return CC_OK;
 }
 
-// Wait for the open batch; relaunch while some stream stopped early (limit_columns reached).
+int sync_all(cc_engine* e)
+{
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
+    e->assoc_pending[0] = e->assoc_pending[1] = false;
+    return CC_OK;
+}
+
+// Wait for everything in flight; run continuation passes while some stream stopped early (limit_columns reached).
 int finish_batch(cc_engine* e)
 {
     if (!e->batch_open)
-    {
-        CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
-        return CC_OK;
-    }
+        return sync_all(e);
     while (true)
     {
-        CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
-        if (e->timing)
-        {
-            int rc = resolve_timing(e);
-            if (rc)
-                return rc;
-        }
-        if (e->g.record_events)
-        {
-            int rc = collect_events(e, e->last_first, e->last_count);
-            if (rc)
-                return rc;
-        }
+        int rc = sync_all(e);
+        if (rc)
+            return rc;
+        if (e->timing && (rc = resolve_timing(e)))
+            return rc;
+        if (e->g.record_events && (rc = collect_events(e, e->last_first, e->last_count)))
+            return rc;
         if (*e->h_remaining == 0)
             break;
         hipLaunchKernelGGL(k_clear_remaining, dim3(1), dim3(1), 0, e->stream, e->d_remaining);
-        int rc = launch_batch(e, e->last_first, e->last_count, e->last_n, e->last_xyz, e->last_int, e->last_pose, false);
+        const int slot = (int) (e->batch_seq & 1);
+        e->batch_seq++;
+        rc = launch_batch(e, e->last_first, e->last_count, e->last_n, e->last_xyz, e->last_int, e->last_pose, false, slot, e->stream,
+                          e->stream);
         if (rc)
             return rc;
-        CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     }
     e->batch_open = false;
+    return CC_OK;
+}
+
+int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose,
+           bool pipeline)
+{
+    int rc;
+    if (e->batch_open)
+    {
+        if (pipeline && e->pipelined)
+        {
+            // the previous batch's insertion chain must be complete before its successor starts; its association chain
+            // keeps running on stream2 while this batch is inserted
+            CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+            if (*e->h_remaining != 0 && (rc = finish_batch(e)))
+                return rc;
+        }
+        else if ((rc = finish_batch(e)))
+            return rc;
+    }
+    const int slot = (int) (e->batch_seq & 1);
+    e->batch_seq++;
+    hipStream_t si = e->stream, sa = pipeline ? e->stream2 : e->stream;
+    if (pipeline && e->assoc_pending[slot])
+    {
+        // descriptor slot and staging planes of batch b - 2 must have been consumed
+        CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_assoc[slot], 0));
+        e->assoc_pending[slot] = false;
+    }
+    hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining,
+                       pipeline ? 1 : 0);
+    rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true, slot, si, sa);
+    if (rc)
+        return rc;
+    e->last_xyz = d_xyz;
+    e->last_int = d_int;
+    e->last_pose = d_pose;
+    e->last_n = n;
+    e->last_first = first_stream;
+    e->last_count = count;
+    e->batch_open = true;
+    e->pipelined = pipeline;
     return CC_OK;
 }
 
@@ -504,10 +552,16 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         return CC_ERR_NO_DEVICE;
     cc_engine* e = new cc_engine();
     e->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess)
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess)
     {
         delete e;
         return CC_ERR_HIP;
+    }
+    for (int i = 0; i < 2; i++)
+    {
+        (void) hipEventCreateWithFlags(&e->ev_ins[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_assoc[i], hipEventDisableTiming);
     }
     e->cfg = *cfg;
     e->g.num_streams = num_streams;
@@ -547,7 +601,14 @@ void cc_engine_destroy(cc_engine* e)
         return;
     (void) hipSetDevice(e->device);
     (void) hipStreamSynchronize(e->stream);
+    (void) hipStreamSynchronize(e->stream2);
     free_all(e);
+    for (int i = 0; i < 2; i++)
+    {
+        (void) hipEventDestroy(e->ev_ins[i]);
+        (void) hipEventDestroy(e->ev_assoc[i]);
+    }
+    (void) hipStreamDestroy(e->stream2);
     for (hipEvent_t ev : e->ev_pool)
         (void) hipEventDestroy(ev);
     if (e->h_remaining)
@@ -599,6 +660,7 @@ int cc_engine_reset(cc_engine* e, int num_rows)
         return rc;
     (void) hipSetDevice(e->device);
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
     e->batch_open = false;
     const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
     if (!same_shape)
@@ -668,7 +730,7 @@ int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz,
         CC_HIP_CHECK(e, hipMemcpyAsync(e->d_stage_int, intensity + (size_t) off * R, (size_t) m * R, hipMemcpyHostToDevice, e->stream));
         CC_HIP_CHECK(e, hipMemcpyAsync(e->d_stage_pose, poses + (size_t) off * 12, (size_t) m * 12 * sizeof(double),
                                        hipMemcpyHostToDevice, e->stream));
-        rc = submit(e, stream, 1, m, e->d_stage_xyz, e->d_stage_int, e->d_stage_pose);
+        rc = submit(e, stream, 1, m, e->d_stage_xyz, e->d_stage_int, e->d_stage_pose, false);
         if (rc)
             return rc;
         rc = finish_batch(e);
@@ -688,10 +750,9 @@ int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, co
     if (n == 0)
         return CC_OK;
     (void) hipSetDevice(e->device);
-    int rc = finish_batch(e); // the previous batch must have consumed all of its firings
-    if (rc)
-        return rc;
-    return submit(e, 0, e->g.num_streams, n, d_xyz, d_intensity, d_poses);
+    // throughput path: when nobody reads events or columns between batches, batch b + 1 is inserted while batch b is still
+    // being segmented and associated (two HIP streams)
+    return submit(e, 0, e->g.num_streams, n, d_xyz, d_intensity, d_poses, e->g.record_events == 0);
 }
 
 int cc_engine_sync(cc_engine* e)
@@ -853,6 +914,29 @@ int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_l
         *d_ground_label = e->P.ground + (size_t) stream * e->g.cells;
     if (d_cluster_id)
         *d_cluster_id = e->P.id + (size_t) stream * e->g.cells;
+    return CC_OK;
+}
+
+int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
+{
+    if (!e || !name)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    const std::string n(name);
+    if (n == "debug_flags")
+        e->g.debug_flags = (int32_t) value;
+    else if (n == "lds_tree_limit")
+        e->g.lds_tree_limit = (int32_t) (value < 1 ? 1 : (value > TREE_SLOTS ? TREE_SLOTS : value));
+    else if (n == "limit_columns")
+        e->g.limit_columns = (int32_t) (value < 1 ? 1 : value);
+    else
+    {
+        e->error = "unknown option " + n;
+        return CC_ERR_INVALID_ARGUMENT;
+    }
     return CC_OK;
 }
 

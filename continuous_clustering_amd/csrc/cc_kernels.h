@@ -155,6 +155,7 @@ struct SP
     double* sc_fin;
     float *sg_x2, *sg_uz;
     uint8_t* sg_flags;
+    float4* sc_rec;
 };
 
 __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, int s)
@@ -206,255 +207,12 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.sg_x2 = P.sg_x2 + co;
     p.sg_uz = P.sg_uz + co;
     p.sg_flags = P.sg_flags + co;
+    p.sc_rec = P.sc_rec + co;
     return p;
 }
 
 // =====================================================================================================
-// k_insert — continuous_clustering.cpp:105-292
-// grid = (number of streams in this launch), block = 64 (one wavefront per stream)
-// =====================================================================================================
-template<int RPL>
-__global__ __launch_bounds__(64) void k_insert(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
-                                               const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
-                                               const double* __restrict__ poses, long long n, int* remaining)
-{
-    const int sl = blockIdx.x;
-    const int s = first_stream + sl;
-    const int lane = lane_id();
-    StreamState* st = &states[s];
-    const SP p = stream_ptrs(P, g, s);
-    const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
-
-    long long prev_rear = st->prev_rearmost, prev_fore = st->prev_foremost, first_unf = st->first_unfinished;
-    long long ring_start = st->ring_start, ring_end = st->ring_end, first_unpub = st->first_unpublished;
-    int reset_required = st->reset_required;
-    const long long cursor0 = st->cursor;
-    const long long seq0 = (long long) st->firings_consumed;
-    long long seg_begin = first_unf; // may be -1 until the first firing with columns arrives
-    const long long limit_base = first_unf;
-    unsigned long long negative_cols = 0;
-
-    float tabv[RPL];
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        int row = k * 64 + lane;
-        tabv[k] = row < R ? p.curtab[row] : 0.f;
-    }
-
-    // clearColumns (cc.cpp:1094-1145) for everything earlier batches released: distance / inclination = NaN,
-    // global column index = -1 are the only cleared fields later stages read.
-    long long clear_done = st->clear_done;
-    if (clear_done >= 0)
-    {
-        const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
-        for (; clear_done < clear_to; clear_done++)
-        {
-            const int clc = (int) (clear_done % RC);
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (row < R)
-                {
-                    const size_t ci = (size_t) clc * R + row;
-                    p.dist[ci] = __builtin_nanf("");
-                    p.incl[ci] = __builtin_nanf("");
-                    p.gcol[ci] = -1;
-                }
-            }
-        }
-    }
-
-    const float* sx = xyz + (size_t) sl * (size_t) n * R * 3;
-    const uint8_t* si = inten + (size_t) sl * (size_t) n * R;
-    const double* sp = poses + (size_t) sl * (size_t) n * 12;
-
-    long long f = cursor0;
-    for (; f < n; f++)
-    {
-        if (limit_base >= 0 && prev_rear - limit_base >= g.limit_columns)
-            break; // keep the distance between insertion and clearing fronts bounded; host relaunches
-        const double* T = sp + f * 12;
-        const double r00 = T[0], r01 = T[1], r02 = T[2], tx = T[3];
-        const double r10 = T[4], r11 = T[5], r12 = T[6], ty = T[7];
-        const double r20 = T[8], r21 = T[9], r22 = T[10], tz = T[11];
-
-        long long rear = 0x7fffffffffffffffll, fore = -1;
-        const long long prev_rot = prev_rear / NC;
-        const int prev_cir = (int) (prev_rear % NC);
-        const int half = NC / 2;
-
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            const int row = k * 64 + lane;
-            if (row >= R)
-                continue;
-            const size_t pi = ((size_t) f * R + row) * 3;
-            const float fx = sx[pi + 0], fy = sx[pi + 1], fz = sx[pi + 2];
-            if (fx != fx)
-                continue; // std::isnan(p.x()) cc.cpp:131
-            const double px = fx, py = fy, pz = fz;
-            const double ox = ((r00 * px + r01 * py) + r02 * pz) + tx;
-            const double oy = ((r10 * px + r11 * py) + r12 * pz) + ty;
-            const double oz = ((r20 * px + r21 * py) + r22 * pz) + tz;
-            const double rx = ox - tx, ry = oy - ty, rz = oz - tz;
-
-            const float az = ccm::atan2f_exact(fy, fx);
-            const float inc_az = cfg.sensor_is_clockwise ? -az + CC_PI_F : az + CC_PI_F;
-            const int cir = f2i_x86(inc_az / g.az_width);
-            long long gc = prev_rot * NC + cir;
-            const int cdiff = cir - prev_cir;
-            int rot_off = 0;
-            if (cdiff < -half)
-            {
-                gc += NC;
-                rot_off = 1;
-            }
-            else if (prev_rear > 0 && cdiff > half)
-            {
-                gc -= NC;
-                rot_off = -1;
-            }
-            if (gc < 0)
-            {
-                negative_cols++; // undefined behaviour in the reference (negative vector index); dropped here
-                continue;
-            }
-            int lc = (int) (gc % RC);
-            size_t ci = (size_t) lc * R + row;
-            const double cazv = CC_2PI_D * (double) (prev_rot + rot_off) + (double) inc_az;
-            const float dist = (float) __builtin_sqrt((rx * rx + ry * ry) + rz * rz);
-            float cd = p.dist[ci];
-            if (!(cd != cd) && !(dist != dist))
-            {
-                int nl = lc + 1;
-                if (nl >= RC)
-                    nl -= RC;
-                const size_t ni = (size_t) nl * R + row;
-                const float nd = p.dist[ni];
-                if (nd != nd)
-                {
-                    ci = ni;
-                    lc = nl;
-                    gc++;
-                    cd = nd;
-                }
-            }
-            if (!(cd != cd) && ((dist != dist) || dist >= cd))
-                continue;
-            const bool too_far_behind = first_unf >= 0 && gc < first_unf;
-            if (!too_far_behind)
-            {
-                p.x[ci] = (float) ox;
-                p.y[ci] = (float) oy;
-                p.z[ci] = (float) oz;
-                p.inten[ci] = si[(size_t) f * R + row];
-                p.src[ci] = seq0 + (f - cursor0);
-                p.dist[ci] = dist;
-                p.incl[ci] = ccm::asinf_exact((float) rz / dist);
-                p.caz[ci] = cazv;
-                p.gcol[ci] = gc;
-            }
-            rear = gc < rear ? gc : rear;
-            fore = gc > fore ? gc : fore;
-        }
-        rear = wave_min_i64(rear);
-        fore = wave_max_i64(fore);
-        if (rear == 0x7fffffffffffffffll)
-            rear = -1;
-
-        if (rear >= 0 && fore >= 0)
-        {
-            if ((fore - rear) > NC / 2)
-            {
-                reset_required = 1; // cc.cpp:252-261
-                continue;
-            }
-            if (rear > prev_rear)
-                prev_rear = rear;
-            if (fore > prev_fore)
-                prev_fore = fore;
-        }
-        if (prev_fore < 0)
-            continue;
-        if (ring_start == -1)
-        {
-            ring_start = prev_rear;
-            first_unpub = prev_rear;
-            clear_done = prev_rear;
-        }
-        if (prev_fore > ring_end)
-            ring_end = prev_fore;
-        if (first_unf == -1)
-        {
-            first_unf = prev_rear;
-            if (seg_begin < 0)
-                seg_begin = first_unf;
-            if (lane == 0)
-                st->first_column = first_unf;
-        }
-        // finished columns: remember the firing whose pose the segmentation job carries (cc.cpp:289-291) and
-        // advance the per-row inclination step table (cc.cpp:353-357) in column order
-        while (first_unf < prev_rear)
-        {
-            const int lc = (int) (first_unf % RC);
-            if (lane == 0)
-                p.trig[lc] = (int) f;
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (row >= R)
-                    continue;
-                const size_t ci = (size_t) lc * R + row;
-                const float cur = p.incl[ci];
-                const float below = row + 1 < R ? p.incl[ci + 1] : 0.f;
-                const float diff = cur - below;
-                if (!(diff != diff))
-                    tabv[k] = diff;
-                p.tab[ci] = tabv[k];
-            }
-            first_unf++;
-        }
-    }
-
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        int row = k * 64 + lane;
-        if (row < R)
-            p.curtab[row] = tabv[k];
-    }
-    if (lane == 0)
-    {
-        st->prev_rearmost = prev_rear;
-        st->prev_foremost = prev_fore;
-        st->first_unfinished = first_unf;
-        st->ring_start = ring_start;
-        st->ring_end = ring_end;
-        st->clear_done = clear_done;
-        st->first_unpublished = first_unpub;
-        st->reset_required = reset_required;
-        st->seg_begin = seg_begin;
-        st->seg_end = seg_begin >= 0 ? first_unf : -1;
-        st->acp_next = seg_begin;
-        st->pub_begin = first_unpub;
-        st->pub_end = first_unpub;
-        st->cursor = f;
-        st->firings_consumed = (unsigned long long) (seq0 + (f - cursor0));
-        if (f < n)
-            atomicAdd(remaining, 1);
-    }
-    negative_cols = (unsigned long long) wave_max_i64((long long) negative_cols);
-    if (lane == 0 && negative_cols)
-        st->error_b += (long long) negative_cols;
-}
-
-// =====================================================================================================
-// k_segment — continuous_clustering.cpp:294-624. One lane per column.
-// grid = (tiles of 64 columns, streams in this launch), block = 64
+// ground-point segmentation — continuous_clustering.cpp:294-624, split into k_seg_pre (per cell) and k_seg_scan (per column)
 // =====================================================================================================
 __device__ __forceinline__ float len2(float a, float b)
 {
@@ -516,7 +274,7 @@ __host__ inline size_t insert2_lds_bytes(int R)
 // block = 128: wavefront 0 is the consumer (the serial algorithm), wavefront 1 the loader that streams the staged points
 // of the coming firings from HBM into an LDS ring, so that the consumer never waits for a global load.
 template<int RPL>
-__global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+__global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
                                                  const uint8_t* __restrict__ inten, long long n, int* remaining)
 {
     const int sl = blockIdx.x;
@@ -619,6 +377,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     }
 
     // ---------------------------------------------------------------------- consumer
+    __builtin_amdgcn_s_setprio(3); // latency-critical serial chain: win issue arbitration against co-resident throughput kernels
     long long prev_rear = st->prev_rearmost, prev_fore = st->prev_foremost, first_unf = st->first_unfinished;
     long long ring_start = st->ring_start, ring_end = st->ring_end, first_unpub = st->first_unpublished;
     int reset_required = st->reset_required;
@@ -626,6 +385,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     long long seg_begin = first_unf;
     const long long limit_base = first_unf;
     unsigned long long negative_cols = 0;
+    bool ring_init = false;
 
     // deferred clearColumns (cc.cpp:1094-1145) for what earlier calls released
     long long clear_done = st->clear_done;
@@ -949,6 +709,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
             ring_start = prev_rear;
             first_unpub = prev_rear;
             clear_done = prev_rear;
+            ring_init = true;
         }
         if (prev_fore > ring_end)
             ring_end = prev_fore;
@@ -1001,16 +762,21 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         st->prev_rearmost = prev_rear;
         st->prev_foremost = prev_fore;
         st->first_unfinished = first_unf;
-        st->ring_start = ring_start;
+        // ring_start / first_unpublished belong to the association chain (which may be running the previous batch right
+        // now); the insertion kernel only gives them their initial value (cc.cpp:274-278)
+        if (ring_init)
+        {
+            st->ring_start = ring_start;
+            st->first_unpublished = first_unpub;
+        }
         st->ring_end = ring_end;
         st->clear_done = clear_done;
-        st->first_unpublished = first_unpub;
         st->reset_required = reset_required;
-        st->seg_begin = seg_begin;
-        st->seg_end = seg_begin >= 0 ? first_unf : -1;
-        st->acp_next = seg_begin;
-        st->pub_begin = first_unpub;
-        st->pub_end = first_unpub;
+        st->batch[slot].seg_begin = seg_begin;
+        st->batch[slot].seg_end = seg_begin >= 0 ? first_unf : -1;
+        st->batch[slot].acp_next = seg_begin;
+        st->batch[slot].pub_begin = -1;
+        st->batch[slot].pub_end = -1;
         st->cursor = f;
         st->firings_consumed = (unsigned long long) (seq0 + (f - cursor0));
         if (f < n)
@@ -1027,12 +793,12 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 // they pipeline. grid = streams, block = 64.
 // =====================================================================================================
 template<int RPL>
-__global__ __launch_bounds__(64) void k_table(Geometry g, Planes P, StreamState* states, int first_stream)
+__global__ __launch_bounds__(64) void k_table(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     StreamState* st = &states[s];
-    const long long seg_begin = st->seg_begin, seg_end = st->seg_end;
+    const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || seg_begin >= seg_end)
         return;
     const SP p = stream_ptrs(P, g, s);
@@ -1045,7 +811,7 @@ __global__ __launch_bounds__(64) void k_table(Geometry g, Planes P, StreamState*
         tabv[k] = row < R ? p.curtab[row] : 0.f;
     }
     int lc = (int) (seg_begin % RC);
-    constexpr int U = 8;
+    constexpr int U = 24;
     for (long long c0 = seg_begin; c0 < seg_end; c0 += U)
     {
         float cur[U][RPL], below[U][RPL];
@@ -1101,13 +867,13 @@ __global__ __launch_bounds__(64) void k_table(Geometry g, Planes P, StreamState*
 constexpr int SEGPRE_BLOCKS = 128;
 
 template<int RPL>
-__global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+__global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
                                                 const double* __restrict__ poses, long long n)
 {
     const int sl = blockIdx.y;
     const int s = first_stream + sl;
     StreamState* st = &states[s];
-    const long long seg_begin = st->seg_begin, seg_end = st->seg_end;
+    const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || seg_begin >= seg_end)
         return;
     if (!st->has_robot_tf)
@@ -1224,10 +990,9 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                 continue;
             const size_t ci = base + row;
             p.gcol[ci] = gc;
-            p.root[ci] = -1;
-            p.id[ci] = 0;
             int flags = 0;
             float x2 = 0.f, uz = 0.f;
+            float4 rec = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), incl[k]);
             if (isnan_[k])
             {
                 flags = SG_NAN;
@@ -1244,6 +1009,9 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                 if (caz < min_az)
                     min_az = caz;
                 const float cx = p.x[ci], cy = p.y[ci], cz = p.z[ci];
+                rec.x = cx;
+                rec.y = cy;
+                rec.z = cz;
                 if (cfg.fog_filtering_enabled && p.inten[ci] < (uint8_t) cfg.fog_filtering_intensity_below &&
                     dist[k] < cfg.fog_filtering_distance_below && incl[k] > cfg.fog_filtering_inclination_above)
                     flags |= SG_FOG;
@@ -1266,6 +1034,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             p.sg_x2[ci] = x2;
             p.sg_uz[ci] = uz;
             p.sg_flags[ci] = (uint8_t) flags;
+            p.sc_rec[ci] = rec;
         }
         min_az = wave_min_f64(min_az);
         if (lane == 0)
@@ -1293,11 +1062,11 @@ __host__ inline size_t seg_scan_lds_bytes(int R)
     return (size_t) 64 * seg_pitch_f(R) * 4 * 2 + (size_t) 64 * seg_pitch_b(R) * 4;
 }
 
-__global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream)
+__global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.y;
     StreamState* st = &states[s];
-    const long long seg_begin = st->seg_begin, seg_end = st->seg_end;
+    const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || st->error != 0)
         return;
     const long long tile0 = seg_begin + (long long) blockIdx.x * 64;
@@ -1317,23 +1086,48 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
     unsigned char* l_ign = l_debug + 64 * PB;
 
     int lc0 = (int) (tile0 % RC);
-    // load: one coalesced row-run per column
+    // load: one coalesced row-run per column, 8 columns in flight
+    if (!(g.debug_flags & 2))
     {
+        constexpr int B = 8;
         int lc = lc0;
-        for (int c = 0; c < ncols; c++)
+        for (int c0 = 0; c0 < ncols; c0 += B)
         {
-            for (int row = lane; row < R; row += 64)
+            for (int r0 = 0; r0 < R; r0 += 64)
             {
-                const size_t ci = (size_t) lc * R + row;
-                l_x2[c * PF + row] = p.sg_x2[ci];
-                l_uz[c * PF + row] = p.sg_uz[ci];
-                l_flags[c * PB + row] = p.sg_flags[ci];
+                const int row = r0 + lane;
+                float vx[B], vz[B];
+                unsigned char vf[B];
+                int lcs = lc;
+#pragma unroll
+                for (int u = 0; u < B; u++)
+                {
+                    vx[u] = vz[u] = 0.f;
+                    vf[u] = 0;
+                    if (row < R && c0 + u < ncols)
+                    {
+                        const size_t ci = (size_t) lcs * R + row;
+                        vx[u] = p.sg_x2[ci];
+                        vz[u] = p.sg_uz[ci];
+                        vf[u] = p.sg_flags[ci];
+                    }
+                    lcs = lcs + 1 == RC ? 0 : lcs + 1;
+                }
+#pragma unroll
+                for (int u = 0; u < B; u++)
+                    if (row < R && c0 + u < ncols)
+                    {
+                        l_x2[(c0 + u) * PF + row] = vx[u];
+                        l_uz[(c0 + u) * PF + row] = vz[u];
+                        l_flags[(c0 + u) * PB + row] = vf[u];
+                    }
             }
-            lc = lc + 1 == RC ? 0 : lc + 1;
+            for (int u = 0; u < B; u++)
+                lc = lc + 1 == RC ? 0 : lc + 1;
         }
     }
     __syncthreads();
-    if (lane < ncols)
+    if (lane < ncols && !(g.debug_flags & 1))
     {
         const long long gc = tile0 + lane;
         const float* x2 = l_x2 + lane * PF;
@@ -1480,6 +1274,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
         }
     }
     __syncthreads();
+    if (!(g.debug_flags & 4))
     {
         int lc = lc0;
         for (int c = 0; c < ncols; c++)
@@ -1558,7 +1353,7 @@ __device__ __forceinline__ void tree_init(const SP& p, int cell, double fin)
 //  LIVE = false: record the first passing candidate as `parent` and later passing candidates as link candidates;
 //                no tree state is read (valid when no attach is refused, checked by the caller).
 //  LIVE = true : exact reference semantics with immediate attach / link (single lane, rows in order).
-template<bool LIVE, bool CODE = false>
+template<bool LIVE, bool CODE = false, bool REC = false>
 __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, const long long gc, const int row, const int first_local,
                                            const float mad, const double pcaz, int& p_root, int& parent, int* links, int& nlinks,
                                            bool& overflow, const int max_links = LINK_SLOTS_V1)
@@ -1566,7 +1361,22 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
     const SP& p = c.p;
     const int R = c.R;
     const int pi = lc * R + row;
-    const float pincl = p.incl[pi], px = p.x[pi], py = p.y[pi], pz = p.z[pi];
+    float pincl, px, py, pz;
+    if (REC)
+    {
+        const float4 me = p.sc_rec[pi]; // the point itself is not ignored: x is the real coordinate
+        px = me.x;
+        py = me.y;
+        pz = me.z;
+        pincl = me.w;
+    }
+    else
+    {
+        pincl = p.incl[pi];
+        px = p.x[pi];
+        py = p.y[pi];
+        pz = p.z[pi];
+    }
     int needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
     needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
     int oc = lc;
@@ -1582,10 +1392,17 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
             while (orow >= 0 && orow < R && sv <= c.max_steps_in_column)
             {
                 const int oi = oc * R + orow;
-                const float oincl = p.incl[oi];
+                float4 orec;
+                unsigned char oign = 0;
+                if (REC)
+                {
+                    orec = p.sc_rec[oi]; // both loads are issued before the first use: one round trip per visit
+                    oign = p.ignored[oi];
+                }
+                const float oincl = REC ? orec.w : p.incl[oi];
                 if (ccm::absf(oincl - pincl) > mad)
                     break;
-                if (!p.ignored[oi])
+                if (REC ? !oign : !p.ignored[oi])
                 {
                     bool consider = true;
                     int oroot = -1;
@@ -1596,7 +1413,7 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                     }
                     if (consider)
                     {
-                        const float dx = px - p.x[oi], dy = py - p.y[oi], dz = pz - p.z[oi];
+                        const float dx = px - (REC ? orec.x : p.x[oi]), dy = py - (REC ? orec.y : p.y[oi]), dz = pz - (REC ? orec.z : p.z[oi]);
                         if (dx * dx + dy * dy + dz * dz < c.maxd2)
                         {
                             if (LIVE)
@@ -1659,12 +1476,12 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
 }
 
 template<int RPL>
-__global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream)
+__global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     StreamState* st = &states[s];
-    if (st->error != 0 || st->seg_begin < 0 || st->assoc_mode != 1 || st->acp_next >= st->seg_end)
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 1 || st->batch[slot].acp_next >= st->batch[slot].seg_end)
         return;
     AssocCtx c;
     c.p = stream_ptrs(P, g, s);
@@ -1687,6 +1504,8 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
     __shared__ long long s_bl[2];
 
     long long first_unpub = st->first_unpublished, ring_start = st->ring_start;
+    if (lane == 0 && st->batch[slot].pub_begin < 0)
+        st->batch[slot].pub_begin = first_unpub; // first association kernel of this pass
     unsigned long long cluster_counter = st->cluster_counter;
     int n_unf = st->n_unfinished;
     long long M = st->min_required;
@@ -1695,7 +1514,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
     unsigned long long cells_published = st->cells_published, clusters_finished = st->clusters_finished;
     unsigned long long exceed = st->exceed_one_rotation, serial_cols = st->serial_columns, alias_rounds = st->stamp_alias_rounds;
     int n_events = st->n_events;
-    const long long col_end = st->seg_end;
+    const long long col_end = st->batch[slot].seg_end;
     int err = 0;
     long long err_a = 0, err_b = 0;
 
@@ -1721,7 +1540,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
         n_events++;
     };
 
-    for (long long gc = st->acp_next; gc < col_end && err == 0; gc++)
+    for (long long gc = st->batch[slot].acp_next; gc < col_end && err == 0; gc++)
     {
         const int lc = (int) (gc % RC);
         const int first_local = (int) (first_unpub % RC);
@@ -1816,8 +1635,8 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                     err_a = n_unf + cnt;
                     break;
                 }
-                if (active[k])
-                    p.root[lc * R + row] = rootc[k];
+                if (row < R)
+                    p.root[lc * R + row] = active[k] ? rootc[k] : -1;
                 if (is_new)
                 {
                     const int cell = lc * R + row;
@@ -1881,7 +1700,10 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 {
                     const int ci = lc * R + row;
                     if (p.ignored[ci])
+                    {
+                        p.root[ci] = -1;
                         continue;
+                    }
                     const float m = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
                     const double caz = p.caz[ci];
                     int proot = -1, par = -1, nl = 0;
@@ -2083,7 +1905,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
     if (lane == 0)
     {
         st->first_unpublished = first_unpub;
-        st->pub_end = first_unpub;
+        st->batch[slot].pub_end = first_unpub;
         st->ring_start = ring_start;
         st->cluster_counter = cluster_counter;
         st->n_unfinished = n_unf;
@@ -2095,7 +1917,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
         st->exceed_one_rotation = exceed;
         st->serial_columns = serial_cols;
         st->stamp_alias_rounds = alias_rounds;
-        st->acp_next = col_end;
+        st->batch[slot].acp_next = col_end;
         st->n_events = n_events < g.event_capacity ? n_events : g.event_capacity;
         if (g.record_events && n_events > g.event_capacity && err == 0)
         {
@@ -2118,12 +1940,12 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
 constexpr int SCAN_BLOCKS = 128;
 
 template<int RPL>
-__global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream)
+__global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.y;
     const int lane = lane_id();
     const StreamState* st = &states[s];
-    if (st->error != 0 || st->seg_begin < 0 || st->assoc_mode != 0)
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0)
         return;
     AssocCtx c;
     c.p = stream_ptrs(P, g, s);
@@ -2138,8 +1960,8 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
     c.stop_enabled = cfg.stop_after_association_enabled;
     c.stop_min_steps = cfg.stop_after_association_min_steps;
     __shared__ int s_links[WAVE * MAX_ROWS_PER_LANE][LINK_SLOTS];
-    const long long col_end = st->seg_end, first_column = st->first_column;
-    for (long long gc = st->acp_next + blockIdx.x; gc < col_end; gc += gridDim.x)
+    const long long col_end = st->batch[slot].seg_end, first_column = st->first_column;
+    for (long long gc = st->batch[slot].acp_next + blockIdx.x; gc < col_end; gc += gridDim.x)
     {
         const int lc = (int) (gc % RC);
         // never look at columns older than the first column ever segmented (their planes are uninitialised)
@@ -2161,7 +1983,7 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 fin = caz + (double) mad;
                 bool overflow = false;
                 int dummy_root = -1;
-                scan_point<false, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent, s_links[row], nlinks, overflow, LINK_SLOTS);
+                scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent, s_links[row], nlinks, overflow, LINK_SLOTS);
                 if (overflow)
                     nlinks = 255;
             }
@@ -2266,7 +2088,10 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
     {
         const int pi = lc * R + row;
         if (p.ignored[pi])
+        {
+            p.root[pi] = -1;
             continue;
+        }
         const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[pi]);
         const double pcaz = p.caz[pi];
         const float pincl = p.incl[pi], px = p.x[pi], py = p.y[pi], pz = p.z[pi];
@@ -2365,12 +2190,12 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
 }
 
 template<int RPL>
-__global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream)
+__global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     StreamState* st = &states[s];
-    if (st->error != 0 || st->seg_begin < 0 || st->assoc_mode != 0 || st->acp_next >= st->seg_end)
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0 || st->batch[slot].acp_next >= st->batch[slot].seg_end)
         return;
     AssocCtx c;
     c.p = stream_ptrs(P, g, s);
@@ -2395,6 +2220,8 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     __shared__ long long s_bl[2];
 
     long long first_unpub = st->first_unpublished, ring_start = st->ring_start;
+    if (lane == 0 && st->batch[slot].pub_begin < 0)
+        st->batch[slot].pub_begin = first_unpub; // first association kernel of this pass
     unsigned long long cluster_counter = st->cluster_counter;
     int n_unf = st->n_unfinished;
     long long M = st->min_required;
@@ -2403,10 +2230,12 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     unsigned long long cells_published = st->cells_published, clusters_finished = st->clusters_finished;
     unsigned long long exceed = st->exceed_one_rotation, serial_cols = st->serial_columns, alias_rounds = st->stamp_alias_rounds;
     int n_events = st->n_events;
-    const long long col_begin = st->acp_next, col_end = st->seg_end, first_column = st->first_column;
+    const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
     int err = 0;
     long long err_a = 0, err_b = 0;
-    bool to_global = n_unf > TREE_SLOTS;
+    const int tree_limit = g.lds_tree_limit;
+    bool to_global = n_unf > tree_limit;
+    __builtin_amdgcn_s_setprio(3); // latency-critical serial chain
 
     auto emit = [&](int type, long long a, long long b, unsigned cc, unsigned dd, long long column)
     {
@@ -2566,7 +2395,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             if (nl[k] == 255)
                 bad = true;
         }
-        if (n_unf + cnt_new > TREE_SLOTS)
+        if (n_unf + cnt_new > tree_limit)
         {
             to_global = true; // continue this stream with the global-memory kernel, starting at this column
             break;
@@ -2678,8 +2507,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 if (row < R)
                 {
                     wcol[row] = slot[k];
-                    if (parent[k] != -2)
-                        p.root[lc * R + row] = rootcell[k];
+                    p.root[lc * R + row] = rootcell[k];
                     if (parent[k] == -1)
                     {
                         const int i = slot[k];
@@ -2956,7 +2784,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     if (lane == 0)
     {
         st->first_unpublished = first_unpub;
-        st->pub_end = first_unpub;
+        st->batch[slot].pub_end = first_unpub;
         st->ring_start = ring_start;
         st->cluster_counter = cluster_counter;
         st->n_unfinished = n_unf;
@@ -2968,7 +2796,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
         st->exceed_one_rotation = exceed;
         st->serial_columns = serial_cols;
         st->stamp_alias_rounds = alias_rounds;
-        st->acp_next = gc;
+        st->batch[slot].acp_next = gc;
         st->n_events = n_events < g.event_capacity ? n_events : g.event_capacity;
         if (g.record_events && n_events > g.event_capacity && err == 0)
         {
@@ -2988,15 +2816,15 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
 // =====================================================================================================
 constexpr int PUBLISH_BLOCKS = 64;
 
-__global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream)
+__global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.y;
     const StreamState* st = &states[s];
-    if (st->pub_begin < 0)
+    if (st->batch[slot].pub_begin < 0)
         return;
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    for (long long pc = st->pub_begin + blockIdx.x; pc < st->pub_end; pc += gridDim.x)
+    for (long long pc = st->batch[slot].pub_begin + blockIdx.x; pc < st->batch[slot].pub_end; pc += gridDim.x)
     {
         const int plc = (int) (pc % RC);
         for (int row = lane_id(); row < R; row += 64)

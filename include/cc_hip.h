@@ -236,6 +236,11 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
  * bench checksums read without leaving HBM. */
 int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_label, const uint32_t** d_cluster_id);
 
+/* Engine tuning / test hooks. Names: "lds_tree_limit" (unfinished point trees per stream kept in LDS before the stream
+ * continues in the global-memory association kernel, 1..512), "limit_columns" (columns one launch may emit per stream before
+ * it hands back to the host), "debug_flags" (experiment switches, 0 in production). */
+int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
+
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every
  * batch (prep, insert+table, segment, scan, assoc_lds, assoc_global, publish). enable resets the accumulators;
  * cc_engine_kernel_times returns the accumulated milliseconds and the number of batches measured. */
