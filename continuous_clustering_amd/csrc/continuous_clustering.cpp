@@ -1,0 +1,418 @@
+// continuous_clustering.cpp — host-side implementation of the reference's class API over the C-ABI (see the header).
+#include "continuous_clustering.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+namespace continuous_clustering
+{
+
+ContinuousClustering::ContinuousClustering() = default;
+
+ContinuousClustering::~ContinuousClustering()
+{
+    if (engine_)
+        cc_engine_destroy(engine_);
+}
+
+void ContinuousClustering::toPod(const Configuration& c, cc_config& o) const
+{
+    cc_config_default(&o);
+    o.is_single_threaded = c.general.is_single_threaded;
+    o.sensor_is_clockwise = c.range_image.sensor_is_clockwise;
+    o.num_columns = c.range_image.num_columns;
+    o.supplement_inclination_angle_for_nan_cells = c.range_image.supplement_inclination_angle_for_nan_cells;
+    const auto& g = c.ground_segmentation;
+    o.max_slope = g.max_slope;
+    o.first_ring_as_ground_max_allowed_z_diff = g.first_ring_as_ground_max_allowed_z_diff;
+    o.first_ring_as_ground_min_allowed_z_diff = g.first_ring_as_ground_min_allowed_z_diff;
+    o.last_ground_point_slope_higher_than = g.last_ground_point_slope_higher_than;
+    o.last_ground_point_distance_smaller_than = g.last_ground_point_distance_smaller_than;
+    o.ground_because_close_to_last_certain_ground_max_z_diff = g.ground_because_close_to_last_certain_ground_max_z_diff;
+    o.ground_because_close_to_last_certain_ground_max_dist_diff = g.ground_because_close_to_last_certain_ground_max_dist_diff;
+    o.obstacle_because_next_certain_obstacle_max_dist_diff = g.obstacle_because_next_certain_obstacle_max_dist_diff;
+    o.use_terrain = g.use_terrain;
+    o.terrain_max_allowed_z_diff = g.terrain_max_allowed_z_diff;
+    o.height_ref_to_maximum_ = g.height_ref_to_maximum_;
+    o.height_ref_to_ground_ = g.height_ref_to_ground_;
+    o.length_ref_to_front_end_ = g.length_ref_to_front_end_;
+    o.length_ref_to_rear_end_ = g.length_ref_to_rear_end_;
+    o.width_ref_to_left_mirror_ = g.width_ref_to_left_mirror_;
+    o.width_ref_to_right_mirror_ = g.width_ref_to_right_mirror_;
+    o.fog_filtering_enabled = g.fog_filtering_enabled;
+    o.fog_filtering_intensity_below = g.fog_filtering_intensity_below;
+    o.fog_filtering_distance_below = g.fog_filtering_distance_below;
+    o.fog_filtering_inclination_above = g.fog_filtering_inclination_above;
+    const auto& k = c.clustering;
+    o.max_distance = k.max_distance;
+    o.max_steps_in_row = k.max_steps_in_row;
+    o.max_steps_in_column = k.max_steps_in_column;
+    o.stop_after_association_enabled = k.stop_after_association_enabled;
+    o.stop_after_association_min_steps = k.stop_after_association_min_steps;
+    o.ignore_points_in_chessboard_pattern = k.ignore_points_in_chessboard_pattern;
+    o.ignore_points_with_too_big_inclination_angle_diff = k.ignore_points_with_too_big_inclination_angle_diff;
+    o.use_last_point_for_cluster_stamp = k.use_last_point_for_cluster_stamp;
+    o.cluster_point_trees_every_nth_column = k.cluster_point_trees_every_nth_column;
+}
+
+// Status codes -> the reference's exceptions (continuous_clustering.cpp:90-91, :298-299, :337-344, :1052, :1073-1075).
+void ContinuousClustering::check(int rc)
+{
+    if (rc == CC_OK)
+        return;
+    cc_stream_state st{};
+    if (engine_)
+        cc_engine_stream_state(engine_, 0, &st);
+    switch (rc)
+    {
+        case CC_ERR_NO_ROBOT_TRANSFORM:
+            throw std::runtime_error("Transform robot frame from sensor frame was not set yet!");
+        case CC_ERR_RING_OVERRUN:
+            throw std::runtime_error(
+                "This column is not cleared. Probably this means the ring buffer is full or there "
+                "is some other issue with clearing (not cleared at all or written after clearing): " +
+                std::to_string(st.error_a) + ", " + std::to_string(st.error_b) + ", " + std::to_string(ring_buffer_max_columns) +
+                "; This typically happens when the clustering is not fast enough to handle all the firings. Consider "
+                "to play the sensor data more slowly or to adjust the parameters to make the clustering faster.");
+        case CC_ERR_BOOKKEEPING:
+            throw std::runtime_error("This shouldn't happen, ring buffer is not allowed to increase at the front: " +
+                                     std::to_string(st.error_a) + ", " + std::to_string(st.error_b));
+        case CC_ERR_NO_DEVICE:
+            throw std::runtime_error("continuous_clustering_amd: no MI355X (gfx950) device is visible; there is no CPU path");
+        default:
+            throw std::runtime_error(std::string("continuous_clustering_amd: engine error ") + std::to_string(rc) + ": " +
+                                     (engine_ ? cc_engine_last_error(engine_) : ""));
+    }
+}
+
+// ---- continuous_clustering.cpp:11-64 ----------------------------------------------------------------------------------
+void ContinuousClustering::reset(int num_rows)
+{
+    num_columns_ = config_.range_image.num_columns;
+    num_rows_ = num_rows;
+    ring_buffer_max_columns = num_columns_ * 10;
+    cc_config pod;
+    toPod(config_, pod);
+    if (!engine_)
+        check(cc_engine_create(&engine_, device_, 1, num_rows, &pod));
+    else
+    {
+        check(cc_engine_set_config(engine_, &pod));
+        check(cc_engine_reset(engine_, num_rows));
+    }
+    check(cc_engine_record_events(engine_, 1));
+    range_image_.assign(static_cast<size_t>(ring_buffer_max_columns) * num_rows, Point{});
+    for (auto& p : range_image_)
+        p.ground_point_label = GP_UNKNOWN; // clearColumns (cc.cpp:1125)
+    ring_buffer_start_global_column_index = -1;
+    ring_buffer_end_global_column_index = -1;
+    reset_required_ = false;
+    has_robot_tf_ = false; // cc.cpp:39
+    buffered_ = 0;
+    firing_log_.clear();
+    firing_log_base_ = 0;
+    firings_submitted_ = 0;
+    buf_xyz_.clear();
+    buf_int_.clear();
+    buf_pose_.clear();
+    col_min_src_.assign(static_cast<size_t>(ring_buffer_max_columns), -1);
+}
+
+// ---- continuous_clustering.cpp:66-81 ----------------------------------------------------------------------------------
+void ContinuousClustering::setConfiguration(const Configuration& config)
+{
+    if (config_.general.is_single_threaded != config.general.is_single_threaded)
+        reset_required_ = true;
+    if (config_.range_image.sensor_is_clockwise != config.range_image.sensor_is_clockwise)
+        reset_required_ = true;
+    if (config_.range_image.num_columns != config.range_image.num_columns)
+        reset_required_ = true;
+    config_ = config;
+    if (engine_ && num_rows_ > 0 && config.range_image.num_columns == num_columns_)
+    {
+        flush();
+        cc_config pod;
+        toPod(config_, pod);
+        check(cc_engine_set_config(engine_, &pod));
+    }
+}
+
+bool ContinuousClustering::resetRequired() const
+{
+    return reset_required_;
+}
+
+void ContinuousClustering::setRobotTransformImpl()
+{
+    has_robot_tf_ = true;
+    if (engine_)
+    {
+        flush();
+        check(cc_engine_set_robot_from_sensor(engine_, 0, robot_from_sensor_));
+    }
+}
+
+bool ContinuousClustering::hasTransformRobotFrameFromSensorFrame()
+{
+    return has_robot_tf_;
+}
+
+void ContinuousClustering::setFinishedColumnCallback(std::function<void(int64_t, int64_t, bool)> cb)
+{
+    finished_column_callback_ = std::move(cb);
+}
+
+void ContinuousClustering::setFinishedClusterCallback(std::function<void(const std::vector<Point>&, uint64_t)> cb)
+{
+    finished_cluster_callback_ = std::move(cb);
+}
+
+void ContinuousClustering::recordJobQueueWorkload(size_t num_jobs_sensor_input)
+{
+    // the reference records 6 queue depths per call (cc.cpp:1147-1159); the stage queues do not exist here
+    num_pending_jobs_.push_back(num_jobs_sensor_input);
+    for (int i = 0; i < 5; i++)
+        num_pending_jobs_.push_back(static_cast<size_t>(buffered_));
+    while (num_pending_jobs_.size() > 100000 * 6)
+        num_pending_jobs_.pop_front();
+}
+
+void ContinuousClustering::setBatchSize(int firings_per_launch)
+{
+    flush();
+    batch_size_ = std::max(1, firings_per_launch);
+}
+
+void ContinuousClustering::setDevice(int hip_device)
+{
+    device_ = hip_device;
+}
+
+// ---- continuous_clustering.cpp:88-93 ----------------------------------------------------------------------------------
+void ContinuousClustering::addFiringImpl(const RawPoints::ConstPtr& firing, const double tf[12])
+{
+    if (static_cast<size_t>(num_rows_) != firing->points.size())
+        throw std::runtime_error("The number of points in a firing has changed. This is probably a bug!");
+    if (!engine_)
+        throw std::runtime_error("continuous_clustering_amd: reset(num_rows) must be called before addFiring");
+    const size_t R = static_cast<size_t>(num_rows_);
+    buf_xyz_.resize((buffered_ + 1) * R * 3);
+    buf_int_.resize((buffered_ + 1) * R);
+    buf_pose_.resize((buffered_ + 1) * 12);
+    float* x = buf_xyz_.data() + buffered_ * R * 3;
+    uint8_t* in = buf_int_.data() + buffered_ * R;
+    for (size_t r = 0; r < R; r++)
+    {
+        const RawPoint& p = firing->points[r];
+        x[r * 3 + 0] = p.x;
+        x[r * 3 + 1] = p.y;
+        x[r * 3 + 2] = p.z;
+        in[r] = p.intensity;
+    }
+    std::memcpy(buf_pose_.data() + buffered_ * 12, tf, 12 * sizeof(double));
+    firing_log_.push_back(firing);
+    buffered_++;
+    // never pass more than 2 * num_columns firings per engine call: everything a call publishes stays readable until the
+    // next call (include/cc_hip.h, cc_engine_add_firings)
+    if (buffered_ >= batch_size_ || buffered_ >= 2 * num_columns_)
+        process();
+}
+
+void ContinuousClustering::flush()
+{
+    if (buffered_ > 0)
+        process();
+}
+
+void ContinuousClustering::clearMirrorColumns(int64_t from, int64_t to)
+{
+    for (int64_t g = std::max<int64_t>(from, 0); g <= to; g++)
+    {
+        const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
+        for (int r = 0; r < num_rows_; r++)
+        {
+            Point& p = range_image_[lc * num_rows_ + r];
+            p = Point{};
+            p.ground_point_label = GP_UNKNOWN;
+        }
+    }
+}
+
+void ContinuousClustering::refreshColumns(int64_t from, int64_t to)
+{
+    if (to < from)
+        return;
+    const size_t R = static_cast<size_t>(num_rows_);
+    const int64_t step = 4096;
+    for (int64_t c0 = from; c0 <= to; c0 += step)
+    {
+        const int64_t c1 = std::min(to, c0 + step - 1);
+        const size_t n = static_cast<size_t>(c1 - c0 + 1) * R;
+        v_x_.resize(n), v_y_.resize(n), v_z_.resize(n), v_d_.resize(n), v_i_.resize(n), v_caz_.resize(n), v_src_.resize(n);
+        v_rootc_.resize(n), v_rootr_.resize(n), v_g_.resize(n), v_dbg_.resize(n), v_ign_.resize(n), v_id_.resize(n);
+        cc_column_view v{};
+        v.x = v_x_.data(), v.y = v_y_.data(), v.z = v_z_.data(), v.distance = v_d_.data(), v.inclination_angle = v_i_.data();
+        v.continuous_azimuth_angle = v_caz_.data(), v.source_firing = v_src_.data();
+        v.ground_point_label = v_g_.data(), v.debug_ground_point_label = v_dbg_.data(), v.is_ignored = v_ign_.data();
+        v.id = v_id_.data(), v.tree_root_global_column = v_rootc_.data(), v.tree_root_row = v_rootr_.data();
+        check(cc_engine_read_columns(engine_, 0, c0, c1, &v));
+        for (int64_t g = c0; g <= c1; g++)
+        {
+            const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
+            int64_t min_src = -1;
+            for (size_t r = 0; r < R; r++)
+            {
+                const size_t i = static_cast<size_t>(g - c0) * R + r;
+                if (v_src_[i] >= 0 && (min_src < 0 || v_src_[i] < min_src))
+                    min_src = v_src_[i];
+                Point& p = range_image_[lc * R + r];
+                p.xyz = Point3D(v_x_[i], v_y_[i], v_z_[i]);
+                p.distance = v_d_[i];
+                p.inclination_angle = v_i_[i];
+                p.continuous_azimuth_angle = v_caz_[i];
+                p.global_column_index = g; // refilled for every cell of a segmented column (cc.cpp:348-350)
+                p.local_column_index = static_cast<int>(lc);
+                p.ground_point_label = v_g_[i];
+                p.debug_ground_point_label = v_dbg_[i];
+                p.is_ignored = v_ign_[i] != 0;
+                p.id = v_id_[i];
+                if (v_rootc_[i] >= 0)
+                {
+                    p.tree_root_ = RangeImageIndex(static_cast<uint16_t>(v_rootr_[i]), v_rootc_[i] % ring_buffer_max_columns);
+                    p.tree_id = static_cast<uint64_t>(v_rootc_[i]) * R + static_cast<uint64_t>(v_rootr_[i]);
+                }
+                else
+                {
+                    p.tree_root_ = RangeImageIndex(0, -1);
+                    p.tree_id = 0;
+                }
+                p.belongs_to_finished_cluster = p.id != 0;
+                const int64_t src = v_src_[i];
+                if (src >= static_cast<int64_t>(firing_log_base_) && src < static_cast<int64_t>(firing_log_base_ + firing_log_.size()))
+                {
+                    const RawPoint& raw = firing_log_[static_cast<size_t>(src - firing_log_base_)]->points[r];
+                    p.row_index = static_cast<int>(r);
+                    p.firing_index = raw.firing_index;
+                    p.intensity = raw.intensity;
+                    p.stamp = raw.stamp;
+                    p.globally_unique_point_index = raw.globally_unique_point_index;
+                    p.azimuth_angle = std::atan2(raw.y, raw.x); // cc.cpp:142 (sensor frame)
+                }
+                else
+                {
+                    p.row_index = -1;
+                    p.firing_index = 0;
+                    p.intensity = 0;
+                    p.stamp = 0;
+                    p.globally_unique_point_index = static_cast<uint64_t>(-1);
+                    p.azimuth_angle = std::nanf("");
+                }
+            }
+            col_min_src_[lc] = min_src;
+        }
+    }
+}
+
+void ContinuousClustering::process()
+{
+    const int n = buffered_;
+    buffered_ = 0;
+    const int rc = cc_engine_add_firings(engine_, 0, n, buf_xyz_.data(), buf_int_.data(), buf_pose_.data());
+    firings_submitted_ += static_cast<uint64_t>(n);
+    cc_stream_state st{};
+    if (cc_engine_stream_state(engine_, 0, &st) == CC_OK)
+    {
+        if (st.reset_required)
+            reset_required_ = true; // cc.cpp:252-261
+        ring_buffer_end_global_column_index = st.ring_buffer_end_global_column_index;
+    }
+    check(rc);
+
+    int64_t pending = 0;
+    check(cc_engine_pending_events(engine_, 0, &pending));
+    events_.resize(static_cast<size_t>(pending));
+    int64_t got = 0;
+    if (pending > 0)
+        check(cc_engine_drain_events(engine_, 0, events_.data(), pending, &got));
+    events_.resize(static_cast<size_t>(got));
+
+    // bring the mirror up to date for every column an event of this batch refers to
+    int64_t lo = std::numeric_limits<int64_t>::max(), hi = -1;
+    for (const cc_event& e : events_)
+    {
+        if (e.type == CC_EV_PUBLISH_COLUMNS && e.b < e.a)
+            continue;
+        lo = std::min(lo, e.a);
+        hi = std::max(hi, e.b);
+    }
+    if (hi >= 0)
+    {
+        lo = std::max(lo, hi - ring_buffer_max_columns + 1);
+        refreshColumns(lo, hi);
+    }
+
+    // replay in the order the single-threaded reference invokes its callbacks
+    for (const cc_event& e : events_)
+    {
+        switch (e.type)
+        {
+            case CC_EV_GROUND_COLUMN:
+                if (ring_buffer_start_global_column_index == -1)
+                    ring_buffer_start_global_column_index = e.a; // cc.cpp:274-278
+                if (finished_column_callback_)
+                    finished_column_callback_(e.a, e.a, true);
+                break;
+            case CC_EV_CLUSTER:
+                if (e.d > 20 && finished_cluster_callback_) // cc.cpp:1023
+                {
+                    cluster_points_.clear();
+                    uint64_t min_stamp = std::numeric_limits<uint64_t>::max(), max_stamp = 0;
+                    for (int64_t g = e.a; g <= e.b; g++)
+                    {
+                        const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
+                        for (int r = 0; r < num_rows_; r++)
+                        {
+                            const Point& p = range_image_[lc * num_rows_ + r];
+                            if (p.id == e.c && p.global_column_index == g && !p.is_ignored)
+                            {
+                                cluster_points_.push_back(p);
+                                min_stamp = std::min(min_stamp, p.stamp);
+                                max_stamp = std::max(max_stamp, p.stamp);
+                            }
+                        }
+                    }
+                    const uint64_t stamp = config_.clustering.use_last_point_for_cluster_stamp ?
+                                               max_stamp :
+                                               min_stamp + (max_stamp - min_stamp) / 2; // cc.cpp:1025-1028
+                    finished_cluster_callback_(cluster_points_, stamp);
+                }
+                break;
+            case CC_EV_PUBLISH_COLUMNS:
+            {
+                const int64_t old_start = ring_buffer_start_global_column_index;
+                ring_buffer_start_global_column_index = std::max<int64_t>(0, (e.b + 1) - num_columns_); // cc.cpp:1079
+                if (finished_column_callback_)
+                    finished_column_callback_(e.a, e.b, false);
+                clearMirrorColumns(old_start, ring_buffer_start_global_column_index - 1); // cc.cpp:1091
+                break;
+            }
+            default:
+                break;
+        }
+    }
+
+    // firings older than anything still in the ring are no longer needed for the pass-through metadata
+    int64_t oldest_needed = -1;
+    if (ring_buffer_start_global_column_index >= 0)
+        for (int64_t g = ring_buffer_start_global_column_index; g < ring_buffer_start_global_column_index + 256 && oldest_needed < 0; g++)
+            oldest_needed = col_min_src_[static_cast<size_t>(g % ring_buffer_max_columns)];
+    const uint64_t hard_cap = static_cast<uint64_t>(ring_buffer_max_columns) * 16 + 8192;
+    while (!firing_log_.empty() &&
+           (firing_log_.size() > hard_cap || (oldest_needed >= 0 && static_cast<int64_t>(firing_log_base_) + 8192 < oldest_needed)))
+    {
+        firing_log_.pop_front();
+        firing_log_base_++;
+    }
+}
+
+} // namespace continuous_clustering

@@ -1,0 +1,142 @@
+// dropin_demo.cpp — drives continuous_clustering::ContinuousClustering (the MI355X build) exactly the way the reference's
+// src/tools/kitti_demo.cpp:276-313,386-403 drives the reference class: setConfiguration, reset(rows),
+// setTransformRobotFrameFromSensorFrame, two callbacks, then addFiring per firing. Inside the cluster-view column callback it
+// reads clustering.range_image_ like kitti_demo.cpp:173-224 does and dumps what it sees, so that the Python test can compare
+// it with the CPU oracle.
+//
+//   dropin_demo <in.bin> <out.bin> [batch]
+// in.bin : int32 rows, cols, n, kitti(1)/default(0); then n*rows*3 float xyz, n*rows uint8 intensity, n*12 double poses
+// out.bin: records, see the writer below
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../continuous_clustering_amd/csrc/continuous_clustering.hpp"
+
+using namespace continuous_clustering;
+
+int main(int argc, char** argv)
+{
+    if (argc < 3)
+        return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f)
+        return 2;
+    int hdr[4];
+    if (fread(hdr, 4, 4, f) != 4)
+        return 2;
+    const int rows = hdr[0], cols = hdr[1], n = hdr[2], kitti = hdr[3];
+    std::vector<float> xyz((size_t) n * rows * 3);
+    std::vector<uint8_t> inten((size_t) n * rows);
+    std::vector<double> poses((size_t) n * 12);
+    if (fread(xyz.data(), 4, xyz.size(), f) != xyz.size() || fread(inten.data(), 1, inten.size(), f) != inten.size() ||
+        fread(poses.data(), 8, poses.size(), f) != poses.size())
+        return 2;
+    fclose(f);
+    const int batch = argc > 3 ? atoi(argv[3]) : 1;
+
+    ContinuousClustering clustering;
+    Configuration config; // kitti_demo.cpp:279-294
+    if (kitti)
+    {
+        config.general.is_single_threaded = true;
+        config.clustering.ignore_points_in_chessboard_pattern = false;
+        config.clustering.max_distance = 0.5;
+        config.ground_segmentation.height_ref_to_maximum_ = 0.5;
+        config.ground_segmentation.height_ref_to_ground_ = -1.7;
+        config.ground_segmentation.length_ref_to_front_end_ = 3;
+        config.ground_segmentation.length_ref_to_rear_end_ = -3;
+        config.ground_segmentation.width_ref_to_left_mirror_ = 1.5;
+        config.ground_segmentation.width_ref_to_right_mirror_ = -1.5;
+    }
+    config.range_image.num_columns = cols;
+    clustering.setConfiguration(config);
+    clustering.reset(rows);
+    clustering.setTransformRobotFrameFromSensorFrame(Pose3d::Identity());
+    clustering.setBatchSize(batch);
+
+    FILE* out = fopen(argv[2], "wb");
+    long long n_ground_cb = 0, n_cluster_cb = 0;
+    clustering.setFinishedColumnCallback(
+        [&](int64_t from, int64_t to, bool ground_points_only)
+        {
+            if (ground_points_only)
+            {
+                n_ground_cb++;
+                return;
+            }
+            // record type 1: published range, then per cell what kitti_demo reads (kitti_demo.cpp:192-216) + a few more fields
+            int32_t tag = 1;
+            fwrite(&tag, 4, 1, out);
+            fwrite(&from, 8, 1, out);
+            fwrite(&to, 8, 1, out);
+            for (int64_t g = from; g <= to; g++)
+            {
+                int lc = static_cast<int>(g % clustering.ring_buffer_max_columns);
+                for (int r = 0; r < clustering.num_rows_; r++)
+                {
+                    const Point& p = clustering.range_image_[lc * clustering.num_rows_ + r];
+                    uint64_t id = p.id, uidx = p.globally_unique_point_index, stamp = p.stamp;
+                    uint8_t lab[3] = {p.ground_point_label, p.debug_ground_point_label, (uint8_t) p.is_ignored};
+                    float geo[3] = {p.distance, p.inclination_angle, p.azimuth_angle};
+                    fwrite(&id, 8, 1, out);
+                    fwrite(&uidx, 8, 1, out);
+                    fwrite(&stamp, 8, 1, out);
+                    fwrite(lab, 1, 3, out);
+                    fwrite(geo, 4, 3, out);
+                }
+            }
+        });
+    clustering.setFinishedClusterCallback(
+        [&](const std::vector<Point>& pts, uint64_t stamp)
+        {
+            n_cluster_cb++;
+            int32_t tag = 2;
+            uint64_t cnt = pts.size(), id = pts.empty() ? 0 : pts[0].id;
+            fwrite(&tag, 4, 1, out);
+            fwrite(&id, 8, 1, out);
+            fwrite(&cnt, 8, 1, out);
+            fwrite(&stamp, 8, 1, out);
+        });
+
+    for (int k = 0; k < n; k++)
+    {
+        RawPoints::Ptr firing(new RawPoints);
+        firing->stamp = 1000000ull + 45ull * k;
+        firing->points.resize(rows);
+        for (int r = 0; r < rows; r++)
+        {
+            RawPoint& q = firing->points[r];
+            q.x = xyz[((size_t) k * rows + r) * 3 + 0];
+            q.y = xyz[((size_t) k * rows + r) * 3 + 1];
+            q.z = xyz[((size_t) k * rows + r) * 3 + 2];
+            q.intensity = inten[(size_t) k * rows + r];
+            q.stamp = firing->stamp;
+            q.firing_index = k;
+            q.globally_unique_point_index = ((uint64_t) k << 16) | (uint64_t) r; // kitti_demo.cpp:153-155 style tag
+        }
+        Pose3d pose;
+        for (int i = 0; i < 12; i++)
+            pose.m[i] = poses[(size_t) k * 12 + i];
+        clustering.addFiring(firing, pose);
+    }
+    clustering.flush();
+    int32_t tag = 3;
+    fwrite(&tag, 4, 1, out);
+    fwrite(&n_ground_cb, 8, 1, out);
+    fwrite(&n_cluster_cb, 8, 1, out);
+    fclose(out);
+    // error behaviour: wrong firing size must throw like continuous_clustering.cpp:90-91
+    try
+    {
+        RawPoints::Ptr bad(new RawPoints);
+        bad->points.resize(rows + 1);
+        clustering.addFiring(bad, Pose3d::Identity());
+        return 3;
+    }
+    catch (const std::runtime_error&)
+    {
+    }
+    printf("ok ground_cb=%lld cluster_cb=%lld\n", n_ground_cb, n_cluster_cb);
+    return 0;
+}
