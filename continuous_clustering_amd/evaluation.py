@@ -1,0 +1,151 @@
+"""Host mirror of the evaluation path around the label compare (src/evaluation/kitti_evaluation.cpp, the frame scatter of
+src/tools/kitti_demo.cpp:173-224) plus the one collective of the whole system: gathering per-frame evaluation records from the
+ranks that own the sensor streams (torch.distributed: RCCL over xGMI on MI355X, gloo in the CPU tests).
+
+The label compare itself (confusion counts, contingency table) runs on the GPU behind ``cc_eval_frame``; nothing here computes it
+on the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import load_library
+
+RESULT_FIELDS = ("tp", "fn", "fp", "tn", "over_segmentation_entropy", "under_segmentation_entropy")
+
+
+def _lib():
+    L = load_library()
+    if not getattr(L, "_eval_ready", False):
+        L.cc_eval_frame.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cc_eval_frame_device.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cc_eval_mean_std.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.cc_eval_mean_std.restype = None
+        L.cc_eval_summarize.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.cc_eval_summarize.restype = None
+        L._eval_ready = True
+    return L
+
+
+def eval_frame(semantic, euclid, is_ground, detection, device: int = 0) -> np.ndarray:
+    """KittiEvaluation::evaluate for one frame on the GPU -> [tp, fn, fp, tn, OSE, USE] (kitti_evaluation.hpp:38-49)."""
+    semantic = np.ascontiguousarray(semantic, dtype=np.uint16)
+    euclid = np.ascontiguousarray(euclid, dtype=np.uint32)
+    is_ground = np.ascontiguousarray(is_ground, dtype=np.uint8)
+    detection = np.ascontiguousarray(detection, dtype=np.uint32)
+    out = np.zeros(6, dtype=np.float64)
+    rc = _lib().cc_eval_frame(device, semantic.shape[0], semantic.ctypes.data, euclid.ctypes.data, is_ground.ctypes.data,
+                              detection.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"cc_eval_frame failed with {rc}")
+    return out
+
+
+def eval_frame_device(n: int, d_semantic, d_euclid, d_is_ground, d_detection) -> np.ndarray:
+    """Same, for arrays already in HBM (torch tensors or raw device pointers)."""
+    from . import _ptr
+    out = np.zeros(6, dtype=np.float64)
+    rc = _lib().cc_eval_frame_device(n, _ptr(d_semantic), _ptr(d_euclid), _ptr(d_is_ground), _ptr(d_detection), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"cc_eval_frame_device failed with {rc}")
+    return out
+
+
+def summarize(frames: np.ndarray) -> dict:
+    """generateEvaluationResults' six (mean, sigma) pairs (kitti_evaluation.cpp:187-208) over per-frame records [k, 6]."""
+    frames = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 6)
+    out = np.zeros(12, dtype=np.float64)
+    _lib().cc_eval_summarize(frames.ctypes.data, frames.shape[0], out.ctypes.data)
+    names = ("recall", "precision", "f1", "accuracy", "use", "ose")
+    return {n: (out[2 * i], out[2 * i + 1]) for i, n in enumerate(names)}
+
+
+def format_row(name: str, summary: dict) -> str:
+    """One line of the reference's Markdown table (kitti_evaluation.cpp:180-208): first four metrics x100, two decimals."""
+    cells = []
+    for i, k in enumerate(("recall", "precision", "f1", "accuracy", "use", "ose")):
+        m, s = summary[k]
+        if i < 4:
+            m, s = m * 100, s * 100
+        cells.append(f"| {m:.2f} / {s:.2f} ")
+    return f"| {name} " + "".join(cells) + "|"
+
+
+class FrameScatter:
+    """Maps published range-image cells back to the points of their frames, like addColumnAndEvaluateFrameIfCompleted
+    (kitti_demo.cpp:173-224): globally_unique_point_index = sequence << 48 | frame << 32 | point index (kitti_demo.cpp:153-155,
+    199-201); frame N is evaluated when the first cell of frame N + 1 is published (kitti_demo.cpp:208-209, 221-222)."""
+
+    def __init__(self, sequence: int, frame_sizes, semantic, euclid, evaluate=eval_frame):
+        self.sequence = sequence
+        self.semantic = semantic      # list of per-frame uint16 arrays
+        self.euclid = euclid          # list of per-frame uint32 arrays
+        self.is_ground = [np.zeros(n, np.uint8) for n in frame_sizes]
+        self.detection = [np.zeros(n, np.uint32) for n in frame_sizes]
+        self.previous_frame = 0
+        self.records = []             # (sequence, frame, 6 result values)
+        self.evaluate = evaluate
+
+    def add_columns(self, unique_index: np.ndarray, ground_label: np.ndarray, ids: np.ndarray, gp_ground: int = 54):
+        """unique_index / ground_label / ids: [columns, rows] of the newly published columns, in column order."""
+        for c in range(unique_index.shape[0]):
+            u = unique_index[c]
+            has = u != np.uint64(2 ** 64 - 1)
+            if not has.any():
+                continue
+            frame = ((u[has] >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64)
+            pt = (u[has] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+            if (frame < self.previous_frame).any():
+                raise RuntimeError("Found a point belonging to a frame that was already evaluated!")
+            if (frame > self.previous_frame + 1).any():
+                raise RuntimeError("Found a point whose frame is too far ahead!")
+            for f in np.unique(frame):
+                m = frame == f
+                self.is_ground[f][pt[m]] = (ground_label[c][has][m] == gp_ground)
+                self.detection[f][pt[m]] = ids[c][has][m].astype(np.uint32)
+            if (frame == self.previous_frame + 1).any():
+                self._evaluate_previous()
+
+    def _evaluate_previous(self):
+        f = self.previous_frame
+        r = self.evaluate(self.semantic[f], self.euclid[f], self.is_ground[f], self.detection[f])
+        self.records.append((self.sequence, f, *[float(v) for v in r]))
+        self.previous_frame += 1
+
+    def finish(self):
+        """Evaluate the last frame that received points (the reference never flushes it; used by tests only)."""
+        self._evaluate_previous()
+
+
+def gather_records(records, group=None) -> np.ndarray:
+    """All-gather the per-frame records [(sequence, frame, tp, fn, fp, tn, OSE, USE)] of every rank and return them sorted by
+    (sequence, frame) — the order in which the reference's single process would have produced them. Fixed-size padded buffers,
+    one collective. Works on any initialised torch.distributed backend; the tensors live on the GPU for nccl
+    (= RCCL) and on the CPU for gloo."""
+    import torch
+    import torch.distributed as dist
+    local = np.asarray(records, dtype=np.float64).reshape(-1, 8)
+    if not dist.is_available() or not dist.is_initialized():
+        order = np.lexsort((local[:, 1], local[:, 0])) if len(local) else np.zeros(0, dtype=np.int64)
+        return local[order]
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    count = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+    counts = [torch.zeros_like(count) for _ in range(world)]
+    dist.all_gather(counts, count, group=group)
+    max_n = max(int(c.item()) for c in counts)
+    buf = torch.zeros((max(max_n, 1), 8), dtype=torch.float64, device=dev)
+    if local.shape[0]:
+        buf[: local.shape[0]] = torch.from_numpy(local).to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    parts = [b[: int(c.item())].cpu().numpy() for b, c in zip(bufs, counts)]
+    allr = np.concatenate(parts) if parts else np.zeros((0, 8))
+    order = np.lexsort((allr[:, 1], allr[:, 0]))
+    return allr[order]
+
+
+def shard_streams(num_streams: int, world: int, rank: int):
+    """Stream s is owned by rank s mod world: streams never interact, so ranks share nothing on the data path."""
+    return [s for s in range(num_streams) if s % world == rank]

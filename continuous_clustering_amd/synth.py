@@ -82,6 +82,7 @@ class Stream:
     intensity: np.ndarray  # [F, rows] uint8
     poses: np.ndarray      # [F, 12] float64, odom_from_sensor as row-major 3x4 [R|t]
     sensor: SensorModel = field(default_factory=SensorModel)
+    hit: np.ndarray | None = None  # [F, rows] uint16: 0 no return, 1 ground, 2 wall, 3 + i object i (ground truth for evaluation)
 
     @property
     def n_firings(self) -> int:
@@ -99,13 +100,14 @@ def _scene_params(scene: SceneModel, seed: int):
 
 
 def _cast(xp, o, d, cx, cy, rad, scene: SceneModel):
-    """o: [F,1,3] ray origins, d: [F,R,3] unit directions (odom frame). Returns range t [F,R] (inf = no hit)."""
+    """o: [F,1,3] ray origins, d: [F,R,3] unit directions (odom frame). Returns (range t [F,R] (inf = no hit), hit id [F,R])."""
     inf = float("inf")
     ox, oy, oz = o[..., 0], o[..., 1], o[..., 2]
     dx, dy, dz = d[..., 0], d[..., 1], d[..., 2]
     # ground plane
     tg = xp.where(dz < 0, (scene.ground_z - oz) / xp.where(dz < 0, dz, -1.0), inf)
     t = tg
+    hit = xp.where(tg < inf, 1, 0)
     dxy2 = dx * dx + dy * dy
     dxy2 = xp.where(dxy2 > 1e-12, dxy2, 1e-12)
     # cylinders: [F,R,N]
@@ -121,7 +123,10 @@ def _cast(xp, o, d, cx, cy, rad, scene: SceneModel):
         zc = oz[..., None] + tc * dz[..., None]
         ok = ok & (tc > 0.05) & (zc <= scene.object_top_z) & (zc >= scene.ground_z)
         tc = xp.where(ok, tc, inf)
-        t = xp.minimum(t, tc.min(-1) if xp is np else tc.min(-1).values)
+        tmin = tc.min(-1) if xp is np else tc.min(-1).values
+        imin = tc.argmin(-1)
+        hit = xp.where(tmin < t, imin + 3, hit)
+        t = xp.minimum(t, tmin)
     # wall ring centred on the world origin, hit from the inside (far root)
     if scene.wall_radius > 0:
         b = ox * dx + oy * dy
@@ -137,8 +142,10 @@ def _cast(xp, o, d, cx, cy, rad, scene: SceneModel):
             ang = xp.where(ang < 0, ang + 360.0, ang)
             for g0, g1 in scene.wall_gaps_deg:
                 ok = ok & ~((ang >= g0) & (ang <= g1))
-        t = xp.minimum(t, xp.where(ok, tw, inf))
-    return t
+        tw = xp.where(ok, tw, inf)
+        hit = xp.where(tw < t, 2, hit)
+        t = xp.minimum(t, tw)
+    return t, hit
 
 
 def make_stream(n_firings: int, seed: int = 1234, sensor: SensorModel | None = None, scene: SceneModel | None = None,
@@ -165,7 +172,9 @@ def make_stream(n_firings: int, seed: int = 1234, sensor: SensorModel | None = N
 
     cxx, cyy, radd, incl_x, offs_x = A(cx), A(cy), A(rad), A(incl), A(offs)
     rng = np.random.default_rng(seed + 7919)
-    xyz_parts, int_parts, pose_parts = [], [], []
+    if not is_np:
+        import torch
+    xyz_parts, int_parts, pose_parts, hit_parts = [], [], [], []
     for f0 in range(0, n_firings, chunk):
         f1 = min(n_firings, f0 + chunk)
         k = A(np.arange(f0, f1, dtype=np.float64))
@@ -192,20 +201,20 @@ def make_stream(n_firings: int, seed: int = 1234, sensor: SensorModel | None = N
         dwy = syw[:, None] * ds[..., 0] + cyw[:, None] * ds[..., 1]
         dw = xp.stack([dwx, dwy, ds[..., 2]], -1)
         o = xp.stack([px, py, pz], -1)[:, None, :]
-        t = _cast(xp, o, dw, cxx, cyy, radd, scene)
+        t, hit = _cast(xp, o, dw, cxx, cyy, radd, scene)
         F = f1 - f0
         if is_np:
             noise = rng.uniform(-scene.range_noise, scene.range_noise, (F, R))
             drop = rng.uniform(0, 1, (F, R)) < scene.dropout
             inten = rng.integers(0, 256, (F, R), dtype=np.uint8)
         else:
-            import torch
             g = torch.Generator(device=device)
             g.manual_seed(seed * 1000003 + f0)
             noise = (torch.rand((F, R), generator=g, device=device, dtype=torch.float64) * 2 - 1) * scene.range_noise
             drop = torch.rand((F, R), generator=g, device=device) < scene.dropout
             inten = torch.randint(0, 256, (F, R), generator=g, device=device, dtype=torch.uint8)
         valid = (t < scene.max_range) & ~drop
+        hit = xp.where(valid, hit, 0)
         tt = xp.where(valid, t + noise, float("nan"))
         pts = ds * tt[..., None]
         pose = xp.stack([cyw, -syw, xp.zeros_like(cyw), px,
@@ -214,11 +223,11 @@ def make_stream(n_firings: int, seed: int = 1234, sensor: SensorModel | None = N
         if is_np:
             xyz_parts.append(pts.astype(np.float32))
         else:
-            import torch
             xyz_parts.append(pts.to(torch.float32))
         int_parts.append(inten)
         pose_parts.append(pose)
+        hit_parts.append(hit.astype(np.uint16) if is_np else hit.to(torch.int16))
     if is_np:
-        return Stream(np.concatenate(xyz_parts), np.concatenate(int_parts), np.concatenate(pose_parts), sensor)
+        return Stream(np.concatenate(xyz_parts), np.concatenate(int_parts), np.concatenate(pose_parts), sensor, np.concatenate(hit_parts))
     import torch
-    return Stream(torch.cat(xyz_parts), torch.cat(int_parts), torch.cat(pose_parts), sensor)
+    return Stream(torch.cat(xyz_parts), torch.cat(int_parts), torch.cat(pose_parts), sensor, torch.cat(hit_parts))

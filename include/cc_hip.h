@@ -250,6 +250,29 @@ int cc_engine_kernel_times(cc_engine* e, double ms[7], uint64_t* launches);
 int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters_finished, uint64_t* firings_consumed,
                      uint64_t* serial_columns);
 
+/* ---- label compare (src/evaluation/kitti_evaluation.cpp) ---------------------------------------------------------------- */
+/* EvaluationResultForFrame, kitti_evaluation.hpp:38-49 */
+typedef struct cc_eval_frame_result
+{
+    double tp, fn, fp, tn;
+    double over_segmentation_entropy;
+    double under_segmentation_entropy;
+} cc_eval_frame_result;
+
+/* KittiEvaluation::evaluate for one frame (kitti_evaluation.cpp:29-146): ground confusion counts over the points whose semantic
+ * label is not "unlabeled", OSE / USE between euclidean ground-truth labels and detection ids. Arrays have n entries (one per
+ * point of the frame): semantic label (SemanticKITTI numeric id), euclidean-clustering label, is_ground flag, detection id.
+ * cc_eval_frame takes host arrays, cc_eval_frame_device device arrays (current HIP device). */
+int cc_eval_frame(int device, int64_t n, const uint16_t* semantic, const uint32_t* euclid, const uint8_t* is_ground,
+                  const uint32_t* detection, cc_eval_frame_result* out);
+int cc_eval_frame_device(int64_t n, const uint16_t* d_semantic, const uint32_t* d_euclid, const uint8_t* d_is_ground,
+                         const uint32_t* d_detection, cc_eval_frame_result* out);
+/* calculateMeanAndStdDev (kitti_evaluation.cpp:277-293) */
+void cc_eval_mean_std(const double* data, int64_t n, double* mean, double* std_dev);
+/* the six {mean, sigma} pairs of generateEvaluationResults (kitti_evaluation.cpp:187-208) over n frames: recall, precision, F1,
+ * accuracy (as fractions), USE, OSE */
+void cc_eval_summarize(const cc_eval_frame_result* frames, int64_t n, double out[12]);
+
 /* Human-readable text of the last failing call on this engine (never NULL). */
 const char* cc_engine_last_error(cc_engine* e);
 /* Library / build identification, e.g. "continuous_clustering_amd 0.1 gfx950". */

@@ -19,10 +19,9 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "cc_oracle.cpp")
-    hdr = os.path.join(_HERE, "..", "include", "cc_hip.h")
+    srcs = [os.path.join(_HERE, "cc_oracle.cpp"), os.path.join(_HERE, "eval_oracle.cpp"), os.path.join(_HERE, "..", "include", "cc_hip.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr))
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "libcc_oracle.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
@@ -55,6 +54,9 @@ def lib():
         L.orc_published_base.argtypes = [C.c_void_p]
         L.orc_published_count.restype = C.c_int64
         L.orc_published_count.argtypes = [C.c_void_p]
+        L.orc_eval_frame.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_eval_mean_std.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_eval_mean_std.restype = None
         _lib = L
     return _lib
 
@@ -133,3 +135,22 @@ class Oracle:
         if rc != 0:
             raise ValueError(f"orc_read_published({frm},{to}) -> {rc}")
         return arrays
+
+
+def eval_frame(semantic, euclid, is_ground, detection) -> np.ndarray:
+    """Reference-order label compare of one frame -> [tp, fn, fp, tn, OSE, USE]."""
+    semantic = np.ascontiguousarray(semantic, dtype=np.uint16)
+    euclid = np.ascontiguousarray(euclid, dtype=np.uint32)
+    is_ground = np.ascontiguousarray(is_ground, dtype=np.uint8)
+    detection = np.ascontiguousarray(detection, dtype=np.uint32)
+    out = np.zeros(6, dtype=np.float64)
+    lib().orc_eval_frame(semantic.shape[0], semantic.ctypes.data, euclid.ctypes.data, is_ground.ctypes.data, detection.ctypes.data,
+                         out.ctypes.data)
+    return out
+
+
+def mean_std(data):
+    data = np.ascontiguousarray(data, dtype=np.float64)
+    m, s = C.c_double(0), C.c_double(0)
+    lib().orc_eval_mean_std(data.ctypes.data, data.shape[0], C.byref(m), C.byref(s))
+    return m.value, s.value

@@ -1,0 +1,152 @@
+"""CPU: the evaluation row — oracle label compare against an independent numpy formulation, the product's host-side summary
+(cc_eval_summarize, no GPU needed), the kitti_demo-style frame scatter, and the world_size-2 gloo gather of per-frame records."""
+import math
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def numpy_eval(semantic, euclid, is_ground, detection):
+    ground_ids = (40, 44, 48, 49, 60, 72)
+    lab = semantic != 0
+    gt = np.isin(semantic, ground_ids)
+    seg = is_ground != 0
+    tp = (lab & gt & seg).sum()
+    fn = (lab & gt & ~seg).sum()
+    fp = (lab & ~gt & seg).sum()
+    tn = (lab & ~gt & ~seg).sum()
+    ose = 0.0
+    for g in np.unique(euclid[euclid != 0]):
+        m = euclid == g
+        _, cnt = np.unique(detection[m], return_counts=True)
+        for c in cnt:  # np.unique sorts ascending, like std::map
+            frac = float(c) / float(m.sum())
+            ose -= frac * math.log(frac)
+    use = 0.0
+    for d in np.unique(detection[detection != 0]):
+        m = detection == d
+        keys, cnt = np.unique(euclid[m], return_counts=True)
+        if len(keys) == 1 and keys[0] == 0:
+            continue
+        for c in cnt:
+            frac = float(c) / float(m.sum())
+            use -= frac * math.log(frac)
+    return np.array([tp, fn, fp, tn, ose, use], dtype=np.float64)
+
+
+def random_frame(rng, n, n_gt=30, n_det=40):
+    semantic = rng.choice(np.array([0, 10, 40, 44, 48, 49, 50, 60, 72, 80], dtype=np.uint16), n)
+    euclid = rng.integers(0, n_gt, n).astype(np.uint32)
+    euclid[rng.random(n) < 0.4] = 0
+    detection = (euclid * 3 + rng.integers(0, 2, n)).astype(np.uint32)
+    detection[rng.random(n) < 0.3] = 0
+    detection[rng.random(n) < 0.1] = rng.integers(1, n_det)
+    is_ground = (rng.random(n) < 0.5).astype(np.uint8)
+    return semantic, euclid, is_ground, detection
+
+
+def test_oracle_eval_matches_numpy_formulation(oracle_lib):
+    from oracle import pyoracle
+    rng = np.random.default_rng(1)
+    for n in (1, 17, 5000, 60000):
+        f = random_frame(rng, n)
+        a, b = pyoracle.eval_frame(*f), numpy_eval(*f)
+        assert np.array_equal(a[:4], b[:4])
+        assert np.allclose(a[4:], b[4:], rtol=1e-12, atol=1e-12)
+    # a detection containing only unlabeled ground truth contributes nothing (kitti_evaluation.cpp:133-134)
+    a = pyoracle.eval_frame(np.array([40, 40, 50]), np.array([0, 0, 0]), np.array([1, 0, 0]), np.array([5, 5, 5]))
+    assert a.tolist() == [1.0, 1.0, 0.0, 1.0, 0.0, 0.0]
+
+
+def test_summary_matches_oracle_mean_std(oracle_lib):
+    from continuous_clustering_amd import build, evaluation
+    from oracle import pyoracle
+    build.build()
+    rng = np.random.default_rng(2)
+    frames = np.stack([pyoracle.eval_frame(*random_frame(rng, 3000)) for _ in range(37)])
+    s = evaluation.summarize(frames)
+    tp, fn, fp, tn, ose, use = frames.T
+    for name, data in (("recall", tp / (tp + fn)), ("precision", tp / (tp + fp)), ("f1", (tp + tp) / (tp + tp + fp + fn)),
+                       ("accuracy", (tp + tn) / (tp + tn + fp + fn)), ("use", use), ("ose", ose)):
+        m, sd = pyoracle.mean_std(data)
+        assert s[name] == (m, sd), name  # bit-equal: same two-pass order (kitti_evaluation.cpp:277-293)
+    row = evaluation.format_row("All (**Ours**)", s)
+    assert row.count("|") == 8 and "/" in row
+
+
+def test_frame_scatter_follows_kitti_demo(oracle_lib):
+    from continuous_clustering_amd import evaluation
+    from oracle import pyoracle
+    rows, cols, frames = 4, 6, 3
+    n_pts = rows * cols
+    rng = np.random.default_rng(3)
+    semantic = [rng.choice(np.array([0, 40, 50], dtype=np.uint16), n_pts) for _ in range(frames)]
+    euclid = [rng.integers(0, 4, n_pts).astype(np.uint32) for _ in range(frames)]
+    sc = evaluation.FrameScatter(7, [n_pts] * frames, semantic, euclid, evaluate=pyoracle.eval_frame)
+    ground = rng.choice(np.array([54, 119, 143], dtype=np.uint8), (frames * cols, rows))
+    ids = rng.integers(0, 5, (frames * cols, rows)).astype(np.uint64)
+    uidx = np.zeros((frames * cols, rows), dtype=np.uint64)
+    for c in range(frames * cols):
+        f, k = divmod(c, cols)
+        for r in range(rows):
+            uidx[c, r] = (7 << 48) | (f << 32) | (k * rows + r)
+    uidx[2, 1] = np.uint64(2 ** 64 - 1)  # an empty cell
+    for c0 in range(0, frames * cols, 5):  # publish in ragged chunks
+        sc.add_columns(uidx[c0:c0 + 5], ground[c0:c0 + 5], ids[c0:c0 + 5])
+    assert [r[1] for r in sc.records] == [0, 1]  # frame N is evaluated when frame N+1 shows up
+    sc.finish()
+    assert len(sc.records) == 3
+    f0 = sc.records[0]
+    exp_ground = (ground[:cols].reshape(-1) == 54).astype(np.uint8)
+    exp_ground[2 * rows + 1] = 0
+    exp_ids = ids[:cols].reshape(-1).astype(np.uint32)
+    exp_ids[2 * rows + 1] = 0
+    assert np.array_equal(np.array(f0[2:]), pyoracle.eval_frame(semantic[0], euclid[0], exp_ground, exp_ids))
+    with pytest.raises(RuntimeError):
+        sc.add_columns(uidx[:1], ground[:1], ids[:1])  # a frame that was already evaluated (kitti_demo.cpp:204-205)
+
+
+def _gloo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from continuous_clustering_amd import evaluation
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    streams = evaluation.shard_streams(7, world, rank)
+    rng = np.random.default_rng(100 + rank)
+    recs = []
+    for s in streams:
+        for f in range(3 + s % 2):
+            recs.append((s, f, *rng.integers(1, 100, 4).astype(float), float(rng.random()), float(rng.random())))
+    out = evaluation.gather_records(recs)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, streams, recs, out))
+
+
+def test_gather_records_world_size_2_gloo():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort()
+    owned = sorted(res[0][1] + res[1][1])
+    assert owned == list(range(7)) and not set(res[0][1]) & set(res[1][1])  # every stream on exactly one rank
+    all_recs = sorted(res[0][2] + res[1][2])
+    for _, _, _, out in res:  # every rank ends up with the same, ordered, complete table
+        assert out.shape == (len(all_recs), 8)
+        assert np.array_equal(out, np.array(all_recs))
