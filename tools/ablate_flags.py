@@ -1,5 +1,5 @@
 import sys, json
-sys.path.insert(0,'.')
+sys.path.insert(0,'.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 from continuous_clustering_amd import Engine, capi, synth
 import bench

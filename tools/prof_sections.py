@@ -1,5 +1,5 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0,'.')
+sys.path.insert(0,'.'); sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import torch
 import continuous_clustering_amd as cca
 cca.LIB_PATH = cca.LIB_PATH.replace("libcc_hip.so","libcc_hip_prof.so")
