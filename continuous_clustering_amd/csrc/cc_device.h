@@ -21,9 +21,9 @@ constexpr int MAX_ROWS_PER_LANE = 2; // num_rows <= 128
 constexpr int LINK_SLOTS = 4;        // link candidates recorded per point by the static window scan
 constexpr int WIN_COLS = 32;         // columns of tree-slot ids kept in LDS by the association kernel
 constexpr int PP_SKIP = 0x7fffffff;
-constexpr int INS_WIN = 128;         // columns of `distance` kept in LDS by the insertion kernel
+constexpr int INS_WIN = 64;          // columns of `distance` kept in LDS by the insertion kernel
 constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLOSE = 16;
-constexpr int TREE_SLOTS = 512;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
+constexpr int TREE_SLOTS = 256;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
 
 // Scalar state of one sensor stream: the srig_*/sgps_*/sc_* members of the reference class
 // (continuous_clustering.hpp:244-275) plus engine bookkeeping.
@@ -51,8 +51,8 @@ struct StreamState
     double last_round_min_az;  // column-min azimuth of the previous tree-combination round (the BFS "visited stamp")
     // batch bookkeeping
     int64_t clear_allowed; // ring_start when the current host call began: clearing never passes what the host has seen
-    // per-batch hand-off from the insertion chain to the segmentation / association chain; two slots because batch b + 1
-    // is inserted (HIP stream 1) while batch b is still segmented and associated (HIP stream 2)
+    // per-batch hand-off from the insertion chain to the segmentation / association chain; four slots because up to three
+    // batches are in flight: b + 2 being inserted, b + 1 segmented / scanned, b associated (three HIP streams)
     struct BatchDesc
     {
         int64_t seg_begin; // columns [seg_begin, seg_end) were emitted by the insertion kernel in this batch
@@ -60,7 +60,7 @@ struct StreamState
         int64_t acp_next;  // next column the association kernels process
         int64_t pub_begin; // columns [pub_begin, pub_end) were published while this batch was associated
         int64_t pub_end;
-    } batch[2];
+    } batch[4];
     int32_t assoc_mode; // 0: tree state in LDS (k_assoc_lds), 1: tree state in global memory (k_associate)
     int32_t pad1;
     int64_t cursor;     // firings of the current batch already consumed

@@ -24,11 +24,12 @@ struct cc_engine
     int* d_remaining{nullptr};
     int* h_remaining{nullptr}; // pinned
     hipStream_t stream{nullptr};  // insertion chain (and everything else when not pipelined)
-    hipStream_t stream2{nullptr}; // segmentation / association chain of the pipelined throughput path
-    hipEvent_t ev_ins[2]{nullptr, nullptr}, ev_assoc[2]{nullptr, nullptr};
-    uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 1
-    bool pipelined{false};        // last submitted batch used both streams
-    bool assoc_pending[2]{false, false};
+    hipStream_t stream2{nullptr}; // table / segmentation / window-scan chain of the pipelined throughput path
+    hipStream_t stream3{nullptr}; // association / publish chain of the pipelined throughput path
+    hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{};
+    uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 3
+    bool pipelined{false};        // last submitted batch used all three streams
+    bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
     std::string error;
     // staging for the single-stream host path
@@ -200,7 +201,8 @@ int reset_state(cc_engine* e, bool keep_table)
     for (auto& v : e->pending_events)
         v.clear();
     e->batch_open = false;
-    e->assoc_pending[0] = e->assoc_pending[1] = false;
+    for (bool& b : e->assoc_pending)
+        b = false;
     return CC_OK;
 }
 
@@ -219,20 +221,21 @@ int ensure_prep(cc_engine* e, size_t points)
     return CC_OK;
 }
 
-// One pass over a batch: insertion chain on `si`, segmentation/association chain on `sa` (si == sa when not pipelined).
+// One pass over a batch: insertion on `si`, table + segmentation + window scan on `sb`, association + publish on `sa`
+// (all three equal when not pipelined).
 int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int,
-                 const double* d_pose, bool first_pass, int slot, hipStream_t si, hipStream_t sa)
+                 const double* d_pose, bool first_pass, int slot, hipStream_t si, hipStream_t sb, hipStream_t sa)
 {
     const Geometry& g = e->g;
     const int rpl = (g.num_rows + WAVE - 1) / WAVE;
     // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
     const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
     dim3 seg_grid((unsigned) ((max_cols + 63) / 64), (unsigned) count);
-    constexpr int NK = 7;
-    hipEvent_t ev[NK + 2] = {};
+    constexpr int NEV = 10;
+    hipEvent_t ev[NEV] = {};
     if (e->timing)
     {
-        for (int i = 0; i < NK + 2; i++)
+        for (int i = 0; i < NEV; i++)
         {
             if (e->ev_used == e->ev_pool.size())
             {
@@ -267,51 +270,58 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         else
             hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, si, g, e->cfg, e->P, e->d_states, first_stream, slot,
                                d_int, (long long) n, e->d_remaining);
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64), 0, si, g, e->P, e->d_states, first_stream, slot);
-        else
-            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64), 0, si, g, e->P, e->d_states, first_stream, slot);
     }
-    CC_MARK(si); // ev2: insert + table
+    CC_MARK(si); // ev2: insert
     CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
-    if (si != sa)
+    if (si != sb)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
-        CC_HIP_CHECK(e, hipStreamWaitEvent(sa, e->ev_ins[slot], 0));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(sb, e->ev_ins[slot], 0));
     }
-    // ---- segmentation / association chain --------------------------------------------------------------------
-    CC_MARK(sa); // ev3: start of the second chain
+    // ---- table + segmentation + window-scan chain ------------------------------------------------------------
+    CC_MARK(sb); // ev3: start of the second chain
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states,
+        hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64), 0, sb, g, e->P, e->d_states, first_stream, slot);
+    else
+        hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64), 0, sb, g, e->P, e->d_states, first_stream, slot);
+    if (rpl == 1)
+        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
                            first_stream, slot, d_pose, (long long) n);
     else
-        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states,
+        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
                            first_stream, slot, d_pose, (long long) n);
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
-        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
-    CC_MARK(sa); // ev4: segment
+    CC_MARK(sb); // ev4: table + segment
     const dim3 scan_grid(cck::SCAN_BLOCKS, (unsigned) count);
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    CC_MARK(sa); // ev5: scan
+        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    CC_MARK(sb); // ev5: scan
+    if (sb != sa)
+    {
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_seg[slot], sb));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(sa, e->ev_seg[slot], 0));
+    }
+    // ---- association + publish chain -------------------------------------------------------------------------
+    CC_MARK(sa); // ev6: start of the third chain
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
         hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    CC_MARK(sa); // ev6: assoc_lds
+    CC_MARK(sa); // ev7: assoc_lds
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    CC_MARK(sa); // ev7: assoc_global
+    CC_MARK(sa); // ev8: assoc_global
     hipLaunchKernelGGL(cck::k_publish, dim3(cck::PUBLISH_BLOCKS, (unsigned) count), dim3(64), 0, sa, g, e->P, e->d_states, first_stream,
                        slot);
-    CC_MARK(sa); // ev8: publish
+    CC_MARK(sa); // ev9: publish
 #undef CC_MARK
     if (si != sa)
     {
@@ -351,10 +361,10 @@ int collect_events(cc_engine* e, int first_stream, int count);
 
 int resolve_timing(cc_engine* e)
 {
-    // 9 events per pass: ev0 | prep | ev1 | insert+table | ev2 ... ev3 | segment | ev4 | scan | ev5 | assoc_lds | ev6 | assoc_global |
-    // ev7 | publish | ev8
-    static const int from[7] = {0, 1, 3, 4, 5, 6, 7};
-    for (size_t i = 0; i + 8 < e->ev_used; i += 9)
+    // 10 events per pass: ev0 | prep | ev1 | insert | ev2 ... ev3 | table+segment | ev4 | scan | ev5 ... ev6 | assoc_lds | ev7 |
+    // assoc_global | ev8 | publish | ev9
+    static const int from[7] = {0, 1, 3, 4, 6, 7, 8};
+    for (size_t i = 0; i + 9 < e->ev_used; i += 10)
     {
         for (int k = 0; k < 7; k++)
         {
@@ -372,7 +382,9 @@ int sync_all(cc_engine* e)
 {
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
-    e->assoc_pending[0] = e->assoc_pending[1] = false;
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
+    for (bool& b : e->assoc_pending)
+        b = false;
     return CC_OK;
 }
 
@@ -393,10 +405,10 @@ int finish_batch(cc_engine* e)
         if (*e->h_remaining == 0)
             break;
         hipLaunchKernelGGL(k_clear_remaining, dim3(1), dim3(1), 0, e->stream, e->d_remaining);
-        const int slot = (int) (e->batch_seq & 1);
+        const int slot = (int) (e->batch_seq & 3);
         e->batch_seq++;
         rc = launch_batch(e, e->last_first, e->last_count, e->last_n, e->last_xyz, e->last_int, e->last_pose, false, slot, e->stream,
-                          e->stream);
+                          e->stream, e->stream);
         if (rc)
             return rc;
     }
@@ -421,18 +433,18 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
         else if ((rc = finish_batch(e)))
             return rc;
     }
-    const int slot = (int) (e->batch_seq & 1);
+    const int slot = (int) (e->batch_seq & 3);
     e->batch_seq++;
-    hipStream_t si = e->stream, sa = pipeline ? e->stream2 : e->stream;
+    hipStream_t si = e->stream, sb = pipeline ? e->stream2 : e->stream, sa = pipeline ? e->stream3 : e->stream;
     if (pipeline && e->assoc_pending[slot])
     {
-        // descriptor slot and staging planes of batch b - 2 must have been consumed
+        // the descriptor slot of batch b - 4 must have been consumed
         CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_assoc[slot], 0));
         e->assoc_pending[slot] = false;
     }
     hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining,
                        pipeline ? 1 : 0);
-    rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true, slot, si, sa);
+    rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true, slot, si, sb, sa);
     if (rc)
         return rc;
     e->last_xyz = d_xyz;
@@ -553,14 +565,16 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     cc_engine* e = new cc_engine();
     e->device = device;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess)
+        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess)
     {
         delete e;
         return CC_ERR_HIP;
     }
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 4; i++)
     {
         (void) hipEventCreateWithFlags(&e->ev_ins[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_seg[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_assoc[i], hipEventDisableTiming);
     }
     e->cfg = *cfg;
@@ -602,13 +616,16 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipSetDevice(e->device);
     (void) hipStreamSynchronize(e->stream);
     (void) hipStreamSynchronize(e->stream2);
+    (void) hipStreamSynchronize(e->stream3);
     free_all(e);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < 4; i++)
     {
         (void) hipEventDestroy(e->ev_ins[i]);
+        (void) hipEventDestroy(e->ev_seg[i]);
         (void) hipEventDestroy(e->ev_assoc[i]);
     }
     (void) hipStreamDestroy(e->stream2);
+    (void) hipStreamDestroy(e->stream3);
     for (hipEvent_t ev : e->ev_pool)
         (void) hipEventDestroy(ev);
     if (e->h_remaining)
@@ -661,6 +678,7 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     (void) hipSetDevice(e->device);
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
     e->batch_open = false;
     const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
     if (!same_shape)

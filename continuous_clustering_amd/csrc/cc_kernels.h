@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes 
 // per stream, lanes = rows; the `distance` plane of the INS_WIN columns around the insertion front lives in LDS so that the
 // occupancy tests never wait for HBM.
 // =====================================================================================================
-constexpr int INS_RING = 16; // firings staged in LDS ahead of the consumer wave
+constexpr int INS_RING = 8;  // firings staged in LDS ahead of the consumer wave
 
 __host__ inline size_t insert2_lds_bytes(int R)
 {

@@ -237,7 +237,7 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
 int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_label, const uint32_t** d_cluster_id);
 
 /* Engine tuning / test hooks. Names: "lds_tree_limit" (unfinished point trees per stream kept in LDS before the stream
- * continues in the global-memory association kernel, 1..512), "limit_columns" (columns one launch may emit per stream before
+ * continues in the global-memory association kernel, 1..256), "limit_columns" (columns one launch may emit per stream before
  * it hands back to the host), "debug_flags" (experiment switches, 0 in production). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
