@@ -65,16 +65,23 @@ def gen_inputs(torch, dev, sensor, n_streams, n_firings, n_batches, seed0):
     return xyz, inten, poses
 
 
-def cpu_baseline(cfg, sensor, xyz, inten, poses, n_threads):
-    """Mode C of BASELINE.md 3: n_threads independent single-threaded oracle instances, one stream each."""
-    from oracle.pyoracle import Oracle
+def cpu_baseline(cfg, sensor, xyz, inten, poses, n_threads, repeats):
+    """Mode C of BASELINE.md 3: n_threads independent single-threaded oracle instances, one stream each, every instance
+    replaying its sample `repeats` times from a fresh reset (only the addFiring loop is timed, like kitti_demo.cpp:421-424)."""
+    from oracle.pyoracle import Oracle, IDENTITY_TF
     n_threads = max(1, n_threads)
     R = sensor.num_rows
     oracles = [Oracle(cfg, R, record=False) for _ in range(n_threads)]
     times = [0.0] * n_threads
+    cells = [0] * n_threads
 
     def work(i):
-        times[i] = oracles[i].time_firings(xyz[i], inten[i], poses[i])
+        for rep in range(repeats):
+            if rep:
+                oracles[i].reset()
+                oracles[i].set_robot_from_sensor(IDENTITY_TF)
+            times[i] += oracles[i].time_firings(xyz[i], inten[i], poses[i])
+            cells[i] += oracles[i].state()["cells_published"]
 
     th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
     t0 = time.perf_counter()
@@ -83,9 +90,9 @@ def cpu_baseline(cfg, sensor, xyz, inten, poses, n_threads):
     for t in th:
         t.join()
     wall = time.perf_counter() - t0
-    cells = sum(o.state()["cells_published"] for o in oracles)
-    single = oracles[0].state()["cells_published"] / times[0] if times[0] > 0 else 0.0
-    return {"value": cells / max(times) / 1e6, "wall_s": wall, "single_core": single / 1e6, "cells": cells}
+    single = cells[0] / times[0] if times[0] > 0 else 0.0
+    return {"value": sum(cells) / max(times) / 1e6, "wall_s": wall, "single_core": single / 1e6, "cells": sum(cells),
+            "cpu_seconds": sum(times)}
 
 
 def main():
@@ -101,8 +108,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even at world size 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     sensor = synth.SensorModel.s64() if args.sensor == "s64" else synth.SensorModel.s128()
@@ -127,14 +138,14 @@ def main():
     eng.enable_timing(True)
 
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     t0 = time.perf_counter()
     for b in range(args.warmup, n_batches):
         step(b)
     rc = eng.sync()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if rc != 0:
@@ -146,7 +157,7 @@ def main():
     cells = after["cells_published"] - before["cells_published"]
     clusters = after["clusters_finished"] - before["clusters_finished"]
     # the one exchange step of the path: gather per-rank result counts (RCCL over xGMI), max of the elapsed times
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -217,23 +228,38 @@ def main():
             lat.append(time.perf_counter() - t1)
         lat = np.array(lat) * 1e6
         out["latency_us_per_column_single_stream"] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
-                                                      "mode": "1 firing per cc_engine_add_firings call (H2D + 3 kernels + sync)"}
+                                                      "mode": "1 firing per cc_engine_add_firings call (H2D + all kernels of the path + sync + event read-back)"}
         e1.close()
 
     # ---- CPU baseline on this box's host cores ------------------------------------------------------------------
     if rank == 0 and not args.no_cpu_baseline:
         ncpu = os.cpu_count() or 1
-        nthreads = args.cpu_threads or min(ncpu, 32, S)
+        nmax = args.cpu_threads or min(ncpu, 64, S)
         nb = min(n_batches, 4)
-        hx = xyz[:nb, :nthreads].permute(1, 0, 2, 3, 4).reshape(nthreads, nb * F, R, 3).cpu().numpy()
-        hi = inten[:nb, :nthreads].permute(1, 0, 2, 3).reshape(nthreads, nb * F, R).cpu().numpy()
-        hp = poses[:nb, :nthreads].permute(1, 0, 2, 3).reshape(nthreads, nb * F, 12).cpu().numpy()
-        cb = cpu_baseline(cfg, sensor, hx, hi, hp, nthreads)
+        repeats = 3
+        hx = xyz[:nb, :nmax].permute(1, 0, 2, 3, 4).reshape(nmax, nb * F, R, 3).cpu().numpy()
+        hi = inten[:nb, :nmax].permute(1, 0, 2, 3).reshape(nmax, nb * F, R).cpu().numpy()
+        hp = poses[:nb, :nmax].permute(1, 0, 2, 3).reshape(nmax, nb * F, 12).cpu().numpy()
+        # the multi-instance CPU path does not scale linearly (allocator / memory-bound AoS ring): sweep the instance count and
+        # report the best aggregate, so that the baseline is the CPU's best case on this host
+        sweep = {}
+        cb, nthreads = None, 1
+        for nt in sorted({1, 4, 8, 16, 32, nmax}):
+            if nt > nmax:
+                continue
+            r = cpu_baseline(cfg, sensor, hx, hi, hp, nt, repeats)
+            sweep[nt] = round(r["value"], 2)
+            if cb is None or r["value"] > cb["value"]:
+                cb, nthreads = r, nt
+            if nt == 1:
+                single = r["value"]
+        cb["single_core"] = single
         out["cpu_baseline"] = {
             "value": cb["value"], "unit": "Mpoints/s", "cores": nthreads, "kind": "port",
-            "sample": f"{nthreads} of the {S} streams x {nb} rotations ({cb['cells']} published cells), one single-threaded oracle "
-                      f"instance per host thread (BASELINE.md mode C); single instance on 1 core: {cb['single_core']:.2f} Mpoints/s",
-            "host_cpus": ncpu, "wall_s": cb["wall_s"],
+            "sample": f"{nthreads} of the {S} streams x {nb} rotations x {repeats} replays ({cb['cells']} published cells, "
+                      f"{cb['cpu_seconds']:.1f} CPU-seconds in the timed addFiring loops), one single-threaded oracle instance per host "
+                      f"thread (BASELINE.md mode C); single instance on 1 core: {cb['single_core']:.2f} Mpoints/s",
+            "host_cpus": ncpu, "wall_s": cb["wall_s"], "single_core_value": cb["single_core"], "sweep_instances_to_mpoints": sweep,
         }
     elif rank == 0:
         out["cpu_baseline"] = None
@@ -241,7 +267,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -70,6 +70,9 @@ def build_case(name: str):
     if name == "s64_no_early_stop":
         # stop_after_association disabled: many links per point -> exercises the exact serial association path
         return synth.make_stream(360 * 2 + 50, seed=12, sensor=_s64(360)), _kitti(360, stop_after_association_enabled=0), None
+    if name == "s64_wide_window_global_kernel":
+        # max_steps_in_row beyond the LDS window of k_assoc_lds: every stream runs the global-memory association kernel
+        return synth.make_stream(720 * 2 + 50, seed=22, sensor=_s64(720)), _kitti(720, max_steps_in_row=31), None
     if name == "s64_min_steps_3":
         return synth.make_stream(720 * 2 + 50, seed=13, sensor=_s64(720)), _kitti(720, stop_after_association_min_steps=3), None
     if name == "s64_dropouts":
@@ -109,7 +112,7 @@ def build_case(name: str):
 
 ALL_CASES = ["s64_static", "s64_translate", "s64_turn", "s64_full_2200", "s64_forced_finish_ring", "s64_ring_with_objects",
              "s64_fog_and_ego", "s64_counterclockwise", "s64_every_2nd_column", "s64_no_early_stop", "s64_min_steps_3",
-             "s64_dropouts", "s64_no_supplement_no_incl_ignore", "s64_robot_tf_tilted", "s128_offsets",
+             "s64_wide_window_global_kernel", "s64_dropouts", "s64_no_supplement_no_incl_ignore", "s64_robot_tf_tilted", "s128_offsets",
              "s128_no_offsets_translate", "s128_full_1700", "s32_small_sensor"]
 
 # cases stored as golden fixtures under tests/golden/ (inputs + expected outputs)

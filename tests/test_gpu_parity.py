@@ -79,3 +79,12 @@ def test_bad_start_sets_reset_required(oracle_lib):
     e2 = Engine(cfg, 64)
     e2.set_config(cfg2)
     assert e2.state()["reset_required"] == 1  # cc.cpp:73-74
+
+
+@pytest.mark.parametrize("name,limit", [("s64_no_supplement_no_incl_ignore", 4), ("s32_small_sensor", 2), ("s64_translate", 1)])
+def test_lds_tree_pool_overflow_continues_in_global_memory(name, limit, oracle_lib):
+    """When a stream has more unfinished point trees than fit the LDS pool, k_assoc_lds hands the stream to the
+    global-memory kernel mid-batch; results must not change. The pool size is lowered to force the hand-over."""
+    stream, cfg, tf = cases.build_case(name)
+    util.run_and_compare(stream, cfg, chunks=[stream.sensor.num_columns // 2], robot_tf=tf,
+                         engine_setup=lambda e: e.set_option("lds_tree_limit", limit))

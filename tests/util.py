@@ -55,7 +55,7 @@ def compare_columns(ao: dict, ae: dict, c0: int, check_raw_ids=True):
         assert bad.size == 0, f"raw cluster ids differ at (col {c0 + bad[0][0]}, row {bad[0][1]})"
 
 
-def run_and_compare(stream, cfg, chunks=None, robot_tf=None, expect_rc=0, check_raw_ids=True):
+def run_and_compare(stream, cfg, chunks=None, robot_tf=None, expect_rc=0, check_raw_ids=True, engine_setup=None):
     """Feed `stream` to the oracle (all at once) and to a 1-stream engine (in `chunks` firings per call); after every
     engine call compare the events it produced and the columns it published with the oracle's record."""
     from continuous_clustering_amd import Engine, IDENTITY_TF
@@ -63,6 +63,8 @@ def run_and_compare(stream, cfg, chunks=None, robot_tf=None, expect_rc=0, check_
     assert orc == expect_rc, f"oracle rc {orc} ({oracle.last_error()}), expected {expect_rc}"
     eo = oracle.drain_events()
     engine = Engine(cfg, stream.sensor.num_rows, 1, 0, IDENTITY_TF if robot_tf is None else robot_tf)
+    if engine_setup is not None:
+        engine_setup(engine)
     n = stream.n_firings
     chunks = chunks or [n]
     f = i = 0
