@@ -1059,8 +1059,19 @@ __host__ __device__ inline int seg_pitch_b(int R)
 }
 __host__ inline size_t seg_scan_lds_bytes(int R)
 {
-    return (size_t) 64 * seg_pitch_f(R) * 4 * 2 + (size_t) 64 * seg_pitch_b(R) * 4;
+    return (size_t) 64 * seg_pitch_f(R) * 4 * 2 + (size_t) 64 * seg_pitch_b(R) * 2;
 }
+
+// compact codes of the label values inside the LDS tile
+__device__ __constant__ const unsigned char SEG_GROUND_VALUE[5] = {CC_GP_UNKNOWN, CC_GP_GROUND, CC_GP_OBSTACLE, CC_GP_EGO_VEHICLE, CC_GP_FOG};
+__device__ __constant__ const unsigned char SEG_DEBUG_VALUE[10] = {CC_DBG_WHITE, CC_DBG_GRAY,   CC_DBG_ORANGE, CC_DBG_GREEN,    CC_DBG_YELLOWGREEN,
+                                                                   CC_DBG_YELLOW, CC_DBG_RED, CC_DBG_DARKRED, CC_DBG_VIOLET, CC_DBG_LIGHTGRAY};
+enum
+{
+    SG_G_UNKNOWN = 0, SG_G_GROUND = 1, SG_G_OBSTACLE = 2, SG_G_EGO = 3, SG_G_FOG = 4,
+    SG_D_WHITE = 0, SG_D_GRAY = 1, SG_D_ORANGE = 2, SG_D_GREEN = 3, SG_D_YELLOWGREEN = 4, SG_D_YELLOW = 5, SG_D_RED = 6, SG_D_DARKRED = 7,
+    SG_D_VIOLET = 8, SG_D_LIGHTGRAY = 9
+};
 
 __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
@@ -1081,9 +1092,9 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
     float* l_x2 = (float*) smem;
     float* l_uz = l_x2 + 64 * PF;
     unsigned char* l_flags = (unsigned char*) (l_uz + 64 * PF);
-    unsigned char* l_ground = l_flags + 64 * PB;
-    unsigned char* l_debug = l_ground + 64 * PB;
-    unsigned char* l_ign = l_debug + 64 * PB;
+    // one output byte per cell: bits 0-2 ground label code, bits 3-6 debug label code, bit 7 is_ignored (keeps the tile small
+    // enough for two blocks per CU next to the serial kernels of the other pipeline stages)
+    unsigned char* l_out = l_flags + 64 * PB;
 
     int lc0 = (int) (tile0 % RC);
     // load: one coalesced row-run per column, 8 columns in flight
@@ -1133,9 +1144,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
         const float* x2 = l_x2 + lane * PF;
         const float* uzp = l_uz + lane * PF;
         const unsigned char* fl = l_flags + lane * PB;
-        unsigned char* og = l_ground + lane * PB;
-        unsigned char* od = l_debug + lane * PB;
-        unsigned char* oi = l_ign + lane * PB;
+        unsigned char* oo = l_out + lane * PB;
         const float height_sensor_to_ground = -(float) st->robot_from_sensor[11] + cfg.height_ref_to_ground_;
         bool first_obstacle_detected = false, first_point_found = false;
         float lg2x = 0.f, lgz = height_sensor_to_ground; // last (quite certain) ground point in the azimuth plane
@@ -1144,23 +1153,20 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
         for (int row = R - 1; row >= 0; row--)
         {
             const int f = fl[row];
-            unsigned char ground = CC_GP_UNKNOWN, debug = CC_DBG_WHITE;
+            unsigned char ground = SG_G_UNKNOWN, debug = SG_D_WHITE;
             if (f & SG_NAN)
             {
-                og[row] = ground;
-                od[row] = debug;
+                oo[row] = (unsigned char) (ground | (debug << 3));
                 continue;
             }
             if (f & SG_FOG)
             {
-                og[row] = CC_GP_FOG;
-                od[row] = CC_DBG_LIGHTGRAY;
+                oo[row] = (unsigned char) (SG_G_FOG | (SG_D_LIGHTGRAY << 3));
                 continue;
             }
             if (f & SG_EGO)
             {
-                og[row] = CC_GP_EGO_VEHICLE;
-                od[row] = CC_DBG_VIOLET;
+                oo[row] = (unsigned char) (SG_G_EGO | (SG_D_VIOLET << 3));
                 continue;
             }
             const float cur2x = x2[row], cur2y = uzp[row];
@@ -1170,23 +1176,22 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 const float h = cur2y - height_sensor_to_ground;
                 if (h > cfg.first_ring_as_ground_min_allowed_z_diff && h < cfg.first_ring_as_ground_max_allowed_z_diff)
                 {
-                    ground = CC_GP_GROUND;
-                    debug = CC_DBG_GRAY;
+                    ground = SG_G_GROUND;
+                    debug = SG_D_GRAY;
                     lg2x = cur2x;
                     lgz = cur2y;
                     first_obstacle_detected = false;
                 }
                 else
                 {
-                    ground = CC_GP_OBSTACLE;
-                    debug = CC_DBG_ORANGE;
+                    ground = SG_G_OBSTACLE;
+                    debug = SG_D_ORANGE;
                     first_obstacle_detected = true;
                 }
                 pv2x = cur2x;
                 pvz = cur2y;
                 previous_label = debug;
-                og[row] = ground;
-                od[row] = debug;
+                oo[row] = (unsigned char) (ground | (debug << 3));
                 continue;
             }
             const float p2cx = cur2x - pv2x, p2cy = cur2y - pvz;
@@ -1198,38 +1203,38 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             const bool flat_lg = ccm::absf(slope_to_lg) < cfg.max_slope && l2cx > 0;
             if (!first_obstacle_detected && flat_prev)
             {
-                ground = CC_GP_GROUND;
-                debug = CC_DBG_GREEN;
+                ground = SG_G_GROUND;
+                debug = SG_D_GREEN;
             }
             else if (!cfg.use_terrain)
             {
                 if (first_obstacle_detected && flat_prev && flat_lg)
                 {
-                    ground = CC_GP_GROUND;
-                    debug = CC_DBG_YELLOWGREEN;
+                    ground = SG_G_GROUND;
+                    debug = SG_D_YELLOWGREEN;
                 }
                 else if (ccm::absf(l2cx) < cfg.ground_because_close_to_last_certain_ground_max_dist_diff &&
                          ccm::absf(l2cy) < cfg.ground_because_close_to_last_certain_ground_max_z_diff)
                 {
-                    ground = CC_GP_GROUND;
-                    debug = CC_DBG_YELLOW;
+                    ground = SG_G_GROUND;
+                    debug = SG_D_YELLOW;
                 }
             }
-            if (ground != CC_GP_GROUND)
+            if (ground != SG_G_GROUND)
             {
-                ground = CC_GP_OBSTACLE;
-                debug = CC_DBG_RED;
+                ground = SG_G_OBSTACLE;
+                debug = SG_D_RED;
                 int below = row + 1; // cc.cpp:513-535
                 while (below < R)
                 {
-                    const unsigned char bg = og[below], bd = od[below];
-                    if (bd == CC_DBG_YELLOW ||
-                        (bg == CC_GP_GROUND && ccm::absf(cur2x - x2[below]) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
+                    const unsigned char bo = oo[below];
+                    const unsigned char bg = bo & 7, bd = (bo >> 3) & 15;
+                    if (bd == SG_D_YELLOW ||
+                        (bg == SG_G_GROUND && ccm::absf(cur2x - x2[below]) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
                     {
-                        if (bg == CC_GP_GROUND)
+                        if (bg == SG_G_GROUND)
                         {
-                            og[below] = CC_GP_OBSTACLE;
-                            od[below] = CC_DBG_DARKRED;
+                            oo[below] = (unsigned char) (SG_G_OBSTACLE | (SG_D_DARKRED << 3));
                         }
                         below++;
                     }
@@ -1237,11 +1242,11 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                         break;
                 }
             }
-            first_obstacle_detected |= ground == CC_GP_OBSTACLE;
-            if (debug == CC_DBG_GREEN || debug == CC_DBG_YELLOWGREEN)
+            first_obstacle_detected |= ground == SG_G_OBSTACLE;
+            if (debug == SG_D_GREEN || debug == SG_D_YELLOWGREEN)
             {
                 if (slope_to_prev > cfg.last_ground_point_slope_higher_than &&
-                    ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than && previous_label != CC_DBG_YELLOW)
+                    ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than && previous_label != SG_D_YELLOW)
                 {
                     lg2x = cur2x;
                     lgz = cur2y;
@@ -1250,8 +1255,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             pv2x = cur2x;
             pvz = cur2y;
             previous_label = debug;
-            og[row] = ground;
-            od[row] = debug;
+            oo[row] = (unsigned char) (ground | (debug << 3));
         }
         for (int row = R - 1; row >= 0; row--) // cc.cpp:567-616
         {
@@ -1259,7 +1263,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             bool ign = false;
             if (f & SG_NAN)
                 ign = true;
-            else if (og[row] != CC_GP_OBSTACLE)
+            else if ((oo[row] & 7) != SG_G_OBSTACLE)
                 ign = true;
             else if (f & (SG_TOO_CLOSE | SG_INCL_IGNORE))
                 ign = true;
@@ -1270,7 +1274,8 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 if ((column_even && !row_even) || (!column_even && row_even))
                     ign = true;
             }
-            oi[row] = ign ? 1 : 0;
+            if (ign)
+                oo[row] |= 0x80;
         }
     }
     __syncthreads();
@@ -1282,9 +1287,10 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             for (int row = lane; row < R; row += 64)
             {
                 const size_t ci = (size_t) lc * R + row;
-                p.ground[ci] = l_ground[c * PB + row];
-                p.debug[ci] = l_debug[c * PB + row];
-                p.ignored[ci] = l_ign[c * PB + row];
+                const unsigned char o = l_out[c * PB + row];
+                p.ground[ci] = SEG_GROUND_VALUE[o & 7];
+                p.debug[ci] = SEG_DEBUG_VALUE[(o >> 3) & 15];
+                p.ignored[ci] = o >> 7;
             }
             lc = lc + 1 == RC ? 0 : lc + 1;
         }
