@@ -265,10 +265,18 @@ __global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes 
 // =====================================================================================================
 constexpr int INS_RING = 8;  // firings staged in LDS ahead of the consumer wave
 
+// columns of the `distance` plane kept in LDS: INS_WIN for sensors whose firing spans a few columns, twice that for sensors with
+// two rows per lane (VLS-128-style firings span ~60 columns)
+__host__ __device__ constexpr int ins_win_cols(int rpl)
+{
+    return rpl == 1 ? INS_WIN : 2 * INS_WIN;
+}
+
 __host__ inline size_t insert2_lds_bytes(int R)
 {
-    // distance window + ring of staged firings (7 float/int planes + intensity bytes) + 2 sync words
-    return (size_t) INS_WIN * R * 4 + (size_t) INS_RING * R * (7 * 4 + 4) + 64;
+    // distance window + ring of staged firings (7 float/int planes + intensity) + 3 sync words
+    const int rpl = (R + WAVE - 1) / WAVE;
+    return (size_t) ins_win_cols(rpl) * R * 4 + (size_t) INS_RING * R * (7 * 4 + 4) + 64;
 }
 
 // block = 128: wavefront 0 is the consumer (the serial algorithm), wavefront 1 the loader that streams the staged points
@@ -284,9 +292,10 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
+    constexpr int WINC = ins_win_cols(RPL);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* w_dist = (float*) smem;                       // [INS_WIN][R]
-    float* r_x = w_dist + INS_WIN * R;                   // [INS_RING][R] each
+    float* w_dist = (float*) smem;                       // [WINC][R]
+    float* r_x = w_dist + WINC * R;                   // [INS_RING][R] each
     float* r_y = r_x + INS_RING * R;
     float* r_z = r_y + INS_RING * R;
     float* r_d = r_z + INS_RING * R;
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         }
     }
 
-    // window = global columns [wbase, wbase + INS_WIN), column gcx at LDS column gcx % INS_WIN
+    // window = global columns [wbase, wbase + WINC), column gcx at LDS column gcx % WINC
     long long wbase = -1;
     auto window_fill = [&](long long from, long long to) // load columns [from, to) from the global distance plane
     {
@@ -436,7 +445,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 #pragma unroll
             for (int u = 0; u < B; u++)
             {
-                const int wc = (int) ((g0 + u) & (INS_WIN - 1));
+                const int wc = (int) ((g0 + u) & (WINC - 1));
 #pragma unroll
                 for (int k = 0; k < RPL; k++)
                 {
@@ -453,14 +462,14 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         long long nb = need_lo - 24;
         if (nb < 0)
             nb = 0;
-        if (wbase < 0 || nb >= wbase + INS_WIN || nb < wbase)
+        if (wbase < 0 || nb >= wbase + WINC || nb < wbase)
         {
             wbase = nb;
-            window_fill(wbase, wbase + INS_WIN);
+            window_fill(wbase, wbase + WINC);
         }
-        else if (need_hi >= wbase + INS_WIN)
+        else if (need_hi >= wbase + WINC)
         {
-            window_fill(wbase + INS_WIN, nb + INS_WIN);
+            window_fill(wbase + WINC, nb + WINC);
             wbase = nb;
         }
         wave_lds_sync();
@@ -481,6 +490,167 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     long long f = cursor0;
     for (; f < n; f++)
     {
+        // ---- tight loop over the common firing shape: every return in one and the same column (kitti_demo's pseudo firings,
+        // kd.cpp:123-159), no rotation wrap relative to the previous rearmost laser, the column inside the LDS window, every
+        // target cell empty, at most 64 columns to emit. Under exactly these conditions the general code below does the same;
+        // here all state stays scalar and nothing of the generic bookkeeping is executed. A lone wavefront retires about one
+        // instruction per 5-8 cycles, so the length of this loop body IS the insertion rate.
+        if (tracked_rear != prev_rear)
+        {
+            const long long dlt = prev_rear - tracked_rear;
+            if (dlt > 0 && dlt < NC)
+            {
+                prev_cir += (int) dlt;
+                if (prev_cir >= NC)
+                {
+                    prev_cir -= NC;
+                    prev_rot++;
+                }
+                rear_lc += (int) dlt;
+                if (rear_lc >= RC)
+                    rear_lc -= RC;
+            }
+            else
+            {
+                prev_rot = prev_rear / NC;
+                prev_cir = (int) (prev_rear - prev_rot * NC);
+                rear_lc = (int) (prev_rear % RC);
+            }
+            tracked_rear = prev_rear;
+        }
+        if (ring_start != -1 && first_unf != -1 && prev_fore >= 0 && wbase >= 0)
+        {
+            const int half_ = NC / 2;
+            long long ready_upto = f;
+            while (f < n)
+            {
+                if (limit_base >= 0 && prev_rear - limit_base >= g.limit_columns)
+                    break;
+                if (ready_upto <= f)
+                {
+                    ready_upto = *v_ready;
+                    if (ready_upto <= f)
+                    {
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    wave_lds_sync();
+                }
+                const int slot = (int) (f & (INS_RING - 1));
+                int cirv[RPL];
+                bool v[RPL];
+                unsigned long long mv = 0;
+                int c0 = 0;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    cirv[k] = row < R ? r_c[slot * R + row] : PP_SKIP;
+                    v[k] = cirv[k] != PP_SKIP;
+                    const unsigned long long m = __ballot(v[k]);
+                    if (mv == 0 && m != 0)
+                        c0 = uniform_i32(__shfl(cirv[k], __ffsll((long long) m) - 1));
+                    mv |= m;
+                }
+                if (mv == 0)
+                    break;
+                bool differs = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                    differs |= v[k] && cirv[k] != c0;
+                const int cdiff = c0 - prev_cir;
+                const long long gc0 = prev_rot * NC + c0;
+                if (__any(differs) || c0 < 0 || cdiff < -half_ || cdiff > half_ || gc0 < wbase || gc0 + 1 >= wbase + WINC ||
+                    gc0 < first_unf || (gc0 > prev_rear && gc0 - first_unf > 64))
+                    break;
+                const int wcol = (int) (gc0 & (WINC - 1)) * R;
+                bool occupied = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    if (v[k])
+                    {
+                        const float cd = w_dist[wcol + row];
+                        occupied |= !(cd != cd);
+                    }
+                }
+                if (__any(occupied))
+                    break;
+                int lc = rear_lc + (int) (gc0 - prev_rear);
+                if (lc < 0)
+                    lc += RC;
+                else if (lc >= RC)
+                    lc -= RC;
+                const double caz_base = CC_2PI_D * (double) prev_rot;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    if (v[k])
+                    {
+                        const int so = slot * R + row;
+                        const size_t ci = (size_t) lc * R + row;
+                        const float d = r_d[so];
+                        p.x[ci] = r_x[so];
+                        p.y[ci] = r_y[so];
+                        p.z[ci] = r_z[so];
+                        p.inten[ci] = (uint8_t) r_t[so];
+                        p.src[ci] = seq0 + (f - cursor0);
+                        p.dist[ci] = d;
+                        p.incl[ci] = r_i[so];
+                        p.caz[ci] = caz_base + (double) r_a[so];
+                        p.gcol[ci] = gc0;
+                        w_dist[wcol + row] = d;
+                    }
+                }
+                // rear = fore = gc0 (cc.cpp:241-266)
+                if (gc0 > prev_rear)
+                {
+                    const int dlt = (int) (gc0 - prev_rear);
+                    prev_rear = gc0;
+                    prev_cir += dlt;
+                    if (prev_cir >= NC)
+                    {
+                        prev_cir -= NC;
+                        prev_rot++;
+                    }
+                    rear_lc += dlt;
+                    if (rear_lc >= RC)
+                        rear_lc -= RC;
+                    tracked_rear = prev_rear;
+                }
+                if (gc0 > prev_fore)
+                    prev_fore = gc0;
+                if (prev_fore > ring_end)
+                    ring_end = prev_fore;
+                // finished columns carry the pose of this firing (cc.cpp:289-291)
+                if (first_unf < prev_rear)
+                {
+                    const int cnt = (int) (prev_rear - first_unf); // <= 64 by the entry condition
+                    if (lane < cnt)
+                    {
+                        int tl = rear_lc - (cnt - lane);
+                        if (tl < 0)
+                            tl += RC;
+                        p.trig[tl] = (int) f;
+                    }
+                    first_unf = prev_rear;
+                }
+                f++;
+                if ((f & 3) == 0)
+                {
+                    wave_lds_sync();
+                    if (lane == 0)
+                        *v_done = f;
+                }
+            }
+            wave_lds_sync();
+            if (lane == 0)
+                *v_done = f;
+            if (f >= n || (limit_base >= 0 && prev_rear - limit_base >= g.limit_columns))
+                break;
+        }
         if (limit_base >= 0 && prev_rear - limit_base >= g.limit_columns)
             break;
 #ifdef CC_PROFILE_SECTIONS
@@ -595,7 +765,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         long long rear = -1, fore = -1;
         if (need_hi >= 0)
         {
-            if (wbase < 0 || need_lo < wbase || need_hi + 1 >= wbase + INS_WIN)
+            if (wbase < 0 || need_lo < wbase || need_hi + 1 >= wbase + WINC)
                 window_seek(need_lo, need_hi + 1);
             long long l_rear = 0x7fffffffffffffffll, l_fore = -1;
 #pragma unroll
@@ -613,11 +783,11 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     lc -= RC;
                 const int so = slot * R + row;
                 const float d = r_d[so];
-                const bool res = gc >= wbase && gc + 1 < wbase + INS_WIN; // both candidate columns resident in LDS
-                float cd = res ? w_dist[(int) (gc & (INS_WIN - 1)) * R + row] : p.dist[(size_t) lc * R + row];
+                const bool res = gc >= wbase && gc + 1 < wbase + WINC; // both candidate columns resident in LDS
+                float cd = res ? w_dist[(int) (gc & (WINC - 1)) * R + row] : p.dist[(size_t) lc * R + row];
                 if (!(cd != cd) && !(d != d)) // cell occupied: try the next column (cc.cpp:188-202)
                 {
-                    const float nd = res ? w_dist[(int) ((gc + 1) & (INS_WIN - 1)) * R + row]
+                    const float nd = res ? w_dist[(int) ((gc + 1) & (WINC - 1)) * R + row]
                                          : p.dist[(size_t) (lc + 1 >= RC ? 0 : lc + 1) * R + row];
                     if (nd != nd)
                     {
@@ -643,8 +813,8 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     p.gcol[ci] = gc;
 #endif
                     p.dist[ci] = d;
-                    if (gc >= wbase && gc < wbase + INS_WIN)
-                        w_dist[(int) (gc & (INS_WIN - 1)) * R + row] = d;
+                    if (gc >= wbase && gc < wbase + WINC)
+                        w_dist[(int) (gc & (WINC - 1)) * R + row] = d;
                 }
                 l_rear = gc < l_rear ? gc : l_rear;
                 l_fore = gc > l_fore ? gc : l_fore;
