@@ -281,9 +281,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // ---- table + segmentation + window-scan chain ------------------------------------------------------------
     CC_MARK(sb); // ev3: start of the second chain
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64), 0, sb, g, e->P, e->d_states, first_stream, slot);
+        hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64), 0, sb, g, e->P, e->d_states, first_stream, slot);
+        hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
                            first_stream, slot, d_pose, (long long) n);

@@ -958,77 +958,135 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 }
 
 // =====================================================================================================
-// k_table — sc_inclination_angles_between_lasers_ (cc.cpp:353-357): per row the last non-NaN inclination step over
-// the emitted columns, in column order. One wavefront per stream, lanes = rows; the loads do not depend on each other, so
-// they pipeline. grid = streams, block = 64.
+// k_table — sc_inclination_angles_between_lasers_ (cc.cpp:353-357): per row the last non-NaN inclination step over the
+// emitted columns, in column order = a per-row "last valid value" scan along the columns. One block of TABLE_WAVES wavefronts
+// per stream, lanes = rows: every wavefront owns a contiguous chunk of the batch's columns; phase 1 finds the last valid step
+// of each chunk, the chunk carries are combined through LDS, phase 2 re-walks the chunk and writes the table plane.
+// grid = streams, block = 64 * TABLE_WAVES.
 // =====================================================================================================
+constexpr int TABLE_WAVES = 8;
+
 template<int RPL>
-__global__ __launch_bounds__(64) void k_table(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
-    const int lane = lane_id();
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     StreamState* st = &states[s];
     const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || seg_begin >= seg_end)
         return;
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    float tabv[RPL];
+    __shared__ float s_last[TABLE_WAVES][WAVE * RPL];
+    __shared__ int s_has[TABLE_WAVES][WAVE * RPL];
+    const long long total = seg_end - seg_begin;
+    const long long per = (total + TABLE_WAVES - 1) / TABLE_WAVES;
+    const long long c_lo = seg_begin + per * wave, c_hi = (c_lo + per < seg_end ? c_lo + per : seg_end);
+    constexpr int U = 16;
+    // phase 1: last valid step of this chunk per row
+    float last[RPL];
+    bool has[RPL];
 #pragma unroll
     for (int k = 0; k < RPL; k++)
     {
-        const int row = k * 64 + lane;
-        tabv[k] = row < R ? p.curtab[row] : 0.f;
+        last[k] = 0.f;
+        has[k] = false;
     }
-    int lc = (int) (seg_begin % RC);
-    constexpr int U = 24;
-    for (long long c0 = seg_begin; c0 < seg_end; c0 += U)
+    for (int pass = 0; pass < 2; pass++)
     {
-        float cur[U][RPL], below[U][RPL];
-        int lcs[U];
-#pragma unroll
-        for (int u = 0; u < U; u++)
+        float carry[RPL];
+        if (pass == 1)
         {
-            lcs[u] = lc;
-            lc = lc + 1 == RC ? 0 : lc + 1;
+            // carry-in of this chunk: the last valid step of the nearest earlier chunk that has one, else the stream's table
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 const int row = k * 64 + lane;
-                cur[u][k] = below[u][k] = 0.f;
-                if (row < R && c0 + u < seg_end)
+                carry[k] = row < R ? p.curtab[row] : 0.f;
+                if (row < R)
+                    for (int w = 0; w < wave; w++)
+                        if (s_has[w][row])
+                            carry[k] = s_last[w][row];
+            }
+        }
+        int lc = c_lo < c_hi ? (int) (c_lo % RC) : 0;
+        for (long long c0 = c_lo; c0 < c_hi; c0 += U)
+        {
+            float cur[U][RPL], below[U][RPL];
+            int lcs[U];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                lcs[u] = lc;
+                lc = lc + 1 == RC ? 0 : lc + 1;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
                 {
-                    const size_t ci = (size_t) lcs[u] * R + row;
-                    cur[u][k] = p.incl[ci];
-                    below[u][k] = row + 1 < R ? p.incl[ci + 1] : 0.f;
+                    const int row = k * 64 + lane;
+                    cur[u][k] = below[u][k] = 0.f;
+                    if (row < R && c0 + u < c_hi)
+                    {
+                        const size_t ci = (size_t) lcs[u] * R + row;
+                        cur[u][k] = p.incl[ci];
+                        below[u][k] = row + 1 < R ? p.incl[ci + 1] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+            {
+                if (c0 + u >= c_hi)
+                    break;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    if (row < R)
+                    {
+                        const float diff = cur[u][k] - below[u][k];
+                        if (pass == 0)
+                        {
+                            if (!(diff != diff))
+                            {
+                                last[k] = diff;
+                                has[k] = true;
+                            }
+                        }
+                        else
+                        {
+                            if (!(diff != diff))
+                                carry[k] = diff;
+                            p.tab[(size_t) lcs[u] * R + row] = carry[k];
+                        }
+                    }
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; u++)
+        if (pass == 0)
         {
-            if (c0 + u >= seg_end)
-                break;
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 const int row = k * 64 + lane;
                 if (row < R)
                 {
-                    const float diff = cur[u][k] - below[u][k];
-                    if (!(diff != diff))
-                        tabv[k] = diff;
-                    p.tab[(size_t) lcs[u] * R + row] = tabv[k];
+                    s_last[wave][row] = last[k];
+                    s_has[wave][row] = has[k] ? 1 : 0;
                 }
             }
+            __syncthreads();
         }
-    }
+        else if (wave == TABLE_WAVES - 1)
+        {
+            // table after the last emitted column = carry of the last chunk (chunks may be empty: then it is the carry-in)
 #pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        const int row = k * 64 + lane;
-        if (row < R)
-            p.curtab[row] = tabv[k];
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                    p.curtab[row] = carry[k];
+            }
+        }
     }
 }
 
@@ -1320,9 +1378,27 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
         float lg2x = 0.f, lgz = height_sensor_to_ground; // last (quite certain) ground point in the azimuth plane
         float pv2x = 0.f, pvz = 0.f;
         unsigned char previous_label = 0;
-        for (int row = R - 1; row >= 0; row--)
+        // inputs of 8 rows at a time into registers (independent LDS reads), so that the row-serial state machine below does not
+        // pay an LDS round trip per row
+        for (int row0 = R - 1; row0 >= 0; row0 -= 8)
         {
-            const int f = fl[row];
+            int f8[8];
+            float x8[8], z8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+                const int rr = row0 - u;
+                f8[u] = rr >= 0 ? fl[rr] : SG_NAN;
+                x8[u] = rr >= 0 ? x2[rr] : 0.f;
+                z8[u] = rr >= 0 ? uzp[rr] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+            {
+            const int row = row0 - u;
+            if (row < 0)
+                break;
+            const int f = f8[u];
             unsigned char ground = SG_G_UNKNOWN, debug = SG_D_WHITE;
             if (f & SG_NAN)
             {
@@ -1339,7 +1415,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 oo[row] = (unsigned char) (SG_G_EGO | (SG_D_VIOLET << 3));
                 continue;
             }
-            const float cur2x = x2[row], cur2y = uzp[row];
+            const float cur2x = x8[u], cur2y = z8[u];
             if (!first_point_found)
             {
                 first_point_found = true;
@@ -1426,6 +1502,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             pvz = cur2y;
             previous_label = debug;
             oo[row] = (unsigned char) (ground | (debug << 3));
+        }
         }
         for (int row = R - 1; row >= 0; row--) // cc.cpp:567-616
         {
