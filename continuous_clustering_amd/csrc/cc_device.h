@@ -71,7 +71,7 @@ struct StreamState
     uint64_t serial_columns;      // columns that took the exact serial association path
     uint64_t stamp_alias_rounds;  // rounds whose min azimuth equalled the previous round's
     // errors raised inside kernels
-    uint64_t dbg[8];              // section cycle counters (CC_PROFILE_SECTIONS builds only)
+    uint64_t dbg[16];             // section cycle counters (CC_PROFILE_SECTIONS builds only): 0-7 insertion, 8-15 association
     int32_t error;
     int32_t n_events;
     int64_t error_a;

@@ -29,6 +29,7 @@ struct cc_engine
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{};
     uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 3
     bool pipelined{false};        // last submitted batch used all three streams
+    bool allow_pipeline{true};    // option "pipeline"
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
     std::string error;
@@ -770,7 +771,7 @@ int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, co
     (void) hipSetDevice(e->device);
     // throughput path: when nobody reads events or columns between batches, batch b + 1 is inserted while batch b is still
     // being segmented and associated (two HIP streams)
-    return submit(e, 0, e->g.num_streams, n, d_xyz, d_intensity, d_poses, e->g.record_events == 0);
+    return submit(e, 0, e->g.num_streams, n, d_xyz, d_intensity, d_poses, e->g.record_events == 0 && e->allow_pipeline);
 }
 
 int cc_engine_sync(cc_engine* e)
@@ -948,6 +949,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->g.debug_flags = (int32_t) value;
     else if (n == "lds_tree_limit")
         e->g.lds_tree_limit = (int32_t) (value < 1 ? 1 : (value > TREE_SLOTS ? TREE_SLOTS : value));
+    else if (n == "pipeline")
+        e->allow_pipeline = value != 0;
     else if (n == "limit_columns")
         e->g.limit_columns = (int32_t) (value < 1 ? 1 : value);
     else
@@ -1018,13 +1021,13 @@ int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters
     return CC_OK;
 }
 
-int cc_engine_debug_counters(cc_engine* e, int stream, uint64_t out[8])
+int cc_engine_debug_counters(cc_engine* e, int stream, uint64_t out[16])
 {
     if (!e || stream < 0 || stream >= e->g.num_streams || !out)
         return CC_ERR_INVALID_ARGUMENT;
     StreamState st;
     CC_HIP_CHECK(e, hipMemcpy(&st, e->d_states + stream, sizeof(st), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 16; i++)
         out[i] = st.dbg[i];
     return CC_OK;
 }

@@ -2318,12 +2318,18 @@ __device__ __forceinline__ void lds_union(int* uf, unsigned long long* c_fin, in
 
 // true iff some cluster's (lower-bounded) max finished_at has been passed by the column's minimum azimuth: only then can the
 // finished-cluster check of cc.cpp:884-885 let a cluster through
-__device__ __forceinline__ bool cluster_may_finish(LdsTrees& T, int n_unf, double min_az)
+__device__ __forceinline__ bool cluster_may_finish(LdsTrees& T, int n_unf, double min_az, double& lower_bound)
 {
     bool may = false;
+    double lb = 1.7976931348623157e308;
     for (int i = lane_id(); i < n_unf; i += 64)
         if (((volatile int*) T.uf)[i] == i)
-            may |= !(__longlong_as_double((long long) ((volatile unsigned long long*) T.c_fin)[i]) > min_az);
+        {
+            const double f = __longlong_as_double((long long) ((volatile unsigned long long*) T.c_fin)[i]);
+            may |= !(f > min_az);
+            lb = f < lb ? f : lb;
+        }
+    lower_bound = uniform_f64(wave_min_f64(lb)); // min over the clusters of (a lower bound of) their max finished_at
     return __any(may);
 }
 
@@ -2613,7 +2619,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
         int parent[RPL], nl[RPL];
         unsigned long long link[RPL];
         double finc[RPL];
-        const double min_az = __shfl(nx_minaz, 0);
+        const double min_az = uniform_f64(__shfl(nx_minaz, 0));
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -2638,7 +2644,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             const unsigned long long mask = __ballot(is_new);
             newpos[k] = n_unf + cnt_new + __popcll(mask & lanes_below());
             cnt_new += __popcll(mask);
-            if (row < R)
+            if (row < R && RPL > 1)
             {
                 // s_parent: row of the same-column parent, or the row itself when the chain ends here
                 const bool same_col = parent[k] >= 0 && (parent[k] >> 8) == 0;
@@ -2661,11 +2667,33 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
         if (RPL == 1)
         {
             // rows = lanes: jump through the cross-lane network (ds_bpermute), no LDS round trips
-            int t = (parent[0] >= 0 && (parent[0] >> 8) == 0) ? (parent[0] & 0xff) : lane;
-#pragma unroll
-            for (int it = 0; it < 6; it++)
-                t = __shfl(t, t);
-            top_of[0] = t;
+            const bool same_col = parent[0] >= 0 && (parent[0] >> 8) == 0;
+            const int prow = parent[0] & 0xff;
+            // Usual shape: the same-column parent of a row is the nearest non-ignored row above it. Then a chain is a run of
+            // linked active rows and its top is the nearest active, unlinked row at or above — two ballots and a count of
+            // leading zeros instead of pointer jumping through the cross-lane network.
+            const unsigned long long active_m = __ballot(parent[0] >= -1);
+            const unsigned long long linked_m = __ballot(same_col);
+            const unsigned long long above = active_m & lanes_below();
+            const int nearest_above = above ? 63 - __clzll((long long) above) : -1;
+            if (!__any(same_col && prow != nearest_above))
+            {
+                const unsigned long long tops = active_m & ~linked_m & (lanes_below() | (1ull << lane));
+                top_of[0] = tops ? 63 - __clzll((long long) tops) : lane;
+            }
+            else
+            {
+                int t = same_col ? prow : lane;
+                for (int it = 0; it < 6; it++)
+                {
+                    const int t2 = __shfl(t, t);
+                    const bool changed = t2 != t;
+                    t = t2;
+                    if (!__any(changed))
+                        break;
+                }
+                top_of[0] = t;
+            }
         }
         else
         {
@@ -2696,6 +2724,12 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 top_of[k] = row < R ? s_parent[row] : 0;
             }
         }
+        int term_info = 0;
+        if (RPL == 1)
+        {
+            const int mine = parent[0] == -1 ? newpos[0] : (parent[0] >= 0 ? -1 - parent[0] : 0x7fffffff);
+            term_info = __shfl(mine, top_of[0]);
+        }
         int slot[RPL], rootcell[RPL];
 #pragma unroll
         for (int k = 0; k < RPL; k++)
@@ -2706,7 +2740,8 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             if (parent[k] >= -1 && row < R)
             {
                 const int top = top_of[k];
-                const int tv = s_newslot[top]; // >= 0: new tree slot, < 0: -1 - code of a candidate in an earlier column
+                // >= 0: new tree slot, < 0: -1 - code of a candidate in an earlier column
+                const int tv = RPL == 1 ? term_info : s_newslot[top];
                 int oldest_delta = 0;
                 if (tv >= 0)
                 {
@@ -2780,7 +2815,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 if (n_unf == 0)
                     M = gc;
                 n_unf += cnt_new;
-                L = wave_min_f64(L);
+                L = uniform_f64(wave_min_f64(L));
             }
             wave_lds_sync();
 #pragma unroll
@@ -2823,15 +2858,15 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 s_bl[0] = MM;
             }
             wave_lds_sync();
-            n_unf = s_bi[0];
+            n_unf = uniform_i32(s_bi[0]);
             if (s_bi[1] == CC_ERR_CAPACITY)
             {
                 // the live replay ran out of slots mid-column: this kernel cannot roll the column back
                 err = CC_ERR_CAPACITY;
                 err_a = n_unf;
             }
-            L = s_bd[0];
-            M = s_bl[0];
+            L = uniform_f64(s_bd[0]);
+            M = uniform_i64(s_bl[0]);
             wave_lds_sync();
         }
         if (err)
@@ -2850,8 +2885,8 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             alias_rounds++;
             M_c = M;
         }
-        else if (!cluster_may_finish(T, n_unf, min_az) && !((gc + 1 - M) >= NC))
-            M_c = M;
+        else if (!((gc + 1 - M) >= NC) && (!(min_az >= L) || !cluster_may_finish(T, n_unf, min_az, L)))
+            M_c = M; // nothing can be finished: first the scalar bound, then (refreshing it) the per-cluster bounds
         else
         {
             for (int i = lane; i < n_unf; i += 64)
@@ -2891,7 +2926,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 }
             for (int o = 32; o > 0; o >>= 1)
                 exceed_local += __shfl_xor(exceed_local, o);
-            exceed += exceed_local;
+            exceed += (unsigned long long) uniform_i32(exceed_local);
             wave_lds_sync();
             int last_first = -1;
             while (true)
@@ -2904,7 +2939,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                         if (fi > last_first && fi < best)
                             best = fi;
                     }
-                best = wave_min_i32(best);
+                best = uniform_i32(wave_min_i32(best));
                 if (best == 0x7fffffff)
                     break;
                 const int j = T.comp[best];
@@ -2974,6 +3009,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 out += __popcll(mask);
             }
             wave_lds_sync();
+            out = uniform_i32(out);
             if (out != n_unf)
             {
                 for (int i = lane; i < out; i += 64)
@@ -2985,9 +3021,9 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                         s_win[i] = T.remap[v];
                 }
             }
-            min_all = wave_min_i64(min_all);
-            min_surv = wave_min_i64(min_surv);
-            L = wave_min_f64(L_new);
+            min_all = uniform_i64(wave_min_i64(min_all));
+            min_surv = uniform_i64(wave_min_i64(min_surv));
+            L = uniform_f64(wave_min_f64(L_new));
             M_c = min_all;
             M = min_surv;
             n_unf = out;
@@ -3030,9 +3066,9 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     }
 #ifdef CC_PROFILE_SECTIONS
     CC_SEC(7)
-    if (lane == 0 && false)
+    if (lane == 0)
         for (int i = 0; i < 8; i++)
-            st->dbg[i] += tsec[i];
+            st->dbg[8 + i] += tsec[i];
 #endif
     if (lane == 0)
     {

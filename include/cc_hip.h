@@ -238,7 +238,8 @@ int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_l
 
 /* Engine tuning / test hooks. Names: "lds_tree_limit" (unfinished point trees per stream kept in LDS before the stream
  * continues in the global-memory association kernel, 1..256), "limit_columns" (columns one launch may emit per stream before
- * it hands back to the host), "debug_flags" (experiment switches, 0 in production). */
+ * it hands back to the host), "pipeline" (0: run the three kernel chains of cc_engine_add_firings_device back to back on one
+ * HIP stream instead of overlapping consecutive batches on three), "debug_flags" (experiment switches, 0 in production). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every

@@ -7,11 +7,12 @@ sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 S,F,NB = 256,2200,4
 xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, S, F, NB, 1234)
 torch.cuda.synchronize()
-for flags in [0,1,2,4,7]:
-    e = Engine(cfg, 64, S); e.record_events(False); e.set_option("debug_flags", flags)
+for pipe in [0, 1]:
+    flags = 0
+    e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", pipe)
     e.add_firings_device(F, xyz[0], inten[0], poses[0]); e.sync()
     e.enable_timing(True)
     for b in range(1,NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])
     e.sync(); k = e.kernel_times()
-    print(flags, {n: round(v/k["batches"],3) for n,v in k.items() if n.endswith("_ms")})
+    print("pipeline", pipe, {n: round(v/k["batches"],3) for n,v in k.items() if n.endswith("_ms")})
     e.close()

@@ -9,13 +9,13 @@ sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 S,F,NB = 256,2200,4
 xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, S, F, NB, 1234)
 torch.cuda.synchronize()
-e = Engine(cfg, 64, S); e.record_events(False)
+e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", 0)
 for b in range(NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])
 print(e.sync())
 L = cca.load_library(); L.cc_engine_debug_counters.argtypes=[C.c_void_p, C.c_int, C.c_void_p]
-tot = np.zeros(8)
+tot = np.zeros(16)
 for s in range(0,S,16):
-    out = np.zeros(8, dtype=np.uint64); L.cc_engine_debug_counters(e.h, s, out.ctypes.data); tot += out
+    out = np.zeros(16, dtype=np.uint64); L.cc_engine_debug_counters(e.h, s, out.ctypes.data); tot += out
 tot /= (S/16)
-names = ["wait ready","gcol calc","ballot peel","window+stores","rear/fore+done","total loop","-","-"]
+names = ["ins wait","ins gcol(general)","ins peel(general)","ins window+stores(general)","ins rear/fore(general)","ins total loop","-","-","assoc init","assoc loop top","assoc issue prefetch","assoc resolve","assoc apply/links","assoc (unused)","assoc C+P","assoc ballots"]
 for n,v in zip(names,tot): print(f"{n:24s} {v:14.0f} ticks  per column {v/(F*NB):10.1f}")
