@@ -30,6 +30,20 @@ struct cc_engine
     uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 3
     bool pipelined{false};        // last submitted batch used all three streams
     bool allow_pipeline{true};    // option "pipeline"
+    // low-latency path of cc_engine_add_firings for small calls: one captured hipGraph per (stream, n), pinned staging
+    struct SmallGraph
+    {
+        int stream;
+        int64_t n;
+        int record;
+        hipGraphExec_t exec;
+    };
+    std::vector<SmallGraph> small_graphs;
+    unsigned char* h_small{nullptr}; // pinned: packed xyz | intensity | poses of up to SMALL_MAX firings
+    unsigned char* d_small{nullptr};
+    StreamState* h_small_state{nullptr}; // pinned
+    cc_event* h_small_events{nullptr};   // pinned
+    bool allow_graphs{true};            // option "graphs"
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
     std::string error;
@@ -126,6 +140,7 @@ int free_all(cc_engine* e)
     e->d_view = nullptr;
     e->view_bytes = 0;
     e->prep_capacity = 0;
+    e->d_small = nullptr;
     return CC_OK;
 }
 
@@ -340,6 +355,7 @@ __global__ void k_begin_batch(StreamState* states, int first_stream, int count, 
     if (i < count)
     {
         states[first_stream + i].cursor = 0;
+        states[first_stream + i].n_events = 0; // every event of the previous call has been collected
         states[first_stream + i].clear_allowed = unlimited_clear ? 0x7fffffffffffffffll : states[first_stream + i].ring_start;
     }
     if (i == 0)
@@ -496,6 +512,119 @@ int first_stream_error(cc_engine* e, int first_stream, int count)
     return CC_OK;
 }
 
+constexpr int64_t SMALL_MAX = 8;   // firings per call served by the captured-graph path
+constexpr int SMALL_EVENTS = 64;   // events copied back together with the state
+
+void destroy_small_graphs(cc_engine* e)
+{
+    for (auto& g : e->small_graphs)
+        (void) hipGraphExecDestroy(g.exec);
+    e->small_graphs.clear();
+}
+
+// One host call = one graph launch + one stream synchronisation: H2D of the packed firings, every kernel of the path, D2H of the
+// stream's scalar state and its first events. Returns -1 when the call is not eligible (the caller then takes the general path).
+int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, const uint8_t* intensity, const double* poses)
+{
+    if (!e->allow_graphs || e->timing || n > SMALL_MAX || e->g.debug_flags)
+        return -1;
+    const int R = e->g.num_rows;
+    const size_t b_xyz = (size_t) SMALL_MAX * R * 3 * sizeof(float), b_int = (((size_t) SMALL_MAX * R) + 15) & ~(size_t) 15,
+                 b_pose = (size_t) SMALL_MAX * 12 * sizeof(double);
+    if (e->h_small && !e->d_small && alloc_plane(e, &e->d_small, b_xyz + b_int + b_pose) != CC_OK)
+        return -1;
+    if (!e->h_small)
+    {
+        if (hipHostMalloc((void**) &e->h_small, b_xyz + b_int + b_pose) != hipSuccess ||
+            hipHostMalloc((void**) &e->h_small_state, sizeof(StreamState)) != hipSuccess ||
+            hipHostMalloc((void**) &e->h_small_events, SMALL_EVENTS * sizeof(cc_event)) != hipSuccess)
+            return -1;
+        int rc = alloc_plane(e, &e->d_small, b_xyz + b_int + b_pose);
+        if (rc)
+            return -1;
+    }
+    const float* d_xyz = (const float*) e->d_small;
+    const uint8_t* d_int = e->d_small + b_xyz;
+    const double* d_pose = (const double*) (e->d_small + b_xyz + b_int);
+    hipGraphExec_t exec = nullptr;
+    for (auto& g : e->small_graphs)
+        if (g.stream == stream && g.n == n && g.record == e->g.record_events)
+            exec = g.exec;
+    if (!exec)
+    {
+        if (ensure_prep(e, (size_t) n * R) != CC_OK)
+            return -1;
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            return -1;
+        bool ok = hipMemcpyAsync(e->d_small, e->h_small, b_xyz + b_int + b_pose, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, e->stream, e->d_states, stream, 1, e->d_remaining, 0);
+        ok = ok && launch_batch(e, stream, 1, n, d_xyz, d_int, d_pose, true, 0, e->stream, e->stream, e->stream) == CC_OK;
+        ok = ok && hipMemcpyAsync(e->h_small_state, e->d_states + stream, sizeof(StreamState), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        if (e->g.record_events)
+            ok = ok && hipMemcpyAsync(e->h_small_events, e->P.events + (size_t) stream * e->g.event_capacity, SMALL_EVENTS * sizeof(cc_event),
+                                      hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        if (hipStreamEndCapture(e->stream, &graph) != hipSuccess || !ok || !graph)
+        {
+            if (graph)
+                (void) hipGraphDestroy(graph);
+            e->allow_graphs = false; // capture is not possible in this environment: keep using the general path
+            return -1;
+        }
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void) hipGraphDestroy(graph);
+        if (ie != hipSuccess)
+        {
+            e->allow_graphs = false;
+            return -1;
+        }
+        if (e->small_graphs.size() >= 16)
+            destroy_small_graphs(e);
+        e->small_graphs.push_back({stream, n, e->g.record_events, exec});
+    }
+    memcpy(e->h_small, xyz, (size_t) n * R * 3 * sizeof(float));
+    memcpy(e->h_small + b_xyz, intensity, (size_t) n * R);
+    memcpy(e->h_small + b_xyz + b_int, poses, (size_t) n * 12 * sizeof(double));
+    CC_HIP_CHECK(e, hipGraphLaunch(exec, e->stream));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    if (*e->h_remaining != 0)
+    {
+        // the kernels stopped early (limit_columns): continue on the general path, which also collects the events
+        e->last_xyz = d_xyz;
+        e->last_int = d_int;
+        e->last_pose = d_pose;
+        e->last_n = n;
+        e->last_first = stream;
+        e->last_count = 1;
+        e->batch_open = true;
+        e->pipelined = false;
+        int rc = finish_batch(e);
+        return rc ? rc : first_stream_error(e, stream, 1);
+    }
+    const StreamState& st = *e->h_small_state;
+    if (e->g.record_events && st.n_events > 0)
+    {
+        auto& dst = e->pending_events[stream];
+        const int first = st.n_events < SMALL_EVENTS ? st.n_events : SMALL_EVENTS;
+        dst.insert(dst.end(), e->h_small_events, e->h_small_events + first);
+        if (st.n_events > SMALL_EVENTS)
+        {
+            const size_t old = dst.size();
+            dst.resize(old + (size_t) (st.n_events - SMALL_EVENTS));
+            CC_HIP_CHECK(e, hipMemcpy(dst.data() + old, e->P.events + (size_t) stream * e->g.event_capacity + SMALL_EVENTS,
+                                      (size_t) (st.n_events - SMALL_EVENTS) * sizeof(cc_event), hipMemcpyDeviceToHost));
+        }
+    }
+    if (st.error)
+    {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "stream %d: kernel-side error %d (%lld, %lld)", stream, st.error, (long long) st.error_a,
+                 (long long) st.error_b);
+        e->error = buf;
+        return st.error;
+    }
+    return CC_OK;
+}
 } // namespace
 
 extern "C" {
@@ -618,6 +747,13 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamSynchronize(e->stream);
     (void) hipStreamSynchronize(e->stream2);
     (void) hipStreamSynchronize(e->stream3);
+    destroy_small_graphs(e);
+    if (e->h_small)
+    {
+        (void) hipHostFree(e->h_small);
+        (void) hipHostFree(e->h_small_state);
+        (void) hipHostFree(e->h_small_events);
+    }
     free_all(e);
     for (int i = 0; i < 4; i++)
     {
@@ -639,6 +775,7 @@ int cc_engine_set_config(cc_engine* e, const cc_config* cfg)
 {
     if (!e || !cfg)
         return CC_ERR_INVALID_ARGUMENT;
+    destroy_small_graphs(e); // captured graphs bake configuration, geometry and plane pointers
     int rc = validate(e, cfg, e->g.num_rows, e->g.num_streams);
     if (rc)
         return rc;
@@ -673,6 +810,7 @@ int cc_engine_reset(cc_engine* e, int num_rows)
 {
     if (!e)
         return CC_ERR_INVALID_ARGUMENT;
+    destroy_small_graphs(e);
     int rc = validate(e, &e->cfg, num_rows, e->g.num_streams);
     if (rc)
         return rc;
@@ -725,6 +863,9 @@ int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz,
     (void) hipSetDevice(e->device);
     int rc = finish_batch(e);
     if (rc)
+        return rc;
+    rc = add_firings_small(e, stream, n, xyz, intensity, poses);
+    if (rc >= 0)
         return rc;
     const int R = e->g.num_rows;
     // bound a host batch so that staging stays small and a batch never outruns the clearing front
@@ -794,6 +935,7 @@ int cc_engine_record_events(cc_engine* e, int enable)
 {
     if (!e)
         return CC_ERR_INVALID_ARGUMENT;
+    destroy_small_graphs(e);
     (void) hipSetDevice(e->device);
     int rc = finish_batch(e);
     if (rc)
@@ -940,6 +1082,7 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
 {
     if (!e || !name)
         return CC_ERR_INVALID_ARGUMENT;
+    destroy_small_graphs(e);
     (void) hipSetDevice(e->device);
     int rc = finish_batch(e);
     if (rc)
@@ -951,6 +1094,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->g.lds_tree_limit = (int32_t) (value < 1 ? 1 : (value > TREE_SLOTS ? TREE_SLOTS : value));
     else if (n == "pipeline")
         e->allow_pipeline = value != 0;
+    else if (n == "graphs")
+        e->allow_graphs = value != 0;
     else if (n == "limit_columns")
         e->g.limit_columns = (int32_t) (value < 1 ? 1 : value);
     else

@@ -2532,22 +2532,48 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
         wave_lds_sync();
         for (int i = lane; i < n_unf; i += 64)
             atomicMax(&T.c_fin[lds_find(T.uf, i)], T.fin[i]);
-        for (int i = lane; i < WIN_COLS * R; i += 64)
+        // window of tree-slot ids for the WIN_COLS columns before col_begin: two dependent gathers per cell (root plane, then the
+        // tree planes at the root) — issued 8 cells at a time so that a launch pays a few memory round trips, not one per cell
+        constexpr int B = 8;
+        for (int i0 = lane; i0 < WIN_COLS * R; i0 += 64 * B)
         {
-            const int wc = i / R, row = i - wc * R;
-            // the global column in [col_begin - WIN_COLS, col_begin) that maps to window column wc
-            long long gcx = col_begin - 1 - (((col_begin - 1) % WIN_COLS - wc + WIN_COLS) % WIN_COLS);
-            int v = -1;
-            if (gcx >= first_column && gcx >= 0 && first_column >= 0)
+            int rr[B];
+#pragma unroll
+            for (int u = 0; u < B; u++)
             {
-                const int r = p.root[(int) (gcx % RC) * R + row];
-                if (r >= 0)
-                    v = p.t_finished[r] ? -2 : p.t_pos[r];
+                const int i = i0 + u * 64;
+                rr[u] = -1;
+                if (i < WIN_COLS * R)
+                {
+                    const int wc = i / R, row = i - wc * R;
+                    // the global column in [col_begin - WIN_COLS, col_begin) that maps to window column wc
+                    const long long gcx = col_begin - 1 - (((col_begin - 1) % WIN_COLS - wc + WIN_COLS) % WIN_COLS);
+                    if (gcx >= first_column && gcx >= 0 && first_column >= 0)
+                        rr[u] = p.root[(int) (gcx % RC) * R + row];
+                }
             }
-            s_win[i] = v;
+            int fin_[B], pos_[B];
+#pragma unroll
+            for (int u = 0; u < B; u++)
+            {
+                fin_[u] = 0;
+                pos_[u] = -1;
+                if (rr[u] >= 0)
+                {
+                    fin_[u] = p.t_finished[rr[u]];
+                    pos_[u] = p.t_pos[rr[u]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < B; u++)
+            {
+                const int i = i0 + u * 64;
+                if (i < WIN_COLS * R)
+                    s_win[i] = rr[u] < 0 ? -1 : (fin_[u] ? -2 : pos_[u]);
+            }
         }
     }
-    wave_lds_sync();
+    __syncthreads();
 
     // staging of the next column (software prefetch; one global round trip per column stays off the critical path)
     int nx_parent[RPL], nx_nl[RPL];

@@ -203,7 +203,8 @@ int cc_engine_set_robot_from_sensor(cc_engine* e, int stream, const double tf[12
  * associated, checked and published; events are queued in reference order.
  * Columns published during a call stay readable (cc_engine_read_columns) until the next call when
  * n <= 2 * num_columns; longer calls are split internally and may clear (cc.cpp:1091) what their first
- * part published. */
+ * part published. Calls with n <= 8 take a low-latency path: one captured hipGraph launch (H2D of the firings,
+ * every kernel, D2H of state and events) and one synchronisation. */
 int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz, const uint8_t* intensity,
                           const double* poses);
 
@@ -239,7 +240,8 @@ int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_l
 /* Engine tuning / test hooks. Names: "lds_tree_limit" (unfinished point trees per stream kept in LDS before the stream
  * continues in the global-memory association kernel, 1..256), "limit_columns" (columns one launch may emit per stream before
  * it hands back to the host), "pipeline" (0: run the three kernel chains of cc_engine_add_firings_device back to back on one
- * HIP stream instead of overlapping consecutive batches on three), "debug_flags" (experiment switches, 0 in production). */
+ * HIP stream instead of overlapping consecutive batches on three), "graphs" (0: never use the captured-hipGraph
+ * low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in production). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every
