@@ -89,6 +89,28 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // Tell the compiler that a value is wave-uniform (it then lives in SGPRs and drives scalar branches instead of exec-masked
 // "divergent" control flow). Only call with values that really are equal in all active lanes.
+// Single-wave blocks: the LDS executes one wave's DS instructions in issue order, so a ds_write followed by a ds_read of the same
+// word is ordered by the hardware even across lanes. Only the compiler has to be kept from moving LDS accesses across the point —
+// no s_waitcnt (which would stall ~100 cycles per use for the stores to drain).
+__device__ __forceinline__ void wave_lds_fence()
+{
+    asm volatile("" ::: "memory");
+}
+
+// Re-read / publish an LDS word that another lane or wave may change. Relaxed workgroup-scope atomics rather than volatile:
+// the compiler leaves volatile accesses in the generic address space (flat_load ... sc0 sc1 followed by s_waitcnt vmcnt(0),
+// which also drains every outstanding global load and store of the wave), while these become plain ds_read / ds_write.
+template<class T>
+__device__ __forceinline__ T lds_ld(const T* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template<class T>
+__device__ __forceinline__ void lds_st(T* p, T v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 __device__ __forceinline__ int uniform_i32(int v)
 {
     return __builtin_amdgcn_readfirstlane(v);
@@ -303,17 +325,17 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     float* r_a = r_i + INS_RING * R;
     int* r_c = (int*) (r_a + INS_RING * R);
     int* r_t = r_c + INS_RING * R;                       // intensity (one int per cell keeps the stores conflict-free)
-    volatile long long* v_ready = (volatile long long*) (r_t + INS_RING * R); // firings [.., v_ready) are staged
-    volatile long long* v_done = v_ready + 1;            // firings [.., v_done) have been consumed
-    volatile long long* v_stop = v_ready + 2;            // consumer stopped early at this firing (or -1)
+    long long* v_ready = (long long*) (r_t + INS_RING * R); // firings [.., v_ready) are staged
+    long long* v_done = v_ready + 1;                     // firings [.., v_done) have been consumed
+    long long* v_stop = v_ready + 2;                     // consumer stopped early at this firing (or -1)
 
     const long long cursor0 = st->cursor;
     const size_t pbase = (size_t) sl * (size_t) n * R;
     if (threadIdx.x == 0)
     {
-        *v_ready = cursor0;
-        *v_done = cursor0;
-        *v_stop = -1;
+        lds_st(v_ready, cursor0);
+        lds_st(v_done, cursor0);
+        lds_st(v_stop, -1ll);
     }
     __syncthreads();
 
@@ -352,9 +374,9 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     }
                 }
             // wait until the ring has room for these U firings (or the consumer stopped)
-            while (*v_done + INS_RING < f0 + U && *v_stop < 0)
+            while (lds_ld(v_done) + INS_RING < f0 + U && lds_ld(v_stop) < 0)
                 __builtin_amdgcn_s_sleep(2);
-            if (*v_stop >= 0)
+            if (lds_ld(v_stop) >= 0)
                 break;
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -380,7 +402,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
             }
             wave_lds_sync();
             if (lane == 0)
-                *v_ready = (f0 + U < n ? f0 + U : n);
+                lds_st(v_ready, (long long) (f0 + U < n ? f0 + U : n));
         }
         return;
     }
@@ -528,7 +550,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     break;
                 if (ready_upto <= f)
                 {
-                    ready_upto = *v_ready;
+                    ready_upto = lds_ld(v_ready);
                     if (ready_upto <= f)
                     {
                         __builtin_amdgcn_s_sleep(1);
@@ -642,12 +664,12 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                 {
                     wave_lds_sync();
                     if (lane == 0)
-                        *v_done = f;
+                        lds_st(v_done, (long long) f);
                 }
             }
             wave_lds_sync();
             if (lane == 0)
-                *v_done = f;
+                lds_st(v_done, (long long) f);
             if (f >= n || (limit_base >= 0 && prev_rear - limit_base >= g.limit_columns))
                 break;
         }
@@ -656,7 +678,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 #ifdef CC_PROFILE_SECTIONS
         const unsigned long long t0_ = __builtin_amdgcn_s_memtime();
 #endif
-        while (*v_ready <= f)
+        while (lds_ld(v_ready) <= f)
             __builtin_amdgcn_s_sleep(1);
         wave_lds_sync();
 #ifdef CC_PROFILE_SECTIONS
@@ -855,7 +877,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         fore = uniform_i64(fore);
         wave_lds_sync();
         if (lane == 0)
-            *v_done = f + 1;
+            lds_st(v_done, (long long) (f + 1));
 #ifdef CC_PROFILE_SECTIONS
         CC_ISEC(3)
 #endif
@@ -914,7 +936,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         }
     }
     if (lane == 0)
-        *v_stop = f; // releases the loader if it is waiting for ring space
+        lds_st(v_stop, (long long) f); // releases the loader if it is waiting for ring space
 #ifdef CC_PROFILE_SECTIONS
     if (lane == 0)
     {
@@ -1287,7 +1309,7 @@ __host__ __device__ inline int seg_pitch_b(int R)
 }
 __host__ inline size_t seg_scan_lds_bytes(int R)
 {
-    return (size_t) 64 * seg_pitch_f(R) * 4 * 2 + (size_t) 64 * seg_pitch_b(R) * 2;
+    return (size_t) 64 * seg_pitch_f(R) * 4 + (size_t) 64 * seg_pitch_b(R);
 }
 
 // compact codes of the label values inside the LDS tile
@@ -1317,88 +1339,88 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
     const int lane = lane_id();
     const int PF = seg_pitch_f(R), PB = seg_pitch_b(R);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // The tile keeps only what the state machine looks back at: the azimuth-plane distance of the rows below (cc.cpp:513-535) and
+    // one output byte per cell (bits 0-2 ground label code, bits 3-6 debug label code, bit 7 "ignored if it ends up an obstacle").
+    // The inputs themselves are read by the lane that consumes them, 8 rows (one 32-byte sector per plane) at a time and one chunk
+    // ahead, so there is no staging phase and the footprint (21 KB at 64 rows) lets four blocks share a CU with the serial kernels.
     float* l_x2 = (float*) smem;
-    float* l_uz = l_x2 + 64 * PF;
-    unsigned char* l_flags = (unsigned char*) (l_uz + 64 * PF);
-    // one output byte per cell: bits 0-2 ground label code, bits 3-6 debug label code, bit 7 is_ignored (keeps the tile small
-    // enough for two blocks per CU next to the serial kernels of the other pipeline stages)
-    unsigned char* l_out = l_flags + 64 * PB;
+    unsigned char* l_out = (unsigned char*) (l_x2 + 64 * PF);
 
-    int lc0 = (int) (tile0 % RC);
-    // load: one coalesced row-run per column, 8 columns in flight
-    if (!(g.debug_flags & 2))
-    {
-        constexpr int B = 8;
-        int lc = lc0;
-        for (int c0 = 0; c0 < ncols; c0 += B)
-        {
-            for (int r0 = 0; r0 < R; r0 += 64)
-            {
-                const int row = r0 + lane;
-                float vx[B], vz[B];
-                unsigned char vf[B];
-                int lcs = lc;
-#pragma unroll
-                for (int u = 0; u < B; u++)
-                {
-                    vx[u] = vz[u] = 0.f;
-                    vf[u] = 0;
-                    if (row < R && c0 + u < ncols)
-                    {
-                        const size_t ci = (size_t) lcs * R + row;
-                        vx[u] = p.sg_x2[ci];
-                        vz[u] = p.sg_uz[ci];
-                        vf[u] = p.sg_flags[ci];
-                    }
-                    lcs = lcs + 1 == RC ? 0 : lcs + 1;
-                }
-#pragma unroll
-                for (int u = 0; u < B; u++)
-                    if (row < R && c0 + u < ncols)
-                    {
-                        l_x2[(c0 + u) * PF + row] = vx[u];
-                        l_uz[(c0 + u) * PF + row] = vz[u];
-                        l_flags[(c0 + u) * PB + row] = vf[u];
-                    }
-            }
-            for (int u = 0; u < B; u++)
-                lc = lc + 1 == RC ? 0 : lc + 1;
-        }
-    }
-    __syncthreads();
+    const int lc0 = (int) (tile0 % RC);
     if (lane < ncols && !(g.debug_flags & 1))
     {
         const long long gc = tile0 + lane;
-        const float* x2 = l_x2 + lane * PF;
-        const float* uzp = l_uz + lane * PF;
-        const unsigned char* fl = l_flags + lane * PB;
+        int lcl = lc0 + lane;
+        lcl = lcl >= RC ? lcl - RC : lcl;
+        const float* gx = p.sg_x2 + (size_t) lcl * R;
+        const float* gz = p.sg_uz + (size_t) lcl * R;
+        const unsigned char* gf = p.sg_flags + (size_t) lcl * R;
+        float* x2 = l_x2 + lane * PF;
         unsigned char* oo = l_out + lane * PB;
         const float height_sensor_to_ground = -(float) st->robot_from_sensor[11] + cfg.height_ref_to_ground_;
+        const bool chess_odd = cfg.ignore_points_in_chessboard_pattern && (gc & 1); // column parity (cc.cpp:600-606)
+        const bool chess_even = cfg.ignore_points_in_chessboard_pattern && !(gc & 1);
         bool first_obstacle_detected = false, first_point_found = false;
         float lg2x = 0.f, lgz = height_sensor_to_ground; // last (quite certain) ground point in the azimuth plane
         float pv2x = 0.f, pvz = 0.f;
         unsigned char previous_label = 0;
-        // inputs of 8 rows at a time into registers (independent LDS reads), so that the row-serial state machine below does not
-        // pay an LDS round trip per row
-        for (int row0 = R - 1; row0 >= 0; row0 -= 8)
+        const bool vec = (R & 7) == 0; // rows come in whole, aligned 32-byte sectors
+        float nx[8], nz[8];
+        unsigned nf0 = 0, nf1 = 0; // flags of the 8 rows, one byte each
+        auto load_chunk = [&](int b) // rows b .. b + 7 (b may be negative in the last chunk of an odd-sized column)
         {
-            int f8[8];
+            if (vec)
+            {
+                const float4 a0 = *(const float4*) (gx + b), a1 = *(const float4*) (gx + b + 4);
+                const float4 c0 = *(const float4*) (gz + b), c1 = *(const float4*) (gz + b + 4);
+                const uint2 ff = *(const uint2*) (gf + b);
+                nx[0] = a0.x, nx[1] = a0.y, nx[2] = a0.z, nx[3] = a0.w, nx[4] = a1.x, nx[5] = a1.y, nx[6] = a1.z, nx[7] = a1.w;
+                nz[0] = c0.x, nz[1] = c0.y, nz[2] = c0.z, nz[3] = c0.w, nz[4] = c1.x, nz[5] = c1.y, nz[6] = c1.z, nz[7] = c1.w;
+                nf0 = ff.x;
+                nf1 = ff.y;
+            }
+            else
+            {
+                nf0 = nf1 = 0;
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                {
+                    const int rr = b + u;
+                    nx[u] = rr >= 0 ? gx[rr] : 0.f;
+                    nz[u] = rr >= 0 ? gz[rr] : 0.f;
+                    const unsigned f = rr >= 0 ? gf[rr] : (unsigned) SG_NAN;
+                    if (u < 4)
+                        nf0 |= f << (8 * u);
+                    else
+                        nf1 |= f << (8 * (u - 4));
+                }
+            }
+        };
+        int b = R - 8; // lowest row of the chunk being processed; chunks run from the bottom ring (row R - 1) upwards
+        load_chunk(b);
+        for (; b > -8; b -= 8)
+        {
             float x8[8], z8[8];
 #pragma unroll
             for (int u = 0; u < 8; u++)
             {
-                const int rr = row0 - u;
-                f8[u] = rr >= 0 ? fl[rr] : SG_NAN;
-                x8[u] = rr >= 0 ? x2[rr] : 0.f;
-                z8[u] = rr >= 0 ? uzp[rr] : 0.f;
+                x8[u] = nx[u];
+                z8[u] = nz[u];
             }
+            const unsigned f0 = nf0, f1 = nf1;
+            if (b - 8 > -8)
+                load_chunk(b - 8);
 #pragma unroll
             for (int u = 0; u < 8; u++)
+                if (b + u >= 0)
+                    x2[b + u] = x8[u];
+#pragma unroll
+            for (int u = 7; u >= 0; u--)
             {
-            const int row = row0 - u;
+            const int row = b + u;
             if (row < 0)
                 break;
-            const int f = f8[u];
+            const int f = (int) (((u < 4 ? f0 : f1) >> (8 * (u & 3))) & 0xffu);
             unsigned char ground = SG_G_UNKNOWN, debug = SG_D_WHITE;
             if (f & SG_NAN)
             {
@@ -1415,6 +1437,9 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 oo[row] = (unsigned char) (SG_G_EGO | (SG_D_VIOLET << 3));
                 continue;
             }
+            // cc.cpp:567-616 for a point that ends up an obstacle: too close / inclination filter / chessboard thinning
+            const unsigned char ign_bit =
+                ((f & (SG_TOO_CLOSE | SG_INCL_IGNORE)) || ((row & 1) ? chess_even : chess_odd)) ? (unsigned char) 0x80 : (unsigned char) 0;
             const float cur2x = x8[u], cur2y = z8[u];
             if (!first_point_found)
             {
@@ -1437,7 +1462,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 pv2x = cur2x;
                 pvz = cur2y;
                 previous_label = debug;
-                oo[row] = (unsigned char) (ground | (debug << 3));
+                oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
                 continue;
             }
             const float p2cx = cur2x - pv2x, p2cy = cur2y - pvz;
@@ -1480,7 +1505,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                     {
                         if (bg == SG_G_GROUND)
                         {
-                            oo[below] = (unsigned char) (SG_G_OBSTACLE | (SG_D_DARKRED << 3));
+                            oo[below] = (unsigned char) ((bo & 0x80) | SG_G_OBSTACLE | (SG_D_DARKRED << 3));
                         }
                         below++;
                     }
@@ -1501,28 +1526,8 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             pv2x = cur2x;
             pvz = cur2y;
             previous_label = debug;
-            oo[row] = (unsigned char) (ground | (debug << 3));
-        }
-        }
-        for (int row = R - 1; row >= 0; row--) // cc.cpp:567-616
-        {
-            const int f = fl[row];
-            bool ign = false;
-            if (f & SG_NAN)
-                ign = true;
-            else if ((oo[row] & 7) != SG_G_OBSTACLE)
-                ign = true;
-            else if (f & (SG_TOO_CLOSE | SG_INCL_IGNORE))
-                ign = true;
-            else if (cfg.ignore_points_in_chessboard_pattern)
-            {
-                const bool column_even = gc % 2 == 0;
-                const bool row_even = row % 2 == 0;
-                if ((column_even && !row_even) || (!column_even && row_even))
-                    ign = true;
+            oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
             }
-            if (ign)
-                oo[row] |= 0x80;
         }
     }
     __syncthreads();
@@ -1537,7 +1542,8 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 const unsigned char o = l_out[c * PB + row];
                 p.ground[ci] = SEG_GROUND_VALUE[o & 7];
                 p.debug[ci] = SEG_DEBUG_VALUE[(o >> 3) & 15];
-                p.ignored[ci] = o >> 7;
+                // cc.cpp:567-616: everything that is not an obstacle is ignored, and so are the filtered obstacles
+                p.ignored[ci] = ((o & 7) != SG_G_OBSTACLE || (o & 0x80)) ? 1 : 0;
             }
             lc = lc + 1 == RC ? 0 : lc + 1;
         }
@@ -2264,7 +2270,7 @@ struct LdsTrees
     int cell[TREE_SLOTS];                // root cell of the tree in list position i
     long long gcol[TREE_SLOTS];          // its global column
     unsigned long long fin[TREE_SLOTS];  // bits of finished_at_continuous_azimuth_angle (non-negative double)
-    unsigned width[TREE_SLOTS];
+    unsigned last[TREE_SLOTS];           // low 32 bits of the last global column that attached a point (width = last - gcol + 1)
     unsigned pts[TREE_SLOTS];
     int uf[TREE_SLOTS];                  // union-find parent (list position)
     unsigned long long c_fin[TREE_SLOTS]; // at a representative: lower bound of the cluster's max finished_at (exact after a scan)
@@ -2284,12 +2290,12 @@ __device__ __forceinline__ int lds_find(int* uf, int a)
 {
     while (true)
     {
-        const int pa = ((volatile int*) uf)[a];
+        const int pa = lds_ld(&uf[a]);
         if (pa == a)
             return a;
-        const int gp = ((volatile int*) uf)[pa];
+        const int gp = lds_ld(&uf[pa]);
         if (gp != pa)
-            ((volatile int*) uf)[a] = gp;
+            lds_st(&uf[a], gp);
         a = pa;
     }
 }
@@ -2310,7 +2316,7 @@ __device__ __forceinline__ void lds_union(int* uf, unsigned long long* c_fin, in
         }
         if (atomicCAS(&uf[a], a, b) == a)
         {
-            atomicMax(&c_fin[b], ((volatile unsigned long long*) c_fin)[a]);
+            atomicMax(&c_fin[b], lds_ld(&c_fin[a]));
             return;
         }
     }
@@ -2323,9 +2329,9 @@ __device__ __forceinline__ bool cluster_may_finish(LdsTrees& T, int n_unf, doubl
     bool may = false;
     double lb = 1.7976931348623157e308;
     for (int i = lane_id(); i < n_unf; i += 64)
-        if (((volatile int*) T.uf)[i] == i)
+        if (lds_ld(&T.uf[i]) == i)
         {
-            const double f = __longlong_as_double((long long) ((volatile unsigned long long*) T.c_fin)[i]);
+            const double f = __longlong_as_double((long long) lds_ld(&T.c_fin[i]));
             may |= !(f > min_az);
             lb = f < lb ? f : lb;
         }
@@ -2391,7 +2397,7 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
                                         if (nw <= (uint32_t) c.NC)
                                         {
                                             pslot = oslot;
-                                            T.width[oslot] = nw;
+                                            T.last[oslot] = (unsigned) gc;
                                             const unsigned long long cand = (unsigned long long) __double_as_longlong(pcaz + (double) mad);
                                             if (cand > T.fin[oslot])
                                                 T.fin[oslot] = cand;
@@ -2433,7 +2439,7 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
             T.cell[pslot] = pi;
             T.gcol[pslot] = gc;
             T.fin[pslot] = (unsigned long long) __double_as_longlong(fin);
-            T.width[pslot] = 1;
+            T.last[pslot] = (unsigned) gc;
             T.pts[pslot] = 1;
             T.uf[pslot] = pslot;
             T.c_fin[pslot] = T.fin[pslot];
@@ -2522,14 +2528,15 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
         {
             const int cell = p.ulist[i];
             T.cell[i] = cell;
-            T.gcol[i] = p.colg[cell / R];
+            const long long tg = p.colg[cell / R];
+            T.gcol[i] = tg;
             T.fin[i] = (unsigned long long) __double_as_longlong(p.t_fin[cell]);
-            T.width[i] = p.t_width[cell];
+            T.last[i] = (unsigned) tg + p.t_width[cell] - 1u;
             T.pts[i] = p.t_pts[cell];
             T.uf[i] = p.t_pos[p.t_uf[cell]];
             T.c_fin[i] = T.fin[i];
         }
-        wave_lds_sync();
+        wave_lds_fence();
         for (int i = lane; i < n_unf; i += 64)
             atomicMax(&T.c_fin[lds_find(T.uf, i)], T.fin[i]);
         // window of tree-slot ids for the WIN_COLS columns before col_begin: two dependent gathers per cell (root plane, then the
@@ -2645,7 +2652,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
         int parent[RPL], nl[RPL];
         unsigned long long link[RPL];
         double finc[RPL];
-        const double min_az = uniform_f64(__shfl(nx_minaz, 0));
+        const double min_az = uniform_f64(nx_minaz); // readfirstlane: lane 0 holds it, all lanes are active here
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -2686,7 +2693,8 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             break;
         }
         emit(CC_EV_GROUND_COLUMN, gc, gc, 0, 0, gc);
-        wave_lds_sync();
+        if (RPL > 1)
+            wave_lds_fence();
         CC_SEC(7)
         // pointer jumping: after ceil(log2(R)) rounds every row knows the top row of its same-column parent chain
         int top_of[RPL];
@@ -2733,7 +2741,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                     const int row = k * 64 + lane;
                     nxt[k] = row < R ? s_parent[s_parent[row]] : 0;
                 }
-                wave_lds_sync();
+                wave_lds_fence();
 #pragma unroll
                 for (int k = 0; k < RPL; k++)
                 {
@@ -2741,7 +2749,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                     if (row < R)
                         s_parent[row] = nxt[k];
                 }
-                wave_lds_sync();
+                wave_lds_fence();
             }
 #pragma unroll
             for (int k = 0; k < RPL; k++)
@@ -2756,13 +2764,19 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             const int mine = parent[0] == -1 ? newpos[0] : (parent[0] >= 0 ? -1 - parent[0] : 0x7fffffff);
             term_info = __shfl(mine, top_of[0]);
         }
-        int slot[RPL], rootcell[RPL];
+        int slot[RPL];
+        int freshcell[RPL]; // root cell of the point's tree
+        // cc.cpp:657 (a tree may not span more than one rotation): M is the oldest start column of any unfinished tree, so while
+        // gc - M + 1 <= NC no tree can fail the test and the per-lane look-up is skipped
+        const bool span_check = n_unf > 0 && (uint32_t) (gc - M + 1) > (uint32_t) NC;
+        // cc.cpp:762-763 (the live scan stops at the first unpublished column): only when the window reaches back that far
+        const bool reach_check = gc - (WIN_COLS - 1) < first_unpub;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
             const int row = k * 64 + lane;
             slot[k] = -1;
-            rootcell[k] = -1;
+            freshcell[k] = -1;
             if (parent[k] >= -1 && row < R)
             {
                 const int top = top_of[k];
@@ -2772,7 +2786,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 if (tv >= 0)
                 {
                     slot[k] = tv;
-                    rootcell[k] = lc * R + top;
+                    freshcell[k] = lc * R + top;
                 }
                 else
                 {
@@ -2785,27 +2799,30 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                     else
                     {
                         slot[k] = v;
-                        rootcell[k] = T.cell[v];
-                        if ((uint32_t) (gc - T.gcol[v] + 1) > (uint32_t) NC)
+                        freshcell[k] = T.cell[v];
+                        if (span_check && (uint32_t) (gc - T.gcol[v] + 1) > (uint32_t) NC)
                             bad = true; // tree would span more than one rotation (cc.cpp:657)
                     }
                 }
                 // nothing may come from columns the live scan would not have reached (cc.cpp:762-763)
-                if (parent[k] >= 0)
+                if (reach_check)
                 {
-                    const int pd = parent[k] >> 8;
-                    oldest_delta = pd > oldest_delta ? pd : oldest_delta;
-                    const int nlk = nl[k] == 255 ? 0 : nl[k];
+                    if (parent[k] >= 0)
+                    {
+                        const int pd = parent[k] >> 8;
+                        oldest_delta = pd > oldest_delta ? pd : oldest_delta;
+                        const int nlk = nl[k] == 255 ? 0 : nl[k];
 #pragma unroll
-                    for (int j = 0; j < LINK_SLOTS; j++)
-                        if (j < nlk)
-                        {
-                            const int d = (int) ((link[k] >> (16 * j + 8)) & 0xff);
-                            oldest_delta = d > oldest_delta ? d : oldest_delta;
-                        }
+                        for (int j = 0; j < LINK_SLOTS; j++)
+                            if (j < nlk)
+                            {
+                                const int d = (int) ((link[k] >> (16 * j + 8)) & 0xff);
+                                oldest_delta = d > oldest_delta ? d : oldest_delta;
+                            }
+                    }
+                    if (gc - oldest_delta < first_unpub)
+                        bad = true;
                 }
-                if (gc - oldest_delta < first_unpub)
-                    bad = true;
             }
         }
         const bool column_live = __any(bad);
@@ -2814,6 +2831,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
         if (!column_live)
         {
             int* wcol = s_win + wcur * R;
+            double l_new = L; // per-lane; L itself must stay wave-uniform (a divergent L drags the whole bookkeeping into VGPRs)
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
@@ -2821,18 +2839,19 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 if (row < R)
                 {
                     wcol[row] = slot[k];
-                    p.root[lc * R + row] = rootcell[k];
+                    // early: the store has a column of work to retire before the vmcnt(0) at the top of the next iteration
+                    p.root[lc * R + row] = freshcell[k];
                     if (parent[k] == -1)
                     {
                         const int i = slot[k];
                         T.cell[i] = lc * R + row;
                         T.gcol[i] = gc;
                         T.fin[i] = (unsigned long long) __double_as_longlong(finc[k]);
-                        T.width[i] = 1;
+                        T.last[i] = (unsigned) gc;
                         T.pts[i] = 1;
                         T.uf[i] = i;
                         T.c_fin[i] = (unsigned long long) __double_as_longlong(finc[k]);
-                        L = finc[k] < L ? finc[k] : L;
+                        l_new = finc[k] < l_new ? finc[k] : l_new;
                     }
                 }
             }
@@ -2841,21 +2860,22 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 if (n_unf == 0)
                     M = gc;
                 n_unf += cnt_new;
-                L = uniform_f64(wave_min_f64(L));
+                L = uniform_f64(wave_min_f64(l_new));
             }
-            wave_lds_sync();
+            wave_lds_fence();
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 if (parent[k] >= 0)
                 {
                     const int i = slot[k];
-                    T.width[i] = (unsigned) (gc - T.gcol[i] + 1);
-                    const unsigned long long fb = (unsigned long long) __double_as_longlong(finc[k]);
-                    atomicMax(&T.fin[i], fb);
-                    atomicMax(&T.c_fin[lds_find(T.uf, i)], fb);
-                    atomicAdd(&T.pts[i], 1u);
                     const int nlk = nl[k];
+                    const int rep = lds_find(T.uf, i);
+                    const unsigned long long fb = (unsigned long long) __double_as_longlong(finc[k]);
+                    T.last[i] = (unsigned) gc;
+                    atomicMax(&T.fin[i], fb);
+                    atomicMax(&T.c_fin[rep], fb);
+                    atomicAdd(&T.pts[i], 1u);
 #pragma unroll
                     for (int j = 0; j < LINK_SLOTS; j++)
                         if (j < nlk)
@@ -2867,7 +2887,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                         }
                 }
             }
-            wave_lds_sync();
+            wave_lds_fence();
         }
         else
         {
@@ -2883,7 +2903,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 s_bd[0] = LL;
                 s_bl[0] = MM;
             }
-            wave_lds_sync();
+            wave_lds_fence();
             n_unf = uniform_i32(s_bi[0]);
             if (s_bi[1] == CC_ERR_CAPACITY)
             {
@@ -2893,7 +2913,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             }
             L = uniform_f64(s_bd[0]);
             M = uniform_i64(s_bl[0]);
-            wave_lds_sync();
+            wave_lds_fence();
         }
         if (err)
             break;
@@ -2925,18 +2945,18 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 T.a_cid[i] = 0;
                 T.a_flag[i] = 0;
             }
-            wave_lds_sync();
+            wave_lds_fence();
             for (int i = lane; i < n_unf; i += 64)
             {
                 const int j = lds_find(T.uf, i);
                 T.comp[i] = j;
                 atomicMax(&T.a_fin[j], T.fin[i]);
                 atomicMin(&T.a_min[j], T.gcol[i]);
-                atomicMax(&T.a_max[j], T.gcol[i] + (long long) T.width[i]);
+                atomicMax(&T.a_max[j], T.gcol[i] + (long long) (T.last[i] - (unsigned) T.gcol[i] + 1u));
                 atomicAdd(&T.a_pts[j], T.pts[i]);
                 atomicMin(&T.a_first[j], i);
             }
-            wave_lds_sync();
+            wave_lds_fence();
             int exceed_local = 0, any_fin = 0;
             for (int i = lane; i < n_unf; i += 64)
                 if (T.comp[i] == i)
@@ -2953,7 +2973,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             for (int o = 32; o > 0; o >>= 1)
                 exceed_local += __shfl_xor(exceed_local, o);
             exceed += (unsigned long long) uniform_i32(exceed_local);
-            wave_lds_sync();
+            wave_lds_fence();
             int last_first = -1;
             while (true)
             {
@@ -2977,7 +2997,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 clusters_finished++;
                 last_first = best;
             }
-            wave_lds_sync();
+            wave_lds_fence();
             // mark + persist finished trees, minimum required column, stable compaction of every slot array
             long long min_all = 0x7fffffffffffffffll, min_surv = 0x7fffffffffffffffll;
             double L_new = 1.7976931348623157e308;
@@ -2996,7 +3016,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                     cell = T.cell[i];
                     tg = T.gcol[i];
                     fin = T.fin[i];
-                    width = T.width[i];
+                    width = T.last[i];
                     pts = T.pts[i];
                     uf = T.uf[i];
                     const int j = T.comp[i];
@@ -3021,20 +3041,20 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 const int np = out + __popcll(mask & lanes_below());
                 if (i < n_unf)
                     T.remap[i] = surv ? np : -2;
-                wave_lds_sync();
+                wave_lds_fence();
                 if (surv)
                 {
                     T.cell[np] = cell;
                     T.gcol[np] = tg;
                     T.fin[np] = fin;
-                    T.width[np] = width;
+                    T.last[np] = width;
                     T.pts[np] = pts;
                     T.uf[np] = uf; // still an old position; remapped below
                     T.c_fin[np] = cfin;
                 }
                 out += __popcll(mask);
             }
-            wave_lds_sync();
+            wave_lds_fence();
             out = uniform_i32(out);
             if (out != n_unf)
             {
@@ -3053,7 +3073,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             M_c = min_all;
             M = min_surv;
             n_unf = out;
-            wave_lds_sync();
+            wave_lds_fence();
         }
         last_min_az = min_az;
 
@@ -3076,14 +3096,14 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     // ---- persist the tree state back to the global planes -------------------------------------------------------
     if (n_unf <= TREE_SLOTS)
     {
-        wave_lds_sync();
+        wave_lds_fence();
         for (int i = lane; i < n_unf; i += 64)
         {
             const int cell = T.cell[i];
             p.ulist[i] = cell;
             p.t_pos[cell] = i;
             p.t_fin[cell] = __longlong_as_double((long long) T.fin[i]);
-            p.t_width[cell] = T.width[i];
+            p.t_width[cell] = T.last[i] - (unsigned) T.gcol[i] + 1u;
             p.t_pts[cell] = T.pts[i];
             p.t_uf[cell] = T.cell[T.uf[i]];
             p.t_cid[cell] = 0;

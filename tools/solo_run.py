@@ -1,0 +1,14 @@
+"""3 batches of the bench workload with the pipeline off (kernels run back to back on one HIP stream): the subject of PMC passes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from continuous_clustering_amd import Engine, capi, synth
+import bench
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
+F, NB = 2200, 3
+xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, S, F, NB, 1234)
+torch.cuda.synchronize()
+e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", 0)
+for b in range(NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])
+print("rc", e.sync())
