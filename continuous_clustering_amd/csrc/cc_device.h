@@ -140,6 +140,10 @@ struct Planes
     float4* sc_rec;
     // candidates are coded as (columns back << 8) | row
     int16_t* sc_parent;  // first accepted candidate, -1 = none, -2 = point is ignored
+    int16_t* sc_term;    // where the point's same-column parent chain ends: >= 256 candidate code (delta << 8 | row) in an earlier
+                         // column, 0..255 index of the chain's new root among the column's new roots, -1 point is ignored
+    double* col_newfin;  // per column: minimum finished_at over the column's new roots (+inf without any)
+    int32_t* col_info;   // per column: new roots | flags << 8 (1: link overflow, 2: any links) | largest delta used << 16
     uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS
     unsigned long long* sc_links; // LINK_SLOTS x 16-bit candidate codes packed into one word per cell
     double* sc_fin;      // continuous azimuth + max angle diff of the point (its contribution to finished_at)

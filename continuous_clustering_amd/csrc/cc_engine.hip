@@ -44,6 +44,7 @@ struct cc_engine
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
+    int assoc_waves{2};                 // option "assoc_waves": 2 = k_assoc2 (front / back wavefronts), 1 = k_assoc_lds
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
     std::string error;
@@ -163,6 +164,7 @@ int allocate(cc_engine* e)
     A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
     A(events, S * (size_t) g.event_capacity);
     A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
+    A(sc_term, C) A(col_newfin, L) A(col_info, L);
     A(sg_x2, C) A(sg_uz, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
 #undef A
@@ -324,7 +326,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     // ---- association + publish chain -------------------------------------------------------------------------
     CC_MARK(sa); // ev6: start of the third chain
-    if (rpl == 1)
+    if (e->assoc_waves == 2)
+    {
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_assoc2<1>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else
+            hipLaunchKernelGGL(cck::k_assoc2<2>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    }
+    else if (rpl == 1)
         hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
         hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -1096,6 +1105,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->allow_pipeline = value != 0;
     else if (n == "graphs")
         e->allow_graphs = value != 0;
+    else if (n == "assoc_waves")
+        e->assoc_waves = value == 1 ? 1 : 2;
     else if (n == "limit_columns")
         e->g.limit_columns = (int32_t) (value < 1 ? 1 : value);
     else

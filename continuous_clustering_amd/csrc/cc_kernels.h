@@ -172,6 +172,9 @@ struct SP
     float* curtab;
     cc_event* events;
     int16_t* sc_parent;
+    int16_t* sc_term;
+    double* col_newfin;
+    int32_t* col_info;
     uint8_t* sc_nlinks;
     unsigned long long* sc_links;
     double* sc_fin;
@@ -223,6 +226,9 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.curtab = P.curtab + (size_t) s * g.num_rows;
     p.events = P.events + (size_t) s * g.event_capacity;
     p.sc_parent = P.sc_parent + co;
+    p.sc_term = P.sc_term + co;
+    p.col_newfin = P.col_newfin + lo;
+    p.col_info = P.col_info + lo;
     p.sc_nlinks = P.sc_nlinks + co;
     p.sc_links = P.sc_links + co;
     p.sc_fin = P.sc_fin + co;
@@ -2225,36 +2231,122 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
         const int lc = (int) (gc % RC);
         // never look at columns older than the first column ever segmented (their planes are uninitialised)
         const int bound = (gc - first_column) <= (long long) cfg.max_steps_in_row + 1 ? (int) (first_column % RC) : -1;
+        int parent[RPL], nlinks[RPL];
+        double fin[RPL];
+        unsigned long long packed[RPL];
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
             const int row = k * 64 + lane;
+            parent[k] = -2;
+            nlinks[k] = 0;
+            fin[k] = 0.;
+            packed[k] = 0;
             if (row >= R)
                 continue;
             const int ci = lc * R + row;
-            int parent = -2, nlinks = 0;
-            double fin = 0.;
             if (!p.ignored[ci])
             {
-                parent = -1;
+                parent[k] = -1;
                 const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
                 const double caz = p.caz[ci];
-                fin = caz + (double) mad;
+                fin[k] = caz + (double) mad;
                 bool overflow = false;
                 int dummy_root = -1;
-                scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent, s_links[row], nlinks, overflow, LINK_SLOTS);
+                scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent[k], s_links[row], nlinks[k], overflow, LINK_SLOTS);
                 if (overflow)
-                    nlinks = 255;
+                    nlinks[k] = 255;
             }
-            p.sc_parent[ci] = (int16_t) parent;
-            p.sc_nlinks[ci] = (uint8_t) nlinks;
-            p.sc_fin[ci] = fin;
-            const int nl = nlinks == 255 ? LINK_SLOTS : nlinks;
-            unsigned long long packed = 0;
+            p.sc_parent[ci] = (int16_t) parent[k];
+            p.sc_nlinks[ci] = (uint8_t) nlinks[k];
+            p.sc_fin[ci] = fin[k];
+            const int nl = nlinks[k] == 255 ? LINK_SLOTS : nlinks[k];
             for (int j = 0; j < nl; j++)
-                packed |= (unsigned long long) (s_links[row][j] & 0xffff) << (16 * j);
+                packed[k] |= (unsigned long long) (s_links[row][j] & 0xffff) << (16 * j);
             if (nl > 0)
-                p.sc_links[ci] = packed;
+                p.sc_links[ci] = packed[k];
+        }
+        // ---- column epilogue: everything about the column that does not depend on the tree state, so that the serial association
+        // kernel finds it precomputed. (1) where every point's chain of same-column parents ends; (2) the column summary.
+        int t[RPL]; // row at the top of the chain so far
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            const bool same_col = parent[k] >= 0 && (parent[k] >> 8) == 0;
+            t[k] = same_col ? (parent[k] & 0xff) : row;
+        }
+        for (int it = 0; it < 7; it++) // pointer jumping: rows <= 128, chains shorter than 2^7
+        {
+            int nt[RPL];
+            bool changed = false;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int src = t[k];
+                const int lo = __shfl(t[0], src & 63);
+                const int hi = RPL > 1 ? __shfl(t[RPL - 1], src & 63) : lo;
+                nt[k] = src < 64 ? lo : hi;
+                changed |= nt[k] != t[k];
+            }
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+                t[k] = nt[k];
+            if (!__any(changed))
+                break;
+        }
+        int cnt_new = 0, mine[RPL];
+        int max_delta = 0;
+        int flags = 0;
+        double newfin = 1.7976931348623157e308;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const bool is_new = parent[k] == -1;
+            const unsigned long long mask = __ballot(is_new);
+            const int newidx = cnt_new + __popcll(mask & lanes_below());
+            cnt_new += __popcll(mask);
+            mine[k] = is_new ? newidx : (parent[k] >= 0 ? parent[k] : -1);
+            if (is_new && fin[k] < newfin)
+                newfin = fin[k];
+            if (parent[k] >= 0)
+            {
+                int d = parent[k] >> 8;
+                const int nl = nlinks[k] == 255 ? LINK_SLOTS : nlinks[k];
+                for (int j = 0; j < nl; j++)
+                {
+                    const int dj = (int) ((packed[k] >> (16 * j + 8)) & 0xff);
+                    d = dj > d ? dj : d;
+                }
+                max_delta = d > max_delta ? d : max_delta;
+            }
+            if (nlinks[k] == 255)
+                flags |= 1;
+            else if (nlinks[k] > 0)
+                flags |= 2;
+        }
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            const int src = t[k];
+            const int lo = __shfl(mine[0], src & 63);
+            const int hi = RPL > 1 ? __shfl(mine[RPL - 1], src & 63) : lo;
+            const int term = parent[k] < -1 ? -1 : (src < 64 ? lo : hi);
+            if (row < R)
+                p.sc_term[lc * R + row] = (int16_t) term;
+        }
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            const int md = __shfl_xor(max_delta, o), fl = __shfl_xor(flags, o);
+            max_delta = md > max_delta ? md : max_delta;
+            flags |= fl;
+        }
+        newfin = wave_min_f64(newfin);
+        if (lane == 0)
+        {
+            p.col_newfin[lc] = newfin;
+            p.col_info[lc] = cnt_new | (flags << 8) | (max_delta << 16);
         }
     }
 }
@@ -3144,6 +3236,8 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
             raise_error(st, err, err_a, err_b);
     }
 }
+
+#include "cc_assoc2.h"
 
 // =====================================================================================================
 // k_publish — cluster ids of the columns published in this pass: Point::id = id of the finished cluster of the point's
