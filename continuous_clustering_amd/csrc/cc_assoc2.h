@@ -34,7 +34,7 @@ struct LdsTrees2
     int cell[TREE_SLOTS];                 // root cell of tree id i
     long long gcol[TREE_SLOTS];           // its global column
     unsigned long long fin[TREE_SLOTS];   // bits of finished_at_continuous_azimuth_angle (non-negative double)
-    unsigned last[TREE_SLOTS];            // low 32 bits of the last global column that attached a point
+    long long last[TREE_SLOTS];           // last global column that attached a point (width = last - gcol + 1)
     unsigned pts[TREE_SLOTS];
     int uf[TREE_SLOTS];                   // union-find parent (tree id)
     unsigned long long c_fin[TREE_SLOTS]; // at a representative: lower bound of the cluster's max finished_at
@@ -66,24 +66,27 @@ struct LdsTrees2
     int bcast_i[4];
     double bcast_d[2];
     long long bcast_l[2];
+    unsigned long long bcast_u64;
 };
 
+// true iff some cluster's (lower-bounded) max finished_at has been passed by the column's minimum azimuth: only then can the
+// finished-cluster check of cc.cpp:884-885 let a cluster through. The minimum over the clusters goes through one LDS word
+// (non-negative doubles order like their bit patterns): two round trips instead of a 12-step cross-lane reduction.
 __device__ __forceinline__ bool cluster_may_finish2(LdsTrees2& T, int n_unf, double min_az, double& lower_bound)
 {
-    bool may = false;
-    double lb = 1.7976931348623157e308;
+    if (lane_id() == 0)
+        T.bcast_u64 = 0x7fefffffffffffffull; // DBL_MAX
+    wave_lds_fence();
     for (int k = lane_id(); k < n_unf; k += 64)
     {
         const int i = T.alist[k];
         if (lds_ld(&T.uf[i]) == i)
-        {
-            const double f = __longlong_as_double((long long) lds_ld(&T.c_fin[i]));
-            may |= !(f > min_az);
-            lb = f < lb ? f : lb;
-        }
+            atomicMin(&T.bcast_u64, lds_ld(&T.c_fin[i]));
     }
-    lower_bound = uniform_f64(wave_min_f64(lb));
-    return __any(may);
+    wave_lds_fence();
+    const double lb = uniform_f64(__longlong_as_double((long long) lds_ld(&T.bcast_u64)));
+    lower_bound = lb; // min over the clusters of (a lower bound of) their max finished_at
+    return !(lb > min_az);
 }
 
 // exact single-lane replay of one column (rare): reference semantics with immediate attach / link; ids come from the free ring
@@ -147,7 +150,7 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
                                         if (nw <= (uint32_t) c.NC)
                                         {
                                             pslot = oslot;
-                                            T.last[oslot] = (unsigned) gc;
+                                            T.last[oslot] = gc;
                                             const unsigned long long cand = (unsigned long long) __double_as_longlong(pcaz + (double) mad);
                                             if (cand > T.fin[oslot])
                                                 T.fin[oslot] = cand;
@@ -189,7 +192,7 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
             T.cell[pslot] = pi;
             T.gcol[pslot] = gc;
             T.fin[pslot] = (unsigned long long) __double_as_longlong(fin);
-            T.last[pslot] = (unsigned) gc;
+            T.last[pslot] = gc;
             T.pts[pslot] = 1;
             T.uf[pslot] = pslot;
             T.c_fin[pslot] = T.fin[pslot];
@@ -205,23 +208,48 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
     }
 }
 
-// one-section-at-a-time cycle probes of wave B (each s_memtime pair costs ~100 cycles, so only the section selected at build time
-// with -DCC_A2_SECTION=k is timed; tools/prof_assoc2.py loops over k)
-#ifdef CC_A2_SECTION
-#define A2_T(k)                  \
-    if ((k) == CC_A2_SECTION)    \
-        a2_t0 = __builtin_amdgcn_s_memtime();
-#define A2_E(k)                  \
-    if ((k) == CC_A2_SECTION)    \
-        a2_acc += __builtin_amdgcn_s_memtime() - a2_t0;
-#else
-#define A2_T(k)
-#define A2_E(k)
-#endif
+// row_shr:N within a row of 16 lanes (lanes without a source keep `fill`): prefix scans over the first lanes without LDS round trips
+template<int N>
+__device__ __forceinline__ int dpp_shr_i32(int v, int fill)
+{
+    return __builtin_amdgcn_update_dpp(fill, v, 0x110 + N, 0xf, 0xf, false);
+}
+template<int N>
+__device__ __forceinline__ long long dpp_shr_i64(long long v, long long fill)
+{
+    const unsigned lo = (unsigned) dpp_shr_i32<N>((int) (unsigned) (unsigned long long) v, (int) (unsigned) (unsigned long long) fill);
+    const unsigned hi = (unsigned) dpp_shr_i32<N>((int) (unsigned) ((unsigned long long) v >> 32), (int) (unsigned) ((unsigned long long) fill >> 32));
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+template<int N>
+__device__ __forceinline__ double dpp_shr_f64(double v, double fill)
+{
+    return __longlong_as_double(dpp_shr_i64<N>(__double_as_longlong(v), __double_as_longlong(fill)));
+}
+__device__ __forceinline__ long long lane_i64(long long v, int u)
+{
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (unsigned long long) v, u);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) v >> 32), u);
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+
+// helpers: lane-indexed per-column scalars of a group (lane u holds column u's value)
+__device__ __forceinline__ int lane_i32(int v, int u)
+{
+    return __builtin_amdgcn_readlane(v, u);
+}
+__device__ __forceinline__ double lane_f64(double v, int u)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (unsigned long long) b, u);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) b >> 32), u);
+    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
 
 template<int RPL>
 __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
+    constexpr int G = RPL == 1 ? 8 : 4; // columns wave B handles per pass
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -244,8 +272,12 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
 
     __shared__ LdsTrees2 T;
     __shared__ short s_win[WIN2_COLS * WAVE * RPL];
-    __shared__ int s_parent[WAVE * RPL];
-    __shared__ int s_newslot[WAVE * RPL];
+    // wave B's current group of columns, staged so that its per-column loops are real loops (small code: the instruction cache
+    // is shared and a fully unrolled group body does not fit)
+    __shared__ double st_fin[G * WAVE * RPL];
+    __shared__ unsigned long long st_link[G * WAVE * RPL];
+    __shared__ short st_parent[G * WAVE * RPL];
+    __shared__ unsigned char st_nl[G * WAVE * RPL];
 
     const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
     const int n_unf0 = st->n_unfinished;
@@ -273,7 +305,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             T.cell[i] = cell;
             T.gcol[i] = tg;
             T.fin[i] = (unsigned long long) __double_as_longlong(p.t_fin[cell]);
-            T.last[i] = (unsigned) tg + p.t_width[cell] - 1u;
+            T.last[i] = tg + (long long) p.t_width[cell] - 1;
             T.pts[i] = p.t_pts[cell];
             T.uf[i] = p.t_pos[p.t_uf[cell]];
             T.c_fin[i] = T.fin[i];
@@ -347,94 +379,80 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
     if (wave == 0)
     {
         // =========================================================================================== wave A: resolve
+        // Per column: one look-up in the id ring per point (k_scan already followed the same-column parent chains), ids from the
+        // free ring for the new roots, the column's ids into the ring. Every flag read is made wave-uniform (readfirstlane): a
+        // divergent loop condition would drag all of the wave's scalar bookkeeping into VGPRs.
         int head = 0;
         long long gcA = col_begin;
         int lc = (int) (col_begin % RC);
         long long b_seen = col_begin;
-        int nx_parent[RPL];
-        auto load_parent = [&](long long gcx, int lcx)
+        int nx_term[RPL], nx_info = 0;
+        auto load_a = [&](long long gcx, int lcx)
         {
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 const int row = k * 64 + lane;
-                nx_parent[k] = -2;
+                nx_term[k] = -1;
                 if (row < R && gcx < col_end)
-                    nx_parent[k] = p.sc_parent[lcx * R + row];
+                    nx_term[k] = p.sc_term[lcx * R + row];
             }
+            if (lane == 0 && gcx < col_end)
+                nx_info = p.col_info[lcx];
         };
-        load_parent(gcA, lc);
+        load_a(gcA, lc);
         bool wait_park = false; // a column could not be resolved: wave B will park us when it gets there
-#ifdef CC_A2_STATS
-        unsigned long long a_lead_waits = 0, a_t0 = __builtin_amdgcn_s_memtime(), a_busy = 0;
-#endif
+        int poll = 0;
         while (true)
         {
-            const int cmd = uniform_i32(lds_ld(&T.cmd)); // every flag read is made wave-uniform: a divergent loop condition would
-                                                         // drag all of the wave's scalar bookkeeping into VGPRs
-            if (cmd == A2_EXIT)
-                break;
-            if (cmd == A2_PARK)
+            const bool idle = wait_park || gcA >= col_end || gcA - b_seen >= A2_LEAD;
+            if (idle || (++poll & 3) == 0)
             {
-                if (lane == 0)
-                    lds_st(&T.a_parked, 1);
-                while (uniform_i32(lds_ld(&T.cmd)) == A2_PARK)
-                    __builtin_amdgcn_s_sleep(1);
-                if (uniform_i32(lds_ld(&T.cmd)) == A2_EXIT)
+                const int cmd = uniform_i32(lds_ld(&T.cmd));
+                if (cmd == A2_EXIT)
                     break;
-                wave_lds_fence();
-                gcA = uniform_i64(lds_ld(&T.restart_col));
-                head = uniform_i32(lds_ld(&T.head));
-                lc = (int) (gcA % RC);
-                b_seen = gcA;
-                wait_park = false;
-                load_parent(gcA, lc);
-                continue;
-            }
-            if (wait_park || gcA >= col_end)
-            {
-                __builtin_amdgcn_s_sleep(2);
-                continue;
-            }
-            if (gcA - b_seen >= A2_LEAD)
-            {
-                b_seen = uniform_i64(lds_ld(&T.b_done));
-                if (gcA - b_seen >= A2_LEAD)
+                if (cmd == A2_PARK)
                 {
-#ifdef CC_A2_STATS
-                    a_lead_waits++;
-#endif
-                    __builtin_amdgcn_s_sleep(1);
+                    if (lane == 0)
+                        lds_st(&T.a_parked, 1);
+                    while (uniform_i32(lds_ld(&T.cmd)) == A2_PARK)
+                        __builtin_amdgcn_s_sleep(1);
+                    if (uniform_i32(lds_ld(&T.cmd)) == A2_EXIT)
+                        break;
+                    wave_lds_fence();
+                    gcA = uniform_i64(lds_ld(&T.restart_col));
+                    head = uniform_i32(lds_ld(&T.head));
+                    lc = (int) (gcA % RC);
+                    b_seen = gcA;
+                    wait_park = false;
+                    load_a(gcA, lc);
                     continue;
                 }
-            }
-            int parent[RPL];
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-                parent[k] = nx_parent[k];
-            {
-                const int lc1 = lc + 1 == RC ? 0 : lc + 1;
-                load_parent(gcA + 1, lc1); // prefetch
-            }
-            const int wcur = (int) (gcA & (WIN2_COLS - 1));
-            int cnt_new = 0;
-            int newidx[RPL];
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                const bool is_new = parent[k] == -1;
-                const unsigned long long mask = __ballot(is_new);
-                newidx[k] = cnt_new + __popcll(mask & lanes_below());
-                cnt_new += __popcll(mask);
-                if (row < R && RPL > 1)
+                if (wait_park || gcA >= col_end)
                 {
-                    const bool same_col = parent[k] >= 0 && (parent[k] >> 8) == 0;
-                    s_parent[row] = same_col ? (parent[k] & 0xff) : row;
-                    s_newslot[row] = is_new ? newidx[k] : (parent[k] >= 0 ? -1 - parent[k] : 0x7fffffff);
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                if (gcA - b_seen >= A2_LEAD)
+                {
+                    b_seen = uniform_i64(lds_ld(&T.b_done));
+                    if (gcA - b_seen >= A2_LEAD)
+                    {
+                        __builtin_amdgcn_s_sleep(16); // wave B needs thousands of cycles per group: poll rarely
+                        continue;
+                    }
                 }
             }
-            // ids for the new trees
+            int term[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+                term[k] = nx_term[k];
+            const int cnt_new = uniform_i32(nx_info) & 0xff;
+            {
+                const int lc1 = lc + 1 == RC ? 0 : lc + 1;
+                load_a(gcA + 1, lc1); // prefetch
+            }
+            const int wcur = (int) (gcA & (WIN2_COLS - 1));
             int bad = 0;
             if (cnt_new > 0)
             {
@@ -443,95 +461,22 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     bad = 2;
                 wave_lds_fence();
             }
-            int top_of[RPL];
-            if (RPL == 1)
-            {
-                const bool same_col = parent[0] >= 0 && (parent[0] >> 8) == 0;
-                const int prow = parent[0] & 0xff;
-                const unsigned long long active_m = __ballot(parent[0] >= -1);
-                const unsigned long long linked_m = __ballot(same_col);
-                const unsigned long long above = active_m & lanes_below();
-                const int nearest_above = above ? 63 - __clzll((long long) above) : -1;
-                if (!__any(same_col && prow != nearest_above))
-                {
-                    const unsigned long long tops = active_m & ~linked_m & (lanes_below() | (1ull << lane));
-                    top_of[0] = tops ? 63 - __clzll((long long) tops) : lane;
-                }
-                else
-                {
-                    int t = same_col ? prow : lane;
-                    for (int it = 0; it < 6; it++)
-                    {
-                        const int t2 = __shfl(t, t);
-                        const bool changed = t2 != t;
-                        t = t2;
-                        if (!__any(changed))
-                            break;
-                    }
-                    top_of[0] = t;
-                }
-            }
-            else
-            {
-                wave_lds_fence();
-#pragma unroll
-                for (int it = 0; it < 7; it++)
-                {
-                    int nxt[RPL];
-#pragma unroll
-                    for (int k = 0; k < RPL; k++)
-                    {
-                        const int row = k * 64 + lane;
-                        nxt[k] = row < R ? s_parent[s_parent[row]] : 0;
-                    }
-                    wave_lds_fence();
-#pragma unroll
-                    for (int k = 0; k < RPL; k++)
-                    {
-                        const int row = k * 64 + lane;
-                        if (row < R)
-                            s_parent[row] = nxt[k];
-                    }
-                    wave_lds_fence();
-                }
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                {
-                    const int row = k * 64 + lane;
-                    top_of[k] = row < R ? s_parent[row] : 0;
-                }
-            }
-            int term_info = 0;
-            if (RPL == 1)
-            {
-                const int mine = parent[0] == -1 ? newidx[0] : (parent[0] >= 0 ? -1 - parent[0] : 0x7fffffff);
-                term_info = __shfl(mine, top_of[0]);
-            }
             int ent[RPL];
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
-                const int row = k * 64 + lane;
                 ent[k] = -1;
-                if (parent[k] >= -1 && row < R)
+                const int tm = term[k];
+                if (tm >= 256)
                 {
-                    const int tv = RPL == 1 ? term_info : s_newslot[top_of[k]];
-                    if (tv >= 0)
-                    {
-                        if (bad == 0)
-                            ent[k] = (int) T.ring_id[(head + tv) & (TREE_SLOTS - 1)] | A2_FRESH;
-                    }
+                    const int v = s_win[((wcur - (tm >> 8)) & (WIN2_COLS - 1)) * R + (tm & 0xff)];
+                    if (v < 0)
+                        bad = bad ? bad : 1; // no tree, or a tree finished before this launch: the exact routine decides
                     else
-                    {
-                        const int code = -1 - tv;
-                        const int delta = code >> 8, prow = code & 0xff;
-                        const int v = s_win[((wcur - delta) & (WIN2_COLS - 1)) * R + prow];
-                        if (v < 0)
-                            bad = bad ? bad : 1; // no tree, or a tree finished before this launch: the exact routine decides
-                        else
-                            ent[k] = v & A2_IDMASK;
-                    }
+                        ent[k] = v & A2_IDMASK;
                 }
+                else if (tm >= 0 && bad == 0)
+                    ent[k] = (int) T.ring_id[(head + tm) & (TREE_SLOTS - 1)] | A2_FRESH;
             }
             bad = uniform_i32(__any(bad == 2) ? 2 : (__any(bad == 1) ? 1 : 0));
             short* wcol = s_win + wcur * R;
@@ -557,13 +502,6 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             gcA++;
             lc = lc + 1 == RC ? 0 : lc + 1;
         }
-#ifdef CC_A2_STATS
-        if (lane == 0)
-        {
-            st->dbg[9] += a_lead_waits;
-            st->dbg[11] += __builtin_amdgcn_s_memtime() - a_t0;
-        }
-#endif
         return;
     }
 
@@ -602,41 +540,51 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
         n_events++;
     };
 
-    int nx_parent[RPL], nx_nl[RPL];
-    double nx_fin[RPL];
-    unsigned long long nx_link[RPL];
-    double nx_minaz = 0.;
-    auto load_column = [&](long long gcx, int lcx)
+    // next group, prefetched into registers: per column and row what k_scan left, per column (lane u) the column summary
+    int q_parent[G][RPL], q_nl[G][RPL];
+    double q_fin[G][RPL];
+    unsigned long long q_link[G][RPL];
+    double q_minaz = 0., q_newfin = 0.;
+    int q_info = 0;
+    auto load_group = [&](long long g0, int lcg) // lcg = g0 % RC
     {
+        int lcx = lcg;
 #pragma unroll
-        for (int k = 0; k < RPL; k++)
+        for (int u = 0; u < G; u++)
         {
-            const int row = k * 64 + lane;
-            nx_parent[k] = -2;
-            nx_nl[k] = 0;
-            nx_fin[k] = 0.;
-            nx_link[k] = 0;
-            if (row < R && gcx < col_end)
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
             {
-                const int ci = lcx * R + row;
-                nx_parent[k] = p.sc_parent[ci];
-                nx_nl[k] = p.sc_nlinks[ci];
-                nx_fin[k] = p.sc_fin[ci];
-                nx_link[k] = p.sc_links[ci];
+                const int row = k * 64 + lane;
+                q_parent[u][k] = -2;
+                q_nl[u][k] = 0;
+                q_fin[u][k] = 0.;
+                q_link[u][k] = 0;
+                if (row < R && g0 + u < col_end)
+                {
+                    const int ci = lcx * R + row;
+                    q_parent[u][k] = p.sc_parent[ci];
+                    q_nl[u][k] = p.sc_nlinks[ci];
+                    q_fin[u][k] = p.sc_fin[ci];
+                    q_link[u][k] = p.sc_links[ci]; // (stale where the point has no links: never looked at)
+                }
             }
+            lcx = lcx + 1 == RC ? 0 : lcx + 1;
         }
-        // lane 0 only: a divergent (vector) load; a uniform one would become a scalar load that every LDS wait has to sit out
-        if (lane == 0 && gcx < col_end)
-            nx_minaz = p.colminaz[lcx];
+        if (lane < G && g0 + lane < col_end)
+        {
+            int lcl = lcg + lane;
+            lcl = lcl >= RC ? lcl - RC : lcl;
+            q_minaz = p.colminaz[lcl];
+            q_newfin = p.col_newfin[lcl];
+            q_info = p.col_info[lcl];
+        }
     };
-    int lc = (int) (col_begin % RC);
-    int nth_phase = (int) (col_begin % nth);
-    long long first_local_of = first_unpub;
-    int first_local = (int) (first_unpub % RC);
-    load_column(col_begin, lc);
     long long a_seen = col_begin;
+#ifdef CC_A2_STATS
+    unsigned long long st_wait_g = 0;
+#endif
 
-    // park wave A, run `body` with exclusive access to the id ring, restart A at `restart`
     auto park_a = [&]()
     {
         if (lane == 0)
@@ -667,250 +615,34 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             lds_st(&T.cmd, (int) A2_RUN);
         a_seen = restart;
     };
-
-#ifdef CC_A2_SECTION
-    unsigned long long a2_t0 = 0, a2_acc = 0;
-#endif
-#ifdef CC_A2_STATS
-    unsigned long long b_waits = 0, b_t0 = __builtin_amdgcn_s_memtime();
-#endif
-    long long gc = col_begin;
-    for (; gc < col_end && err == 0; gc++, lc = (lc + 1 == RC ? 0 : lc + 1), nth_phase = (nth_phase + 1 == nth ? 0 : nth_phase + 1))
+    auto wait_a = [&](long long upto) // columns < upto resolved by wave A
     {
-        A2_E(6)
-        A2_T(6)
-        A2_T(0)
-        if (first_local_of != first_unpub)
-        {
-            const long long d = first_unpub - first_local_of;
-            if (d > 0 && d < RC)
-            {
-                first_local += (int) d;
-                if (first_local >= RC)
-                    first_local -= RC;
-            }
-            else
-                first_local = (int) (first_unpub % RC);
-            first_local_of = first_unpub;
-        }
-        int parent[RPL], nl[RPL];
-        unsigned long long link[RPL];
-        double finc[RPL];
-        const double min_az = uniform_f64(nx_minaz); // readfirstlane: lane 0 holds it, all lanes are active here
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            parent[k] = nx_parent[k];
-            nl[k] = nx_nl[k];
-            finc[k] = nx_fin[k];
-            link[k] = nx_link[k];
-        }
-        A2_E(0)
-        A2_T(1)
-        load_column(gc + 1, lc + 1 == RC ? 0 : lc + 1); // prefetch: nothing below depends on it
-        for (int spins = 0; a_seen <= gc;)
+        for (int spins = 0; a_seen < upto;)
         {
             a_seen = uniform_i64(lds_ld(&T.a_done));
-            if (a_seen <= gc)
+            if (a_seen < upto)
             {
 #ifdef CC_A2_STATS
-                b_waits++;
+                st_wait_g++;
 #endif
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > A2_SPIN_LIMIT)
                 {
                     err = CC_ERR_BOOKKEEPING;
                     err_a = -772;
-                    err_b = gc;
+                    err_b = upto;
                     break;
                 }
             }
         }
-        if (err)
-            break;
-        wave_lds_fence(); // the column's ring entries are read after the flag
-        const int wcur = (int) (gc & (WIN2_COLS - 1));
-        short* wcol = s_win + wcur * R;
-        const int info_bad = uniform_i32(lds_ld(&T.info_bad[(int) (gc & (A2_INFO - 1))]));
-        const int info_head = uniform_i32(lds_ld(&T.info_head[(int) (gc & (A2_INFO - 1))]));
+        wave_lds_fence(); // ring entries are read after the flag
+    };
 
-        A2_E(1)
-        A2_T(2)
-        int cnt_new = 0;
-        int newrank[RPL];
-        bool bad = info_bad != 0;
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            const unsigned long long mask = __ballot(parent[k] == -1);
-            newrank[k] = cnt_new + __popcll(mask & lanes_below());
-            cnt_new += __popcll(mask);
-            if (nl[k] == 255)
-                bad = true; // more links than the scan records: exact routine
-        }
-        if (n_unf + cnt_new > tree_limit || info_bad == 2)
-        {
-            to_global = true; // continue this stream with the global-memory kernel, starting at this column
-            break;
-        }
-        emit(CC_EV_GROUND_COLUMN, gc, gc, 0, 0, gc);
-
-        // ---- what wave A assumed (cc.cpp:657-658, 762-763) -------------------------------------------------------------------
-        int id[RPL];
-        const bool span_check = n_unf > 0 && (uint32_t) (gc - M + 1) > (uint32_t) NC;
-        const bool reach_check = gc - (WIN_COLS - 1) < first_unpub;
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            const int row = k * 64 + lane;
-            id[k] = -1;
-            if (!bad && parent[k] >= -1 && row < R)
-            {
-                const int e = wcol[row];
-                id[k] = e & A2_IDMASK;
-                if (!(e & A2_FRESH))
-                {
-                    if (!T.alive[id[k]])
-                        bad = true; // finished tree: attach refused (cc.cpp:658)
-                    else if (span_check && (uint32_t) (gc - T.gcol[id[k]] + 1) > (uint32_t) NC)
-                        bad = true; // tree would span more than one rotation (cc.cpp:657)
-                }
-                if (reach_check)
-                {
-                    // nothing may come from columns the live scan would not have reached (cc.cpp:762-763)
-                    int oldest_delta = 0;
-                    if (parent[k] >= 0)
-                    {
-                        oldest_delta = parent[k] >> 8;
-                        const int nlk = nl[k] == 255 ? 0 : nl[k];
-#pragma unroll
-                        for (int j = 0; j < LINK_SLOTS; j++)
-                            if (j < nlk)
-                            {
-                                const int d = (int) ((link[k] >> (16 * j + 8)) & 0xff);
-                                oldest_delta = d > oldest_delta ? d : oldest_delta;
-                            }
-                    }
-                    if (gc - oldest_delta < first_unpub)
-                        bad = true;
-                }
-            }
-        }
-        // (the terminal of a same-column chain is checked by the chain's top row: its own parent code carries that delta)
-        const bool column_live = __any(bad);
-        A2_E(2)
-
-        if (!column_live)
-        {
-            A2_T(3)
-            double l_new = L;
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (row < R && parent[k] == -1)
-                {
-                    const int i = id[k];
-                    T.cell[i] = lc * R + row;
-                    T.gcol[i] = gc;
-                    T.fin[i] = (unsigned long long) __double_as_longlong(finc[k]);
-                    T.last[i] = (unsigned) gc;
-                    T.pts[i] = 1;
-                    T.uf[i] = i;
-                    T.c_fin[i] = (unsigned long long) __double_as_longlong(finc[k]);
-                    T.alist[n_unf + newrank[k]] = (short) i;
-                    T.alive[i] = 1;
-                    l_new = finc[k] < l_new ? finc[k] : l_new;
-                }
-            }
-            if (cnt_new > 0)
-            {
-                if (n_unf == 0)
-                    M = gc;
-                n_unf += cnt_new;
-                L = uniform_f64(wave_min_f64(l_new));
-            }
-            wave_lds_fence();
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (row < R)
-                    p.root[lc * R + row] = id[k] >= 0 ? T.cell[id[k]] : -1; // early: retires long before the next loop-top wait
-            }
-            A2_E(3)
-            A2_T(4)
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                if (parent[k] >= 0)
-                {
-                    const int i = id[k];
-                    const int nlk = nl[k];
-                    const int rep = lds_find(T.uf, i);
-                    const unsigned long long fb = (unsigned long long) __double_as_longlong(finc[k]);
-                    T.last[i] = (unsigned) gc;
-                    atomicMax(&T.fin[i], fb);
-                    atomicMax(&T.c_fin[rep], fb);
-                    atomicAdd(&T.pts[i], 1u);
-#pragma unroll
-                    for (int j = 0; j < LINK_SLOTS; j++)
-                        if (j < nlk)
-                        {
-                            const int code = (int) ((link[k] >> (16 * j)) & 0xffff);
-                            int v = s_win[((wcur - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
-                            v = v < 0 ? v : (v & A2_IDMASK);
-                            if (v >= 0 && v != i && T.alive[v])
-                                lds_union(T.uf, T.c_fin, i, v);
-                        }
-                }
-            }
-            wave_lds_fence();
-            A2_E(4)
-        }
-        else
-        {
-            serial_cols++;
-            park_a();
-            if (err)
-                break;
-            if (lane == 0)
-            {
-                int nn = n_unf, e = 0, hd = info_head;
-                double LL = L;
-                long long MM = M;
-                assoc_column_live2<RPL>(c, cfg, g, T, s_win, lc, gc, first_local, nn, LL, MM, hd, e);
-                T.bcast_i[0] = nn;
-                T.bcast_i[1] = e;
-                T.bcast_i[3] = hd;
-                T.bcast_d[0] = LL;
-                T.bcast_l[0] = MM;
-            }
-            wave_lds_fence();
-            n_unf = uniform_i32(T.bcast_i[0]);
-            const int hd = uniform_i32(T.bcast_i[3]);
-            if (uniform_i32(T.bcast_i[1]) == CC_ERR_CAPACITY)
-            {
-                err = CC_ERR_CAPACITY;
-                err_a = n_unf;
-            }
-            L = uniform_f64(T.bcast_d[0]);
-            M = uniform_i64(T.bcast_l[0]);
-            wave_lds_fence();
-            if (!err)
-                resume_a(gc + 1, hd);
-        }
-        if (err)
-            break;
-
-        // ------------------------------------------------------------------ finished-cluster check (cc.cpp:837-974)
-        if (nth_phase != 0)
-        {
-            if (lane == 0)
-                lds_st(&T.b_done, gc + 1);
-            continue;
-        }
-        A2_T(5)
+    // finished-cluster check (cc.cpp:837-974) and publish bookkeeping (cc.cpp:1035-1092) of one column, exact tree state
+    bool killed = false; // the last finished-cluster check retired trees
+    auto finish_and_publish = [&](const long long gc, const double min_az)
+    {
+        killed = false;
         long long M_c;
         if (n_unf == 0)
             M_c = gc + 1;
@@ -923,7 +655,6 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             M_c = M; // nothing can be finished: first the scalar bound, then (refreshing it) the per-cluster bounds
         else
         {
-            A2_T(7)
             for (int k = lane; k < n_unf; k += 64)
             {
                 const int i = T.alist[k];
@@ -943,7 +674,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 T.comp[i] = j;
                 atomicMax(&T.a_fin[j], T.fin[i]);
                 atomicMin(&T.a_min[j], T.gcol[i]);
-                atomicMax(&T.a_max[j], T.gcol[i] + (long long) (T.last[i] - (unsigned) T.gcol[i] + 1u));
+                atomicMax(&T.a_max[j], T.last[i] + 1);
                 atomicAdd(&T.a_pts[j], T.pts[i]);
                 atomicMin(&T.a_first[j], (unsigned) k);
             }
@@ -1053,51 +784,487 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             M_c = min_all;
             M = min_surv;
             n_unf -= removed;
+            killed = removed > 0;
             wave_lds_fence();
-            A2_E(7)
         }
         last_min_az = min_az;
-
-        // ------------------------------------------------------------------ publish bookkeeping (cc.cpp:1035-1092)
         if (M_c < first_unpub)
         {
             err = CC_ERR_BOOKKEEPING;
             err_a = M_c;
             err_b = first_unpub;
-            break;
+            return;
         }
         const long long old_unpub = first_unpub;
         first_unpub = M_c;
         ring_start = first_unpub - NC > 0 ? first_unpub - NC : 0;
         emit(CC_EV_PUBLISH_COLUMNS, old_unpub, first_unpub - 1, 0, 0, gc);
         cells_published += (unsigned long long) (first_unpub - old_unpub) * (unsigned long long) R;
-        if (lane == 0)
-            lds_st(&T.b_done, gc + 1);
-        A2_E(5)
-    }
-#ifdef CC_A2_SECTION
-    if (lane == 0)
-        st->dbg[CC_A2_SECTION] += a2_acc;
+    };
+
+#ifdef CC_A2_STATS
+    unsigned long long st_ph[5] = {0, 0, 0, 0, 0}, st_sub = 0, st_check = 0, st_live = 0, st_wait = 0, st_t0 = __builtin_amdgcn_s_memtime(), st_pass = 0;
 #endif
+    long long gc = col_begin; // first column of the current group
+    int lc0 = (int) (col_begin % RC);
+    load_group(gc, lc0);
+    while (gc < col_end && err == 0 && !to_global)
+    {
+        const int gcount = (int) (col_end - gc < G ? col_end - gc : G);
+#pragma unroll
+        for (int u = 0; u < G; u++)
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int o = u * R + k * 64 + lane;
+                if (k * 64 + lane < R)
+                {
+                    st_parent[o] = (short) q_parent[u][k];
+                    st_nl[o] = (unsigned char) q_nl[u][k];
+                    st_fin[o] = q_fin[u][k];
+                    st_link[o] = q_link[u][k];
+                }
+            }
+        wave_lds_fence();
+        const double v_minaz = q_minaz, v_newfin = q_newfin;
+        const int v_info = q_info;
+        {
+            int lcn = lc0 + gcount;
+            lcn = lcn >= RC ? lcn - RC : lcn;
+            load_group(gc + gcount, lcn); // prefetch: nothing below depends on it
+        }
+
+        int u0 = 0;          // first column of the group not yet processed
+        bool ids_stale = true; // ids of the columns >= u0 have to be (re)read from the ring
+        bool verify = true;    // ... and checked against the tree state (again after trees were finished)
+        unsigned badmask = 0;
+        int v_abad = 0;
+        while (u0 < gcount && err == 0 && !to_global)
+        {
+#ifdef CC_A2_STATS
+            unsigned long long tq = __builtin_amdgcn_s_memtime();
+#define A2_PH(i)                                                     \
+    {                                                                \
+        const unsigned long long _n = __builtin_amdgcn_s_memtime();  \
+        st_ph[i] += _n - tq;                                         \
+        tq = _n;                                                     \
+    }
+#else
+#define A2_PH(i)
+#endif
+            if (ids_stale)
+            {
+                wait_a(gc + gcount);
+                if (err)
+                    break;
+                if (lane < G)
+                    v_abad = T.info_bad[(int) ((gc + lane) & (A2_INFO - 1))];
+                ids_stale = false;
+                verify = true;
+            }
+            A2_PH(0)
+            // ---- what wave A assumed: every tree joined from an earlier column is still unfinished (cc.cpp:658); trees that
+            // start in one of these columns count as unfinished for the columns after them --------------------------------------
+            if (verify)
+            {
+                verify = false;
+                badmask = 0;
+                for (int u = u0; u < gcount; u++)
+                {
+                    const short* wc = s_win + (int) ((gc + u) & (WIN2_COLS - 1)) * R;
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                    {
+                        const int row = k * 64 + lane;
+                        if (row < R)
+                        {
+                            const int par = st_parent[u * R + row];
+                            const int e = wc[row];
+                            if (par == -1 && e >= 0)
+                                T.alive[e & A2_IDMASK] = 1;
+                            else if (par >= 0)
+                            {
+                                if (e < 0)
+                                    bad = true;
+                                else if (!(e & A2_FRESH))
+                                    bad |= !T.alive[e & A2_IDMASK];
+                            }
+                        }
+                    }
+                    wave_lds_fence();
+                    if (__any(bad))
+                        badmask |= 1u << u;
+                }
+            }
+            A2_PH(1)
+            // ---- walk over the columns, one lane per column (lane u = column gc + u): bookkeeping as if no column needed the
+            // exact tree state, then the first column that does (the "cut") bounds the batch -----------------------------------
+            enum
+            {
+                CUT_NONE = 0,
+                CUT_CHECK = 1, // finished-cluster check may let something through: needs the tree state after this column
+                CUT_LIVE = 2,  // the column's static scan result may differ from the live scan: exact serial routine
+                CUT_GLOBAL = 3
+            };
+            const int wu = lane;
+            const bool inr = wu >= u0 && wu < gcount;
+            const int w_cnt = inr ? (v_info & 0xff) : 0;
+            const int w_flags = (v_info >> 8) & 0xff, w_maxd = v_info >> 16;
+            int ps = w_cnt; // inclusive prefix sums / minima over the columns u0 .. u
+            ps += dpp_shr_i32<1>(ps, 0);
+            ps += dpp_shr_i32<2>(ps, 0);
+            ps += dpp_shr_i32<4>(ps, 0);
+            const double inf = 1.7976931348623157e308;
+            double pm = (inr && w_cnt > 0) ? v_newfin : inf;
+            {
+                double o = dpp_shr_f64<1>(pm, inf);
+                pm = o < pm ? o : pm;
+                o = dpp_shr_f64<2>(pm, inf);
+                pm = o < pm ? o : pm;
+                o = dpp_shr_f64<4>(pm, inf);
+                pm = o < pm ? o : pm;
+            }
+            const int w_nafter = n_unf + ps, w_nbefore = w_nafter - w_cnt;
+            const double w_L = pm < L ? pm : L;
+            const long long gcu_l = gc + wu;
+            // the oldest root column: set by the first new tree while there is none (cc.cpp:1035-1050 keeps the minimum)
+            int firstnew = 64;
+            if (n_unf == 0)
+            {
+                const unsigned long long nm = __ballot(inr && w_cnt > 0);
+                firstnew = nm ? (int) __ffsll((long long) nm) - 1 : 64;
+            }
+            const long long w_M = (n_unf == 0 && wu >= firstnew) ? gc + firstnew : M;
+            const long long w_Mbefore = (n_unf == 0 && wu > firstnew) ? gc + firstnew : M;
+            const long long w_Mc = w_nafter == 0 ? gcu_l + 1 : w_M; // first unpublished column after this column, nothing finishing
+            long long w_fub = dpp_shr_i64<1>(w_Mc, first_unpub);
+            w_fub = wu == u0 ? first_unpub : w_fub;
+            double w_azprev = dpp_shr_f64<1>(v_minaz, last_min_az);
+            w_azprev = wu == u0 ? last_min_az : w_azprev;
+            const bool w_badbit = (badmask >> wu) & 1u;
+            const bool c_global = inr && (w_nafter > tree_limit || v_abad == 2);
+            const bool c_live = inr && (w_badbit || (w_flags & 1) || v_abad == 1 ||
+                                        (w_nbefore > 0 && (uint32_t) (gcu_l - w_Mbefore + 1) > (uint32_t) NC) // cc.cpp:657
+                                        || gcu_l - w_maxd < w_fub);                                            // cc.cpp:762-763
+            const bool w_alias = w_nafter > 0 && v_minaz == w_azprev;
+            const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || v_minaz >= w_L);
+            const unsigned long long m_global = __ballot(c_global), m_live = __ballot(c_live), m_check = __ballot(c_check);
+            const unsigned long long m_cut = m_global | m_live | m_check;
+            const int ucut = m_cut ? (int) __ffsll((long long) m_cut) - 1 : gcount;
+            int cut = CUT_NONE;
+            if (m_cut)
+                cut = ((m_global >> ucut) & 1ull) ? CUT_GLOBAL : (((m_live >> ucut) & 1ull) ? CUT_LIVE : CUT_CHECK);
+            const int u1 = ucut + (cut == CUT_CHECK ? 1 : 0); // columns [u0, u1) are applied as one batch
+            const int ucomp = ucut;                            // columns [u0, ucomp) are complete (checked + published)
+            const bool w_done = wu >= u0 && wu < ucomp;
+            {
+                const unsigned long long m_err = __ballot(w_done && w_Mc < w_fub);
+                if (m_err)
+                {
+                    const int ue = (int) __ffsll((long long) m_err) - 1;
+                    err = CC_ERR_BOOKKEEPING;
+                    err_a = lane_i64(w_Mc, ue);
+                    err_b = lane_i64(w_fub, ue);
+                    break;
+                }
+            }
+            if (g.record_events)
+            {
+                // per complete column: ground-column event, publish event (cc.cpp:618-620, 1087-1089)
+                const int idx = n_events + 2 * (wu - u0);
+                if (w_done && idx + 1 < g.event_capacity + 1)
+                {
+                    cc_event e;
+                    e.stream = s;
+                    e.c = 0;
+                    e.d = 0;
+                    e.column = gcu_l;
+                    if (idx < g.event_capacity)
+                    {
+                        e.type = CC_EV_GROUND_COLUMN;
+                        e.a = gcu_l;
+                        e.b = gcu_l;
+                        p.events[idx] = e;
+                    }
+                    if (idx + 1 < g.event_capacity)
+                    {
+                        e.type = CC_EV_PUBLISH_COLUMNS;
+                        e.a = w_fub;
+                        e.b = w_Mc - 1;
+                        p.events[idx + 1] = e;
+                    }
+                }
+                n_events += 2 * (ucomp - u0);
+            }
+            if (ucomp > u0)
+            {
+                const long long fu_new = lane_i64(w_Mc, ucomp - 1);
+                cells_published += (unsigned long long) (fu_new - first_unpub) * (unsigned long long) R;
+                first_unpub = fu_new;
+                ring_start = first_unpub - NC > 0 ? first_unpub - NC : 0;
+                last_min_az = lane_f64(v_minaz, ucomp - 1);
+                alias_rounds += (unsigned long long) __popcll(__ballot(w_done && w_alias));
+            }
+            if (u1 > u0)
+            {
+                n_unf = lane_i32(w_nafter, u1 - 1);
+                L = lane_f64(w_L, u1 - 1);
+                M = lane_i64(w_M, u1 - 1);
+            }
+            if (cut == CUT_CHECK)
+                emit(CC_EV_GROUND_COLUMN, gc + ucut, gc + ucut, 0, 0, gc + ucut);
+            A2_PH(2)
+
+            // ---- the batch [u0, u1), column by column: new trees (list order = column, then row), then the point and link
+            // updates. Point updates are run-length aggregated per row: consecutive columns of a row mostly join the same tree, so
+            // a lane keeps (tree, points, max finished_at, last column) in registers and touches the tree state only when its
+            // tree changes and at the end of the batch. -------------------------------------------------------------------------
+            if (u1 > u0)
+            {
+                int cur[RPL], curcell[RPL], joined[RPL][LINK_SLOTS];
+                unsigned rcnt[RPL];
+                unsigned long long rfin[RPL];
+                long long rlast[RPL];
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    cur[k] = -1;
+                    curcell[k] = -1;
+#pragma unroll
+                    for (int j = 0; j < LINK_SLOTS; j++)
+                        joined[k][j] = -1;
+                    rcnt[k] = 0;
+                    rfin[k] = 0;
+                    rlast[k] = 0;
+                }
+                auto flush = [&](int k)
+                {
+                    const int i = cur[k];
+                    const int rep = lds_find(T.uf, i);
+                    atomicMax(&T.last[i], rlast[k]);
+                    atomicMax(&T.fin[i], rfin[k]);
+                    atomicMax(&T.c_fin[rep], rfin[k]);
+                    atomicAdd(&T.pts[i], rcnt[k]);
+                };
+                int lcu = lc0 + u0;
+                lcu = lcu >= RC ? lcu - RC : lcu;
+                for (int u = u0; u < u1; u++, lcu = (lcu + 1 == RC ? 0 : lcu + 1))
+                {
+                    const long long gcu = gc + u;
+                    const int wcu = (int) (gcu & (WIN2_COLS - 1));
+                    const int info = lane_i32(v_info, u);
+                    const bool has_new = (info & 0xff) != 0, has_links = (info >> 8) & 2;
+                    int par[RPL], e[RPL];
+                    double fc[RPL];
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                    {
+                        const int row = k * 64 + lane;
+                        par[k] = -2;
+                        e[k] = -1;
+                        fc[k] = 0.;
+                        if (row < R)
+                        {
+                            par[k] = st_parent[u * R + row];
+                            fc[k] = st_fin[u * R + row];
+                            e[k] = s_win[wcu * R + row];
+                        }
+                    }
+                    if (has_new)
+                    {
+                        const int nb = lane_i32(w_nbefore, u);
+                        int cnt = 0;
+#pragma unroll
+                        for (int k = 0; k < RPL; k++)
+                        {
+                            const int row = k * 64 + lane;
+                            const bool is_new = par[k] == -1;
+                            const unsigned long long mask = __ballot(is_new);
+                            if (is_new)
+                            {
+                                const int i = e[k] & A2_IDMASK;
+                                T.cell[i] = lcu * R + row;
+                                T.gcol[i] = gcu;
+                                T.fin[i] = (unsigned long long) __double_as_longlong(fc[k]);
+                                T.last[i] = gcu;
+                                T.pts[i] = 1;
+                                T.uf[i] = i;
+                                T.c_fin[i] = (unsigned long long) __double_as_longlong(fc[k]);
+                                T.alist[nb + cnt + __popcll(mask & lanes_below())] = (short) i;
+                                T.alive[i] = 1;
+                            }
+                            cnt += __popcll(mask);
+                        }
+                        wave_lds_fence();
+                    }
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                    {
+                        const int row = k * 64 + lane;
+                        const int i = e[k] & A2_IDMASK;
+                        if (e[k] >= 0 && i != cur[k])
+                        {
+                            if (rcnt[k] > 0)
+                                flush(k);
+                            cur[k] = i;
+                            curcell[k] = T.cell[i];
+                            rcnt[k] = 0;
+                            rfin[k] = 0;
+                        }
+                        if (row < R)
+                            p.root[lcu * R + row] = e[k] >= 0 ? curcell[k] : -1;
+                        if (par[k] >= 0)
+                        {
+                            const unsigned long long fb = (unsigned long long) __double_as_longlong(fc[k]);
+                            rcnt[k]++;
+                            rfin[k] = fb > rfin[k] ? fb : rfin[k];
+                            rlast[k] = gcu;
+                        }
+                    }
+                    if (has_links)
+                    {
+#pragma unroll
+                        for (int k = 0; k < RPL; k++)
+                        {
+                            const int row = k * 64 + lane;
+                            const int nlk = (par[k] >= 0 && row < R) ? (int) st_nl[u * R + row] : 0;
+                            if (nlk > 0)
+                            {
+                                const int i = e[k] & A2_IDMASK;
+                                const unsigned long long lk = st_link[u * R + row];
+                                int v[LINK_SLOTS]; // all link targets first: one LDS round trip
+#pragma unroll
+                                for (int j = 0; j < LINK_SLOTS; j++)
+                                {
+                                    v[j] = -1;
+                                    if (j < nlk)
+                                    {
+                                        const int code = (int) ((lk >> (16 * j)) & 0xffff);
+                                        v[j] = s_win[((wcu - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
+                                    }
+                                }
+#pragma unroll
+                                for (int j = 0; j < LINK_SLOTS; j++)
+                                {
+                                    const int vv = v[j] & A2_IDMASK;
+                                    const int pair = (i << 16) | vv;
+                                    // the same two trees usually meet again in the next column: a pair already joined in this
+                                    // batch needs nothing (nothing is finished inside a batch, so a union lasts)
+                                    if (v[j] >= 0 && vv != i && pair != joined[k][j])
+                                    {
+                                        if (T.alive[vv])
+                                            lds_union(T.uf, T.c_fin, i, vv);
+                                        joined[k][j] = pair;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                    if (rcnt[k] > 0)
+                        flush(k);
+                wave_lds_fence();
+            }
+
+            A2_PH(3)
+            // ---- the cut column ----------------------------------------------------------------------------------------------
+#ifdef CC_A2_STATS
+            st_sub++;
+            st_check += cut == CUT_CHECK;
+            st_live += cut == CUT_LIVE;
+#endif
+            if (cut == CUT_CHECK)
+            {
+                const int u = u1 - 1;
+                finish_and_publish(gc + u, lane_f64(v_minaz, u));
+                verify = killed;
+                u0 = u1;
+            }
+            else if (cut == CUT_LIVE)
+            {
+                const int u = u1;
+                const long long gcu = gc + u;
+                int lcu = lc0 + u;
+                lcu = lcu >= RC ? lcu - RC : lcu;
+                emit(CC_EV_GROUND_COLUMN, gcu, gcu, 0, 0, gcu);
+                serial_cols++;
+                wait_a(gcu + 1); // the hand-off record of this column (ring head before it)
+                if (err)
+                    break;
+                const int info_head = uniform_i32(lds_ld(&T.info_head[(int) (gcu & (A2_INFO - 1))]));
+                park_a();
+                if (err)
+                    break;
+                if (lane == 0)
+                {
+                    int nn = n_unf, e = 0, hd = info_head;
+                    double LL = L;
+                    long long MM = M;
+                    assoc_column_live2<RPL>(c, cfg, g, T, s_win, lcu, gcu, (int) (first_unpub % RC), nn, LL, MM, hd, e); // (64-bit modulo: rare path)
+                    T.bcast_i[0] = nn;
+                    T.bcast_i[1] = e;
+                    T.bcast_i[3] = hd;
+                    T.bcast_d[0] = LL;
+                    T.bcast_l[0] = MM;
+                }
+                wave_lds_fence();
+                n_unf = uniform_i32(T.bcast_i[0]);
+                const int hd = uniform_i32(T.bcast_i[3]);
+                if (uniform_i32(T.bcast_i[1]) == CC_ERR_CAPACITY)
+                {
+                    err = CC_ERR_CAPACITY; // the live replay ran out of tree ids mid-column: the column cannot be rolled back
+                    err_a = n_unf;
+                }
+                L = uniform_f64(T.bcast_d[0]);
+                M = uniform_i64(T.bcast_l[0]);
+                wave_lds_fence();
+                if (err)
+                    break;
+                resume_a(gcu + 1, hd);
+                if (nth == 1 || (gcu % nth) == 0)
+                    finish_and_publish(gcu, lane_f64(v_minaz, u));
+                u0 = u1 + 1;
+                ids_stale = true; // wave A resolves the rest of the group again
+            }
+            else if (cut == CUT_GLOBAL)
+            {
+                to_global = true; // continue this stream with the global-memory kernel, starting at this column
+                gc += u1;
+                break;
+            }
+            else
+                u0 = gcount;
+            if (lane == 0)
+                lds_st(&T.b_done, gc + u0);
+            A2_PH(4)
+        }
+        if (to_global || err)
+            break;
+        gc += gcount;
+        lc0 += gcount;
+        lc0 = lc0 >= RC ? lc0 - RC : lc0;
+    }
+    if (lane == 0)
+        lds_st(&T.cmd, (int) A2_EXIT);
 #ifdef CC_A2_STATS
     if (lane == 0)
     {
-        st->dbg[8] += b_waits;
-        st->dbg[10] += __builtin_amdgcn_s_memtime() - b_t0;
+        st->dbg[8] += st_sub;
+        st->dbg[9] += st_check;
+        st->dbg[10] += __builtin_amdgcn_s_memtime() - st_t0;
+        st->dbg[11] += st_live;
         st->dbg[12] += (unsigned long long) (gc - col_begin);
+        st->dbg[13] += st_wait_g;
+        for (int i = 0; i < 5; i++)
+            st->dbg[i] += st_ph[i];
     }
 #endif
-    if (lane == 0)
-        lds_st(&T.cmd, (int) A2_EXIT);
 
     // ---- persist the tree state back to the global planes: list order = creation order -----------------------------------------
     {
-        wave_lds_fence();
-        for (int r = lane; r < n_unf; r += 64)
-        {
-            const int i = T.alist[r];
-            T.a_first[i] = (unsigned) r; // list position of every unfinished tree (t_uf names the representative's root cell)
-        }
         wave_lds_fence();
         for (int r = lane; r < n_unf; r += 64)
         {
@@ -1106,7 +1273,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             p.ulist[r] = cell;
             p.t_pos[cell] = r;
             p.t_fin[cell] = __longlong_as_double((long long) T.fin[i]);
-            p.t_width[cell] = T.last[i] - (unsigned) T.gcol[i] + 1u;
+            p.t_width[cell] = (unsigned) (T.last[i] - T.gcol[i] + 1);
             p.t_pts[cell] = T.pts[i];
             p.t_uf[cell] = T.cell[T.uf[i]];
             p.t_cid[cell] = 0;

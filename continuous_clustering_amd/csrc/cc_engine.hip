@@ -326,7 +326,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     // ---- association + publish chain -------------------------------------------------------------------------
     CC_MARK(sa); // ev6: start of the third chain
-    if (e->assoc_waves == 2)
+    // k_assoc2 walks the finished-cluster checks of several columns at once and assumes one check per column
+    if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_assoc2<1>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);

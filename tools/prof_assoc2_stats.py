@@ -18,4 +18,7 @@ for s in range(0, S, 8):
     out = np.zeros(16, dtype=np.uint64); L.cc_engine_debug_counters(e.h, s, out.ctypes.data); tot += out
 tot /= (S / 8)
 cols = tot[12]
-print("columns", cols, "B waits/col", tot[8] / cols, "A lead waits/col", tot[9] / cols, "B cycles/col", tot[10] / cols, "A cycles/col", tot[11] / cols, "serial", e.totals())
+print(f"columns {cols:.0f}  sub-batches/col {tot[8]/cols:.3f}  check cuts/col {tot[9]/cols:.3f}  live cuts/col {tot[11]/cols:.4f}  "
+      f"B cycles/col {tot[10]/cols:.0f}  B waits for A /col {tot[13]/cols:.3f}")
+names = ["ids (re)load", "verification", "scalar walk", "batch apply", "cut column + b_done"]
+for i, n in enumerate(names): print(f"  {n:22s} {tot[i]/cols:8.0f} cycles/col   {tot[i]/max(tot[8],1):8.0f} per sub-batch")
