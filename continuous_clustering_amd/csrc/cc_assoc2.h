@@ -386,7 +386,8 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
         long long gcA = col_begin;
         int lc = (int) (col_begin % RC);
         long long b_seen = col_begin;
-        int nx_term[RPL], nx_info = 0;
+        int nx_term[RPL], nx_info = 0, nx_nl[RPL];
+        unsigned long long nx_link[RPL];
         auto load_a = [&](long long gcx, int lcx)
         {
 #pragma unroll
@@ -394,8 +395,14 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             {
                 const int row = k * 64 + lane;
                 nx_term[k] = -1;
+                nx_nl[k] = 0;
+                nx_link[k] = 0;
                 if (row < R && gcx < col_end)
+                {
                     nx_term[k] = p.sc_term[lcx * R + row];
+                    nx_nl[k] = p.sc_nlinks[lcx * R + row];
+                    nx_link[k] = p.sc_links[lcx * R + row]; // (stale where the point has no links: never looked at)
+                }
             }
             if (lane == 0 && gcx < col_end)
                 nx_info = p.col_info[lcx];
@@ -443,11 +450,17 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     }
                 }
             }
-            int term[RPL];
+            int term[RPL], nlk[RPL];
+            unsigned long long lk[RPL];
 #pragma unroll
             for (int k = 0; k < RPL; k++)
+            {
                 term[k] = nx_term[k];
+                nlk[k] = nx_nl[k];
+                lk[k] = nx_link[k];
+            }
             const int cnt_new = uniform_i32(nx_info) & 0xff;
+            const bool col_links = (uniform_i32(nx_info) >> 8) & 2;
             {
                 const int lc1 = lc + 1 == RC ? 0 : lc + 1;
                 load_a(gcA + 1, lc1); // prefetch
@@ -487,10 +500,38 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 if (row < R)
                     wcol[row] = (short) ent[k];
             }
+            // Links (further accepted candidates) only matter where they lead to another tree, which is rare (two trees of one
+            // object meeting): this wave, which has the time, looks the targets up and tells wave B whether the column has any.
+            int foreign = 0;
+            if (col_links && bad == 0)
+            {
+                wave_lds_fence(); // same-column targets: read what was just written
+                bool f = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int mine = ent[k] & A2_IDMASK;
+                    int v[LINK_SLOTS];
+#pragma unroll
+                    for (int j = 0; j < LINK_SLOTS; j++)
+                    {
+                        v[j] = -1;
+                        if (term[k] >= 0 && j < nlk[k])
+                        {
+                            const int code = (int) ((lk[k] >> (16 * j)) & 0xffff);
+                            v[j] = s_win[((wcur - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < LINK_SLOTS; j++)
+                        f |= v[j] >= 0 && (v[j] & A2_IDMASK) != mine;
+                }
+                foreign = __any(f) ? 16 : 0;
+            }
             if (lane == 0)
             {
                 T.info_head[(int) (gcA & (A2_INFO - 1))] = head;
-                T.info_bad[(int) (gcA & (A2_INFO - 1))] = bad;
+                T.info_bad[(int) (gcA & (A2_INFO - 1))] = bad | foreign;
             }
             wave_lds_fence();
             if (lane == 0)
@@ -943,8 +984,8 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             double w_azprev = dpp_shr_f64<1>(v_minaz, last_min_az);
             w_azprev = wu == u0 ? last_min_az : w_azprev;
             const bool w_badbit = (badmask >> wu) & 1u;
-            const bool c_global = inr && (w_nafter > tree_limit || v_abad == 2);
-            const bool c_live = inr && (w_badbit || (w_flags & 1) || v_abad == 1 ||
+            const bool c_global = inr && (w_nafter > tree_limit || (v_abad & 3) == 2);
+            const bool c_live = inr && (w_badbit || (w_flags & 1) || (v_abad & 3) == 1 ||
                                         (w_nbefore > 0 && (uint32_t) (gcu_l - w_Mbefore + 1) > (uint32_t) NC) // cc.cpp:657
                                         || gcu_l - w_maxd < w_fub);                                            // cc.cpp:762-763
             const bool w_alias = w_nafter > 0 && v_minaz == w_azprev;
@@ -1054,7 +1095,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     const long long gcu = gc + u;
                     const int wcu = (int) (gcu & (WIN2_COLS - 1));
                     const int info = lane_i32(v_info, u);
-                    const bool has_new = (info & 0xff) != 0, has_links = (info >> 8) & 2;
+                    const bool has_new = (info & 0xff) != 0, has_links = (lane_i32(v_abad, u) >> 4) & 1; // links to other trees
                     int par[RPL], e[RPL];
                     double fc[RPL];
 #pragma unroll
