@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             // tree changes and at the end of the batch. -------------------------------------------------------------------------
             if (u1 > u0)
             {
-                int cur[RPL], curcell[RPL], joined[RPL][LINK_SLOTS];
+                int cur[RPL], curcell[RPL];
                 unsigned rcnt[RPL];
                 unsigned long long rfin[RPL];
                 long long rlast[RPL];
@@ -1072,9 +1072,6 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 {
                     cur[k] = -1;
                     curcell[k] = -1;
-#pragma unroll
-                    for (int j = 0; j < LINK_SLOTS; j++)
-                        joined[k][j] = -1;
                     rcnt[k] = 0;
                     rfin[k] = 0;
                     rlast[k] = 0;
@@ -1174,30 +1171,13 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                             {
                                 const int i = e[k] & A2_IDMASK;
                                 const unsigned long long lk = st_link[u * R + row];
-                                int v[LINK_SLOTS]; // all link targets first: one LDS round trip
-#pragma unroll
-                                for (int j = 0; j < LINK_SLOTS; j++)
+                                for (int j = 0; j < nlk; j++) // (rare path since wave A filters the columns: small, not fast)
                                 {
-                                    v[j] = -1;
-                                    if (j < nlk)
-                                    {
-                                        const int code = (int) ((lk >> (16 * j)) & 0xffff);
-                                        v[j] = s_win[((wcu - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
-                                    }
-                                }
-#pragma unroll
-                                for (int j = 0; j < LINK_SLOTS; j++)
-                                {
-                                    const int vv = v[j] & A2_IDMASK;
-                                    const int pair = (i << 16) | vv;
-                                    // the same two trees usually meet again in the next column: a pair already joined in this
-                                    // batch needs nothing (nothing is finished inside a batch, so a union lasts)
-                                    if (v[j] >= 0 && vv != i && pair != joined[k][j])
-                                    {
-                                        if (T.alive[vv])
-                                            lds_union(T.uf, T.c_fin, i, vv);
-                                        joined[k][j] = pair;
-                                    }
+                                    const int code = (int) ((lk >> (16 * j)) & 0xffff);
+                                    const int v = s_win[((wcu - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
+                                    const int vv = v & A2_IDMASK;
+                                    if (v >= 0 && vv != i && T.alive[vv])
+                                        lds_union(T.uf, T.c_fin, i, vv);
                                 }
                             }
                         }
@@ -1217,11 +1197,10 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             st_check += cut == CUT_CHECK;
             st_live += cut == CUT_LIVE;
 #endif
+            int check_u = -1; // column whose finished-cluster check runs with the exact tree state (one call site: code size)
             if (cut == CUT_CHECK)
             {
-                const int u = u1 - 1;
-                finish_and_publish(gc + u, lane_f64(v_minaz, u));
-                verify = killed;
+                check_u = u1 - 1;
                 u0 = u1;
             }
             else if (cut == CUT_LIVE)
@@ -1265,8 +1244,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 if (err)
                     break;
                 resume_a(gcu + 1, hd);
-                if (nth == 1 || (gcu % nth) == 0)
-                    finish_and_publish(gcu, lane_f64(v_minaz, u));
+                check_u = u;
                 u0 = u1 + 1;
                 ids_stale = true; // wave A resolves the rest of the group again
             }
@@ -1278,6 +1256,11 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             }
             else
                 u0 = gcount;
+            if (check_u >= 0)
+            {
+                finish_and_publish(gc + check_u, lane_f64(v_minaz, check_u));
+                verify |= killed;
+            }
             if (lane == 0)
                 lds_st(&T.b_done, gc + u0);
             A2_PH(4)
