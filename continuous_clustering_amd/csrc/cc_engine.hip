@@ -704,9 +704,14 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         return CC_ERR_NO_DEVICE;
     cc_engine* e = new cc_engine();
     e->device = device;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) != hipSuccess)
+    // The serial chains (insertion, association) bound a pipelined step; the table / segmentation / scan chain between them is
+    // throughput work with slack, so it gets the low-priority queue and yields issue slots and memory bandwidth to the other two.
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipSetDevice(device);
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess)
     {
         delete e;
         return CC_ERR_HIP;
