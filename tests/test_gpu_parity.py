@@ -88,3 +88,21 @@ def test_lds_tree_pool_overflow_continues_in_global_memory(name, limit, oracle_l
     stream, cfg, tf = cases.build_case(name)
     util.run_and_compare(stream, cfg, chunks=[stream.sensor.num_columns // 2], robot_tf=tf,
                          engine_setup=lambda e: e.set_option("lds_tree_limit", limit))
+
+
+@pytest.mark.parametrize("name", ["s64_translate", "s64_forced_finish_ring", "s64_no_early_stop", "s128_full_1700"])
+def test_single_wave_association_kernel(name, oracle_lib):
+    """k_assoc_lds (one wavefront per stream; the engine uses it for cluster_point_trees_every_nth_column != 1) stays exact:
+    option assoc_waves = 1 selects it for every configuration."""
+    stream, cfg, tf = cases.build_case(name)
+    summary = util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns]), robot_tf=tf,
+                                   engine_setup=lambda e: e.set_option("assoc_waves", 1))
+    assert summary["clusters"] >= 3
+
+
+def test_two_wave_kernel_rolls_back_speculation(oracle_lib):
+    """Small calls make the front wavefront of k_assoc2 run ahead of freshly finished trees on every launch; the serially
+    replayed columns must show up (error_b doubles as their count) and nothing may change."""
+    stream, cfg, tf = cases.build_case("s64_forced_finish_ring")
+    summary = util.run_and_compare(stream, cfg, chunks=[37, 5, 211], robot_tf=tf)
+    assert summary["engine_state"]["error_b"] > 0
