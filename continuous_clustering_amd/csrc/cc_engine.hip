@@ -26,7 +26,18 @@ struct cc_engine
     hipStream_t stream{nullptr};  // insertion chain (and everything else when not pipelined)
     hipStream_t stream2{nullptr}; // table / segmentation / window-scan chain of the pipelined throughput path
     hipStream_t stream3{nullptr}; // association / publish chain of the pipelined throughput path
-    hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{};
+    hipStream_t stream4{nullptr}; // window-scan stage of the four-stage pipeline (option "pipeline" = 2)
+    hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
+    hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
+    int pipeline_depth{1};        // 1: three chains (default: four are not faster, the GPU is throughput-bound by then), 2: four
+    int prep_buf{0};              // staging buffer (of two) the open batch was prepared into
+    std::vector<hipEvent_t> pev_pool; // pairs of events around every k_prep that ran ahead (outside the per-pass event groups)
+    size_t pev_used{0};
+    struct PrepPlanes
+    {
+        float *x, *y, *z, *dist, *incl, *incaz;
+        int32_t* cir;
+    } pp[2]{};
     uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 3
     bool pipelined{false};        // last submitted batch used all three streams
     bool allow_pipeline{true};    // option "pipeline"
@@ -228,22 +239,70 @@ int ensure_prep(cc_engine* e, size_t points)
 {
     if (e->prep_capacity >= points)
         return CC_OK;
-    Planes& P = e->P;
     int rc;
-    // old blocks stay in `allocations` until the engine is destroyed or re-shaped (growth is rare: batch sizes repeat)
-    if ((rc = alloc_plane(e, &P.pp_x, points)) || (rc = alloc_plane(e, &P.pp_y, points)) || (rc = alloc_plane(e, &P.pp_z, points)) ||
-        (rc = alloc_plane(e, &P.pp_dist, points)) || (rc = alloc_plane(e, &P.pp_incl, points)) ||
-        (rc = alloc_plane(e, &P.pp_incaz, points)) || (rc = alloc_plane(e, &P.pp_cir, points)))
-        return rc;
+    // old blocks stay in `allocations` until the engine is destroyed or re-shaped (growth is rare: batch sizes repeat).
+    // Two buffers: the points of batch b + 1 are prepared while batch b is still being inserted.
+    for (auto& q : e->pp)
+        if ((rc = alloc_plane(e, &q.x, points)) || (rc = alloc_plane(e, &q.y, points)) || (rc = alloc_plane(e, &q.z, points)) ||
+            (rc = alloc_plane(e, &q.dist, points)) || (rc = alloc_plane(e, &q.incl, points)) ||
+            (rc = alloc_plane(e, &q.incaz, points)) || (rc = alloc_plane(e, &q.cir, points)))
+            return rc;
     e->prep_capacity = points;
+    return CC_OK;
+}
+
+int take_timing_events(cc_engine* e, hipEvent_t* ev)
+{
+    for (int i = 0; i < 10; i++)
+    {
+        if (e->ev_used == e->ev_pool.size())
+        {
+            hipEvent_t x;
+            CC_HIP_CHECK(e, hipEventCreate(&x));
+            e->ev_pool.push_back(x);
+        }
+        ev[i] = e->ev_pool[e->ev_used++];
+    }
+    return CC_OK;
+}
+
+static Planes planes_with_prep(const cc_engine* e, int buf)
+{
+    Planes P = e->P;
+    const auto& q = e->pp[buf];
+    P.pp_x = q.x;
+    P.pp_y = q.y;
+    P.pp_z = q.z;
+    P.pp_dist = q.dist;
+    P.pp_incl = q.incl;
+    P.pp_incaz = q.incaz;
+    P.pp_cir = q.cir;
+    return P;
+}
+
+// k_prep of a batch on stream `sp` into staging buffer `buf` (the per-point part of insertion does not depend on engine state)
+int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const double* d_pose, int buf, hipStream_t sp)
+{
+    const size_t points = (size_t) count * (size_t) n * e->g.num_rows;
+    int rcp = ensure_prep(e, points);
+    if (rcp)
+        return rcp;
+    const Planes P = planes_with_prep(e, buf);
+    hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((points + 255) / 256)), dim3(256), 0, sp, e->g, e->cfg, P, d_xyz, d_pose,
+                       (long long) points);
     return CC_OK;
 }
 
 // One pass over a batch: insertion on `si`, table + segmentation + window scan on `sb`, association + publish on `sa`
 // (all three equal when not pipelined).
 int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int,
-                 const double* d_pose, bool first_pass, int slot, hipStream_t si, hipStream_t sb, hipStream_t sa)
+                 const double* d_pose, bool first_pass, int slot, hipStream_t si, hipStream_t sb, hipStream_t sa,
+                 hipStream_t sc = nullptr, hipStream_t sp = nullptr, bool prep_done = false)
 {
+    if (!sc)
+        sc = sb; // window scan on the segmentation chain unless the four-stage pipeline gives it its own stream
+    if (!sp)
+        sp = si; // preparation on the insertion chain unless it runs ahead on its own stream
     const Geometry& g = e->g;
     const int rpl = (g.num_rows + WAVE - 1) / WAVE;
     // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
@@ -253,40 +312,36 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     hipEvent_t ev[NEV] = {};
     if (e->timing)
     {
-        for (int i = 0; i < NEV; i++)
-        {
-            if (e->ev_used == e->ev_pool.size())
-            {
-                hipEvent_t x;
-                CC_HIP_CHECK(e, hipEventCreate(&x));
-                e->ev_pool.push_back(x);
-            }
-            ev[i] = e->ev_pool[e->ev_used++];
-        }
+        int rct = take_timing_events(e, ev);
+        if (rct)
+            return rct;
     }
     int k = 0;
 #define CC_MARK(st_) \
     if (e->timing)   \
         CC_HIP_CHECK(e, hipEventRecord(ev[k++], st_));
     // ---- insertion chain -----------------------------------------------------------------------------------------
-    CC_MARK(si); // ev0
-    const size_t points = (size_t) count * (size_t) n * g.num_rows;
-    if (first_pass) // relaunch passes of the same batch reuse the staged points
+    CC_MARK(sp); // ev0
+    if (first_pass && !prep_done) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
     {
-        int rcp = ensure_prep(e, points);
+        int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp);
         if (rcp)
             return rcp;
-        hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((points + 255) / 256)), dim3(256), 0, si, g, e->cfg, e->P, d_xyz, d_pose,
-                           (long long) points);
     }
-    CC_MARK(si); // ev1: prep
+    CC_MARK(sp); // ev1: prep
+    if (sp != si)
+    {
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], sp));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_prep[slot], 0));
+    }
+    const Planes Pins = planes_with_prep(e, e->prep_buf);
     {
         const size_t lds = cck::insert2_lds_bytes(g.num_rows);
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, si, g, e->cfg, e->P, e->d_states, first_stream, slot,
+            hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
                                d_int, (long long) n, e->d_remaining);
         else
-            hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, si, g, e->cfg, e->P, e->d_states, first_stream, slot,
+            hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
                                d_int, (long long) n, e->d_remaining);
     }
     CC_MARK(si); // ev2: insert
@@ -312,16 +367,21 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
         hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
-    CC_MARK(sb); // ev4: table + segment
+    if (sc != sb)
+    {
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_segscan[slot], sb));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(sc, e->ev_segscan[slot], 0));
+    }
+    CC_MARK(sc); // ev4: table + segment (start of the window scan)
     const dim3 scan_grid(cck::SCAN_BLOCKS, (unsigned) count);
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    CC_MARK(sb); // ev5: scan
-    if (sb != sa)
+        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    CC_MARK(sc); // ev5: scan
+    if (sc != sa)
     {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_seg[slot], sb));
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_seg[slot], sc));
         CC_HIP_CHECK(e, hipStreamWaitEvent(sa, e->ev_seg[slot], 0));
     }
     // ---- association + publish chain -------------------------------------------------------------------------
@@ -401,6 +461,13 @@ int resolve_timing(cc_engine* e)
         }
         e->kernel_launches++;
     }
+    for (size_t i = 0; i + 1 < e->pev_used; i += 2)
+    {
+        float ms = 0.f;
+        CC_HIP_CHECK(e, hipEventElapsedTime(&ms, e->pev_pool[i], e->pev_pool[i + 1]));
+        e->kernel_ms[0] += ms;
+    }
+    e->pev_used = 0;
     e->ev_used = 0;
     return CC_OK;
 }
@@ -410,6 +477,8 @@ int sync_all(cc_engine* e)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream4));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream5));
     for (bool& b : e->assoc_pending)
         b = false;
     return CC_OK;
@@ -447,6 +516,31 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
            bool pipeline)
 {
     int rc;
+    bool prepared = false;
+    const int next_buf = e->prep_buf ^ 1;
+    if (pipeline && e->batch_open && e->pipelined)
+    {
+        // The per-point preparation of this batch depends on nothing the engine holds: it starts now, on its own stream and
+        // into the other staging buffer, while the previous batch is still being inserted.
+        if (e->timing)
+        {
+            while (e->pev_pool.size() < e->pev_used + 2)
+            {
+                hipEvent_t x;
+                CC_HIP_CHECK(e, hipEventCreate(&x));
+                e->pev_pool.push_back(x);
+            }
+            CC_HIP_CHECK(e, hipEventRecord(e->pev_pool[e->pev_used], e->stream5));
+        }
+        if ((rc = launch_prep(e, count, n, d_xyz, d_pose, next_buf, e->stream5)))
+            return rc;
+        if (e->timing)
+        {
+            CC_HIP_CHECK(e, hipEventRecord(e->pev_pool[e->pev_used + 1], e->stream5));
+            e->pev_used += 2;
+        }
+        prepared = true;
+    }
     if (e->batch_open)
     {
         if (pipeline && e->pipelined)
@@ -454,15 +548,23 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
             // the previous batch's insertion chain must be complete before its successor starts; its association chain
             // keeps running on stream2 while this batch is inserted
             CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
-            if (*e->h_remaining != 0 && (rc = finish_batch(e)))
-                return rc;
+            if (*e->h_remaining != 0)
+            {
+                // continuation passes of the previous batch still read its staged points: this batch's preparation went to the
+                // other buffer, so nothing is lost
+                if ((rc = finish_batch(e)))
+                    return rc;
+            }
         }
         else if ((rc = finish_batch(e)))
             return rc;
     }
+    e->prep_buf = next_buf;
     const int slot = (int) (e->batch_seq & 3);
     e->batch_seq++;
     hipStream_t si = e->stream, sb = pipeline ? e->stream2 : e->stream, sa = pipeline ? e->stream3 : e->stream;
+    hipStream_t sc = (pipeline && e->pipeline_depth >= 2) ? e->stream4 : sb;
+    hipStream_t sp = pipeline ? e->stream5 : si;
     if (pipeline && e->assoc_pending[slot])
     {
         // the descriptor slot of batch b - 4 must have been consumed
@@ -471,7 +573,12 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
     }
     hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining,
                        pipeline ? 1 : 0);
-    rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true, slot, si, sb, sa);
+    if (prepared)
+    {
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], e->stream5));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_prep[slot], 0));
+    }
+    rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true, slot, si, sb, sa, sc, prepared ? si : sp, prepared);
     if (rc)
         return rc;
     e->last_xyz = d_xyz;
@@ -711,7 +818,9 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess)
+        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess)
     {
         delete e;
         return CC_ERR_HIP;
@@ -721,6 +830,9 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         (void) hipEventCreateWithFlags(&e->ev_ins[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_seg[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_assoc[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_segscan[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming);
+
     }
     e->cfg = *cfg;
     e->g.num_streams = num_streams;
@@ -762,6 +874,8 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamSynchronize(e->stream);
     (void) hipStreamSynchronize(e->stream2);
     (void) hipStreamSynchronize(e->stream3);
+    (void) hipStreamSynchronize(e->stream4);
+    (void) hipStreamSynchronize(e->stream5);
     destroy_small_graphs(e);
     if (e->h_small)
     {
@@ -775,9 +889,15 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipEventDestroy(e->ev_ins[i]);
         (void) hipEventDestroy(e->ev_seg[i]);
         (void) hipEventDestroy(e->ev_assoc[i]);
+        (void) hipEventDestroy(e->ev_segscan[i]);
+        (void) hipEventDestroy(e->ev_prep[i]);
     }
+    for (hipEvent_t ev : e->pev_pool)
+        (void) hipEventDestroy(ev);
     (void) hipStreamDestroy(e->stream2);
     (void) hipStreamDestroy(e->stream3);
+    (void) hipStreamDestroy(e->stream4);
+    (void) hipStreamDestroy(e->stream5);
     for (hipEvent_t ev : e->ev_pool)
         (void) hipEventDestroy(ev);
     if (e->h_remaining)
@@ -833,6 +953,8 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream4));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream5));
     e->batch_open = false;
     const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
     if (!same_shape)
@@ -1108,7 +1230,10 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "lds_tree_limit")
         e->g.lds_tree_limit = (int32_t) (value < 1 ? 1 : (value > TREE_SLOTS ? TREE_SLOTS : value));
     else if (n == "pipeline")
-        e->allow_pipeline = value != 0;
+    {
+        e->allow_pipeline = value != 0; // 0: one stream, 1: three chains, 2: four (window scan on its own stream)
+        e->pipeline_depth = value >= 2 ? 2 : 1;
+    }
     else if (n == "graphs")
         e->allow_graphs = value != 0;
     else if (n == "assoc_waves")
