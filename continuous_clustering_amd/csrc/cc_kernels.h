@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
 
         float dist[RPL], incl[RPL], tabv[RPL];
-        bool isnan_[RPL], overrun = false;
+        bool isnan_[RPL], empty_cell[RPL], overrun = false;
         double min_az = 1.7976931348623157e308;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
@@ -1177,12 +1177,14 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             const int row = k * 64 + lane;
             dist[k] = incl[k] = tabv[k] = 0.f;
             isnan_[k] = true;
+            empty_cell[k] = false;
             if (row < R)
             {
                 const size_t ci = base + row;
                 const long long cg = p.gcol[ci];
                 if (cg != gc && cg != -1)
                     overrun = true; // cc.cpp:320-345
+                empty_cell[k] = cg != gc;
                 dist[k] = p.dist[ci];
                 incl[k] = p.incl[ci];
                 tabv[k] = p.tab[ci];
@@ -1245,7 +1247,8 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             if (row >= R)
                 continue;
             const size_t ci = base + row;
-            p.gcol[ci] = gc;
+            if (empty_cell[k])
+                p.gcol[ci] = gc; // cells that received a return already carry the column index (k_insert2)
             int flags = 0;
             float x2 = 0.f, uz = 0.f;
             float4 rec = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), incl[k]);
