@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=256, help="sensor streams per GPU")
     ap.add_argument("--firings", type=int, default=2200, help="firings per stream per step (2200 = one rotation)")
     ap.add_argument("--sensor", default="s64", choices=["s64", "s128"])
@@ -172,14 +172,17 @@ def main():
         alg_bytes_per_cell = 18.0 + 96.0 / R  # 13 B read + 5 B written per cell + 96 B pose per column
         batches = max(1, ktimes["batches"])
         per_kernel = {k: v / batches for k, v in ktimes.items() if k.endswith("_ms")}
-        dom = max(per_kernel, key=per_kernel.get)
+        # dominant single kernel (segment_ms is the sum of k_table + k_seg_pre + k_seg_scan, profiles/ lists them separately)
+        KERNEL_OF = {"prep_ms": "k_prep", "insert_ms": "k_insert2", "scan_ms": "k_scan", "assoc_lds_ms": "k_assoc2",
+                     "assoc_global_ms": "k_associate", "publish_ms": "k_publish"}
+        dom = max(KERNEL_OF, key=lambda k: per_kernel.get(k, 0.0))
         cells_per_launch = float(S * F * R)
         achieved = cells_per_launch * alg_bytes_per_cell / (per_kernel[dom] * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom.replace("_ms", ""), {}).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(KERNEL_OF[dom], {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -207,7 +210,7 @@ def main():
             "serial_columns": after["serial_columns"],
             "kernel_ms_per_step": per_kernel,
             "roofline": {
-                "bound": "hbm", "kernel": "k_" + dom.replace("_ms", ""), "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": cells_per_launch * alg_bytes_per_cell,
                 "note": "path is latency/dependency-bound (serial per-stream column recurrence), not bandwidth-bound",
