@@ -1552,7 +1552,12 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 p.ground[ci] = SEG_GROUND_VALUE[o & 7];
                 p.debug[ci] = SEG_DEBUG_VALUE[(o >> 3) & 15];
                 // cc.cpp:567-616: everything that is not an obstacle is ignored, and so are the filtered obstacles
-                p.ignored[ci] = ((o & 7) != SG_G_OBSTACLE || (o & 0x80)) ? 1 : 0;
+                const bool ign = (o & 7) != SG_G_OBSTACLE || (o & 0x80);
+                p.ignored[ci] = ign ? 1 : 0;
+                // the window scan reads one 16-byte record per visited cell: an ignored cell is marked there (x = NaN; its
+                // inclination stays), so that the scan needs no second load per visit
+                if (ign)
+                    ((float*) &p.sc_rec[ci])[0] = __builtin_nanf("");
             }
             lc = lc + 1 == RC ? 0 : lc + 1;
         }
@@ -1664,8 +1669,8 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                 unsigned char oign = 0;
                 if (REC)
                 {
-                    orec = p.sc_rec[oi]; // both loads are issued before the first use: one round trip per visit
-                    oign = p.ignored[oi];
+                    orec = p.sc_rec[oi]; // x = NaN marks an ignored cell (k_seg_scan): one load per visit
+                    oign = orec.x != orec.x;
                 }
                 const float oincl = REC ? orec.w : p.incl[oi];
                 if (ccm::absf(oincl - pincl) > mad)
