@@ -39,45 +39,67 @@ __device__ __forceinline__ int f2i_x86(float v)
     return (int) v;
 }
 
+// Wave-wide reductions over all 64 lanes by DPP (row_shr 1/2/4/8 inside the rows of 16, then row_bcast 15 and 31): ~30 VALU
+// instructions and no LDS traffic, where the ds_bpermute butterfly costs a lone wave twelve LDS round trips (~700 cycles).
+// All lanes must be active; the result is wave-uniform (read from lane 63).
+template<int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov_i32(int fill, int v)
+{
+    return __builtin_amdgcn_update_dpp(fill, v, CTRL, ROW_MASK, 0xf, false);
+}
+template<int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_mov_i64(long long fill, long long v)
+{
+    const unsigned lo = (unsigned) dpp_mov_i32<CTRL, ROW_MASK>((int) (unsigned) (unsigned long long) fill, (int) (unsigned) (unsigned long long) v);
+    const unsigned hi = (unsigned) dpp_mov_i32<CTRL, ROW_MASK>((int) (unsigned) ((unsigned long long) fill >> 32),
+                                                               (int) (unsigned) ((unsigned long long) v >> 32));
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+#define CC_DPP_REDUCE(T, MOV, v, fill, better)                   \
+    {                                                            \
+        T t_;                                                    \
+        t_ = MOV<0x111, 0xf>(fill, v); v = better(t_, v) ? t_ : v; \
+        t_ = MOV<0x112, 0xf>(fill, v); v = better(t_, v) ? t_ : v; \
+        t_ = MOV<0x114, 0xf>(fill, v); v = better(t_, v) ? t_ : v; \
+        t_ = MOV<0x118, 0xf>(fill, v); v = better(t_, v) ? t_ : v; \
+        t_ = MOV<0x142, 0xa>(fill, v); v = better(t_, v) ? t_ : v; \
+        t_ = MOV<0x143, 0xc>(fill, v); v = better(t_, v) ? t_ : v; \
+    }
+#define CC_LESS(a, b) ((a) < (b))
+#define CC_GREATER(a, b) ((a) > (b))
+__device__ __forceinline__ long long lane63_i64(long long v)
+{
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (unsigned long long) v, 63);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) v >> 32), 63);
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
 __device__ __forceinline__ long long wave_min_i64(long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        long long w = __shfl_xor(v, o);
-        v = w < v ? w : v;
-    }
-    return v;
+    const long long fill = 0x7fffffffffffffffll;
+    CC_DPP_REDUCE(long long, dpp_mov_i64, v, fill, CC_LESS)
+    return lane63_i64(v);
 }
 __device__ __forceinline__ long long wave_max_i64(long long v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        long long w = __shfl_xor(v, o);
-        v = w > v ? w : v;
-    }
-    return v;
+    const long long fill = (long long) 0x8000000000000000ull;
+    CC_DPP_REDUCE(long long, dpp_mov_i64, v, fill, CC_GREATER)
+    return lane63_i64(v);
 }
 __device__ __forceinline__ int wave_min_i32(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        int w = __shfl_xor(v, o);
-        v = w < v ? w : v;
-    }
-    return v;
+    const int fill = 0x7fffffff;
+    CC_DPP_REDUCE(int, dpp_mov_i32, v, fill, CC_LESS)
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ double wave_min_f64(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-    {
-        double w = __shfl_xor(v, o);
-        v = w < v ? w : v;
-    }
-    return v;
+    // (no NaNs reach this: azimuths and finished_at values)
+    const long long fill = 0x7ff0000000000000ll; // +inf
+    long long b = __double_as_longlong(v);
+#define CC_LESS_F64(a, b) (__longlong_as_double(a) < __longlong_as_double(b))
+    CC_DPP_REDUCE(long long, dpp_mov_i64, b, fill, CC_LESS_F64)
+#undef CC_LESS_F64
+    return __longlong_as_double(lane63_i64(b));
 }
 // Single-wavefront workgroups: LDS operations of one wave execute in issue order, so ordering LDS writes before LDS reads
 // of other lanes needs neither s_barrier nor a vmcnt drain (which __syncthreads() implies and which would expose the
@@ -760,30 +782,19 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 #ifdef CC_PROFILE_SECTIONS
         CC_ISEC(0)
 #endif
-        // wave-wide range of touched columns: few distinct values per firing -> peel them off with ballots
+        // wave-wide range of touched columns (DPP reductions: no LDS round trips)
         long long need_lo = 0x7fffffffffffffffll, need_hi = -1;
         {
-            bool todo[RPL];
+            long long lo = 0x7fffffffffffffffll, hi = -1;
 #pragma unroll
             for (int k = 0; k < RPL; k++)
-                todo[k] = have[k];
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                unsigned long long m = __ballot(todo[k]);
-                while (m)
+                if (have[k])
                 {
-                    const int src = __ffsll((long long) m) - 1;
-                    const long long v = __shfl(gcv[k], src);
-                    need_lo = v < need_lo ? v : need_lo;
-                    need_hi = v > need_hi ? v : need_hi;
-#pragma unroll
-                    for (int k2 = 0; k2 < RPL; k2++)
-                        if (todo[k2] && gcv[k2] == v)
-                            todo[k2] = false;
-                    m = __ballot(todo[k]);
+                    lo = gcv[k] < lo ? gcv[k] : lo;
+                    hi = gcv[k] > hi ? gcv[k] : hi;
                 }
-            }
+            need_lo = wave_min_i64(lo);
+            need_hi = wave_max_i64(hi);
         }
 #ifdef CC_PROFILE_SECTIONS
         CC_ISEC(1)
