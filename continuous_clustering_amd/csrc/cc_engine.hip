@@ -75,6 +75,8 @@ struct cc_engine
     const uint8_t* last_int{nullptr};
     const double* last_pose{nullptr};
     int64_t last_n{0};
+    int64_t cur_ntotal{0}, cur_f0{0}; // the open batch is firings [cur_f0, cur_f0 + last_n) of buffers holding cur_ntotal per stream
+    int64_t sub_batch{0};             // option "sub_batch": firings per pipelined sub-batch of a device call (0 = whole call)
     int last_first{0}, last_count{0};
     bool batch_open{false};
     // optional per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
@@ -281,15 +283,17 @@ static Planes planes_with_prep(const cc_engine* e, int buf)
 }
 
 // k_prep of a batch on stream `sp` into staging buffer `buf` (the per-point part of insertion does not depend on engine state)
-int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const double* d_pose, int buf, hipStream_t sp)
+int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const double* d_pose, int buf, hipStream_t sp, int64_t n_total,
+                int64_t f0)
 {
     const size_t points = (size_t) count * (size_t) n * e->g.num_rows;
     int rcp = ensure_prep(e, points);
     if (rcp)
         return rcp;
     const Planes P = planes_with_prep(e, buf);
-    hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((points + 255) / 256)), dim3(256), 0, sp, e->g, e->cfg, P, d_xyz, d_pose,
-                       (long long) points);
+    const size_t per_stream = (size_t) n * e->g.num_rows;
+    hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((per_stream + 255) / 256), (unsigned) count), dim3(256), 0, sp, e->g, e->cfg, P,
+                       d_xyz, d_pose, (long long) n, (long long) n_total, (long long) f0);
     return CC_OK;
 }
 
@@ -324,7 +328,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     CC_MARK(sp); // ev0
     if (first_pass && !prep_done) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
     {
-        int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp);
+        int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp, e->cur_ntotal, e->cur_f0);
         if (rcp)
             return rcp;
     }
@@ -339,10 +343,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         const size_t lds = cck::insert2_lds_bytes(g.num_rows);
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
-                               d_int, (long long) n, e->d_remaining);
+                               d_int, (long long) n, e->d_remaining, (long long) e->cur_ntotal, (long long) e->cur_f0);
         else
             hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
-                               d_int, (long long) n, e->d_remaining);
+                               d_int, (long long) n, e->d_remaining, (long long) e->cur_ntotal, (long long) e->cur_f0);
     }
     CC_MARK(si); // ev2: insert
     CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
@@ -359,10 +363,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
-                           first_stream, slot, d_pose, (long long) n);
+                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0);
     else
         hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
-                           first_stream, slot, d_pose, (long long) n);
+                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0);
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
         hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -512,9 +516,15 @@ int finish_batch(cc_engine* e)
     return CC_OK;
 }
 
+// Firings [f0, f0 + n) of buffers that hold n_total firings per stream (n_total <= 0: the buffers hold exactly n).
 int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose,
-           bool pipeline)
+           bool pipeline, int64_t n_total = 0, int64_t f0 = 0)
 {
+    if (n_total <= 0)
+    {
+        n_total = n;
+        f0 = 0;
+    }
     int rc;
     bool prepared = false;
     const int next_buf = e->prep_buf ^ 1;
@@ -532,7 +542,7 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
             }
             CC_HIP_CHECK(e, hipEventRecord(e->pev_pool[e->pev_used], e->stream5));
         }
-        if ((rc = launch_prep(e, count, n, d_xyz, d_pose, next_buf, e->stream5)))
+        if ((rc = launch_prep(e, count, n, d_xyz, d_pose, next_buf, e->stream5, n_total, f0)))
             return rc;
         if (e->timing)
         {
@@ -560,6 +570,8 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
             return rc;
     }
     e->prep_buf = next_buf;
+    e->cur_ntotal = n_total;
+    e->cur_f0 = f0;
     const int slot = (int) (e->batch_seq & 3);
     e->batch_seq++;
     hipStream_t si = e->stream, sb = pipeline ? e->stream2 : e->stream, sa = pipeline ? e->stream3 : e->stream;
@@ -671,6 +683,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     {
         if (ensure_prep(e, (size_t) n * R) != CC_OK)
             return -1;
+        e->cur_ntotal = n; // the staged call is a whole buffer of its own
+        e->cur_f0 = 0;
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
             return -1;
@@ -711,6 +725,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         e->last_int = d_int;
         e->last_pose = d_pose;
         e->last_n = n;
+        e->cur_ntotal = n;
+        e->cur_f0 = 0;
         e->last_first = stream;
         e->last_count = 1;
         e->batch_open = true;
@@ -1048,8 +1064,22 @@ int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, co
         return CC_OK;
     (void) hipSetDevice(e->device);
     // throughput path: when nobody reads events or columns between batches, batch b + 1 is inserted while batch b is still
-    // being segmented and associated (two HIP streams)
-    return submit(e, 0, e->g.num_streams, n, d_xyz, d_intensity, d_poses, e->g.record_events == 0 && e->allow_pipeline);
+    // being segmented and associated (three chains of HIP streams). A large call is cut into sub-batches that enter the
+    // pipeline one after the other: same work, but the last firing of the call leaves the pipeline a sub-batch (not a whole
+    // call) after it entered.
+    const bool pipeline = e->g.record_events == 0 && e->allow_pipeline;
+    // (measured: per-launch fixed costs outweigh the shorter fill / drain at 2200-firing calls, so it is off unless asked for)
+    int64_t sub = e->sub_batch > 0 ? e->sub_batch : n;
+    if (!pipeline || sub >= n)
+        return submit(e, 0, e->g.num_streams, n, d_xyz, d_intensity, d_poses, pipeline);
+    for (int64_t f0 = 0; f0 < n; f0 += sub)
+    {
+        const int64_t m = std::min<int64_t>(sub, n - f0);
+        int rc = submit(e, 0, e->g.num_streams, m, d_xyz, d_intensity, d_poses, true, n, f0);
+        if (rc)
+            return rc;
+    }
+    return CC_OK;
 }
 
 int cc_engine_sync(cc_engine* e)
@@ -1236,6 +1266,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     }
     else if (n == "graphs")
         e->allow_graphs = value != 0;
+    else if (n == "sub_batch")
+        e->sub_batch = value < 0 ? 0 : value;
     else if (n == "assoc_waves")
         e->assoc_waves = value == 1 ? 1 : 2;
     else if (n == "limit_columns")

@@ -274,15 +274,20 @@ __device__ __forceinline__ float len2(float a, float b)
 // azimuth -> column within the rotation, inclination. Independent per point, so it runs over all points of the batch
 // in parallel; the serial kernel below only decides where each point lands. grid = points / 256, block = 256.
 // =====================================================================================================
+// grid = (points of one stream's sub-batch / 256, streams). The caller's buffers hold n_total firings per stream; this launch
+// prepares firings [f0, f0 + m) of every stream into the compact staging planes (index [stream][m][row]).
 __global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes P, const float* __restrict__ xyz,
-                                             const double* __restrict__ poses, long long n_points)
+                                             const double* __restrict__ poses, long long m, long long n_total, long long f0)
 {
-    const long long i = (long long) blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_points)
-        return;
     const int R = g.num_rows;
-    const long long firing = i / R; // [stream][firing] flattened
-    const float fx = xyz[i * 3 + 0], fy = xyz[i * 3 + 1], fz = xyz[i * 3 + 2];
+    const long long local = (long long) blockIdx.x * 256 + threadIdx.x; // [firing within the sub-batch][row]
+    if (local >= m * R)
+        return;
+    const long long sl = blockIdx.y;
+    const long long src = (sl * n_total + f0) * R + local; // index into the caller's [stream][n_total][row] buffers
+    const long long firing = src / R;                      // [stream][firing] flattened
+    const long long i = sl * m * R + local;                // index into the staging planes
+    const float fx = xyz[src * 3 + 0], fy = xyz[src * 3 + 1], fz = xyz[src * 3 + 2];
     if (fx != fx)
     {
         P.pp_cir[i] = PP_SKIP; // std::isnan(p.x()) cc.cpp:131
@@ -333,7 +338,7 @@ __host__ inline size_t insert2_lds_bytes(int R)
 // of the coming firings from HBM into an LDS ring, so that the consumer never waits for a global load.
 template<int RPL>
 __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                 const uint8_t* __restrict__ inten, long long n, int* remaining)
+                                                 const uint8_t* __restrict__ inten, long long n, int* remaining, long long n_total, long long fbase)
 {
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     if (wave == 1)
     {
         // ------------------------------------------------------------------ loader
-        const uint8_t* si = inten + pbase;
+        const uint8_t* si = inten + ((size_t) sl * (size_t) n_total + (size_t) fbase) * R; // caller's [stream][n_total][row] buffer
         const float *qx = P.pp_x + pbase, *qy = P.pp_y + pbase, *qz = P.pp_z + pbase, *qd = P.pp_dist + pbase, *qi = P.pp_incl + pbase,
                     *qa = P.pp_incaz + pbase;
         const int32_t* qc = P.pp_cir + pbase;
@@ -1135,7 +1140,7 @@ constexpr int SEGPRE_BLOCKS = 128;
 
 template<int RPL>
 __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                const double* __restrict__ poses, long long n)
+                                                const double* __restrict__ poses, long long n_total, long long fbase)
 {
     const int sl = blockIdx.y;
     const int s = first_stream + sl;
@@ -1162,7 +1167,8 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     {
         const int lc = (int) (gc % RC);
         const size_t base = (size_t) lc * R;
-        const double* T = poses + ((size_t) sl * (size_t) n + (size_t) p.trig[lc]) * 12;
+        // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
+        const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) p.trig[lc]) * 12;
         // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301)
         double ir[9], it[3];
         for (int i = 0; i < 3; i++)

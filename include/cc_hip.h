@@ -242,7 +242,8 @@ int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_l
  * it hands back to the host), "pipeline" (0: run the kernel chains of cc_engine_add_firings_device back to back on one
  * HIP stream; 1 (default): overlap consecutive batches on three chains, with the per-point preparation of the next batch running
  * ahead; 2: window scan on a fourth chain), "assoc_waves" (2 (default): two cooperating wavefronts per stream in the association
- * kernel; 1: the one-wavefront kernel, which is also what cluster_point_trees_every_nth_column != 1 uses), "graphs" (0: never
+ * kernel; 1: the one-wavefront kernel, which is also what cluster_point_trees_every_nth_column != 1 uses), "sub_batch" (firings
+ * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never
  * use the captured-hipGraph low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in
  * production). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
