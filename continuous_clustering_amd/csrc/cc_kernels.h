@@ -1163,9 +1163,11 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     const float height_sensor_to_ground = -(float) A[11] + cfg.height_ref_to_ground_;
     (void) height_sensor_to_ground;
 
-    for (long long gc = seg_begin + blockIdx.x; gc < seg_end; gc += gridDim.x)
+    // (ring column advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
+    int lc = (int) ((seg_begin + blockIdx.x) % RC);
+    const int lc_step = (int) (gridDim.x % (unsigned) RC);
+    for (long long gc = seg_begin + blockIdx.x; gc < seg_end; gc += gridDim.x, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
     {
-        const int lc = (int) (gc % RC);
         const size_t base = (size_t) lc * R;
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
         const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) p.trig[lc]) * 12;
@@ -2251,45 +2253,148 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
     c.stop_min_steps = cfg.stop_after_association_min_steps;
     __shared__ int s_links[WAVE * MAX_ROWS_PER_LANE][LINK_SLOTS];
     const long long col_end = st->batch[slot].seg_end, first_column = st->first_column;
-    for (long long gc = st->batch[slot].acp_next + blockIdx.x; gc < col_end; gc += gridDim.x)
+    // (ring columns advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
+    const int first_lc = (int) (first_column % RC);
+    int lc = (int) ((st->batch[slot].acp_next + blockIdx.x) % RC);
+    const int lc_step = (int) (gridDim.x % (unsigned) RC);
+    for (long long gc = st->batch[slot].acp_next + blockIdx.x; gc < col_end;
+         gc += gridDim.x, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
     {
-        const int lc = (int) (gc % RC);
         // never look at columns older than the first column ever segmented (their planes are uninitialised)
-        const int bound = (gc - first_column) <= (long long) cfg.max_steps_in_row + 1 ? (int) (first_column % RC) : -1;
+        const int bound = (gc - first_column) <= (long long) cfg.max_steps_in_row + 1 ? first_lc : -1;
         int parent[RPL], nlinks[RPL];
         double fin[RPL];
         unsigned long long packed[RPL];
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
+        if (RPL == 1)
         {
-            const int row = k * 64 + lane;
-            parent[k] = -2;
-            nlinks[k] = 0;
-            fin[k] = 0.;
-            packed[k] = 0;
-            if (row >= R)
-                continue;
+            // Rows = lanes: the scan of all 64 points of the column runs in lock step. Every lane visits the same relative cell
+            // (sb columns back, d rows up or down) at the same time, in the reference's order (cc.cpp:706-769): the candidate
+            // column is loaded once per sb (one coalesced 16-byte record per lane) and the cell each lane wants arrives by a
+            // cross-lane read, instead of one gathered load plus divergent-loop bookkeeping per visit and lane.
+            const int row = lane;
             const int ci = lc * R + row;
-            if (!p.ignored[ci])
+            const bool inrow = row < R;
+            float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool live = false; // this lane's point is still scanning further columns
+            float mad = 0.f;
+            int needed = -1;
+            parent[0] = -2;
+            nlinks[0] = 0;
+            fin[0] = 0.;
+            packed[0] = 0;
+            if (inrow && !p.ignored[ci])
             {
-                parent[k] = -1;
-                const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                const double caz = p.caz[ci];
-                fin[k] = caz + (double) mad;
-                bool overflow = false;
-                int dummy_root = -1;
-                scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent[k], s_links[row], nlinks[k], overflow, LINK_SLOTS);
-                if (overflow)
-                    nlinks[k] = 255;
+                live = true;
+                parent[0] = -1;
+                me = p.sc_rec[ci]; // the point itself is not ignored: x is the real coordinate
+                mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                fin[0] = p.caz[ci] + (double) mad;
+                needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
+                needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
             }
-            p.sc_parent[ci] = (int16_t) parent[k];
-            p.sc_nlinks[ci] = (uint8_t) nlinks[k];
-            p.sc_fin[ci] = fin[k];
-            const int nl = nlinks[k] == 255 ? LINK_SLOTS : nlinks[k];
-            for (int j = 0; j < nl; j++)
-                packed[k] |= (unsigned long long) (s_links[row][j] & 0xffff) << (16 * j);
-            if (nl > 0)
-                p.sc_links[ci] = packed[k];
+            bool rooted = false, overflow = false;
+            int oc = lc;
+            for (int sb = 0;; sb++)
+            {
+                live = live && sb <= needed;
+                if (!__any(live))
+                    break;
+                const float4 cr = inrow ? p.sc_rec[oc * R + row] : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int down = 0; down < 2; down++) // dir = -1 (rows above), then dir = +1 (cc.cpp:712-716)
+                {
+                    if (down == 1 && sb == 0)
+                        continue;
+                    bool run = live;
+                    for (int d = (down == 1 || sb == 0) ? 1 : 0; d <= c.max_steps_in_column; d++) // d = sv = |orow - row|
+                    {
+                        const int orow = down ? row + d : row - d;
+                        run = run && orow >= 0 && orow < R;
+                        if (!__any(run))
+                            break;
+                        const int src = orow & 63;
+                        const float ox = __shfl(cr.x, src), oy = __shfl(cr.y, src), oz = __shfl(cr.z, src), ow = __shfl(cr.w, src);
+                        if (run)
+                        {
+                            if (ccm::absf(ow - me.w) > mad)
+                                run = false;
+                            else
+                            {
+                                if (ox == ox) // x = NaN marks an ignored cell (k_seg_scan)
+                                {
+                                    const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
+                                    if (dx * dx + dy * dy + dz * dz < c.maxd2)
+                                    {
+                                        const unsigned long long cand = (unsigned long long) ((sb << 8) | orow);
+                                        if (!rooted)
+                                        {
+                                            parent[0] = (int) cand;
+                                            rooted = true;
+                                        }
+                                        else if (nlinks[0] < LINK_SLOTS)
+                                        {
+                                            packed[0] |= cand << (16 * nlinks[0]);
+                                            nlinks[0]++;
+                                        }
+                                        else
+                                            overflow = true;
+                                    }
+                                }
+                                if (rooted && c.stop_enabled && d >= c.stop_min_steps)
+                                    run = false;
+                            }
+                        }
+                    }
+                }
+                if (rooted && c.stop_enabled && sb >= c.stop_min_steps)
+                    live = false;
+                if (oc == bound)
+                    break;
+                oc = oc == 0 ? RC - 1 : oc - 1;
+            }
+            if (overflow)
+                nlinks[0] = 255;
+            if (inrow)
+            {
+                p.sc_parent[ci] = (int16_t) parent[0];
+                p.sc_nlinks[ci] = (uint8_t) nlinks[0];
+                p.sc_fin[ci] = fin[0];
+                if (nlinks[0] > 0)
+                    p.sc_links[ci] = packed[0];
+            }
+        }
+        else
+        {
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                parent[k] = -2;
+                nlinks[k] = 0;
+                fin[k] = 0.;
+                packed[k] = 0;
+                if (row >= R)
+                    continue;
+                const int ci = lc * R + row;
+                if (!p.ignored[ci])
+                {
+                    parent[k] = -1;
+                    const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                    const double caz = p.caz[ci];
+                    fin[k] = caz + (double) mad;
+                    bool overflow = false;
+                    int dummy_root = -1;
+                    scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent[k], s_links[row], nlinks[k], overflow, LINK_SLOTS);
+                    if (overflow)
+                        nlinks[k] = 255;
+                }
+                p.sc_parent[ci] = (int16_t) parent[k];
+                p.sc_nlinks[ci] = (uint8_t) nlinks[k];
+                p.sc_fin[ci] = fin[k];
+                const int nl = nlinks[k] == 255 ? LINK_SLOTS : nlinks[k];
+                for (int j = 0; j < nl; j++)
+                    packed[k] |= (unsigned long long) (s_links[row][j] & 0xffff) << (16 * j);
+                if (nl > 0)
+                    p.sc_links[ci] = packed[k];
+            }
         }
         // ---- column epilogue: everything about the column that does not depend on the tree state, so that the serial association
         // kernel finds it precomputed. (1) where every point's chain of same-column parents ends; (2) the column summary.
@@ -3278,9 +3383,11 @@ __global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const Stre
         return;
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    for (long long pc = st->batch[slot].pub_begin + blockIdx.x; pc < st->batch[slot].pub_end; pc += gridDim.x)
+    int plc = (int) ((st->batch[slot].pub_begin + blockIdx.x) % RC);
+    const int plc_step = (int) (gridDim.x % (unsigned) RC);
+    for (long long pc = st->batch[slot].pub_begin + blockIdx.x; pc < st->batch[slot].pub_end;
+         pc += gridDim.x, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
     {
-        const int plc = (int) (pc % RC);
         for (int row = lane_id(); row < R; row += 64)
         {
             const int ci = plc * R + row;
