@@ -2313,36 +2313,20 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                             break;
                         const int src = orow & 63;
                         const float ox = __shfl(cr.x, src), oy = __shfl(cr.y, src), oz = __shfl(cr.z, src), ow = __shfl(cr.w, src);
-                        if (run)
-                        {
-                            if (ccm::absf(ow - me.w) > mad)
-                                run = false;
-                            else
-                            {
-                                if (ox == ox) // x = NaN marks an ignored cell (k_seg_scan)
-                                {
-                                    const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
-                                    if (dx * dx + dy * dy + dz * dz < c.maxd2)
-                                    {
-                                        const unsigned long long cand = (unsigned long long) ((sb << 8) | orow);
-                                        if (!rooted)
-                                        {
-                                            parent[0] = (int) cand;
-                                            rooted = true;
-                                        }
-                                        else if (nlinks[0] < LINK_SLOTS)
-                                        {
-                                            packed[0] |= cand << (16 * nlinks[0]);
-                                            nlinks[0]++;
-                                        }
-                                        else
-                                            overflow = true;
-                                    }
-                                }
-                                if (rooted && c.stop_enabled && d >= c.stop_min_steps)
-                                    run = false;
-                            }
-                        }
+                        // branch-free (nested divergent ifs cost a dozen exec-mask instructions per level and visit):
+                        // cc.cpp:721 inclination window, :729 ignored cell, :738 distance, :745-757 parent / link, :759 early stop
+                        const bool cont = run && !(ccm::absf(ow - me.w) > mad);
+                        const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
+                        const bool acc = cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2; // x = NaN: ignored cell
+                        const unsigned long long cand = (unsigned long long) ((sb << 8) | (orow & 0xff));
+                        const bool as_parent = acc && !rooted;
+                        const bool as_link = acc && rooted && nlinks[0] < LINK_SLOTS;
+                        overflow = overflow || (acc && rooted && nlinks[0] >= LINK_SLOTS);
+                        parent[0] = as_parent ? (int) cand : parent[0];
+                        packed[0] |= as_link ? cand << (16 * nlinks[0]) : 0ull;
+                        nlinks[0] += as_link ? 1 : 0;
+                        rooted = rooted || acc;
+                        run = cont && !(rooted && c.stop_enabled && d >= c.stop_min_steps);
                     }
                 }
                 if (rooted && c.stop_enabled && sb >= c.stop_min_steps)
