@@ -2450,12 +2450,8 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
             if (row < R)
                 p.sc_term[lc * R + row] = (int16_t) term;
         }
-        for (int o = 32; o > 0; o >>= 1)
-        {
-            const int md = __shfl_xor(max_delta, o), fl = __shfl_xor(flags, o);
-            max_delta = md > max_delta ? md : max_delta;
-            flags |= fl;
-        }
+        max_delta = -wave_min_i32(-max_delta); // DPP reductions, ballots: no LDS round trips
+        flags = (__any(flags & 1) ? 1 : 0) | (__any(flags & 2) ? 2 : 0);
         newfin = wave_min_f64(newfin);
         if (lane == 0)
         {
