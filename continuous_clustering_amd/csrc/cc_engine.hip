@@ -311,7 +311,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     const int rpl = (g.num_rows + WAVE - 1) / WAVE;
     // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
     const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
-    dim3 seg_grid((unsigned) ((max_cols + 63) / 64), (unsigned) count);
+    // grids are (streams, blocks): the stream index is the fast dimension so that one stream's blocks share an XCD (and its L2)
+    dim3 seg_grid((unsigned) count, (unsigned) ((max_cols + 63) / 64));
     constexpr int NEV = 10;
     hipEvent_t ev[NEV] = {};
     if (e->timing)
@@ -362,10 +363,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     else
         hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
+        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0);
     else
-        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3(cck::SEGPRE_BLOCKS, (unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
+        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0);
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
@@ -377,7 +378,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         CC_HIP_CHECK(e, hipStreamWaitEvent(sc, e->ev_segscan[slot], 0));
     }
     CC_MARK(sc); // ev4: table + segment (start of the window scan)
-    const dim3 scan_grid(cck::SCAN_BLOCKS, (unsigned) count);
+    const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
@@ -409,7 +410,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     else
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     CC_MARK(sa); // ev8: assoc_global
-    hipLaunchKernelGGL(cck::k_publish, dim3(cck::PUBLISH_BLOCKS, (unsigned) count), dim3(64), 0, sa, g, e->P, e->d_states, first_stream,
+    hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, sa, g, e->P, e->d_states, first_stream,
                        slot);
     CC_MARK(sa); // ev9: publish
 #undef CC_MARK

@@ -1142,7 +1142,7 @@ template<int RPL>
 __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
                                                 const double* __restrict__ poses, long long n_total, long long fbase)
 {
-    const int sl = blockIdx.y;
+    const int sl = blockIdx.x;
     const int s = first_stream + sl;
     StreamState* st = &states[s];
     const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
@@ -1150,7 +1150,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         return;
     if (!st->has_robot_tf)
     {
-        if (blockIdx.x == 0 && lane_id() == 0)
+        if (blockIdx.y == 0 && lane_id() == 0)
             raise_error(st, CC_ERR_NO_ROBOT_TRANSFORM, seg_begin, 0);
         return;
     }
@@ -1164,9 +1164,9 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     (void) height_sensor_to_ground;
 
     // (ring column advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
-    int lc = (int) ((seg_begin + blockIdx.x) % RC);
-    const int lc_step = (int) (gridDim.x % (unsigned) RC);
-    for (long long gc = seg_begin + blockIdx.x; gc < seg_end; gc += gridDim.x, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
+    int lc = (int) ((seg_begin + blockIdx.y) % RC);
+    const int lc_step = (int) (gridDim.y % (unsigned) RC);
+    for (long long gc = seg_begin + blockIdx.y; gc < seg_end; gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
     {
         const size_t base = (size_t) lc * R;
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
@@ -1353,12 +1353,12 @@ enum
 
 __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
-    const int s = first_stream + blockIdx.y;
+    const int s = first_stream + blockIdx.x;
     StreamState* st = &states[s];
     const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || st->error != 0)
         return;
-    const long long tile0 = seg_begin + (long long) blockIdx.x * 64;
+    const long long tile0 = seg_begin + (long long) blockIdx.y * 64;
     if (tile0 >= seg_end)
         return;
     const int ncols = (int) (seg_end - tile0 < 64 ? seg_end - tile0 : 64);
@@ -2227,14 +2227,16 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
 // function of static per-cell data (SURVEY.md 8a "derived fact"): first accepted candidate = parent, later accepted
 // candidates = links, early stops as if the first match roots the point. Massively parallel; the serial kernel below
 // validates the assumption per column (no refused attach, nothing used from columns the live scan would not reach).
-// grid = (SCAN_BLOCKS, streams), block = 64, blocks stride over the columns of the batch.
+// grid = (streams, SCAN_BLOCKS), block = 64, blocks stride over the columns of the batch. The stream index is the fast grid
+// dimension: workgroups are dealt to the 8 XCDs round-robin by linear id, so with a multiple of 8 streams all blocks of one stream
+// run on one XCD and share its L2 (every candidate column is read by the scans of several later columns).
 // =====================================================================================================
 constexpr int SCAN_BLOCKS = 128;
 
 template<int RPL>
 __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
-    const int s = first_stream + blockIdx.y;
+    const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const StreamState* st = &states[s];
     if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0)
@@ -2255,10 +2257,10 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
     const long long col_end = st->batch[slot].seg_end, first_column = st->first_column;
     // (ring columns advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
     const int first_lc = (int) (first_column % RC);
-    int lc = (int) ((st->batch[slot].acp_next + blockIdx.x) % RC);
-    const int lc_step = (int) (gridDim.x % (unsigned) RC);
-    for (long long gc = st->batch[slot].acp_next + blockIdx.x; gc < col_end;
-         gc += gridDim.x, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
+    int lc = (int) ((st->batch[slot].acp_next + blockIdx.y) % RC);
+    const int lc_step = (int) (gridDim.y % (unsigned) RC);
+    for (long long gc = st->batch[slot].acp_next + blockIdx.y; gc < col_end;
+         gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
     {
         // never look at columns older than the first column ever segmented (their planes are uninitialised)
         const int bound = (gc - first_column) <= (long long) cfg.max_steps_in_row + 1 ? first_lc : -1;
@@ -3357,16 +3359,16 @@ constexpr int PUBLISH_BLOCKS = 64;
 
 __global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot)
 {
-    const int s = first_stream + blockIdx.y;
+    const int s = first_stream + blockIdx.x;
     const StreamState* st = &states[s];
     if (st->batch[slot].pub_begin < 0)
         return;
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    int plc = (int) ((st->batch[slot].pub_begin + blockIdx.x) % RC);
-    const int plc_step = (int) (gridDim.x % (unsigned) RC);
-    for (long long pc = st->batch[slot].pub_begin + blockIdx.x; pc < st->batch[slot].pub_end;
-         pc += gridDim.x, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
+    int plc = (int) ((st->batch[slot].pub_begin + blockIdx.y) % RC);
+    const int plc_step = (int) (gridDim.y % (unsigned) RC);
+    for (long long pc = st->batch[slot].pub_begin + blockIdx.y; pc < st->batch[slot].pub_end;
+         pc += gridDim.y, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
     {
         for (int row = lane_id(); row < R; row += 64)
         {
