@@ -1571,12 +1571,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 p.ground[ci] = SEG_GROUND_VALUE[o & 7];
                 p.debug[ci] = SEG_DEBUG_VALUE[(o >> 3) & 15];
                 // cc.cpp:567-616: everything that is not an obstacle is ignored, and so are the filtered obstacles
-                const bool ign = (o & 7) != SG_G_OBSTACLE || (o & 0x80);
-                p.ignored[ci] = ign ? 1 : 0;
-                // the window scan reads one 16-byte record per visited cell: an ignored cell is marked there (x = NaN; its
-                // inclination stays), so that the scan needs no second load per visit
-                if (ign)
-                    ((float*) &p.sc_rec[ci])[0] = __builtin_nanf("");
+                p.ignored[ci] = ((o & 7) != SG_G_OBSTACLE || (o & 0x80)) ? 1 : 0;
             }
             lc = lc + 1 == RC ? 0 : lc + 1;
         }
@@ -1688,8 +1683,8 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                 unsigned char oign = 0;
                 if (REC)
                 {
-                    orec = p.sc_rec[oi]; // x = NaN marks an ignored cell (k_seg_scan): one load per visit
-                    oign = orec.x != orec.x;
+                    orec = p.sc_rec[oi]; // both loads are issued before the first use: one round trip per visit
+                    oign = p.ignored[oi];
                 }
                 const float oincl = REC ? orec.w : p.incl[oi];
                 if (ccm::absf(oincl - pincl) > mad)
@@ -2301,7 +2296,13 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 live = live && sb <= needed;
                 if (!__any(live))
                     break;
-                const float4 cr = inrow ? p.sc_rec[oc * R + row] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (inrow)
+                {
+                    cr = p.sc_rec[oc * R + row];
+                    if (p.ignored[oc * R + row])
+                        cr.x = __builtin_nanf(""); // in registers only: an ignored cell travels through the cross-lane reads as x = NaN
+                }
                 for (int down = 0; down < 2; down++) // dir = -1 (rows above), then dir = +1 (cc.cpp:712-716)
                 {
                     if (down == 1 && sb == 0)
@@ -2319,7 +2320,7 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                         // cc.cpp:721 inclination window, :729 ignored cell, :738 distance, :745-757 parent / link, :759 early stop
                         const bool cont = run && !(ccm::absf(ow - me.w) > mad);
                         const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
-                        const bool acc = cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2; // x = NaN: ignored cell
+                        const bool acc = cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2; // x = NaN: ignored (or empty) cell
                         const unsigned long long cand = (unsigned long long) ((sb << 8) | (orow & 0xff));
                         const bool as_parent = acc && !rooted;
                         const bool as_link = acc && rooted && nlinks[0] < LINK_SLOTS;
