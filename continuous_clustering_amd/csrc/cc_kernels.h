@@ -2289,12 +2289,14 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
                 needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
             }
-            bool rooted = false, overflow = false;
+            // per-lane state as 0/1 integers in VGPRs: booleans carried through the loops as lane masks cost three scalar
+            // instructions per variable at every loop exit
+            int rooted = 0, overflow = 0, live_i = live ? 1 : 0;
             int oc = lc;
             for (int sb = 0;; sb++)
             {
-                live = live && sb <= needed;
-                if (!__any(live))
+                live_i = (live_i && sb <= needed) ? 1 : 0;
+                if (!__any(live_i != 0))
                     break;
                 float4 cr = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (inrow)
@@ -2307,33 +2309,33 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 {
                     if (down == 1 && sb == 0)
                         continue;
-                    bool run = live;
-                    for (int d = (down == 1 || sb == 0) ? 1 : 0; d <= c.max_steps_in_column; d++) // d = sv = |orow - row|
+                    int d = (down == 1 || sb == 0) ? 1 : 0; // d = sv = |orow - row|
+                    int orow = down ? row + d : row - d;
+                    int run = (live_i && orow >= 0 && orow < R && d <= c.max_steps_in_column) ? 1 : 0;
+                    while (__any(run != 0))
                     {
-                        const int orow = down ? row + d : row - d;
-                        run = run && orow >= 0 && orow < R;
-                        if (!__any(run))
-                            break;
                         const int src = orow & 63;
                         const float ox = __shfl(cr.x, src), oy = __shfl(cr.y, src), oz = __shfl(cr.z, src), ow = __shfl(cr.w, src);
-                        // branch-free (nested divergent ifs cost a dozen exec-mask instructions per level and visit):
-                        // cc.cpp:721 inclination window, :729 ignored cell, :738 distance, :745-757 parent / link, :759 early stop
-                        const bool cont = run && !(ccm::absf(ow - me.w) > mad);
+                        // branch-free: cc.cpp:721 inclination window, :729 ignored cell, :738 distance, :745-757 parent / link,
+                        // :759 early stop
+                        const int cont = (run && !(ccm::absf(ow - me.w) > mad)) ? 1 : 0;
                         const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
-                        const bool acc = cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2; // x = NaN: ignored (or empty) cell
+                        const int acc = (cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2) ? 1 : 0; // x = NaN: ignored / empty
                         const unsigned long long cand = (unsigned long long) ((sb << 8) | (orow & 0xff));
-                        const bool as_parent = acc && !rooted;
-                        const bool as_link = acc && rooted && nlinks[0] < LINK_SLOTS;
-                        overflow = overflow || (acc && rooted && nlinks[0] >= LINK_SLOTS);
-                        parent[0] = as_parent ? (int) cand : parent[0];
+                        const int as_link = (acc && rooted && nlinks[0] < LINK_SLOTS) ? 1 : 0;
+                        overflow |= (acc && rooted && nlinks[0] >= LINK_SLOTS) ? 1 : 0;
+                        parent[0] = (acc && !rooted) ? (int) cand : parent[0];
                         packed[0] |= as_link ? cand << (16 * nlinks[0]) : 0ull;
-                        nlinks[0] += as_link ? 1 : 0;
-                        rooted = rooted || acc;
-                        run = cont && !(rooted && c.stop_enabled && d >= c.stop_min_steps);
+                        nlinks[0] += as_link;
+                        rooted |= acc;
+                        const int stop = (rooted && c.stop_enabled && d >= c.stop_min_steps) ? 1 : 0;
+                        d++;
+                        orow = down ? orow + 1 : orow - 1;
+                        run = (cont && !stop && orow >= 0 && orow < R && d <= c.max_steps_in_column) ? 1 : 0;
                     }
                 }
                 if (rooted && c.stop_enabled && sb >= c.stop_min_steps)
-                    live = false;
+                    live_i = 0;
                 if (oc == bound)
                     break;
                 oc = oc == 0 ? RC - 1 : oc - 1;
