@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         }
         // NaN cells: inclination of the cell below (already supplemented) + the per-row step (cc.cpp:364-369); runs of NaN
         // cells resolve bottom-up, one row per iteration
-        __syncthreads();
+        wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
         while (true)
         {
             bool pending = false;
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                         pending = true;
                 }
             }
-            __syncthreads();
+            wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
@@ -1255,7 +1255,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                     incl[k] = nv[k];
                 }
             }
-            __syncthreads();
+            wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
             if (!__any(pending))
                 break;
         }
