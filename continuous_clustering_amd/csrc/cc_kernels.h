@@ -604,7 +604,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     v[k] = cirv[k] != PP_SKIP;
                     const unsigned long long m = __ballot(v[k]);
                     if (mv == 0 && m != 0)
-                        c0 = uniform_i32(__shfl(cirv[k], __ffsll((long long) m) - 1));
+                        c0 = __builtin_amdgcn_readlane(cirv[k], (int) __ffsll((long long) m) - 1); // v_readlane: no LDS round trip
                     mv |= m;
                 }
                 if (mv == 0)
