@@ -19,6 +19,7 @@
 constexpr int WIN2_COLS = 64;      // ring of per-cell tree ids: WIN_COLS of look-back + the lead of wave A
 constexpr int A2_LEAD = 24;        // columns wave A may run ahead of wave B (WIN_COLS + A2_LEAD + 1 <= WIN2_COLS)
 constexpr int A2_INFO = 32;        // per-column hand-off records (power of two > A2_LEAD)
+constexpr int A2_STAGE = 32;       // columns of staged per-point data wave A keeps ahead for wave B (power of two >= A2_LEAD + 8)
 constexpr int A2_FRESH = 0x4000;   // s_win entry flag: the point's tree starts in this very column
 constexpr int A2_IDMASK = 0x3fff;
 constexpr int A2_SPIN_LIMIT = 1 << 20; // ~30 ms of polling: a broken hand-shake raises an error instead of hanging
@@ -272,12 +273,11 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
 
     __shared__ LdsTrees2 T;
     __shared__ short s_win[WIN2_COLS * WAVE * RPL];
-    // wave B's current group of columns, staged so that its per-column loops are real loops (small code: the instruction cache
-    // is shared and a fully unrolled group body does not fit)
-    __shared__ double st_fin[G * WAVE * RPL];
-    __shared__ unsigned long long st_link[G * WAVE * RPL];
-    __shared__ short st_parent[G * WAVE * RPL];
-    __shared__ unsigned char st_nl[G * WAVE * RPL];
+    // per-point inputs of the columns between the two waves (parent code, finished_at), staged by wave A, which has the time: wave B
+    // then issues no per-point global load at all, and its per-column loops are real loops over LDS (small code: the instruction
+    // cache is shared and a fully unrolled group body does not fit)
+    __shared__ double st_fin[A2_STAGE * WAVE * RPL];
+    __shared__ short st_parent[A2_STAGE * WAVE * RPL];
 
     const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
     const int n_unf0 = st->n_unfinished;
@@ -386,8 +386,9 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
         long long gcA = col_begin;
         int lc = (int) (col_begin % RC);
         long long b_seen = col_begin;
-        int nx_term[RPL], nx_info = 0, nx_nl[RPL];
+        int nx_term[RPL], nx_info = 0, nx_nl[RPL], nx_par[RPL];
         unsigned long long nx_link[RPL];
+        double nx_fin[RPL];
         auto load_a = [&](long long gcx, int lcx)
         {
 #pragma unroll
@@ -397,8 +398,12 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 nx_term[k] = -1;
                 nx_nl[k] = 0;
                 nx_link[k] = 0;
+                nx_par[k] = -2;
+                nx_fin[k] = 0.;
                 if (row < R && gcx < col_end)
                 {
+                    nx_par[k] = p.sc_parent[lcx * R + row];
+                    nx_fin[k] = p.sc_fin[lcx * R + row];
                     nx_term[k] = p.sc_term[lcx * R + row];
                     nx_nl[k] = p.sc_nlinks[lcx * R + row];
                     nx_link[k] = p.sc_links[lcx * R + row]; // (stale where the point has no links: never looked at)
@@ -458,6 +463,13 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 term[k] = nx_term[k];
                 nlk[k] = nx_nl[k];
                 lk[k] = nx_link[k];
+                const int row = k * 64 + lane;
+                if (row < R) // stage what wave B needs of this column
+                {
+                    const int o = (int) (gcA & (A2_STAGE - 1)) * R + row;
+                    st_parent[o] = (short) nx_par[k];
+                    st_fin[o] = nx_fin[k];
+                }
             }
             const int cnt_new = uniform_i32(nx_info) & 0xff;
             const bool col_links = (uniform_i32(nx_info) >> 8) & 2;
@@ -581,37 +593,11 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
         n_events++;
     };
 
-    // next group, prefetched into registers: per column and row what k_scan left, per column (lane u) the column summary
-    int q_parent[G][RPL], q_nl[G][RPL];
-    double q_fin[G][RPL];
-    unsigned long long q_link[G][RPL];
+    // next group's column summaries (lane u holds column u's), prefetched one group ahead
     double q_minaz = 0., q_newfin = 0.;
     int q_info = 0;
     auto load_group = [&](long long g0, int lcg) // lcg = g0 % RC
     {
-        int lcx = lcg;
-#pragma unroll
-        for (int u = 0; u < G; u++)
-        {
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                q_parent[u][k] = -2;
-                q_nl[u][k] = 0;
-                q_fin[u][k] = 0.;
-                q_link[u][k] = 0;
-                if (row < R && g0 + u < col_end)
-                {
-                    const int ci = lcx * R + row;
-                    q_parent[u][k] = p.sc_parent[ci];
-                    q_nl[u][k] = p.sc_nlinks[ci];
-                    q_fin[u][k] = p.sc_fin[ci];
-                    q_link[u][k] = p.sc_links[ci]; // (stale where the point has no links: never looked at)
-                }
-            }
-            lcx = lcx + 1 == RC ? 0 : lcx + 1;
-        }
         if (lane < G && g0 + lane < col_end)
         {
             int lcl = lcg + lane;
@@ -852,21 +838,6 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
     while (gc < col_end && err == 0 && !to_global)
     {
         const int gcount = (int) (col_end - gc < G ? col_end - gc : G);
-#pragma unroll
-        for (int u = 0; u < G; u++)
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int o = u * R + k * 64 + lane;
-                if (k * 64 + lane < R)
-                {
-                    st_parent[o] = (short) q_parent[u][k];
-                    st_nl[o] = (unsigned char) q_nl[u][k];
-                    st_fin[o] = q_fin[u][k];
-                    st_link[o] = q_link[u][k];
-                }
-            }
-        wave_lds_fence();
         const double v_minaz = q_minaz, v_newfin = q_newfin;
         const int v_info = q_info;
         {
@@ -920,7 +891,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                         const int row = k * 64 + lane;
                         if (row < R)
                         {
-                            const int par = st_parent[u * R + row];
+                            const int par = st_parent[(int) ((gc + u) & (A2_STAGE - 1)) * R + row];
                             const int e = wc[row];
                             if (par == -1 && e >= 0)
                                 T.alive[e & A2_IDMASK] = 1;
@@ -1104,8 +1075,8 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                         fc[k] = 0.;
                         if (row < R)
                         {
-                            par[k] = st_parent[u * R + row];
-                            fc[k] = st_fin[u * R + row];
+                            par[k] = st_parent[(int) (gcu & (A2_STAGE - 1)) * R + row];
+                            fc[k] = st_fin[(int) (gcu & (A2_STAGE - 1)) * R + row];
                             e[k] = s_win[wcu * R + row];
                         }
                     }
@@ -1166,11 +1137,11 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                         for (int k = 0; k < RPL; k++)
                         {
                             const int row = k * 64 + lane;
-                            const int nlk = (par[k] >= 0 && row < R) ? (int) st_nl[u * R + row] : 0;
+                            const int nlk = (par[k] >= 0 && row < R) ? (int) p.sc_nlinks[lcu * R + row] : 0; // (rare path: straight from HBM)
                             if (nlk > 0)
                             {
                                 const int i = e[k] & A2_IDMASK;
-                                const unsigned long long lk = st_link[u * R + row];
+                                const unsigned long long lk = p.sc_links[lcu * R + row];
                                 for (int j = 0; j < nlk; j++) // (rare path since wave A filters the columns: small, not fast)
                                 {
                                     const int code = (int) ((lk >> (16 * j)) & 0xffff);
