@@ -102,3 +102,36 @@ def test_full_size_properties_256_streams():
             util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo)
     g_ptr, id_ptr = e.output_planes(0)
     assert g_ptr and id_ptr
+
+
+@pytest.mark.parametrize("pipeline,sub_batch", [(1, 0), (2, 0), (1, 300), (0, 0)])
+def test_pipelined_throughput_path_matches_oracle(pipeline, sub_batch, oracle_lib):
+    """The bench configuration of the engine (events off: consecutive batches overlap on three or four chains of HIP streams,
+    the per-point preparation of the next batch runs ahead, a call may be cut into sub-batches) must leave every stream in the
+    oracle's state and with the oracle's published columns."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    sen = synth.SensorModel(num_rows=64, num_columns=720)
+    cfg = capi.Config.kitti()
+    cfg.num_columns = 720
+    S, F, NB = 8, 720, 5
+    motions = [synth.Motion.static(), synth.Motion.translate(), synth.Motion.turn()]
+    streams = [synth.make_stream(F * NB, seed=300 + s, sensor=sen, motion=motions[s % 3]) for s in range(S)]
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    e.set_option("pipeline", pipeline)
+    e.set_option("sub_batch", sub_batch)
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+    assert e.sync() == 0, e.last_error()
+    for s in range(S):
+        o = Oracle(cfg, 64)
+        assert o.add_firings(streams[s].xyz, streams[s].intensity, streams[s].poses) == 0
+        so, se = o.state(), e.state(s)
+        for k in util.STATE_FIELDS:
+            assert so[k] == se[k], (s, k)
+        hi = se["first_unpublished_global_column_index"] - 1
+        lo = max(hi - 600, se["ring_buffer_start_global_column_index"])
+        util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo)
