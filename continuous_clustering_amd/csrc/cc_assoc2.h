@@ -255,7 +255,8 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     StreamState* st = &states[s];
-    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0 || st->batch[slot].acp_next >= st->batch[slot].seg_end)
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0 || st->batch[slot].mode != 0 ||
+        st->batch[slot].acp_next >= st->batch[slot].seg_end)
         return;
     AssocCtx c;
     c.p = stream_ptrs(P, g, s);

@@ -60,8 +60,12 @@ struct StreamState
         int64_t acp_next;  // next column the association kernels process
         int64_t pub_begin; // columns [pub_begin, pub_end) were published while this batch was associated
         int64_t pub_end;
+        int64_t mode;      // assoc_mode as of the start of the batch's segmentation chain (k_table): decides whether k_scan stages the
+                           // batch for the LDS association kernels; the global-memory kernel takes the batch if either this or the
+                           // current assoc_mode is non-zero
     } batch[4];
-    int32_t assoc_mode; // 0: tree state in LDS (k_assoc_lds), 1: tree state in global memory (k_associate)
+    int32_t assoc_mode; // 0: tree state in LDS (k_assoc2 / k_assoc_lds), 1: tree state in global memory (k_associate); the global kernel
+                        // hands a stream back once its unfinished trees fit the LDS pool comfortably again
     int32_t pad1;
     int64_t cursor;     // firings of the current batch already consumed
     uint64_t firings_consumed;

@@ -224,7 +224,7 @@ int reset_state(cc_engine* e, bool keep_table)
         st.finish_lower_bound = std::numeric_limits<double>::max();
         st.last_round_min_az = -1.0; // Point::visited_at_continuous_azimuth_angle{-1.} cc.hpp:158
         for (auto& d : st.batch)
-            d.seg_begin = d.seg_end = d.acp_next = d.pub_begin = d.pub_end = -1;
+            d.seg_begin = d.seg_end = d.acp_next = d.pub_begin = d.pub_end = -1, d.mode = 0;
         st.assoc_mode = e->cfg.max_steps_in_row > WIN_COLS - 2 ? 1 : 0;
     }
     CC_HIP_CHECK(e, hipMemcpyAsync(e->d_states, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice, e->stream));

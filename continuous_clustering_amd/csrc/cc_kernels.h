@@ -1016,6 +1016,9 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     StreamState* st = &states[s];
+    if (threadIdx.x == 0)
+        st->batch[slot].mode = st->assoc_mode; // one decision per batch and stream for every kernel behind this one (any value the
+                                               // association chain of the previous batch is just writing is fine)
     const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || seg_begin >= seg_end)
         return;
@@ -1768,8 +1771,9 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     StreamState* st = &states[s];
-    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 1 || st->batch[slot].acp_next >= st->batch[slot].seg_end)
-        return;
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || (st->assoc_mode == 0 && st->batch[slot].mode == 0) ||
+        st->batch[slot].acp_next >= st->batch[slot].seg_end)
+        return; // (the LDS kernels take batches that were staged for them, unless the stream overflowed their tree pool meanwhile)
     AssocCtx c;
     c.p = stream_ptrs(P, g, s);
     const SP& p = c.p;
@@ -2205,6 +2209,10 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
         st->serial_columns = serial_cols;
         st->stamp_alias_rounds = alias_rounds;
         st->batch[slot].acp_next = col_end;
+        // back to the LDS kernels once the unfinished trees fit their pool comfortably again (never for window configurations
+        // they do not support)
+        if (err == 0)
+            st->assoc_mode = (cfg.max_steps_in_row > WIN_COLS - 2 || n_unf * 2 > g.lds_tree_limit) ? 1 : 0;
         st->n_events = n_events < g.event_capacity ? n_events : g.event_capacity;
         if (g.record_events && n_events > g.event_capacity && err == 0)
         {
@@ -2234,7 +2242,7 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const StreamState* st = &states[s];
-    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0)
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->batch[slot].mode != 0)
         return;
     AssocCtx c;
     c.p = stream_ptrs(P, g, s);
@@ -2667,7 +2675,8 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     StreamState* st = &states[s];
-    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0 || st->batch[slot].acp_next >= st->batch[slot].seg_end)
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0 || st->batch[slot].mode != 0 ||
+        st->batch[slot].acp_next >= st->batch[slot].seg_end)
         return;
     AssocCtx c;
     c.p = stream_ptrs(P, g, s);
