@@ -22,7 +22,7 @@ constexpr int A2_INFO = 32;        // per-column hand-off records (power of two 
 constexpr int A2_STAGE = 32;       // columns of staged per-point data wave A keeps ahead for wave B (power of two >= A2_LEAD + 8)
 constexpr int A2_FRESH = 0x4000;   // s_win entry flag: the point's tree starts in this very column
 constexpr int A2_IDMASK = 0x3fff;
-constexpr int A2_SPIN_LIMIT = 1 << 20; // ~30 ms of polling: a broken hand-shake raises an error instead of hanging
+constexpr int A2_SPIN_LIMIT = 1 << 23; // ~0.25 s of polling: a broken hand-shake raises an error instead of hanging
 enum
 {
     A2_RUN = 0,
