@@ -828,11 +828,24 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                 const int so = slot * R + row;
                 const float d = r_d[so];
                 const bool res = gc >= wbase && gc + 1 < wbase + WINC; // both candidate columns resident in LDS
-                float cd = res ? w_dist[(int) (gc & (WINC - 1)) * R + row] : p.dist[(size_t) lc * R + row];
+                // (two separate loads, not a select between an LDS and a global address: that becomes a flat load, whose wait
+                // drains every outstanding global store of the wave)
+                // (the LDS read is unconditional and the global one an exception, so that the two are never merged into one flat
+                // load)
+                float cd = lds_ld(&w_dist[res ? (int) (gc & (WINC - 1)) * R + row : row]);
+                if (__any(!res)) // (uniform test first: the exception stays a branch)
+                {
+                    if (!res)
+                        cd = ld_agent(&p.dist[(size_t) lc * R + row]);
+                }
                 if (!(cd != cd) && !(d != d)) // cell occupied: try the next column (cc.cpp:188-202)
                 {
-                    const float nd = res ? w_dist[(int) ((gc + 1) & (WINC - 1)) * R + row]
-                                         : p.dist[(size_t) (lc + 1 >= RC ? 0 : lc + 1) * R + row];
+                    float nd = lds_ld(&w_dist[res ? (int) ((gc + 1) & (WINC - 1)) * R + row : row]);
+                    if (__any(!res))
+                    {
+                        if (!res)
+                            nd = ld_agent(&p.dist[(size_t) (lc + 1 >= RC ? 0 : lc + 1) * R + row]);
+                    }
                     if (nd != nd)
                     {
                         gc++;
