@@ -17,9 +17,18 @@
 #pragma once
 
 constexpr int WIN2_COLS = 64;      // ring of per-cell tree ids: WIN_COLS of look-back + the lead of wave A
-constexpr int A2_LEAD = 24;        // columns wave A may run ahead of wave B (WIN_COLS + A2_LEAD + 1 <= WIN2_COLS)
-constexpr int A2_INFO = 32;        // per-column hand-off records (power of two > A2_LEAD)
-constexpr int A2_STAGE = 32;       // columns of staged per-point data wave A keeps ahead for wave B (power of two >= A2_LEAD + 8)
+// columns wave A may run ahead of wave B (WIN_COLS + lead + 1 <= WIN2_COLS); two rows per lane: half the lead, half the staging
+// (the block has to share the CU's LDS with the 96 KB of k_insert2<2>)
+constexpr int a2_lead(int rpl)
+{
+    return rpl == 1 ? 24 : 12;
+}
+constexpr int A2_INFO = 32;        // per-column hand-off records (power of two > lead)
+// columns of staged per-point data wave A keeps ahead for wave B (power of two >= lead + group size)
+constexpr int a2_stage(int rpl)
+{
+    return rpl == 1 ? 32 : 16;
+}
 constexpr int A2_FRESH = 0x4000;   // s_win entry flag: the point's tree starts in this very column
 constexpr int A2_IDMASK = 0x3fff;
 constexpr int A2_SPIN_LIMIT = 1 << 23; // ~0.25 s of polling: a broken hand-shake raises an error instead of hanging
@@ -251,6 +260,8 @@ template<int RPL>
 __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     constexpr int G = RPL == 1 ? 8 : 4; // columns wave B handles per pass
+    constexpr int A2_LEAD = a2_lead(RPL), A2_STAGE = a2_stage(RPL);
+    static_assert(WIN_COLS + A2_LEAD + 1 <= WIN2_COLS && A2_LEAD + G <= A2_STAGE && A2_LEAD < A2_INFO, "ring sizes");
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
