@@ -1584,8 +1584,19 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             {
                 const size_t ci = (size_t) lc * R + row;
                 const unsigned char o = l_out[c * PB + row];
-                p.ground[ci] = SEG_GROUND_VALUE[o & 7];
-                p.debug[ci] = SEG_DEBUG_VALUE[(o >> 3) & 15];
+                // label codes -> the reference's label values by shifts of packed constants (a table in memory would cost two more
+                // loads per cell)
+                constexpr unsigned long long GV = (unsigned long long) CC_GP_UNKNOWN | ((unsigned long long) CC_GP_GROUND << 8) |
+                                                  ((unsigned long long) CC_GP_OBSTACLE << 16) | ((unsigned long long) CC_GP_EGO_VEHICLE << 24) |
+                                                  ((unsigned long long) CC_GP_FOG << 32);
+                constexpr unsigned long long DV0 = (unsigned long long) CC_DBG_WHITE | ((unsigned long long) CC_DBG_GRAY << 8) |
+                                                   ((unsigned long long) CC_DBG_ORANGE << 16) | ((unsigned long long) CC_DBG_GREEN << 24) |
+                                                   ((unsigned long long) CC_DBG_YELLOWGREEN << 32) | ((unsigned long long) CC_DBG_YELLOW << 40) |
+                                                   ((unsigned long long) CC_DBG_RED << 48) | ((unsigned long long) CC_DBG_DARKRED << 56);
+                constexpr unsigned DV1 = (unsigned) CC_DBG_VIOLET | ((unsigned) CC_DBG_LIGHTGRAY << 8);
+                const unsigned dcode = (o >> 3) & 15;
+                p.ground[ci] = (unsigned char) (GV >> (8 * (o & 7)));
+                p.debug[ci] = (unsigned char) (dcode < 8 ? (DV0 >> (8 * dcode)) : (unsigned long long) (DV1 >> (8 * (dcode - 8))));
                 // cc.cpp:567-616: everything that is not an obstacle is ignored, and so are the filtered obstacles
                 p.ignored[ci] = ((o & 7) != SG_G_OBSTACLE || (o & 0x80)) ? 1 : 0;
             }
