@@ -1357,9 +1357,6 @@ __host__ inline size_t seg_scan_lds_bytes(int R)
 }
 
 // compact codes of the label values inside the LDS tile
-__device__ __constant__ const unsigned char SEG_GROUND_VALUE[5] = {CC_GP_UNKNOWN, CC_GP_GROUND, CC_GP_OBSTACLE, CC_GP_EGO_VEHICLE, CC_GP_FOG};
-__device__ __constant__ const unsigned char SEG_DEBUG_VALUE[10] = {CC_DBG_WHITE, CC_DBG_GRAY,   CC_DBG_ORANGE, CC_DBG_GREEN,    CC_DBG_YELLOWGREEN,
-                                                                   CC_DBG_YELLOW, CC_DBG_RED, CC_DBG_DARKRED, CC_DBG_VIOLET, CC_DBG_LIGHTGRAY};
 enum
 {
     SG_G_UNKNOWN = 0, SG_G_GROUND = 1, SG_G_OBSTACLE = 2, SG_G_EGO = 3, SG_G_FOG = 4,
