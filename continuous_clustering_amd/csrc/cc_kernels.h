@@ -1275,6 +1275,31 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             if (!__any(pending))
                 break;
         }
+        // cc.cpp:597-603: atan2f(max_distance, distance) < inclination step to the next laser. The exact (glibc-identical) atan2f
+        // costs ~100 instructions per wave, and the test can only hold beyond ~100 m: a rigorous filter first. With
+        // x = max_distance / distance >= 1.01 t (0 <= t < 0.05): atan(x) >= x - x^3/3 >= 1.006 t for x <= 0.1, atan(x) > 0.099 > t
+        // otherwise, and atan2f is within an ulp of atan — so the test is false without evaluating it.
+        bool incl_ignore[RPL], need_exact = false;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            incl_ignore[k] = false;
+            if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1) && !isnan_[k])
+            {
+                const float t = tabv[k];
+                const bool surely_false = cfg.max_distance > 0.f && t >= 0.f && t < 0.05f && cfg.max_distance >= 1.01f * dist[k] * t;
+                incl_ignore[k] = !surely_false; // provisional: "needs the exact evaluation"
+                need_exact |= !surely_false;
+            }
+        }
+        if (__any(need_exact))
+        {
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+                if (incl_ignore[k])
+                    incl_ignore[k] = ccm::atan2f_exact(cfg.max_distance, dist[k]) < tabv[k];
+        }
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -1321,8 +1346,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                 x2 = len2(ux, uy);
                 if ((double) dist[k] < 1. * (double) cfg.max_distance)
                     flags |= SG_TOO_CLOSE;
-                if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1) &&
-                    ccm::atan2f_exact(cfg.max_distance, dist[k]) < tabv[k])
+                if (incl_ignore[k])
                     flags |= SG_INCL_IGNORE;
             }
             p.sg_x2[ci] = x2;

@@ -11,7 +11,7 @@ sys.argv = ['bench.py', '--steps', %r, '--warmup', '3', '--no-cpu-baseline', '--
 import bench
 bench.main()
 """ % (ROOT, steps)
-for rep in range(2):
+for rep in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
     for lib in sys.argv[1:3]:
         r = subprocess.run([sys.executable, "-c", code % lib], capture_output=True, text=True, cwd=ROOT)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
