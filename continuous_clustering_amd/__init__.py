@@ -87,6 +87,7 @@ def load_library():
     L.cc_engine_read_columns.argtypes = [vp, i32, i64, i64, C.POINTER(capi.ColumnView)]
     L.cc_engine_output_planes.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.cc_engine_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.cc_engine_gather_cluster_points.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
     L.cc_engine_enable_timing.argtypes = [vp, i32]
     L.cc_engine_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 7), C.POINTER(C.c_uint64)]
     L.cc_engine_totals.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
@@ -202,6 +203,23 @@ class Engine:
         v, arrays = capi.make_column_view(to - frm + 1, self.num_rows, fields)
         self._check(self.L.cc_engine_read_columns(self.h, stream, frm, to, C.byref(v)))
         return arrays
+
+    def gather_cluster_points(self, cluster_events: np.ndarray, stream: int = 0):
+        """Member points of finished clusters (CC_EV_CLUSTER events drained from this stream), gathered on the device:
+        returns (offsets[n + 1], global_column[total], row[total]); cluster i owns [offsets[i], offsets[i + 1])."""
+        ev = cluster_events[cluster_events["type"] == capi.EV_CLUSTER]
+        n = len(ev)
+        cid = np.ascontiguousarray(ev["c"], dtype=np.uint32)
+        a = np.ascontiguousarray(ev["a"], dtype=np.int64)
+        b = np.ascontiguousarray(ev["b"], dtype=np.int64)
+        cnt = np.ascontiguousarray(ev["d"], dtype=np.uint32)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        offsets[1:] = np.cumsum(cnt.astype(np.int64))
+        gcol = np.zeros(max(1, int(offsets[-1])), dtype=np.int64)
+        row = np.zeros(max(1, int(offsets[-1])), dtype=np.int32)
+        self._check(self.L.cc_engine_gather_cluster_points(self.h, stream, n, cid.ctypes.data, a.ctypes.data, b.ctypes.data,
+                                                           cnt.ctypes.data, gcol.ctypes.data, row.ctypes.data))
+        return offsets, gcol[: offsets[-1]], row[: offsets[-1]]
 
     def set_option(self, name: str, value: int):
         self._check(self.L.cc_engine_set_option(self.h, name.encode(), int(value)))

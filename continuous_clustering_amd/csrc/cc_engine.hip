@@ -1235,6 +1235,82 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     return CC_OK;
 }
 
+int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const uint32_t* cluster_ids, const int64_t* col_from,
+                                    const int64_t* col_to, const uint32_t* n_points, int64_t* h_gcol, int32_t* h_row)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || n < 0 || (n > 0 && (!cluster_ids || !col_from || !col_to || !n_points)))
+        return CC_ERR_INVALID_ARGUMENT;
+    if (n == 0)
+        return CC_OK;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    std::vector<long long> offs((size_t) n);
+    long long total = 0;
+    for (int64_t i = 0; i < n; i++)
+    {
+        offs[(size_t) i] = total;
+        total += n_points[i];
+    }
+    if (total > 0 && (!h_gcol || !h_row))
+        return CC_ERR_INVALID_ARGUMENT;
+    // one device block: descriptors (cid, n_points: u32; from, to, offset: i64), mismatch counter, outputs
+    const size_t desc = (size_t) n * (4 + 4 + 8 + 8 + 8) + 64, outb = (size_t) total * (8 + 4) + 64;
+    char* d = nullptr;
+    CC_HIP_CHECK(e, hipMalloc((void**) &d, desc + outb));
+    auto fail = [&](int code)
+    {
+        (void) hipFree(d);
+        return code;
+    };
+    cck::ClusterQuery q;
+    char* b = d;
+    q.col_from = (const long long*) b;
+    b += (size_t) n * 8;
+    q.col_to = (const long long*) b;
+    b += (size_t) n * 8;
+    q.offset = (const long long*) b;
+    b += (size_t) n * 8;
+    q.cid = (const unsigned*) b;
+    b += (size_t) n * 4;
+    q.n_points = (const unsigned*) b;
+    b += (size_t) n * 4;
+    b = d + ((b - d + 63) / 64) * 64;
+    q.mismatch = (int*) b;
+    b += 64;
+    q.out_gcol = (long long*) b;
+    b += (size_t) total * 8;
+    q.out_row = (int*) b;
+    if (hipMemcpyAsync((void*) q.col_from, col_from, (size_t) n * 8, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync((void*) q.col_to, col_to, (size_t) n * 8, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync((void*) q.offset, offs.data(), (size_t) n * 8, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync((void*) q.cid, cluster_ids, (size_t) n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemcpyAsync((void*) q.n_points, n_points, (size_t) n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
+        hipMemsetAsync(q.mismatch, 0, 64, e->stream) != hipSuccess)
+    {
+        e->error = "cc_engine_gather_cluster_points: copy failed";
+        return fail(CC_ERR_HIP);
+    }
+    hipLaunchKernelGGL(cck::k_gather_clusters, dim3((unsigned) n), dim3(64), 0, e->stream, e->g, e->P, e->d_states, stream, q);
+    int mismatch = 0;
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&mismatch, q.mismatch, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        (total > 0 && (hipMemcpyAsync(h_gcol, q.out_gcol, (size_t) total * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+                       hipMemcpyAsync(h_row, q.out_row, (size_t) total * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess)) ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+    {
+        e->error = "cc_engine_gather_cluster_points: launch / copy failed";
+        return fail(CC_ERR_HIP);
+    }
+    (void) hipFree(d);
+    if (mismatch != 0)
+    {
+        e->error = "cc_engine_gather_cluster_points: " + std::to_string(mismatch) + " cluster descriptor(s) do not match the engine state";
+        return CC_ERR_INVALID_ARGUMENT;
+    }
+    return CC_OK;
+}
+
 int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_label, const uint32_t** d_cluster_id)
 {
     if (!e || stream < 0 || stream >= e->g.num_streams)

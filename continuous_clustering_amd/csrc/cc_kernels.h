@@ -3437,6 +3437,67 @@ __global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const Stre
 }
 
 // =====================================================================================================
+// k_gather_clusters — member points of finished clusters, compacted on the device (the point gathering of
+// collectPointsForCusterAndPublish, cc.cpp:985-1033): cluster i owns out[offset[i] .. offset[i] + n_points[i]) and receives its
+// points in (global column, row) order. grid = clusters, block = 64 (lanes = rows), one pass over the cluster's column range.
+// A point belongs to cluster c iff the root of its point tree carries c (t_cid, set when the cluster is finished).
+// =====================================================================================================
+struct ClusterQuery
+{
+    const unsigned* cid;       // [n] cluster ids (CC_EV_CLUSTER.c)
+    const long long* col_from; // [n] first column (CC_EV_CLUSTER.a)
+    const long long* col_to;   // [n] last column (CC_EV_CLUSTER.b)
+    const long long* offset;   // [n] first output element of the cluster
+    const unsigned* n_points;  // [n] expected number of points (CC_EV_CLUSTER.d)
+    long long* out_gcol;
+    int* out_row;
+    int* mismatch; // incremented per cluster whose point count differs from n_points (columns cleared already, wrong descriptor)
+};
+
+__global__ __launch_bounds__(64) void k_gather_clusters(Geometry g, Planes P, const StreamState* states, int s, ClusterQuery q)
+{
+    const int ci_ = blockIdx.x;
+    const SP p = stream_ptrs(P, g, s);
+    const StreamState* st = &states[s];
+    const int R = g.num_rows, RC = g.ring_cols;
+    const int lane = lane_id();
+    const unsigned cid = q.cid[ci_];
+    const long long a = q.col_from[ci_], b = q.col_to[ci_];
+    long long pos = q.offset[ci_];
+    const long long end = pos + q.n_points[ci_];
+    const bool readable = cid != 0 && a >= 0 && b >= a && b - a < RC && a >= st->clear_done && b <= st->ring_end;
+    if (readable)
+    {
+        int lc = (int) (a % RC);
+        for (long long gc = a; gc <= b; gc++, lc = (lc + 1 == RC ? 0 : lc + 1))
+            for (int r0 = 0; r0 < R; r0 += 64)
+            {
+                const int row = r0 + lane;
+                bool mine = false;
+                if (row < R)
+                {
+                    const int cell = lc * R + row;
+                    const int root = p.root[cell];
+                    mine = p.colg[lc] == gc && root >= 0 && p.t_cid[root] == cid && p.t_finished[root];
+                }
+                const unsigned long long mask = __ballot(mine);
+                if (mine)
+                {
+                    const long long o = pos + __popcll(mask & lanes_below());
+                    if (o < end)
+                    {
+                        q.out_gcol[o] = gc;
+                        q.out_row[o] = row;
+                    }
+                }
+                pos += __popcll(mask);
+            }
+    }
+    if (lane == 0 && pos != end)
+        atomicAdd(q.mismatch, 1);
+}
+
+// =====================================================================================================
 // k_view — host view of columns [from, from + ncols) of one stream (cc_engine_read_columns)
 // grid = ncols, block = 64
 // =====================================================================================================

@@ -351,6 +351,32 @@ void ContinuousClustering::process()
         refreshColumns(lo, hi);
     }
 
+    // member points of the clusters that get a callback: gathered and compacted on the device (cc_engine_gather_cluster_points),
+    // in column-then-row order; the mirror supplies the Point payload
+    std::vector<uint32_t> g_cid, g_cnt;
+    std::vector<int64_t> g_from, g_to, g_col;
+    std::vector<int32_t> g_row;
+    if (finished_cluster_callback_)
+    {
+        for (const cc_event& e : events_)
+            if (e.type == CC_EV_CLUSTER && e.d > 20) // cc.cpp:1023
+            {
+                g_cid.push_back(e.c);
+                g_cnt.push_back(e.d);
+                g_from.push_back(e.a);
+                g_to.push_back(e.b);
+            }
+        size_t total = 0;
+        for (uint32_t c : g_cnt)
+            total += c;
+        g_col.resize(total);
+        g_row.resize(total);
+        if (!g_cid.empty())
+            check(cc_engine_gather_cluster_points(engine_, 0, static_cast<int64_t>(g_cid.size()), g_cid.data(), g_from.data(),
+                                                  g_to.data(), g_cnt.data(), g_col.data(), g_row.data()));
+    }
+    size_t g_next = 0, g_pos = 0;
+
     // replay in the order the single-threaded reference invokes its callbacks
     for (const cc_event& e : events_)
     {
@@ -367,20 +393,16 @@ void ContinuousClustering::process()
                 {
                     cluster_points_.clear();
                     uint64_t min_stamp = std::numeric_limits<uint64_t>::max(), max_stamp = 0;
-                    for (int64_t g = e.a; g <= e.b; g++)
+                    const size_t cnt = g_cnt[g_next++];
+                    for (size_t k = g_pos; k < g_pos + cnt; k++)
                     {
-                        const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
-                        for (int r = 0; r < num_rows_; r++)
-                        {
-                            const Point& p = range_image_[lc * num_rows_ + r];
-                            if (p.id == e.c && p.global_column_index == g && !p.is_ignored)
-                            {
-                                cluster_points_.push_back(p);
-                                min_stamp = std::min(min_stamp, p.stamp);
-                                max_stamp = std::max(max_stamp, p.stamp);
-                            }
-                        }
+                        const size_t lc = static_cast<size_t>(g_col[k] % ring_buffer_max_columns);
+                        const Point& p = range_image_[lc * num_rows_ + static_cast<size_t>(g_row[k])];
+                        cluster_points_.push_back(p);
+                        min_stamp = std::min(min_stamp, p.stamp);
+                        max_stamp = std::max(max_stamp, p.stamp);
                     }
+                    g_pos += cnt;
                     const uint64_t stamp = config_.clustering.use_last_point_for_cluster_stamp ?
                                                max_stamp :
                                                min_stamp + (max_stamp - min_stamp) / 2; // cc.cpp:1025-1028

@@ -237,6 +237,16 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
  * bench checksums read without leaving HBM. */
 int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_label, const uint32_t** d_cluster_id);
 
+/* Cluster hand-off: the member points of n finished clusters of `stream`, gathered and compacted on the device — the point
+ * collection of collectPointsForCusterAndPublish (cc.cpp:985-1033; the reference walks the point trees, this returns the same set
+ * ordered by global column, then row). Describe every cluster by its CC_EV_CLUSTER event: cluster_ids[i] = event.c,
+ * col_from[i] = event.a, col_to[i] = event.b, n_points[i] = event.d. Cluster i receives elements
+ * [sum(n_points[0..i)), sum(n_points[0..i])) of h_gcol / h_row (host buffers of sum(n_points) elements). Call it before the
+ * cluster's columns leave the ring (i.e. right after the call that finished it). CC_ERR_INVALID_ARGUMENT if a descriptor does
+ * not match what the engine holds. */
+int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const uint32_t* cluster_ids, const int64_t* col_from,
+                                    const int64_t* col_to, const uint32_t* n_points, int64_t* h_gcol, int32_t* h_row);
+
 /* Engine tuning / test hooks. Names: "lds_tree_limit" (unfinished point trees per stream kept in LDS before the stream
  * continues in the global-memory association kernel, 1..256), "limit_columns" (columns one launch may emit per stream before
  * it hands back to the host), "pipeline" (0: run the kernel chains of cc_engine_add_firings_device back to back on one
