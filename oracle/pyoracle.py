@@ -19,7 +19,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, "cc_oracle.cpp"), os.path.join(_HERE, "eval_oracle.cpp"), os.path.join(_HERE, "..", "include", "cc_hip.h")]
+    srcs = [os.path.join(_HERE, "cc_oracle.cpp"), os.path.join(_HERE, "eval_oracle.cpp"), os.path.join(_HERE, "kitti_oracle.cpp"),
+            os.path.join(_HERE, "..", "include", "cc_hip.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in srcs)
     if force or stale:
@@ -57,6 +58,22 @@ def lib():
         L.orc_eval_frame.argtypes = [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_eval_mean_std.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.orc_eval_mean_std.restype = None
+        vp, i64, u64 = C.c_void_p, C.c_int64, C.c_uint64
+        L.korc_recover_laser_indices.argtypes = [i64, vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.korc_bin_transforms.argtypes = [i64, vp, vp, u64, u64, vp, vp, C.c_int32]
+        L.korc_bin_transforms.restype = C.c_int32
+        L.korc_undo_ego_motion.argtypes = [i64, vp, u64, u64, vp, i64, vp, vp]
+        L.korc_undo_ego_motion.restype = None
+        L.korc_generate_range_image.argtypes = [i64, vp, vp, C.c_int, vp]
+        L.korc_generate_range_image.restype = i64
+        L.korc_make_firings.argtypes = [i64, vp, vp, u64, u64, C.c_int, C.c_int, vp, vp, vp, vp]
+        L.korc_make_firings.restype = None
+        L.korc_interpolate.argtypes = [i64, vp, vp, u64, vp]
+        L.korc_interpolate.restype = None
+        L.korc_start_end_stamps.argtypes = [i64, vp, vp, vp]
+        L.korc_start_end_stamps.restype = None
+        L.korc_pose_from_line.argtypes = [vp, vp, vp]
+        L.korc_pose_from_line.restype = None
         _lib = L
     return _lib
 
@@ -154,3 +171,82 @@ def mean_std(data):
     m, s = C.c_double(0), C.c_double(0)
     lib().orc_eval_mean_std(data.ctypes.data, data.shape[0], C.byref(m), C.byref(s))
     return m.value, s.value
+
+
+# ---- KITTI replay path (oracle/kitti_oracle.cpp) -----------------------------------------------------------------------------
+
+KITTI_ROWS, KITTI_COLS = 64, 2200
+
+
+def _poses(stamps, poses):
+    stamps = np.ascontiguousarray(stamps, dtype=np.uint64)
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 12)
+    return stamps, poses
+
+
+def kitti_recover_laser_indices(points):
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+    laser = np.zeros(pts.shape[0], dtype=np.uint8)
+    rows, maxc = C.c_int32(0), C.c_int32(0)
+    threw = lib().korc_recover_laser_indices(pts.shape[0], pts.ctypes.data, laser.ctypes.data, C.byref(rows), C.byref(maxc))
+    return laser, rows.value, maxc.value, bool(threw)
+
+
+def kitti_bin_transforms(stamps, poses, start, end, mid_pose):
+    stamps, poses = _poses(stamps, poses)
+    mid = np.ascontiguousarray(mid_pose, dtype=np.float64).reshape(12)
+    out = np.zeros((512, 12), dtype=np.float64)
+    nb = lib().korc_bin_transforms(stamps.shape[0], stamps.ctypes.data, poses.ctypes.data, int(start), int(end), mid.ctypes.data,
+                                   out.ctypes.data, 512)
+    return out[:nb].copy()
+
+
+def kitti_undo_ego_motion(points, start, end, mid_pose, stamps, poses):
+    pts = np.array(points, dtype=np.float32).reshape(-1, 4)
+    stamps, poses = _poses(stamps, poses)
+    mid = np.ascontiguousarray(mid_pose, dtype=np.float64).reshape(12)
+    lib().korc_undo_ego_motion(pts.shape[0], pts.ctypes.data, int(start), int(end), mid.ctypes.data, stamps.shape[0], stamps.ctypes.data,
+                               poses.ctypes.data)
+    return pts
+
+
+def kitti_generate_range_image(points, laser, shift=True):
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+    laser = np.ascontiguousarray(laser, dtype=np.uint8)
+    cells = np.zeros((KITTI_ROWS, KITTI_COLS), dtype=np.int32)
+    skipped = lib().korc_generate_range_image(pts.shape[0], pts.ctypes.data, laser.ctypes.data, 1 if shift else 0, cells.ctypes.data)
+    return cells, skipped
+
+
+def kitti_make_firings(points, cells, start, end, sequence=0, frame=0):
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    xyz = np.zeros((KITTI_COLS, KITTI_ROWS, 3), dtype=np.float32)
+    inten = np.zeros((KITTI_COLS, KITTI_ROWS), dtype=np.uint8)
+    unique = np.zeros((KITTI_COLS, KITTI_ROWS), dtype=np.uint64)
+    stamps = np.zeros(KITTI_COLS, dtype=np.uint64)
+    lib().korc_make_firings(pts.shape[0], pts.ctypes.data, cells.ctypes.data, int(start), int(end), sequence, frame, xyz.ctypes.data,
+                            inten.ctypes.data, unique.ctypes.data, stamps.ctypes.data)
+    return xyz, inten, unique, stamps
+
+
+def kitti_interpolate(stamps, poses, stamp):
+    stamps, poses = _poses(stamps, poses)
+    out = np.zeros(12, dtype=np.float64)
+    lib().korc_interpolate(stamps.shape[0], stamps.ctypes.data, poses.ctypes.data, int(stamp), out.ctypes.data)
+    return out
+
+
+def kitti_start_end_stamps(middle):
+    middle = np.ascontiguousarray(middle, dtype=np.uint64)
+    start, end = np.zeros_like(middle), np.zeros_like(middle)
+    lib().korc_start_end_stamps(middle.shape[0], middle.ctypes.data, start.ctypes.data, end.ctypes.data)
+    return start, end
+
+
+def kitti_pose_from_line(row12, cam0_from_x):
+    row = np.ascontiguousarray(row12, dtype=np.float64).reshape(12)
+    cam = np.ascontiguousarray(cam0_from_x, dtype=np.float64).reshape(12)
+    out = np.zeros(12, dtype=np.float64)
+    lib().korc_pose_from_line(row.ctypes.data, cam.ctypes.data, out.ctypes.data)
+    return out

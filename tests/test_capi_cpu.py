@@ -17,16 +17,19 @@ def lib():
 
 
 def declared_functions():
-    txt = open(os.path.join(ROOT, "include", "cc_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(cc_[a-z_0-9]+)\s*\(", txt)))
+    names = set()
+    for header in ("cc_hip.h", "cc_kitti.h"):
+        txt = open(os.path.join(ROOT, "include", header)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(cc_[a-z_0-9]+)\s*\(", txt))
+    return sorted(names)
 
 
 def test_header_symbols_are_exported(lib):
     names = declared_functions()
-    assert len(names) >= 20
+    assert len(names) >= 30 and "cc_kitti_convert_frames" in names
     for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/cc_hip.h but not exported by libcc_hip.so"
+        assert hasattr(lib, n), f"{n} declared in include/*.h but not exported by libcc_hip.so"
 
 
 def test_struct_layouts_match_header(lib):
