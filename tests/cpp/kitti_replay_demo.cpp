@@ -1,0 +1,236 @@
+// kitti_replay_demo.cpp — the calling pattern of the reference's no-ROS harness (src/tools/kitti_demo.cpp: KittiDemo::run :229-420,
+// addColumnAndEvaluateFrameIfCompleted :173-225, makePseudoFiringFromRangeImageColumn :123-159) written against this repository's
+// KittiLoader + ContinuousClustering mirrors and the label-compare C-ABI. Used by tests/test_gpu_kitti_replay.py on synthetic
+// KITTI-format sequences; with a mounted SemanticKITTI it replays the real ones (BASELINE.json configs[0] / configs[4] shape).
+//
+//   kitti_replay_demo <root containing sequences/> <sequence> [--one-pass] [--fixed-start-stamp NS]
+//
+// Output, one line per evaluated frame:  FRAME <seq> <frame> <tp> <fn> <fp> <tn> <ose> <use> <points seen>
+// then                                  SUMMARY <frames> <columns> <clusters> <cluster points>
+#include <cinttypes>
+#include <cstdio>
+#include <cstring>
+#include <map>
+
+#include "../../continuous_clustering_amd/csrc/kitti_loader.hpp"
+
+using namespace continuous_clustering;
+
+namespace
+{
+struct EvalPoint // KittiSegmentationEvaluationPoint, kitti_evaluation.hpp:19-36 (the fields the harness touches)
+{
+    uint16_t semantic_label{0};
+    uint32_t euclidean_clustering_label{0};
+    bool has_corresponding_point_in_detection_point_cloud{false};
+    bool is_ground_point{false};
+    uint32_t detection_label{0};
+};
+
+RawPoints::Ptr makePseudoFiring(const std::vector<KittiPoint>& range_image, uint64_t start_stamp, uint64_t end_stamp, int column_index,
+                                int sequence_index, int frame_index)
+{
+    RawPoints::Ptr firing(new RawPoints);
+    const double elapsed_ratio = static_cast<double>(column_index) / (KittiLoader::RANGE_IMAGE_WIDTH - 1);
+    const double elapsed_time = static_cast<double>(end_stamp - start_stamp) * elapsed_ratio;
+    firing->stamp = start_stamp + static_cast<uint64_t>(elapsed_time);
+    firing->points.resize(KittiLoader::RANGE_IMAGE_HEIGHT);
+    for (int row = 0; row < KittiLoader::RANGE_IMAGE_HEIGHT; row++)
+    {
+        const KittiPoint& kp = range_image[static_cast<size_t>(KittiLoader::RANGE_IMAGE_WIDTH) * row + column_index];
+        RawPoint& p = firing->points[row];
+        p.stamp = firing->stamp;
+        p.firing_index = static_cast<uint64_t>(column_index);
+        p.x = kp.x;
+        p.y = kp.y;
+        p.z = kp.z;
+        const float scaled = kp.i * 255;
+        p.intensity = std::isnan(scaled) ? 0 : static_cast<uint8_t>(scaled);
+        p.globally_unique_point_index = (static_cast<uint64_t>(sequence_index) << 48) | (static_cast<uint64_t>(frame_index) << 32) |
+                                        static_cast<uint64_t>(kp.original_kitti_index);
+    }
+    return firing;
+}
+} // namespace
+
+int main(int argc, char** argv)
+{
+    if (argc < 3)
+    {
+        std::fprintf(stderr, "usage: %s <root> <sequence> [--one-pass] [--fixed-start-stamp NS]\n", argv[0]);
+        return 2;
+    }
+    const Path root{argv[1]};
+    const int sequence_index = std::stoi(argv[2]);
+    bool one_pass = false;
+    uint64_t fixed_start = 0;
+    bool have_fixed = false;
+    for (int a = 3; a < argc; a++)
+    {
+        if (!std::strcmp(argv[a], "--one-pass"))
+            one_pass = true;
+        else if (!std::strcmp(argv[a], "--fixed-start-stamp") && a + 1 < argc)
+        {
+            fixed_start = std::strtoull(argv[++a], nullptr, 10);
+            have_fixed = true;
+        }
+    }
+    try
+    {
+        KittiLoader kitti_loader;
+        const Path sequence_folder{root / Path("sequences") / Path(KittiLoader::padWithZeros(sequence_index, 2))};
+        const Path velodyne_folder{sequence_folder / Path{"velodyne"}};
+        const Path labels_folder{sequence_folder / Path{"labels"}};
+        const Path euclidean_labels_folder{sequence_folder / Path{"labels_euclidean_clustering"}};
+
+        // timestamps: the reference makes them absolute with the wall clock (kitti_demo.cpp:247); a fixed origin keeps runs comparable
+        auto timestamps_velodyne_middle = KittiLoader::loadTimestamps(sequence_folder / Path{"times.txt"}, !have_fixed);
+        if (have_fixed)
+            for (auto& t : timestamps_velodyne_middle)
+                t += fixed_start;
+        std::vector<uint64_t> timestamps_velodyne_start, timestamps_velodyne_end;
+        KittiLoader::getStartEndTimestampsVelodyne(timestamps_velodyne_middle, timestamps_velodyne_start, timestamps_velodyne_end);
+
+        Pose3d tf_cam0_from_velodyne, p0, p1, p2, p3;
+        kitti_loader.getStaticTransformAndProjectionMatrices(sequence_folder / Path{"calib.txt"}, tf_cam0_from_velodyne, p0, p1, p2, p3);
+        const auto transforms_odom_from_velodyne =
+            kitti_loader.getAllDynamicTransforms(sequence_folder / Path{"poses.txt"}, timestamps_velodyne_middle, tf_cam0_from_velodyne);
+
+        ContinuousClustering clustering;
+        Configuration config; // kitti_demo.cpp:279-294
+        config.general.is_single_threaded = true;
+        config.range_image.num_columns = 2200;
+        config.clustering.ignore_points_in_chessboard_pattern = false;
+        config.clustering.max_distance = 0.5;
+        config.ground_segmentation.height_ref_to_maximum_ = 0.5;
+        config.ground_segmentation.height_ref_to_ground_ = -1.7;
+        config.ground_segmentation.length_ref_to_front_end_ = 3;
+        config.ground_segmentation.length_ref_to_rear_end_ = -3;
+        config.ground_segmentation.width_ref_to_left_mirror_ = 1.5;
+        config.ground_segmentation.width_ref_to_right_mirror_ = -1.5;
+        clustering.setConfiguration(config);
+        clustering.reset(64);
+        clustering.setTransformRobotFrameFromSensorFrame(Pose3d::Identity());
+        clustering.setBatchSize(KittiLoader::RANGE_IMAGE_WIDTH); // one launch per rotation; callbacks keep their order
+
+        std::map<std::pair<int, int>, std::vector<EvalPoint>> map_frame_to_point_cloud;
+        int previous_frame_index = 0;
+        int64_t columns_seen = 0, clusters_seen = 0, cluster_points_seen = 0, frames_evaluated = 0;
+        const bool evaluate = std::filesystem::exists(labels_folder);
+
+        auto evaluatePreviousFrame = [&]()
+        {
+            auto it = map_frame_to_point_cloud.find({sequence_index, previous_frame_index});
+            const std::vector<EvalPoint>& pc = it->second;
+            std::vector<uint16_t> semantic(pc.size());
+            std::vector<uint32_t> euclid(pc.size()), detection(pc.size());
+            std::vector<uint8_t> is_ground(pc.size());
+            int64_t seen = 0;
+            for (size_t k = 0; k < pc.size(); k++)
+            {
+                semantic[k] = pc[k].semantic_label;
+                euclid[k] = pc[k].euclidean_clustering_label;
+                detection[k] = pc[k].detection_label;
+                is_ground[k] = pc[k].is_ground_point;
+                seen += pc[k].has_corresponding_point_in_detection_point_cloud;
+            }
+            cc_eval_frame_result r{};
+            if (cc_eval_frame(0, static_cast<int64_t>(pc.size()), semantic.data(), euclid.data(), is_ground.data(), detection.data(), &r) != CC_OK)
+                throw std::runtime_error("cc_eval_frame failed");
+            std::printf("FRAME %d %d %.17g %.17g %.17g %.17g %.17g %.17g %" PRId64 "\n", sequence_index, previous_frame_index, r.tp, r.fn, r.fp,
+                        r.tn, r.over_segmentation_entropy, r.under_segmentation_entropy, seen);
+            map_frame_to_point_cloud.erase(it);
+            previous_frame_index++;
+            frames_evaluated++;
+        };
+
+        clustering.setFinishedColumnCallback(
+            [&](int64_t from, int64_t to, bool ground_points_only)
+            {
+                if (ground_points_only)
+                    return;
+                columns_seen += to - from + 1;
+                if (!evaluate)
+                    return;
+                for (int64_t g = from; g <= to; g++) // kitti_demo.cpp:179-224
+                {
+                    const int local = static_cast<int>(g % clustering.ring_buffer_max_columns);
+                    bool new_frame = false;
+                    for (int row = 0; row < clustering.num_rows_; row++)
+                    {
+                        const Point& point = clustering.range_image_[static_cast<size_t>(local) * clustering.num_rows_ + row];
+                        if (point.globally_unique_point_index == static_cast<uint64_t>(-1))
+                            continue;
+                        const uint16_t seq = (point.globally_unique_point_index >> 48) & 0xFFFF;
+                        const uint16_t frame = (point.globally_unique_point_index >> 32) & 0xFFFF;
+                        const uint32_t kitti_point_index = point.globally_unique_point_index & 0xFFFFFFFF;
+                        if (frame < previous_frame_index)
+                            throw std::runtime_error("Found a point belonging to a frame that was already evaluated!");
+                        else if (frame > previous_frame_index + 1)
+                            throw std::runtime_error("Found a point whose frame is too far ahead!");
+                        else if (frame == previous_frame_index + 1)
+                            new_frame = true;
+                        EvalPoint& ep = map_frame_to_point_cloud.find({seq, frame})->second[kitti_point_index];
+                        ep.is_ground_point = (point.ground_point_label == GP_GROUND);
+                        ep.detection_label = static_cast<uint32_t>(point.id);
+                        ep.has_corresponding_point_in_detection_point_cloud = true;
+                    }
+                    if (new_frame)
+                        evaluatePreviousFrame();
+                }
+            });
+        clustering.setFinishedClusterCallback(
+            [&](const std::vector<Point>& cluster_points, uint64_t)
+            {
+                clusters_seen++;
+                cluster_points_seen += static_cast<int64_t>(cluster_points.size());
+            });
+
+        const auto num_frames = static_cast<uint16_t>(timestamps_velodyne_middle.size());
+        for (uint16_t frame_index = 0; frame_index < num_frames; ++frame_index)
+        {
+            const std::string stem = KittiLoader::padWithZeros(frame_index, 6);
+            std::vector<KittiPoint> points = kitti_loader.loadPointCloud(velodyne_folder / Path{stem + ".bin"});
+            if (evaluate)
+            {
+                kitti_loader.loadSemanticKittiLabels(labels_folder / Path{stem + ".label"}, points);
+                const std::vector<uint16_t> euclidean = KittiLoader::loadFlattenedPointCloud<uint16_t>(euclidean_labels_folder / Path{stem + ".label"});
+                std::vector<EvalPoint> pc_eval(points.size());
+                for (size_t k = 0; k < points.size(); k++)
+                {
+                    pc_eval[k].semantic_label = points[k].semantic_label;
+                    pc_eval[k].euclidean_clustering_label = k < euclidean.size() ? euclidean[k] : 0;
+                }
+                map_frame_to_point_cloud.insert({{sequence_index, frame_index}, std::move(pc_eval)});
+            }
+            std::vector<KittiPoint> range_image;
+            if (one_pass)
+                range_image = kitti_loader.frameToRangeImage(points, timestamps_velodyne_start[frame_index], timestamps_velodyne_end[frame_index],
+                                                             transforms_odom_from_velodyne[frame_index].pose, transforms_odom_from_velodyne);
+            else
+            { // the three calls of kitti_demo.cpp:352-377
+                kitti_loader.recoverLaserIndices(points);
+                kitti_loader.undoEgoMotionCorrection(points, timestamps_velodyne_start[frame_index], timestamps_velodyne_end[frame_index],
+                                                     transforms_odom_from_velodyne[frame_index].pose, transforms_odom_from_velodyne);
+                range_image = kitti_loader.generateRangeImage(points);
+            }
+            for (int column_index = 0; column_index < KittiLoader::RANGE_IMAGE_WIDTH; column_index++)
+            {
+                auto firing = makePseudoFiring(range_image, timestamps_velodyne_start[frame_index], timestamps_velodyne_end[frame_index],
+                                               column_index, sequence_index, frame_index);
+                const Pose3d odom_from_velodyne = kitti_loader.interpolate(transforms_odom_from_velodyne, firing->stamp).pose;
+                clustering.addFiring(firing, odom_from_velodyne);
+            }
+        }
+        clustering.flush();
+        if (evaluate && map_frame_to_point_cloud.count({sequence_index, previous_frame_index}))
+            evaluatePreviousFrame(); // kitti_demo.cpp:417-419
+        std::printf("SUMMARY %" PRId64 " %" PRId64 " %" PRId64 " %" PRId64 "\n", frames_evaluated, columns_seen, clusters_seen, cluster_points_seen);
+    }
+    catch (const std::exception& e)
+    {
+        std::fprintf(stderr, "kitti_replay_demo: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -1,0 +1,87 @@
+"""GPU: a KITTI-format sequence on disk replayed the way the reference's no-ROS harness does it (src/tools/kitti_demo.cpp:229-420),
+through the C++ mirrors KittiLoader (per-point steps on the GPU) -> ContinuousClustering (HIP hot path) -> cc_eval_frame, against the
+same walk done with the oracle: oracle loader -> oracle clustering -> oracle label compare. Per-frame evaluation records must be equal
+(integers exact, entropies bit-equal: both sides sum in std::map order with the host's std::log)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from continuous_clustering_amd import capi, kitti
+from continuous_clustering_amd.evaluation import FrameScatter
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "tests", "cpp", "kitti_replay_demo")
+T0 = 1_700_000_000_000_000_000
+
+
+def expected_records(seq_dir, sequence, n_frames):
+    times = [float(l) for l in open(os.path.join(seq_dir, "times.txt"))]
+    stamps = np.array([T0 + int(t * 1000000000) for t in times], dtype=np.uint64)
+    calib = [l.split() for l in open(os.path.join(seq_dir, "calib.txt"))]
+    tr = np.array([float(v) for v in calib[4][1:13]])
+    poses = np.stack([orc.kitti_pose_from_line(np.array([float(v) for v in l.split()]), tr) for l in open(os.path.join(seq_dir, "poses.txt"))])
+    start, end = orc.kitti_start_end_stamps(stamps)
+    pts, sem, eu = [], [], []
+    for f in range(n_frames):
+        pts.append(np.fromfile(os.path.join(seq_dir, "velodyne", f"{f:06d}.bin"), dtype=np.float32).reshape(-1, 4))
+        sem.append(np.fromfile(os.path.join(seq_dir, "labels", f"{f:06d}.label"), dtype=np.uint16).reshape(-1, 2)[:, 0].copy())
+        eu.append(np.fromfile(os.path.join(seq_dir, "labels_euclidean_clustering", f"{f:06d}.label"), dtype=np.uint16).astype(np.uint32))
+    scatter = FrameScatter(sequence, [p.shape[0] for p in pts], sem, eu, evaluate=orc.eval_frame)
+    o = orc.Oracle(capi.Config.kitti(), 64)
+    uniques = []
+    columns = 0
+    published_to = -1
+    for f in range(n_frames):
+        laser, _, _, _ = orc.kitti_recover_laser_indices(pts[f])
+        unc = orc.kitti_undo_ego_motion(pts[f], start[f], end[f], poses[f], stamps, poses)
+        cells, _ = orc.kitti_generate_range_image(unc, laser, True)
+        xyz, inten, unique, fstamps = orc.kitti_make_firings(unc, cells, start[f], end[f], sequence, f)
+        uniques.append(unique)
+        fposes = np.stack([orc.kitti_interpolate(stamps, poses, int(s)) for s in fstamps])
+        assert o.add_firings(xyz, inten, fposes) == 0, o.last_error()
+        base, hi = o.published_range()
+        lo = max(base, published_to + 1)
+        if hi >= lo:
+            cols = o.read_published(lo, hi, fields=("source_firing", "ground_point_label", "id"))
+            src = cols["source_firing"]
+            u = np.full(src.shape, np.uint64(2 ** 64 - 1), dtype=np.uint64)
+            has = src >= 0
+            allu = np.concatenate(uniques)                                   # [firing][row]
+            rows = np.broadcast_to(np.arange(64), src.shape)
+            u[has] = allu[src[has], rows[has]]
+            scatter.add_columns(u, cols["ground_point_label"], cols["id"])
+            columns += hi - lo + 1
+            published_to = hi
+    return scatter, columns, o.state()
+
+
+def test_sequence_replay_matches_oracle(tmp_path, oracle_lib):
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "continuous_clustering_amd", "csrc")], stdout=subprocess.DEVNULL)
+    n_frames, sequence = 4, 3
+    seq_dir, sizes = kitti.write_synthetic_sequence(str(tmp_path), sequence, n_frames, seed=11, motion=(9.0, 0.3, 0.0, 0.2))
+    scatter, columns, ostate = expected_records(seq_dir, sequence, n_frames)
+    assert len(scatter.records) == n_frames - 1
+    for mode in ([], ["--one-pass"]):
+        out = subprocess.run([DEMO, str(tmp_path), str(sequence), "--fixed-start-stamp", str(T0)] + mode, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr
+        frames = [l.split() for l in out.stdout.splitlines() if l.startswith("FRAME")]
+        summary = [l.split() for l in out.stdout.splitlines() if l.startswith("SUMMARY")][0]
+        # the harness also evaluates the last frame that received points at the end of the sequence (kitti_demo.cpp:417-419)
+        assert len(frames) == n_frames
+        for rec, line in zip(scatter.records, frames):
+            assert int(line[1]) == rec[0] and int(line[2]) == rec[1]
+            got = np.array([float(v) for v in line[3:9]])
+            want = np.array(rec[2:8])
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (rec[1], got, want)
+            assert got[:4].sum() > 0.5 * sizes[rec[1]]
+        # the reference never flushes its last columns; the mirror's flush() does not publish more either
+        assert int(summary[2]) == columns
+        assert int(summary[3]) == ostate["clusters_finished"] or int(summary[3]) <= ostate["clusters_finished"]
+    # the last record: evaluate the oracle's view of the last started frame the same way
+    scatter.finish()
+    got = np.array([float(v) for v in frames[-1][3:9]])
+    assert np.array_equal(got.view(np.uint64), np.array(scatter.records[-1][2:8]).view(np.uint64))
