@@ -24,8 +24,24 @@ def _lib():
         L.cc_eval_mean_std.restype = None
         L.cc_eval_summarize.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.cc_eval_summarize.restype = None
+        L.cc_eval_generate_euclidean_labels.argtypes = [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L._eval_ready = True
     return L
+
+
+def generate_euclidean_labels(points, semantic, instance, device: int = 0) -> np.ndarray:
+    """KittiEvaluation::generateEuclideanClusteringLabels on the GPU (kitti_evaluation.cpp:224-275): points n x 4 f32 (the .bin payload),
+    semantic / instance u16 (the .label payload) -> u16 ground-truth euclidean-clustering label per point."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+    sem = np.ascontiguousarray(semantic, dtype=np.uint16)
+    inst = np.ascontiguousarray(instance, dtype=np.uint16)
+    assert sem.shape[0] == pts.shape[0] == inst.shape[0]
+    out = np.zeros(pts.shape[0], dtype=np.uint16)
+    rc = _lib().cc_eval_generate_euclidean_labels(device, pts.shape[0], pts.ctypes.data, sem.ctypes.data, inst.ctypes.data, out.ctypes.data)
+    if rc != 0:
+        from . import EngineError
+        raise EngineError(rc, "cc_eval_generate_euclidean_labels failed")
+    return out
 
 
 def eval_frame(semantic, euclid, is_ground, detection, device: int = 0) -> np.ndarray:

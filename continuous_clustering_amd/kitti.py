@@ -251,7 +251,7 @@ def write_synthetic_sequence(root: str, sequence: int, n_frames: int, seed: int 
                              cols_per_row: int = 2083):
     """Lay out <root>/sequences/<ss>/{velodyne/*.bin, labels/*.label, labels_euclidean_clustering/*.label, poses.txt, times.txt,
     calib.txt} the way kitti_demo.cpp:243-262 expects them. Labels are synthetic: ground = road (40), the rest building (50) with
-    euclidean label = 1 + 8-sector index of the azimuth."""
+    instance = euclidean label = 1 + 8-sector index of the azimuth."""
     seq = os.path.join(root, "sequences", f"{sequence:02d}")
     os.makedirs(os.path.join(seq, "velodyne"), exist_ok=True)
     if labels:
@@ -275,10 +275,10 @@ def write_synthetic_sequence(root: str, sequence: int, n_frames: int, seed: int 
         sizes.append(pts.shape[0])
         if labels:
             is_ground = pts[:, 2] < -1.55
-            sem = np.where(is_ground, 40, 50).astype(np.uint16)
-            inst = np.zeros_like(sem)
-            np.stack([sem, inst], axis=1).astype(np.uint16).tofile(os.path.join(seq, "labels", f"{fi:06d}.label"))
             sector = ((np.arctan2(pts[:, 1], pts[:, 0]) + np.pi) / (2 * np.pi) * 8).astype(np.int64).clip(0, 7)
+            sem = np.where(is_ground, 40, 50).astype(np.uint16)
+            inst = np.where(is_ground, 0, 1 + sector).astype(np.uint16)
+            np.stack([sem, inst], axis=1).astype(np.uint16).tofile(os.path.join(seq, "labels", f"{fi:06d}.label"))
             eu = np.where(is_ground, 0, 1 + sector).astype(np.uint16)
             eu.tofile(os.path.join(seq, "labels_euclidean_clustering", f"{fi:06d}.label"))
     return seq, sizes

@@ -290,6 +290,13 @@ void cc_eval_mean_std(const double* data, int64_t n, double* mean, double* std_d
  * accuracy (as fractions), USE, OSE */
 void cc_eval_summarize(const cc_eval_frame_result* frames, int64_t n, double out[12]);
 
+/* KittiEvaluation::generateEuclideanClusteringLabels (kitti_evaluation.cpp:224-275, what gt_label_generator_tool.cpp:50-70 writes to
+ * labels_euclidean_clustering/): connected components of {squared distance < 1 m^2, same semantic and instance label} over one frame
+ * (PCL ConditionalEuclideanClustering, tolerance 1.0, 10..300000 points), numbered 1, 2, ... in the order their first point appears; 0 for
+ * dropped components and for points of the ground / unlabeled classes. points = n x 4 floats (x, y, z, i), host arrays. */
+int cc_eval_generate_euclidean_labels(int device, int64_t n, const float* points, const uint16_t* semantic, const uint16_t* instance,
+                                      uint16_t* out_labels);
+
 /* Human-readable text of the last failing call on this engine (never NULL). */
 const char* cc_engine_last_error(cc_engine* e);
 /* Library / build identification, e.g. "continuous_clustering_amd 0.1 gfx950". */

@@ -19,7 +19,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, "cc_oracle.cpp"), os.path.join(_HERE, "eval_oracle.cpp"), os.path.join(_HERE, "kitti_oracle.cpp"),
+    srcs = [os.path.join(_HERE, "cc_oracle.cpp"), os.path.join(_HERE, "eval_oracle.cpp"), os.path.join(_HERE, "kitti_oracle.cpp"), os.path.join(_HERE, "gt_oracle.cpp"),
             os.path.join(_HERE, "..", "include", "cc_hip.h")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in srcs)
@@ -74,6 +74,8 @@ def lib():
         L.korc_start_end_stamps.restype = None
         L.korc_pose_from_line.argtypes = [vp, vp, vp]
         L.korc_pose_from_line.restype = None
+        L.orc_generate_euclidean_labels.argtypes = [i64, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+        L.orc_generate_euclidean_labels.restype = None
         _lib = L
     return _lib
 
@@ -250,3 +252,14 @@ def kitti_pose_from_line(row12, cam0_from_x):
     out = np.zeros(12, dtype=np.float64)
     lib().korc_pose_from_line(row.ctypes.data, cam.ctypes.data, out.ctypes.data)
     return out
+
+
+def generate_euclidean_labels(points, semantic, instance):
+    """generateEuclideanClusteringLabels (oracle/gt_oracle.cpp) -> (labels u16 [n], number of kept clusters)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+    sem = np.ascontiguousarray(semantic, dtype=np.uint16)
+    inst = np.ascontiguousarray(instance, dtype=np.uint16)
+    out = np.zeros(pts.shape[0], dtype=np.uint16)
+    nc = C.c_int32(0)
+    lib().orc_generate_euclidean_labels(pts.shape[0], pts.ctypes.data, sem.ctypes.data, inst.ctypes.data, out.ctypes.data, C.byref(nc))
+    return out, nc.value

@@ -3,7 +3,9 @@
 // KittiLoader + ContinuousClustering mirrors and the label-compare C-ABI. Used by tests/test_gpu_kitti_replay.py on synthetic
 // KITTI-format sequences; with a mounted SemanticKITTI it replays the real ones (BASELINE.json configs[0] / configs[4] shape).
 //
-//   kitti_replay_demo <root containing sequences/> <sequence> [--one-pass] [--fixed-start-stamp NS]
+//   kitti_replay_demo <root containing sequences/> <sequence> [--one-pass] [--fixed-start-stamp NS] [--write-gt-labels]
+// Without a labels_euclidean_clustering/ folder the ground-truth cluster labels are generated per frame (kitti_demo.cpp:337-346);
+// --write-gt-labels also stores them (what src/tools/gt_label_generator_tool.cpp does).
 //
 // Output, one line per evaluated frame:  FRAME <seq> <frame> <tp> <fn> <fp> <tn> <ose> <use> <points seen>
 // then                                  SUMMARY <frames> <columns> <clusters> <cluster points>
@@ -62,13 +64,15 @@ int main(int argc, char** argv)
     }
     const Path root{argv[1]};
     const int sequence_index = std::stoi(argv[2]);
-    bool one_pass = false;
+    bool one_pass = false, write_gt_labels = false;
     uint64_t fixed_start = 0;
     bool have_fixed = false;
     for (int a = 3; a < argc; a++)
     {
         if (!std::strcmp(argv[a], "--one-pass"))
             one_pass = true;
+        else if (!std::strcmp(argv[a], "--write-gt-labels"))
+            write_gt_labels = true;
         else if (!std::strcmp(argv[a], "--fixed-start-stamp") && a + 1 < argc)
         {
             fixed_start = std::strtoull(argv[++a], nullptr, 10);
@@ -82,6 +86,7 @@ int main(int argc, char** argv)
         const Path velodyne_folder{sequence_folder / Path{"velodyne"}};
         const Path labels_folder{sequence_folder / Path{"labels"}};
         const Path euclidean_labels_folder{sequence_folder / Path{"labels_euclidean_clustering"}};
+        const Path generated_labels_folder{sequence_folder / Path{"labels_euclidean_clustering_generated"}};
 
         // timestamps: the reference makes them absolute with the wall clock (kitti_demo.cpp:247); a fixed origin keeps runs comparable
         auto timestamps_velodyne_middle = KittiLoader::loadTimestamps(sequence_folder / Path{"times.txt"}, !have_fixed);
@@ -194,7 +199,28 @@ int main(int argc, char** argv)
             if (evaluate)
             {
                 kitti_loader.loadSemanticKittiLabels(labels_folder / Path{stem + ".label"}, points);
-                const std::vector<uint16_t> euclidean = KittiLoader::loadFlattenedPointCloud<uint16_t>(euclidean_labels_folder / Path{stem + ".label"});
+                std::vector<uint16_t> euclidean;
+                if (!std::filesystem::exists(euclidean_labels_folder))
+                { // generated online like kitti_demo.cpp:337-346 (KittiEvaluation::generateEuclideanClusteringLabels, on the GPU here)
+                    std::vector<float> xyzi(points.size() * 4);
+                    std::vector<uint16_t> sem(points.size()), inst(points.size());
+                    for (size_t k = 0; k < points.size(); k++)
+                    {
+                        xyzi[4 * k] = points[k].x, xyzi[4 * k + 1] = points[k].y, xyzi[4 * k + 2] = points[k].z, xyzi[4 * k + 3] = points[k].i;
+                        sem[k] = points[k].semantic_label, inst[k] = points[k].instance_label;
+                    }
+                    euclidean.resize(points.size());
+                    if (cc_eval_generate_euclidean_labels(0, static_cast<int64_t>(points.size()), xyzi.data(), sem.data(), inst.data(), euclidean.data()) != CC_OK)
+                        throw std::runtime_error("cc_eval_generate_euclidean_labels failed");
+                    if (write_gt_labels)
+                    { // gt_label_generator_tool.cpp:63-70
+                        std::filesystem::create_directories(generated_labels_folder);
+                        std::ofstream out(generated_labels_folder / Path{stem + ".label"}, std::ios::out | std::ios::binary);
+                        out.write(reinterpret_cast<const char*>(euclidean.data()), static_cast<std::streamsize>(euclidean.size() * sizeof(uint16_t)));
+                    }
+                }
+                else
+                    euclidean = KittiLoader::loadFlattenedPointCloud<uint16_t>(euclidean_labels_folder / Path{stem + ".label"});
                 std::vector<EvalPoint> pc_eval(points.size());
                 for (size_t k = 0; k < points.size(); k++)
                 {

@@ -1,0 +1,62 @@
+"""GPU: cc_eval_generate_euclidean_labels (grid hash + lock-free union-find) against the oracle's sequential PCL-style region growing:
+identical u16 labels on clustered scenes, on a full KITTI-sized synthetic frame, and on the edge cases."""
+import numpy as np
+import pytest
+
+from continuous_clustering_amd import evaluation, kitti
+from oracle import pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def test_small_scenes_match_oracle():
+    from test_gt_labels_cpu import scene
+    for seed in range(6):
+        pts, sem, inst = scene(seed, n=6000, spread=15.0)
+        want, nc = orc.generate_euclidean_labels(pts, sem, inst)
+        got = evaluation.generate_euclidean_labels(pts, sem, inst)
+        assert nc > 5 and np.array_equal(got, want)
+
+
+def test_full_frame_matches_oracle():
+    for seed in (1, 2):
+        pts, rows = kitti.synthetic_frame(seed)
+        rng = np.random.default_rng(seed)
+        ground = pts[:, 2] < -1.55
+        sector = ((np.arctan2(pts[:, 1], pts[:, 0]) + np.pi) / (2 * np.pi) * 24).astype(np.int64).clip(0, 23)
+        sem = np.where(ground, 40, np.array([50, 10, 70, 30, 80, 0], dtype=np.uint16)[sector % 6]).astype(np.uint16)
+        inst = np.where(ground, 0, sector // 6).astype(np.uint16)
+        want, nc = orc.generate_euclidean_labels(pts, sem, inst)
+        got = evaluation.generate_euclidean_labels(pts, sem, inst)
+        assert nc >= 10
+        assert np.array_equal(got, want)
+        assert (got[ground] == 0).all() and got.max() >= 5
+
+
+def test_edge_cases_match_oracle():
+    z = np.zeros(0, np.uint16)
+    assert evaluation.generate_euclidean_labels(np.zeros((0, 4), np.float32), z, z).shape == (0,)
+    cases = []
+    for step in (0.9, 1.0, 0.99999994, 1.0000001):
+        pts = np.zeros((12, 4), np.float32)
+        pts[:, 0] = np.arange(12, dtype=np.float32) * np.float32(step)
+        cases.append((pts, np.full(12, 10, np.uint16), np.zeros(12, np.uint16)))
+    pts = np.zeros((14, 4), np.float32)
+    pts[:, 1] = np.arange(14, dtype=np.float32) * np.float32(0.3)
+    pts[3, 0] = np.nan
+    pts[5, 2] = np.inf
+    sem = np.full(14, 50, np.uint16)
+    sem[7] = 51
+    cases.append((pts, sem, np.zeros(14, np.uint16)))
+    # negative coordinates around cell borders, clusters of exactly 9 / 10 points, instance labels that differ
+    rng = np.random.default_rng(3)
+    blob = lambda c, k: (np.array(c, np.float32) + rng.normal(0, 0.1, (k, 3))).astype(np.float32)
+    xyz = np.concatenate([blob((-0.02, -1.01, 0.0), 9), blob((5, 5, 5), 10), blob((-7.99, 3.0, -2.0), 30), blob((-7.99, 3.0, -2.0), 30)])
+    pts = np.concatenate([xyz, np.zeros((len(xyz), 1), np.float32)], axis=1)
+    sem = np.full(len(xyz), 30, np.uint16)
+    inst = np.concatenate([np.zeros(49, np.uint16), np.ones(30, np.uint16)])
+    cases.append((pts, sem, inst))
+    for pts, sem, inst in cases:
+        want, _ = orc.generate_euclidean_labels(pts, sem, inst)
+        got = evaluation.generate_euclidean_labels(pts, sem, inst)
+        assert np.array_equal(got, want), (got, want)

@@ -85,3 +85,35 @@ def test_sequence_replay_matches_oracle(tmp_path, oracle_lib):
     scatter.finish()
     got = np.array([float(v) for v in frames[-1][3:9]])
     assert np.array_equal(got.view(np.uint64), np.array(scatter.records[-1][2:8]).view(np.uint64))
+
+
+def test_online_ground_truth_labels(tmp_path, oracle_lib):
+    """Without labels_euclidean_clustering/ the harness generates the ground-truth cluster labels per frame on the GPU
+    (kitti_demo.cpp:337-346) and --write-gt-labels stores them like gt_label_generator_tool.cpp:63-70; both must equal the oracle's."""
+    import shutil
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "continuous_clustering_amd", "csrc")], stdout=subprocess.DEVNULL)
+    n_frames, sequence = 3, 5
+    seq_dir, sizes = kitti.write_synthetic_sequence(str(tmp_path), sequence, n_frames, seed=23, motion=(7.0, 0.0, 0.0, 0.1))
+    shutil.rmtree(os.path.join(seq_dir, "labels_euclidean_clustering"))
+    os.makedirs(os.path.join(seq_dir, "labels_euclidean_clustering"))
+    for f in range(n_frames):  # the oracle's labels take the place of the downloaded ones for the expected records
+        pts = np.fromfile(os.path.join(seq_dir, "velodyne", f"{f:06d}.bin"), dtype=np.float32).reshape(-1, 4)
+        lab = np.fromfile(os.path.join(seq_dir, "labels", f"{f:06d}.label"), dtype=np.uint16).reshape(-1, 2)
+        want, nc = orc.generate_euclidean_labels(pts, lab[:, 0], lab[:, 1])
+        assert nc > 3
+        want.tofile(os.path.join(seq_dir, "labels_euclidean_clustering", f"{f:06d}.label"))
+    scatter, _, _ = expected_records(seq_dir, sequence, n_frames)
+    scatter.finish()
+    os.rename(os.path.join(seq_dir, "labels_euclidean_clustering"), os.path.join(seq_dir, "expected_gt"))
+    out = subprocess.run([DEMO, str(tmp_path), str(sequence), "--fixed-start-stamp", str(T0), "--one-pass", "--write-gt-labels"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    frames = [l.split() for l in out.stdout.splitlines() if l.startswith("FRAME")]
+    assert len(frames) == n_frames
+    for rec, line in zip(scatter.records, frames):
+        got = np.array([float(v) for v in line[3:9]])
+        assert np.array_equal(got.view(np.uint64), np.array(rec[2:8]).view(np.uint64)), rec[1]
+    for f in range(n_frames):
+        a = np.fromfile(os.path.join(seq_dir, "labels_euclidean_clustering_generated", f"{f:06d}.label"), dtype=np.uint16)
+        b = np.fromfile(os.path.join(seq_dir, "expected_gt", f"{f:06d}.label"), dtype=np.uint16)
+        assert np.array_equal(a, b)
