@@ -29,6 +29,7 @@ struct cc_engine
     hipStream_t stream4{nullptr}; // window-scan stage of the four-stage pipeline (option "pipeline" = 2)
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
+    hipEvent_t ev_input{};            // option "input_on_engine_stream": recorded on `stream` when a device call arrives
     int pipeline_depth{1};        // 1: three chains (default: four are not faster, the GPU is throughput-bound by then), 2: four
     int prep_buf{0};              // staging buffer (of two) the open batch was prepared into
     std::vector<hipEvent_t> pev_pool; // pairs of events around every k_prep that ran ahead (outside the per-pass event groups)
@@ -77,6 +78,7 @@ struct cc_engine
     int64_t last_n{0};
     int64_t cur_ntotal{0}, cur_f0{0}; // the open batch is firings [cur_f0, cur_f0 + last_n) of buffers holding cur_ntotal per stream
     int64_t sub_batch{0};             // option "sub_batch": firings per pipelined sub-batch of a device call (0 = whole call)
+    bool input_on_engine_stream{false}; // the producer of the device input buffers was enqueued on `stream`: order the preparation chain after it
     int last_first{0}, last_count{0};
     bool batch_open{false};
     // optional per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
@@ -529,6 +531,13 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
     int rc;
     bool prepared = false;
     const int next_buf = e->prep_buf ^ 1;
+    if (pipeline && e->input_on_engine_stream)
+    {
+        // the caller produced d_xyz / d_int / d_pose with work enqueued on `stream` (e.g. cc_kitti_convert_frames): the preparation
+        // chain reads them from its own stream and has to wait for that work (and, with it, for what the engine queued there before)
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_input, e->stream));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(e->stream5, e->ev_input, 0));
+    }
     if (pipeline && e->batch_open && e->pipelined)
     {
         // The per-point preparation of this batch depends on nothing the engine holds: it starts now, on its own stream and
@@ -849,6 +858,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         (void) hipEventCreateWithFlags(&e->ev_assoc[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_segscan[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming);
+        if (i == 0)
+            (void) hipEventCreateWithFlags(&e->ev_input, hipEventDisableTiming);
 
     }
     e->cfg = *cfg;
@@ -908,6 +919,8 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipEventDestroy(e->ev_assoc[i]);
         (void) hipEventDestroy(e->ev_segscan[i]);
         (void) hipEventDestroy(e->ev_prep[i]);
+        if (i == 0)
+            (void) hipEventDestroy(e->ev_input);
     }
     for (hipEvent_t ev : e->pev_pool)
         (void) hipEventDestroy(ev);
@@ -1345,6 +1358,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->allow_graphs = value != 0;
     else if (n == "sub_batch")
         e->sub_batch = value < 0 ? 0 : value;
+    else if (n == "input_on_engine_stream")
+        e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")
         e->assoc_waves = value == 1 ? 1 : 2;
     else if (n == "limit_columns")

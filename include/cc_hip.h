@@ -212,7 +212,9 @@ int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz,
  *   d_xyz        [num_streams][n][num_rows][3] float
  *   d_intensity  [num_streams][n][num_rows]    uint8
  *   d_poses      [num_streams][n][12]          double
- * Launches on the engine's HIP stream and returns without synchronising. */
+ * Launches on the engine's HIP streams and returns without synchronising. The buffers must be complete when the call is made
+ * (the kernels that read them run on internal streams), unless their producer was enqueued on cc_engine_hip_stream(e) AND the
+ * option "input_on_engine_stream" is set: then the engine orders its reads after that work. */
 int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, const uint8_t* d_intensity,
                                  const double* d_poses);
 /* Block until everything launched so far has finished. */
@@ -255,7 +257,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * kernel; 1: the one-wavefront kernel, which is also what cluster_point_trees_every_nth_column != 1 uses), "sub_batch" (firings
  * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never
  * use the captured-hipGraph low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in
- * production). */
+ * production), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
+ * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every

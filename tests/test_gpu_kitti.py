@@ -179,6 +179,7 @@ def test_replay_into_the_engine_matches_oracle_end_to_end():
     e = Engine(cfg, 64, 1)
     o = Oracle(cfg, 64)
     conv = kitti.KittiConverter(max_frames=1, hip_stream=e.hip_stream())
+    e.set_option("input_on_engine_stream", 1)
     d_xyz = torch.empty((1, 2200, 64, 3), dtype=torch.float32, device="cuda")
     d_int = torch.empty((1, 2200, 64), dtype=torch.uint8, device="cuda")
     for f in range(NF):
@@ -188,6 +189,7 @@ def test_replay_into_the_engine_matches_oracle_end_to_end():
         assert o.add_firings(oc["xyz"], oc["inten"], fposes) == 0, o.last_error()
         _, gposes = kitti.firing_stamps_and_poses(stamps, poses, start[f], end[f])
         d_pose = torch.from_numpy(gposes.reshape(1, 2200, 12)).cuda()
+        torch.cuda.synchronize()
         conv.convert([dict(points=pts, stages=kitti.ALL_STAGES, start=start[f], end=end[f],
                            bins=kitti.bin_transforms(stamps, poses, start[f], end[f], poses[f]), d_xyz=d_xyz.data_ptr(),
                            d_intensity=d_int.data_ptr())])
