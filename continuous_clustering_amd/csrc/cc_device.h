@@ -21,7 +21,10 @@ constexpr int MAX_ROWS_PER_LANE = 2; // num_rows <= 128
 constexpr int LINK_SLOTS = 4;        // link candidates recorded per point by the static window scan
 constexpr int WIN_COLS = 32;         // columns of tree-slot ids kept in LDS by the association kernel
 constexpr int PP_SKIP = 0x7fffffff;
-constexpr int INS_WIN = 64;          // columns of `distance` kept in LDS by the insertion kernel
+#ifndef CC_INS_WIN
+#define CC_INS_WIN 64
+#endif
+constexpr int INS_WIN = CC_INS_WIN;          // columns of `distance` kept in LDS by the insertion kernel
 constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLOSE = 16;
 constexpr int TREE_SLOTS = 256;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
 
@@ -68,6 +71,7 @@ struct StreamState
                         // hands a stream back once its unfinished trees fit the LDS pool comfortably again
     int32_t pad1;
     int64_t cursor;     // firings of the current batch already consumed
+    int64_t pre_seg_begin; // first column emitted by k_insert_par in this batch (0 = it emitted none): k_insert2 continues its batch
     uint64_t firings_consumed;
     uint64_t cells_published;
     uint64_t clusters_finished;

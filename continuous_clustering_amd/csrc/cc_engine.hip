@@ -27,6 +27,8 @@ struct cc_engine
     hipStream_t stream2{nullptr}; // table / segmentation / window-scan chain of the pipelined throughput path
     hipStream_t stream3{nullptr}; // association / publish chain of the pipelined throughput path
     hipStream_t stream4{nullptr}; // window-scan stage of the four-stage pipeline (option "pipeline" = 2)
+    hipStream_t stream6{nullptr}; // k_publish of a pipelined batch: off the association chain, which is the longest of the three
+    hipEvent_t ev_pubrdy[4]{};
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
     hipEvent_t ev_input{};            // option "input_on_engine_stream": recorded on `stream` when a device call arrives
@@ -42,6 +44,8 @@ struct cc_engine
     uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 3
     bool pipelined{false};        // last submitted batch used all three streams
     bool allow_pipeline{true};    // option "pipeline"
+    bool publish_off_chain{true}; // option "publish_off_chain"
+    bool parallel_insert{true};   // option "parallel_insert": k_insert_par takes the single-column-firing head of every batch
     // low-latency path of cc_engine_add_firings for small calls: one captured hipGraph per (stream, n), pinned staging
     struct SmallGraph
     {
@@ -286,7 +290,7 @@ static Planes planes_with_prep(const cc_engine* e, int buf)
 
 // k_prep of a batch on stream `sp` into staging buffer `buf` (the per-point part of insertion does not depend on engine state)
 int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const double* d_pose, int buf, hipStream_t sp, int64_t n_total,
-                int64_t f0)
+                int64_t f0, bool skip_inserted = false, int first_stream = 0)
 {
     const size_t points = (size_t) count * (size_t) n * e->g.num_rows;
     int rcp = ensure_prep(e, points);
@@ -295,7 +299,8 @@ int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const do
     const Planes P = planes_with_prep(e, buf);
     const size_t per_stream = (size_t) n * e->g.num_rows;
     hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((per_stream + 255) / 256), (unsigned) count), dim3(256), 0, sp, e->g, e->cfg, P,
-                       d_xyz, d_pose, (long long) n, (long long) n_total, (long long) f0);
+                       d_xyz, d_pose, (long long) n, (long long) n_total, (long long) f0, skip_inserted ? (const StreamState*) e->d_states : nullptr,
+                       first_stream);
     return CC_OK;
 }
 
@@ -328,14 +333,28 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (e->timing)   \
         CC_HIP_CHECK(e, hipEventRecord(ev[k++], st_));
     // ---- insertion chain -----------------------------------------------------------------------------------------
+    // The head of the batch that has the single-column firing shape is inserted by all wavefronts of a block at once, straight from
+    // the caller's buffers; preparation and the serial kernel then only see what is left (StreamState::cursor).
+    const bool par = first_pass && !prep_done && e->parallel_insert && n >= 64; // (small calls are latency-bound: one kernel less)
+    if (par)
+        sp = si;
     CC_MARK(sp); // ev0
+    if (par)
+    {
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_insert_par<1>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
+                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
+        else
+            hipLaunchKernelGGL(cck::k_insert_par<2>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
+                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
+    }
     if (first_pass && !prep_done) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
     {
-        int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp, e->cur_ntotal, e->cur_f0);
+        int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp, e->cur_ntotal, e->cur_f0, par, first_stream);
         if (rcp)
             return rcp;
     }
-    CC_MARK(sp); // ev1: prep
+    CC_MARK(sp); // ev1: prep (with k_insert_par in front of it when that is on)
     if (sp != si)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], sp));
@@ -412,13 +431,22 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     else
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     CC_MARK(sa); // ev8: assoc_global
-    hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, sa, g, e->P, e->d_states, first_stream,
+    // The ids of the published columns only read what the association of THIS batch left behind (tree root of every cell, cluster id
+    // at the root cell; neither is touched again before the ring wraps), so in the pipelined mode they are written on a stream of their
+    // own and the next batch's association starts without waiting for them.
+    hipStream_t spub = (si != sa && !e->timing && e->publish_off_chain) ? e->stream6 : sa;
+    if (spub != sa)
+    {
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_pubrdy[slot], sa));
+        CC_HIP_CHECK(e, hipStreamWaitEvent(spub, e->ev_pubrdy[slot], 0));
+    }
+    hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, spub, g, e->P, e->d_states, first_stream,
                        slot);
     CC_MARK(sa); // ev9: publish
 #undef CC_MARK
     if (si != sa)
     {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_assoc[slot], sa));
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_assoc[slot], spub)); // the batch descriptor slot is free again after its publish
         e->assoc_pending[slot] = true;
     }
     CC_HIP_CHECK(e, hipGetLastError());
@@ -486,6 +514,7 @@ int sync_all(cc_engine* e)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream4));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream5));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream6));
     for (bool& b : e->assoc_pending)
         b = false;
     return CC_OK;
@@ -538,7 +567,7 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
         CC_HIP_CHECK(e, hipEventRecord(e->ev_input, e->stream));
         CC_HIP_CHECK(e, hipStreamWaitEvent(e->stream5, e->ev_input, 0));
     }
-    if (pipeline && e->batch_open && e->pipelined)
+    if (pipeline && e->batch_open && e->pipelined && !(e->parallel_insert && n >= 64))
     {
         // The per-point preparation of this batch depends on nothing the engine holds: it starts now, on its own stream and
         // into the other staging buffer, while the previous batch is still being inserted.
@@ -842,11 +871,16 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     int prio_lo = 0, prio_hi = 0;
     (void) hipSetDevice(device);
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+    // experiment hook: CC_STREAM_PRIO = three letters h/l for the insertion, segmentation and association chains (default "hlh")
+    const char* pe = getenv("CC_STREAM_PRIO");
+    const int p1 = (pe && strlen(pe) >= 3 && pe[0] == 'l') ? prio_lo : prio_hi, p2 = (pe && strlen(pe) >= 3 && pe[1] == 'h') ? prio_hi : prio_lo,
+              p3 = (pe && strlen(pe) >= 3 && pe[2] == 'l') ? prio_lo : prio_hi;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, p1) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, p2) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, p3) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess)
+        hipStreamCreateWithPriority(&e->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream6, hipStreamNonBlocking, prio_lo) != hipSuccess)
     {
         delete e;
         return CC_ERR_HIP;
@@ -858,6 +892,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         (void) hipEventCreateWithFlags(&e->ev_assoc[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_segscan[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_pubrdy[i], hipEventDisableTiming);
         if (i == 0)
             (void) hipEventCreateWithFlags(&e->ev_input, hipEventDisableTiming);
 
@@ -903,6 +938,7 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamSynchronize(e->stream2);
     (void) hipStreamSynchronize(e->stream3);
     (void) hipStreamSynchronize(e->stream4);
+    (void) hipStreamSynchronize(e->stream6);
     (void) hipStreamSynchronize(e->stream5);
     destroy_small_graphs(e);
     if (e->h_small)
@@ -919,6 +955,7 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipEventDestroy(e->ev_assoc[i]);
         (void) hipEventDestroy(e->ev_segscan[i]);
         (void) hipEventDestroy(e->ev_prep[i]);
+        (void) hipEventDestroy(e->ev_pubrdy[i]);
         if (i == 0)
             (void) hipEventDestroy(e->ev_input);
     }
@@ -927,6 +964,7 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamDestroy(e->stream2);
     (void) hipStreamDestroy(e->stream3);
     (void) hipStreamDestroy(e->stream4);
+    (void) hipStreamDestroy(e->stream6);
     (void) hipStreamDestroy(e->stream5);
     for (hipEvent_t ev : e->ev_pool)
         (void) hipEventDestroy(ev);
@@ -985,6 +1023,7 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream4));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream5));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream6));
     e->batch_open = false;
     const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
     if (!same_shape)
@@ -1358,6 +1397,10 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->allow_graphs = value != 0;
     else if (n == "sub_batch")
         e->sub_batch = value < 0 ? 0 : value;
+    else if (n == "publish_off_chain")
+        e->publish_off_chain = value != 0;
+    else if (n == "parallel_insert")
+        e->parallel_insert = value != 0;
     else if (n == "input_on_engine_stream")
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")

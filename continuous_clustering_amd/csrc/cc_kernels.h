@@ -274,26 +274,21 @@ __device__ __forceinline__ float len2(float a, float b)
 // azimuth -> column within the rotation, inclination. Independent per point, so it runs over all points of the batch
 // in parallel; the serial kernel below only decides where each point lands. grid = points / 256, block = 256.
 // =====================================================================================================
-// grid = (points of one stream's sub-batch / 256, streams). The caller's buffers hold n_total firings per stream; this launch
-// prepares firings [f0, f0 + m) of every stream into the compact staging planes (index [stream][m][row]).
-__global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes P, const float* __restrict__ xyz,
-                                             const double* __restrict__ poses, long long m, long long n_total, long long f0)
+// The per-point arithmetic, shared by k_prep and k_insert_par so that both produce the same bits.
+struct PreppedPoint
 {
-    const int R = g.num_rows;
-    const long long local = (long long) blockIdx.x * 256 + threadIdx.x; // [firing within the sub-batch][row]
-    if (local >= m * R)
-        return;
-    const long long sl = blockIdx.y;
-    const long long src = (sl * n_total + f0) * R + local; // index into the caller's [stream][n_total][row] buffers
-    const long long firing = src / R;                      // [stream][firing] flattened
-    const long long i = sl * m * R + local;                // index into the staging planes
-    const float fx = xyz[src * 3 + 0], fy = xyz[src * 3 + 1], fz = xyz[src * 3 + 2];
+    float x, y, z, dist, incl, incaz;
+    int cir; // column within the rotation, PP_SKIP for a NaN return
+};
+
+__device__ __forceinline__ PreppedPoint prep_point(const float fx, const float fy, const float fz, const double* __restrict__ T, const bool clockwise,
+                                                   const float az_width)
+{
+    PreppedPoint o;
+    o.x = o.y = o.z = o.dist = o.incl = o.incaz = 0.f;
+    o.cir = PP_SKIP; // std::isnan(p.x()) cc.cpp:131
     if (fx != fx)
-    {
-        P.pp_cir[i] = PP_SKIP; // std::isnan(p.x()) cc.cpp:131
-        return;
-    }
-    const double* T = poses + firing * 12;
+        return o;
     const double px = fx, py = fy, pz = fz;
     const double tx = T[3], ty = T[7], tz = T[11];
     const double ox = ((T[0] * px + T[1] * py) + T[2] * pz) + tx;
@@ -301,15 +296,45 @@ __global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes 
     const double oz = ((T[8] * px + T[9] * py) + T[10] * pz) + tz;
     const double rx = ox - tx, ry = oy - ty, rz = oz - tz;
     const float az = ccm::atan2f_exact(fy, fx);
-    const float inc_az = cfg.sensor_is_clockwise ? -az + CC_PI_F : az + CC_PI_F;
+    const float inc_az = clockwise ? -az + CC_PI_F : az + CC_PI_F;
     const float dist = (float) __builtin_sqrt((rx * rx + ry * ry) + rz * rz);
-    P.pp_x[i] = (float) ox;
-    P.pp_y[i] = (float) oy;
-    P.pp_z[i] = (float) oz;
-    P.pp_dist[i] = dist;
-    P.pp_incl[i] = ccm::asinf_exact((float) rz / dist);
-    P.pp_incaz[i] = inc_az;
-    P.pp_cir[i] = f2i_x86(inc_az / g.az_width);
+    o.x = (float) ox;
+    o.y = (float) oy;
+    o.z = (float) oz;
+    o.dist = dist;
+    o.incl = ccm::asinf_exact((float) rz / dist);
+    o.incaz = inc_az;
+    o.cir = f2i_x86(inc_az / az_width);
+    return o;
+}
+
+// grid = (points of one stream's sub-batch / 256, streams). The caller's buffers hold n_total firings per stream; this launch
+// prepares firings [f0, f0 + m) of every stream into the compact staging planes (index [stream][m][row]). Firings that k_insert_par
+// has already inserted (below the stream's cursor) are skipped: nobody reads their staging cells.
+__global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes P, const float* __restrict__ xyz,
+                                             const double* __restrict__ poses, long long m, long long n_total, long long f0,
+                                             const StreamState* __restrict__ states, int first_stream)
+{
+    const int R = g.num_rows;
+    const long long local = (long long) blockIdx.x * 256 + threadIdx.x; // [firing within the sub-batch][row]
+    if (local >= m * R)
+        return;
+    const long long sl = blockIdx.y;
+    if (states && local / R < states[first_stream + sl].cursor)
+        return;
+    const long long src = (sl * n_total + f0) * R + local; // index into the caller's [stream][n_total][row] buffers
+    const long long firing = src / R;                      // [stream][firing] flattened
+    const long long i = sl * m * R + local;                // index into the staging planes
+    const PreppedPoint q = prep_point(xyz[src * 3 + 0], xyz[src * 3 + 1], xyz[src * 3 + 2], poses + firing * 12, cfg.sensor_is_clockwise != 0, g.az_width);
+    P.pp_cir[i] = q.cir;
+    if (q.cir == PP_SKIP)
+        return;
+    P.pp_x[i] = q.x;
+    P.pp_y[i] = q.y;
+    P.pp_z[i] = q.z;
+    P.pp_dist[i] = q.dist;
+    P.pp_incl[i] = q.incl;
+    P.pp_incaz[i] = q.incaz;
 }
 
 // =====================================================================================================
@@ -318,7 +343,10 @@ __global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes 
 // per stream, lanes = rows; the `distance` plane of the INS_WIN columns around the insertion front lives in LDS so that the
 // occupancy tests never wait for HBM.
 // =====================================================================================================
-constexpr int INS_RING = 8;  // firings staged in LDS ahead of the consumer wave
+#ifndef CC_INS_RING
+#define CC_INS_RING 8
+#endif
+constexpr int INS_RING = CC_INS_RING;  // firings staged in LDS ahead of the consumer wave
 
 // columns of the `distance` plane kept in LDS: INS_WIN for sensors whose firing spans a few columns, twice that for sensors with
 // two rows per lane (VLS-128-style firings span ~60 columns)
@@ -447,7 +475,13 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     int reset_required = st->reset_required;
     const long long seq0 = (long long) st->firings_consumed;
     long long seg_begin = first_unf;
-    const long long limit_base = first_unf;
+    long long limit_base = first_unf;
+    if (st->pre_seg_begin > 0)
+    {
+        // k_insert_par consumed the head of this batch: the batch's column range and its emission limit start where it started
+        seg_begin = st->pre_seg_begin;
+        limit_base = st->pre_seg_begin;
+    }
     unsigned long long negative_cols = 0;
     bool ring_init = false;
 
@@ -1005,6 +1039,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         st->batch[slot].pub_begin = -1;
         st->batch[slot].pub_end = -1;
         st->cursor = f;
+        st->pre_seg_begin = 0;
         st->firings_consumed = (unsigned long long) (seq0 + (f - cursor0));
         if (f < n)
             atomicAdd(remaining, 1);
@@ -1012,6 +1047,245 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     negative_cols = (unsigned long long) wave_max_i64((long long) negative_cols);
     if (lane == 0 && negative_cols)
         st->error_b += (long long) negative_cols;
+}
+
+// =====================================================================================================
+// k_insert_par — insertFiringIntoRangeImage (cc.cpp:105-292) for the head of a batch, all firings at once, straight from the
+// caller's buffers (the per-point preparation is done inline: what this kernel takes never touches the staging planes).
+//
+// The serial recurrence of the insertion is "global column of this firing relative to the previous rearmost laser". For the firing
+// shape the reference's own harness produces (kd.cpp:123-159: every return of a firing in one column) and a sensor that advances by
+// at least one column per firing, that recurrence is a prefix sum: with c_f the column-in-rotation of firing f, the global column is
+// G_f = G_(f-1) + d_f, d_f = c_f - c_(f-1) (+ num_columns across the rotation wrap, cc.cpp:165-175), and under d_f > 0 the rearmost =
+// foremost = G_f, nothing is "too far behind", firing f finishes exactly the columns [G_(f-1), G_f) (cc.cpp:289-291), and no target
+// cell can be occupied: nothing was ever written ahead of the foremost laser, and the previous tenant of the ring slot, column
+// G_f - ring_cols, has been cleared when it lies below StreamState::clear_done. One block per stream walks the batch in chunks of
+// IP_CHUNK firings (IP_FPW per wavefront, prepared points kept in registers):
+//   A  wave per firing: rigid transform, range, azimuth, inclination of its returns; their common column c_f (or "not this shape")
+//   B  one wavefront: scan of d_f -> G_f; the first firing that breaks a condition (shape, d_f <= 0 or backwards, emission limit, ring
+//      slot not provably clear) ends the run
+//   D  wave per firing: the nine planes of the cells, the finishing firing of the columns it completes
+// and hands the rest of the batch (from the first firing that does not fit: an empty firing, two firings in one column, a multi-column
+// sensor, a stream that is not in steady state yet) to k_prep + k_insert2 through StreamState::cursor, with exactly the state the
+// serial kernel would have at that firing. grid = streams, block = 64 * IP_WAVES.
+// =====================================================================================================
+constexpr int IP_WAVES = 16, IP_FPW = 4, IP_CHUNK = IP_WAVES * IP_FPW;
+static_assert(IP_CHUNK == 64, "phase B is one wavefront wide");
+
+template<int RPL>
+__global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+                                                            const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
+                                                            const double* __restrict__ poses, long long n, long long n_total, long long fbase)
+{
+    const int sl = blockIdx.x;
+    const int s = first_stream + sl;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    StreamState* st = &states[s];
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
+    __shared__ int s_c[IP_CHUNK];   // column-in-rotation of the chunk's firings, -1 = not the single-column shape
+    __shared__ int s_off[IP_CHUNK]; // G_f - (G before the chunk)
+    __shared__ int s_upto, s_cprev;
+
+    const long long prev_rear0 = st->prev_rearmost, prev_fore0 = st->prev_foremost, first_unf0 = st->first_unfinished;
+    const long long ring_end0 = st->ring_end;
+    // ring_start belongs to the association chain, which may be advancing it right now (previous batch): every wavefront has to work
+    // with the same value, or the columns between two wavefronts' views would be skipped by the clearing below
+    __shared__ long long s_ring_start;
+    if (tid == 0)
+        s_ring_start = __hip_atomic_load(&st->ring_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long long ring_start = s_ring_start;
+    // deferred clearColumns (cc.cpp:1094-1145) exactly as k_insert2 would do it first, spread over the wavefronts
+    long long clear_done = st->clear_done;
+    if (clear_done >= 0)
+    {
+        const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
+        for (long long c = clear_done + wave; c < clear_to; c += IP_WAVES)
+        {
+            const int clc = (int) (c % RC);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const size_t ci = (size_t) clc * R + row;
+                    p.dist[ci] = __builtin_nanf("");
+                    p.incl[ci] = __builtin_nanf("");
+                    p.gcol[ci] = -1;
+                }
+            }
+        }
+        if (clear_to > clear_done)
+            clear_done = clear_to;
+    }
+    const bool steady = st->cursor == 0 && ring_start != -1 && first_unf0 > 0 && first_unf0 == prev_rear0 && prev_fore0 == prev_rear0 &&
+                        st->reset_required == 0 && st->pre_seg_begin == 0 && clear_done >= 0;
+    if (tid == 0)
+        s_cprev = (int) (prev_rear0 % NC);
+    __syncthreads(); // the cleared cells are ordered before everything this block writes from here on
+    if (!steady)
+    {
+        if (tid == 0)
+            st->clear_done = clear_done;
+        return;
+    }
+    const int half = NC / 2;
+    const bool clockwise = cfg.sensor_is_clockwise != 0;
+    const size_t fglob = (size_t) sl * (size_t) n_total + (size_t) fbase; // first firing of this batch in the caller's buffers
+    const long long seq0 = (long long) st->firings_consumed;
+    const long long rot0 = prev_rear0 / NC;
+    const int cir0 = (int) (prev_rear0 - rot0 * NC);
+    const int lc0 = (int) (prev_rear0 % RC);
+    long long gsum = 0; // G before the current chunk, relative to prev_rear0
+    long long done = 0;
+    for (long long chunk0 = 0; chunk0 < n; chunk0 += IP_CHUNK)
+    {
+        const int cn = (int) (n - chunk0 < IP_CHUNK ? n - chunk0 : IP_CHUNK);
+        // ---- A: prepare the returns of this wavefront's firings, find each firing's common column
+        PreppedPoint q[IP_FPW][RPL];
+#pragma unroll
+        for (int j = 0; j < IP_FPW; j++)
+        {
+            const int t = wave + IP_WAVES * j;
+            if (t < cn) // wave-uniform
+            {
+                const size_t fi = fglob + (size_t) (chunk0 + t);
+                const double* T = poses + fi * 12;
+                unsigned long long mv = 0;
+                int c0 = 0;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    q[j][k].cir = PP_SKIP;
+                    if (row < R)
+                    {
+                        const size_t src = (fi * R + row) * 3;
+                        q[j][k] = prep_point(xyz[src], xyz[src + 1], xyz[src + 2], T, clockwise, g.az_width);
+                    }
+                    const unsigned long long m = __ballot(q[j][k].cir != PP_SKIP);
+                    if (mv == 0 && m != 0)
+                        c0 = __builtin_amdgcn_readlane(q[j][k].cir, (int) __ffsll((long long) m) - 1);
+                    mv |= m;
+                }
+                bool differs = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                    differs |= q[j][k].cir != PP_SKIP && q[j][k].cir != c0;
+                const bool shape = mv != 0 && !__any(differs) && c0 >= 0 && c0 < NC;
+                if (lane == 0)
+                    s_c[t] = shape ? c0 : -1;
+            }
+        }
+        __syncthreads();
+        // ---- B: column advance of every firing, its prefix sum, first firing that ends the run (one wavefront: lane = firing)
+        if (wave == 0)
+        {
+            const int c = lane < cn ? s_c[lane] : -1;
+            int cp = __shfl_up(c, 1, 64);
+            if (lane == 0)
+                cp = s_cprev;
+            const int diff = c - cp;
+            // strictly forward, also across the wrap (cc.cpp:165-175)
+            const bool ok = lane < cn && c >= 0 && cp >= 0 && ((diff > 0 && diff <= half) || diff < -half);
+            const int delta = ok ? (diff < -half ? diff + NC : diff) : 0;
+            int v = delta;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1)
+            {
+                const int o = __shfl_up(v, d, 64);
+                if (lane >= d)
+                    v += o;
+            }
+            s_off[lane] = v;
+            const long long G = prev_rear0 + gsum + v;
+            const long long rear_before = G - delta;
+            // a firing is only taken while the batch has emitted fewer than limit_columns columns before it (k_insert2's loop head), and
+            // while the previous tenant of its ring slot is known to be cleared
+            const bool stop = !ok || rear_before - first_unf0 >= g.limit_columns || G - RC >= clear_done;
+            const unsigned long long mstop = __ballot(stop);
+            if (lane == 0)
+                s_upto = mstop ? (int) __ffsll((long long) mstop) - 1 : cn;
+        }
+        __syncthreads();
+        const int upto = s_upto < cn ? s_upto : cn;
+        // ---- D: the cells and the columns each firing finishes
+#pragma unroll
+        for (int j = 0; j < IP_FPW; j++)
+        {
+            const int t = wave + IP_WAVES * j;
+            if (t < upto)
+            {
+                const long long f = chunk0 + t;
+                const long long rel = gsum + s_off[t];                        // G_f - prev_rear0
+                const long long rel_prev = gsum + (t > 0 ? s_off[t - 1] : 0); // G_(f-1) - prev_rear0
+                const long long G = prev_rear0 + rel;
+                const int lc = (int) (((long long) lc0 + rel) % RC);
+                const long long rot = rot0 + ((long long) cir0 + rel) / NC;
+                const double caz_base = CC_2PI_D * (double) rot;
+                const uint8_t* si = inten + (fglob + (size_t) f) * R;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    if (q[j][k].cir != PP_SKIP)
+                    {
+                        const size_t ci = (size_t) lc * R + row;
+                        p.x[ci] = q[j][k].x;
+                        p.y[ci] = q[j][k].y;
+                        p.z[ci] = q[j][k].z;
+                        p.inten[ci] = si[row];
+                        p.src[ci] = seq0 + f;
+                        p.dist[ci] = q[j][k].dist;
+                        p.incl[ci] = q[j][k].incl;
+                        p.caz[ci] = caz_base + (double) q[j][k].incaz;
+                        p.gcol[ci] = G;
+                    }
+                }
+                // columns [G_(f-1), G_f) are finished by this firing and carry its pose (cc.cpp:289-291)
+                const int cnt = (int) (rel - rel_prev);
+                for (int jj = lane; jj < cnt; jj += 64)
+                    p.trig[(int) (((long long) lc0 + rel_prev + jj) % RC)] = (int) f;
+            }
+        }
+        if (upto < cn)
+        {
+            done = chunk0 + upto;
+            if (upto > 0)
+                gsum += s_off[upto - 1];
+            break;
+        }
+        done = chunk0 + cn;
+        const int adv = s_off[cn - 1];
+        const int lastc = s_c[cn - 1];
+        __syncthreads();
+        gsum += adv;
+        if (tid == 0)
+            s_cprev = lastc;
+        // (s_cprev is read by wave 0 after the next chunk's first barrier)
+    }
+    if (tid == 0)
+    {
+        st->clear_done = clear_done;
+        st->dbg[6] += (unsigned long long) done; // firings taken by this kernel / batches it saw (cc_engine_debug_counters)
+        st->dbg[7] += 1;
+        if (done > 0)
+        {
+            const long long G = prev_rear0 + gsum;
+            st->prev_rearmost = G;
+            st->prev_foremost = G;
+            st->first_unfinished = G;
+            if (G > ring_end0)
+                st->ring_end = G;
+            st->cursor = done;
+            st->firings_consumed = (unsigned long long) (seq0 + done);
+            st->pre_seg_begin = first_unf0;
+        }
+    }
 }
 
 // =====================================================================================================

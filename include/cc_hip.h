@@ -257,7 +257,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * kernel; 1: the one-wavefront kernel, which is also what cluster_point_trees_every_nth_column != 1 uses), "sub_batch" (firings
  * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never
  * use the captured-hipGraph low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in
- * production), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
+ * production), "parallel_insert" (1 (default): the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a
+ * block-parallel kernel, the serial insertion kernel continues behind it; 0: serial kernel only), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
  * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
