@@ -1,0 +1,71 @@
+"""GPU: the block-parallel insertion kernel (k_insert_par) against the oracle on KITTI-shaped streams that leave its fast
+shape in the middle of a call — duplicated firings (two firings in one column), empty firings, a backwards firing, skipped columns,
+a rotation wrap inside the call — so that every hand-over to the serial kernel (and back at the next call) is exercised; with the
+emission limit inside the parallel part (continuation passes), through the pipelined device entry, and with the option off."""
+import numpy as np
+import pytest
+
+import util
+from continuous_clustering_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def perturbed_stream(seed, n=2200 * 3 + 300):
+    st = synth.make_stream(n, seed=seed, motion=synth.Motion.translate())
+    rng = np.random.default_rng(seed)
+    order = np.arange(n)
+    # duplicates (same firing twice in a row -> second one lands in occupied cells)
+    dup = np.sort(rng.choice(np.arange(300, n - 300), 6, replace=False))
+    order = np.insert(order, dup, order[dup])
+    # a backwards pair
+    k = int(rng.integers(1500, n - 1500))
+    order[k], order[k + 1] = order[k + 1], order[k]
+    # skipped columns
+    k2 = int(rng.integers(800, n - 800))
+    order = np.delete(order, np.arange(k2, k2 + 37))
+    xyz, inten, poses = st.xyz[order].copy(), st.intensity[order].copy(), st.poses[order].copy()
+    # empty firings
+    for e in rng.choice(np.arange(200, len(order) - 200), 5, replace=False):
+        xyz[e] = np.nan
+    # a firing whose returns straddle two columns (not the single-column shape)
+    e = int(rng.integers(1000, len(order) - 1000))
+    xyz[e, ::2] = xyz[e + 1, ::2]
+    return synth.Stream(xyz=xyz, intensity=inten, poses=poses, sensor=st.sensor)
+
+
+@pytest.mark.parametrize("seed,chunks", [(1, [2200]), (2, [997, 64, 1300]), (3, [150, 2200, 63, 700])])
+def test_hand_over_between_parallel_and_serial_insertion(seed, chunks, oracle_lib):
+    cfg = capi.Config.kitti()
+    s = util.run_and_compare(perturbed_stream(seed), cfg, chunks=chunks)
+    assert s["published_columns"] > 4000 and s["clusters"] > 50
+
+
+def test_emission_limit_inside_the_parallel_part(oracle_lib):
+    cfg = capi.Config.kitti()
+    stream = synth.make_stream(2200 * 3, seed=9, motion=synth.Motion.translate())
+    s = util.run_and_compare(stream, cfg, chunks=[2200], engine_setup=lambda e: e.set_option("limit_columns", 700))
+    assert s["published_columns"] > 4000
+
+
+def test_option_off_gives_the_same_result(oracle_lib):
+    cfg = capi.Config.kitti()
+    stream = perturbed_stream(5)
+    a = util.run_and_compare(stream, cfg, chunks=[1100], engine_setup=lambda e: e.set_option("parallel_insert", 0))
+    b = util.run_and_compare(stream, cfg, chunks=[1100])
+    assert a["events"] == b["events"] and a["published_columns"] == b["published_columns"]
+
+
+def test_counters_show_the_parallel_kernel_took_the_steady_part(oracle_lib):
+    import ctypes as C
+    from continuous_clustering_amd import Engine, load_library
+    cfg = capi.Config.kitti()
+    stream = synth.make_stream(2200 * 3, seed=11, motion=synth.Motion.translate())
+    e = Engine(cfg, 64, 1)
+    for b in range(3):
+        assert e.add_firings(stream.xyz[b * 2200:(b + 1) * 2200], stream.intensity[b * 2200:(b + 1) * 2200], stream.poses[b * 2200:(b + 1) * 2200]) == 0
+    L = load_library()
+    L.cc_engine_debug_counters.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    out = np.zeros(16, dtype=np.uint64)
+    L.cc_engine_debug_counters(e.h, 0, out.ctypes.data)
+    assert out[7] == 2 and out[6] == 2 * 2200      # not entered in the first call (ring not started), everything afterwards
