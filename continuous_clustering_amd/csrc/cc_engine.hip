@@ -434,7 +434,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // The ids of the published columns only read what the association of THIS batch left behind (tree root of every cell, cluster id
     // at the root cell; neither is touched again before the ring wraps), so in the pipelined mode they are written on a stream of their
     // own and the next batch's association starts without waiting for them.
-    hipStream_t spub = (si != sa && !e->timing && e->publish_off_chain) ? e->stream6 : sa;
+    hipStream_t spub = (si != sa && e->publish_off_chain) ? e->stream6 : sa;
     if (spub != sa)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_pubrdy[slot], sa));
@@ -442,7 +442,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, spub, g, e->P, e->d_states, first_stream,
                        slot);
-    CC_MARK(sa); // ev9: publish
+    CC_MARK(spub); // ev9: publish
 #undef CC_MARK
     if (si != sa)
     {

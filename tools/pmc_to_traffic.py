@@ -10,7 +10,7 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
-ALIAS = {"k_prep": "prep", "k_insert2": "insert", "k_seg_pre": "segment_pre", "k_seg_scan": "segment", "k_scan": "scan",
+ALIAS = {"k_prep": "prep", "k_insert_par": "insert_parallel", "k_insert2": "insert", "k_seg_pre": "segment_pre", "k_seg_scan": "segment", "k_scan": "scan",
          "k_assoc_lds": "assoc_lds_1wave", "k_assoc2": "assoc_lds", "k_associate": "assoc_global", "k_publish": "publish", "k_table": "table"}
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
