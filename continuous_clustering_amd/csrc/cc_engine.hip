@@ -871,13 +871,9 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     int prio_lo = 0, prio_hi = 0;
     (void) hipSetDevice(device);
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
-    // experiment hook: CC_STREAM_PRIO = three letters h/l for the insertion, segmentation and association chains (default "hlh")
-    const char* pe = getenv("CC_STREAM_PRIO");
-    const int p1 = (pe && strlen(pe) >= 3 && pe[0] == 'l') ? prio_lo : prio_hi, p2 = (pe && strlen(pe) >= 3 && pe[1] == 'h') ? prio_hi : prio_lo,
-              p3 = (pe && strlen(pe) >= 3 && pe[2] == 'l') ? prio_lo : prio_hi;
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, p1) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, p2) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, p3) != hipSuccess ||
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream6, hipStreamNonBlocking, prio_lo) != hipSuccess)

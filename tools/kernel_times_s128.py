@@ -7,12 +7,12 @@ sensor = synth.SensorModel.s128(); cfg = capi.Config.vls128()
 S,F,NB = 128,1700,4
 xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, S, F, NB, 1234)
 torch.cuda.synchronize()
-for pipe in [0, 1]:
+for pipe, par in [(0, 0), (0, 1), (1, 0), (1, 1)]:
     flags = 0
-    e = Engine(cfg, 128, S); e.record_events(False); e.set_option("pipeline", pipe)
+    e = Engine(cfg, 128, S); e.record_events(False); e.set_option("pipeline", pipe); e.set_option("parallel_insert", par)
     e.add_firings_device(F, xyz[0], inten[0], poses[0]); e.sync()
     e.enable_timing(True)
     for b in range(1,NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])
     e.sync(); k = e.kernel_times()
-    print("pipeline", pipe, {n: round(v/k["batches"],3) for n,v in k.items() if n.endswith("_ms")})
+    print("pipeline", pipe, "parallel_insert", par, {n: round(v/k["batches"],3) for n,v in k.items() if n.endswith("_ms")})
     e.close()
