@@ -60,3 +60,18 @@ def test_edge_cases_match_oracle():
         want, _ = orc.generate_euclidean_labels(pts, sem, inst)
         got = evaluation.generate_euclidean_labels(pts, sem, inst)
         assert np.array_equal(got, want), (got, want)
+
+
+def test_randomised_scenes_match_oracle():
+    rng = np.random.default_rng(77)
+    for case in range(10):
+        n = int(rng.choice([1, 9, 10, 500, 4000, 20000]))
+        spread = float(rng.choice([0.5, 3.0, 20.0, 80.0]))
+        pts = np.concatenate([rng.normal(0, spread, (n, 3)), rng.random((n, 1))], axis=1).astype(np.float32)
+        if n > 20 and rng.random() < 0.5:
+            pts[rng.integers(0, n, 5), :3] = pts[rng.integers(0, n, 5), :3]      # exact duplicates (in clusters larger than themselves)
+        sem = rng.choice(np.array([0, 10, 40, 50, 72, 252], dtype=np.uint16), n)
+        inst = rng.integers(0, 3, n).astype(np.uint16)
+        want, _ = orc.generate_euclidean_labels(pts, sem, inst)
+        got = evaluation.generate_euclidean_labels(pts, sem, inst)
+        assert np.array_equal(got, want), (case, n, spread)

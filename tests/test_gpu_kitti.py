@@ -204,3 +204,49 @@ def test_replay_into_the_engine_matches_oracle_end_to_end():
         if hi >= lo:
             util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi), lo)
     assert se["clusters_finished"] > 5 and se["cells_published"] > 64 * 2 * 2200
+
+
+def _random_cloud(rng):
+    """An unorganised cloud in .bin order with random row count (also > 64), row lengths (also > 2200: the reference throws), azimuth
+    jitter, duplicates, gaps and a few NaN / zero points."""
+    n_rows = int(rng.choice([1, 3, 17, 63, 64, 64, 64, 65, 70]))
+    rows = []
+    for r in range(n_rows):
+        m = int(rng.choice([0, 5, 300, 1500, 2083, 2199, 2200, 2300], p=[.05, .05, .1, .2, .4, .1, .05, .05]))
+        az = np.sort(rng.uniform(0, 2 * np.pi, m))
+        if m and rng.random() < 0.5:
+            az = np.round(az / (2 * np.pi / 2200) * rng.choice([1, 2])) * (2 * np.pi / 2200) / rng.choice([1, 2])  # pile-ups in cells
+        az = np.where(az > np.pi, az - 2 * np.pi, az)           # file order 0 -> pi -> -pi -> 0
+        rad = rng.uniform(2, 60, m)
+        incl = np.deg2rad(2.0 - 0.42 * r)
+        p = np.stack([rad * np.cos(incl) * np.cos(az), rad * np.cos(incl) * np.sin(az), rad * np.sin(incl), rng.random(m)], axis=1)
+        rows.append(p)
+    pts = np.concatenate(rows).astype(np.float32) if rows else np.zeros((0, 4), np.float32)
+    if len(pts) > 10:
+        k = rng.integers(0, len(pts), 3)
+        pts[k[0], 0] = np.nan
+        pts[k[1], :2] = 0
+        pts[k[2], 1] = -0.0
+    return pts
+
+
+def test_randomised_frames_all_stages():
+    rng = np.random.default_rng(2024)
+    stamps, poses, start, end = _drive(4, (13.0, -0.4, 0.05, 0.5))
+    clouds = [_random_cloud(rng) for _ in range(14)]
+    conv = kitti.KittiConverter(max_frames=len(clouds), max_points=max(len(c) for c in clouds) + 1)
+    frames = []
+    for i, pts in enumerate(clouds):
+        f = i % 4
+        frames.append(dict(points=pts, stages=kitti.ALL_STAGES & ~kitti.FIRINGS, start=start[f], end=end[f],
+                           bins=kitti.bin_transforms(stamps, poses, start[f], end[f], poses[f])))
+    conv.convert(frames)
+    for i, pts in enumerate(clouds):
+        f = i % 4
+        o = _oracle_chain(pts, stamps, poses, start, end, f)
+        res = conv.result(i, pts.shape[0])
+        assert res["rows_found"] == o["found"] and res["max_columns"] == o["maxc"] and res["skipped"] == o["skipped"], i
+        assert np.array_equal(res["laser_index"], o["laser"]), i
+        a, b = res["points"], o["unc"]
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(_bits(a)[~np.isnan(a)], _bits(b)[~np.isnan(b)]), i
+        assert np.array_equal(res["cell_source"], o["cells"]), i
