@@ -1059,18 +1059,19 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 // G_f = G_(f-1) + d_f, d_f = c_f - c_(f-1) (+ num_columns across the rotation wrap, cc.cpp:165-175), and under d_f > 0 the rearmost =
 // foremost = G_f, nothing is "too far behind", firing f finishes exactly the columns [G_(f-1), G_f) (cc.cpp:289-291), and no target
 // cell can be occupied: nothing was ever written ahead of the foremost laser, and the previous tenant of the ring slot, column
-// G_f - ring_cols, has been cleared when it lies below StreamState::clear_done. One block per stream walks the batch in chunks of
-// IP_CHUNK firings (IP_FPW per wavefront, prepared points kept in registers):
-//   A  wave per firing: rigid transform, range, azimuth, inclination of its returns; their common column c_f (or "not this shape")
-//   B  one wavefront: scan of d_f -> G_f; the first firing that breaks a condition (shape, d_f <= 0 or backwards, emission limit, ring
-//      slot not provably clear) ends the run
-//   D  wave per firing: the nine planes of the cells, the finishing firing of the columns it completes
-// and hands the rest of the batch (from the first firing that does not fit: an empty firing, two firings in one column, a multi-column
-// sensor, a stream that is not in steady state yet) to k_prep + k_insert2 through StreamState::cursor, with exactly the state the
-// serial kernel would have at that firing. grid = streams, block = 64 * IP_WAVES.
+// G_f - ring_cols, has been cleared when it lies below StreamState::clear_done. One block per stream:
+//   0  one lane per firing: the column c_f of its first valid return (one atan2f per firing)
+//   B  block scan of d_f -> G_f for the whole batch; the first firing that breaks a condition (empty firing, d_f <= 0 or backwards,
+//      emission limit, ring slot not provably clear) ends the run
+//   D  wave per firing, no barriers: rigid transform, range, azimuth, inclination of its returns, the nine planes of its cells, the
+//      finishing firing of the columns it completes. The one condition only this phase can see — a return in another column than
+//      the firing's first — is rare; the run then ends at that firing and whatever later firings have already written is taken back
+//      (their cells return to the cleared state, which is all the serial kernel looks at).
+// The rest of the batch (from the first firing that does not fit: a multi-column sensor, a stream that is not in steady state yet,
+// two firings in one column ...) goes to k_prep + k_insert2 through StreamState::cursor, with exactly the state the serial kernel
+// would have at that firing. grid = streams, block = 64 * IP_WAVES.
 // =====================================================================================================
-constexpr int IP_WAVES = 16, IP_FPW = 4, IP_CHUNK = IP_WAVES * IP_FPW;
-static_assert(IP_CHUNK == 64, "phase B is one wavefront wide");
+constexpr int IP_WAVES = 16, IP_MAXF = 4608;
 
 template<int RPL>
 __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
@@ -1085,9 +1086,10 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
-    __shared__ int s_c[IP_CHUNK];   // column-in-rotation of the chunk's firings, -1 = not the single-column shape
-    __shared__ int s_off[IP_CHUNK]; // G_f - (G before the chunk)
-    __shared__ int s_upto, s_cprev;
+    __shared__ int s_c[IP_MAXF];   // column-in-rotation of every firing (its first valid return), -1 = empty firing
+    __shared__ int s_off[IP_MAXF]; // G_f - prev_rearmost at entry
+    __shared__ int s_wsum[IP_WAVES];
+    __shared__ int s_upto, s_bad, s_carry;
 
     const long long prev_rear0 = st->prev_rearmost, prev_fore0 = st->prev_foremost, first_unf0 = st->first_unfinished;
     const long long ring_end0 = st->ring_end;
@@ -1124,8 +1126,12 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     }
     const bool steady = st->cursor == 0 && ring_start != -1 && first_unf0 > 0 && first_unf0 == prev_rear0 && prev_fore0 == prev_rear0 &&
                         st->reset_required == 0 && st->pre_seg_begin == 0 && clear_done >= 0;
+    const int nn = (int) (n < IP_MAXF ? n : IP_MAXF);
     if (tid == 0)
-        s_cprev = (int) (prev_rear0 % NC);
+    {
+        s_upto = nn;
+        s_carry = 0;
+    }
     __syncthreads(); // the cleared cells are ordered before everything this block writes from here on
     if (!steady)
     {
@@ -1140,133 +1146,156 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     const long long rot0 = prev_rear0 / NC;
     const int cir0 = (int) (prev_rear0 - rot0 * NC);
     const int lc0 = (int) (prev_rear0 % RC);
-    long long gsum = 0; // G before the current chunk, relative to prev_rear0
-    long long done = 0;
-    for (long long chunk0 = 0; chunk0 < n; chunk0 += IP_CHUNK)
+
+    // ---- 0: the column of every firing from its first valid return (prep_point's column arithmetic, nothing else of it)
+    for (int f = tid; f < nn; f += 64 * IP_WAVES)
     {
-        const int cn = (int) (n - chunk0 < IP_CHUNK ? n - chunk0 : IP_CHUNK);
-        // ---- A: prepare the returns of this wavefront's firings, find each firing's common column
-        PreppedPoint q[IP_FPW][RPL];
-#pragma unroll
-        for (int j = 0; j < IP_FPW; j++)
+        const size_t base = (fglob + (size_t) f) * R * 3;
+        int c = -1;
+        for (int row = 0; row < R; row++)
         {
-            const int t = wave + IP_WAVES * j;
-            if (t < cn) // wave-uniform
+            const float fx = xyz[base + (size_t) row * 3];
+            if (fx == fx)
             {
-                const size_t fi = fglob + (size_t) (chunk0 + t);
-                const double* T = poses + fi * 12;
-                unsigned long long mv = 0;
-                int c0 = 0;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                {
-                    const int row = k * 64 + lane;
-                    q[j][k].cir = PP_SKIP;
-                    if (row < R)
-                    {
-                        const size_t src = (fi * R + row) * 3;
-                        q[j][k] = prep_point(xyz[src], xyz[src + 1], xyz[src + 2], T, clockwise, g.az_width);
-                    }
-                    const unsigned long long m = __ballot(q[j][k].cir != PP_SKIP);
-                    if (mv == 0 && m != 0)
-                        c0 = __builtin_amdgcn_readlane(q[j][k].cir, (int) __ffsll((long long) m) - 1);
-                    mv |= m;
-                }
-                bool differs = false;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                    differs |= q[j][k].cir != PP_SKIP && q[j][k].cir != c0;
-                const bool shape = mv != 0 && !__any(differs) && c0 >= 0 && c0 < NC;
-                if (lane == 0)
-                    s_c[t] = shape ? c0 : -1;
+                const float fy = xyz[base + (size_t) row * 3 + 1];
+                const float az = ccm::atan2f_exact(fy, fx);
+                const float inc_az = clockwise ? -az + CC_PI_F : az + CC_PI_F;
+                c = f2i_x86(inc_az / g.az_width);
+                break;
             }
         }
-        __syncthreads();
-        // ---- B: column advance of every firing, its prefix sum, first firing that ends the run (one wavefront: lane = firing)
-        if (wave == 0)
-        {
-            const int c = lane < cn ? s_c[lane] : -1;
-            int cp = __shfl_up(c, 1, 64);
-            if (lane == 0)
-                cp = s_cprev;
-            const int diff = c - cp;
-            // strictly forward, also across the wrap (cc.cpp:165-175)
-            const bool ok = lane < cn && c >= 0 && cp >= 0 && ((diff > 0 && diff <= half) || diff < -half);
-            const int delta = ok ? (diff < -half ? diff + NC : diff) : 0;
-            int v = delta;
+        s_c[f] = (c >= 0 && c < NC) ? c : -1;
+    }
+    __syncthreads();
+    // ---- B: column advance of every firing, its prefix sum over the batch, first firing that ends the run
+    for (int base = 0; base < nn; base += 64 * IP_WAVES)
+    {
+        const int f = base + tid;
+        const int c = f < nn ? s_c[f] : -1;
+        const int cp = f == 0 ? cir0 : (f < nn ? s_c[f - 1] : -1);
+        const int diff = c - cp;
+        // strictly forward, also across the wrap (cc.cpp:165-175)
+        const bool ok = f < nn && c >= 0 && cp >= 0 && ((diff > 0 && diff <= half) || diff < -half);
+        const int delta = ok ? (diff < -half ? diff + NC : diff) : 0;
+        int v = delta;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1)
-            {
-                const int o = __shfl_up(v, d, 64);
-                if (lane >= d)
-                    v += o;
-            }
-            s_off[lane] = v;
-            const long long G = prev_rear0 + gsum + v;
+        for (int d = 1; d < 64; d <<= 1)
+        {
+            const int o = __shfl_up(v, d, 64);
+            if (lane >= d)
+                v += o;
+        }
+        if (lane == 63)
+            s_wsum[wave] = v;
+        __syncthreads();
+        int before = s_carry;
+        for (int w = 0; w < wave; w++)
+            before += s_wsum[w];
+        const int incl = before + v;
+        if (f < nn)
+        {
+            s_off[f] = incl;
+            const long long G = prev_rear0 + incl;
             const long long rear_before = G - delta;
             // a firing is only taken while the batch has emitted fewer than limit_columns columns before it (k_insert2's loop head), and
             // while the previous tenant of its ring slot is known to be cleared
-            const bool stop = !ok || rear_before - first_unf0 >= g.limit_columns || G - RC >= clear_done;
-            const unsigned long long mstop = __ballot(stop);
-            if (lane == 0)
-                s_upto = mstop ? (int) __ffsll((long long) mstop) - 1 : cn;
+            if (!ok || rear_before - first_unf0 >= g.limit_columns || G - RC >= clear_done)
+                atomicMin(&s_upto, f);
         }
         __syncthreads();
-        const int upto = s_upto < cn ? s_upto : cn;
-        // ---- D: the cells and the columns each firing finishes
+        if (tid == 64 * IP_WAVES - 1)
+            s_carry = incl;
+        __syncthreads();
+    }
+    const int upto = s_upto;
+    if (tid == 0)
+        s_bad = upto;
+    __syncthreads();
+    // ---- D: the cells and the columns each firing finishes; wavefronts run independently
+    for (int f = wave; f < upto; f += IP_WAVES)
+    {
+        if (f > lds_ld(&s_bad)) // some earlier firing left the shape: nothing behind it is wanted (wave-uniform)
+            break;
+        const size_t fi = fglob + (size_t) f;
+        const double* T = poses + fi * 12;
+        const int c0 = s_c[f];
+        PreppedPoint q[RPL];
+        bool differs = false;
 #pragma unroll
-        for (int j = 0; j < IP_FPW; j++)
+        for (int k = 0; k < RPL; k++)
         {
-            const int t = wave + IP_WAVES * j;
-            if (t < upto)
+            const int row = k * 64 + lane;
+            q[k].cir = PP_SKIP;
+            if (row < R)
             {
-                const long long f = chunk0 + t;
-                const long long rel = gsum + s_off[t];                        // G_f - prev_rear0
-                const long long rel_prev = gsum + (t > 0 ? s_off[t - 1] : 0); // G_(f-1) - prev_rear0
-                const long long G = prev_rear0 + rel;
-                const int lc = (int) (((long long) lc0 + rel) % RC);
-                const long long rot = rot0 + ((long long) cir0 + rel) / NC;
-                const double caz_base = CC_2PI_D * (double) rot;
-                const uint8_t* si = inten + (fglob + (size_t) f) * R;
+                const size_t src = (fi * R + row) * 3;
+                q[k] = prep_point(xyz[src], xyz[src + 1], xyz[src + 2], T, clockwise, g.az_width);
+            }
+            differs |= q[k].cir != PP_SKIP && q[k].cir != c0;
+        }
+        if (__any(differs))
+        {
+            if (lane == 0)
+                atomicMin(&s_bad, f);
+            break; // this wavefront's later firings lie behind it
+        }
+        const long long rel = s_off[f];                    // G_f - prev_rear0
+        const long long rel_prev = f > 0 ? s_off[f - 1] : 0; // G_(f-1) - prev_rear0
+        const long long G = prev_rear0 + rel;
+        const int lc = (int) ((unsigned) (lc0 + (int) rel) % (unsigned) RC);
+        const long long rot = rot0 + (long long) ((unsigned) (cir0 + (int) rel) / (unsigned) NC);
+        const double caz_base = CC_2PI_D * (double) rot;
+        const uint8_t* si = inten + fi * R;
 #pragma unroll
-                for (int k = 0; k < RPL; k++)
-                {
-                    const int row = k * 64 + lane;
-                    if (q[j][k].cir != PP_SKIP)
-                    {
-                        const size_t ci = (size_t) lc * R + row;
-                        p.x[ci] = q[j][k].x;
-                        p.y[ci] = q[j][k].y;
-                        p.z[ci] = q[j][k].z;
-                        p.inten[ci] = si[row];
-                        p.src[ci] = seq0 + f;
-                        p.dist[ci] = q[j][k].dist;
-                        p.incl[ci] = q[j][k].incl;
-                        p.caz[ci] = caz_base + (double) q[j][k].incaz;
-                        p.gcol[ci] = G;
-                    }
-                }
-                // columns [G_(f-1), G_f) are finished by this firing and carry its pose (cc.cpp:289-291)
-                const int cnt = (int) (rel - rel_prev);
-                for (int jj = lane; jj < cnt; jj += 64)
-                    p.trig[(int) (((long long) lc0 + rel_prev + jj) % RC)] = (int) f;
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (q[k].cir != PP_SKIP)
+            {
+                const size_t ci = (size_t) lc * R + row;
+                p.x[ci] = q[k].x;
+                p.y[ci] = q[k].y;
+                p.z[ci] = q[k].z;
+                p.inten[ci] = si[row];
+                p.src[ci] = seq0 + f;
+                p.dist[ci] = q[k].dist;
+                p.incl[ci] = q[k].incl;
+                p.caz[ci] = caz_base + (double) q[k].incaz;
+                p.gcol[ci] = G;
             }
         }
-        if (upto < cn)
+        // columns [G_(f-1), G_f) are finished by this firing and carry its pose (cc.cpp:289-291)
+        const int cnt = (int) (rel - rel_prev);
+        for (int jj = lane; jj < cnt; jj += 64)
+            p.trig[(int) ((unsigned) (lc0 + (int) rel_prev + jj) % (unsigned) RC)] = f;
+    }
+    __syncthreads();
+    const int done = s_bad < upto ? s_bad : upto;
+    if (done < upto)
+    {
+        // take back what firings behind the offending one have written: their cells return to the cleared state (clearColumns'
+        // three planes); cells they never wrote are in that state already
+        for (int f = done + 1 + wave; f < upto; f += IP_WAVES)
         {
-            done = chunk0 + upto;
-            if (upto > 0)
-                gsum += s_off[upto - 1];
-            break;
+            const size_t fi = fglob + (size_t) f;
+            const int lc = (int) ((unsigned) (lc0 + s_off[f]) % (unsigned) RC);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const float fx = xyz[(fi * R + row) * 3];
+                    if (fx == fx)
+                    {
+                        const size_t ci = (size_t) lc * R + row;
+                        p.dist[ci] = __builtin_nanf("");
+                        p.incl[ci] = __builtin_nanf("");
+                        p.gcol[ci] = -1;
+                    }
+                }
+            }
         }
-        done = chunk0 + cn;
-        const int adv = s_off[cn - 1];
-        const int lastc = s_c[cn - 1];
-        __syncthreads();
-        gsum += adv;
-        if (tid == 0)
-            s_cprev = lastc;
-        // (s_cprev is read by wave 0 after the next chunk's first barrier)
     }
     if (tid == 0)
     {
@@ -1275,7 +1304,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
         st->dbg[7] += 1;
         if (done > 0)
         {
-            const long long G = prev_rear0 + gsum;
+            const long long G = prev_rear0 + s_off[done - 1];
             st->prev_rearmost = G;
             st->prev_foremost = G;
             st->first_unfinished = G;
@@ -1295,7 +1324,10 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
 // of each chunk, the chunk carries are combined through LDS, phase 2 re-walks the chunk and writes the table plane.
 // grid = streams, block = 64 * TABLE_WAVES.
 // =====================================================================================================
-constexpr int TABLE_WAVES = 8;
+#ifndef CC_TABLE_WAVES
+#define CC_TABLE_WAVES 8
+#endif
+constexpr int TABLE_WAVES = CC_TABLE_WAVES;
 
 template<int RPL>
 __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
