@@ -127,6 +127,8 @@ def main():
     eng.record_events(False)
     if os.environ.get("CC_SUB_BATCH"):
         eng.set_option("sub_batch", int(os.environ["CC_SUB_BATCH"]))
+    if os.environ.get("CC_TABLE_EARLY"):
+        eng.set_option("table_on_insert_chain", int(os.environ["CC_TABLE_EARLY"]))
     if os.environ.get("CC_PIPELINE"):
         eng.set_option("pipeline", int(os.environ["CC_PIPELINE"]))
     if os.environ.get("CC_PUBLISH_OFF_CHAIN"):

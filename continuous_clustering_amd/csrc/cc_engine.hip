@@ -45,6 +45,7 @@ struct cc_engine
     bool pipelined{false};        // last submitted batch used all three streams
     bool allow_pipeline{true};    // option "pipeline"
     bool publish_off_chain{true}; // option "publish_off_chain"
+    bool table_on_insert_chain{true}; // option "table_on_insert_chain"
     bool parallel_insert{true};   // option "parallel_insert": k_insert_par takes the single-column-firing head of every batch
     // low-latency path of cc_engine_add_firings for small calls: one captured hipGraph per (stream, n), pinned staging
     struct SmallGraph
@@ -298,7 +299,8 @@ int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const do
         return rcp;
     const Planes P = planes_with_prep(e, buf);
     const size_t per_stream = (size_t) n * e->g.num_rows;
-    hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((per_stream + 255) / 256), (unsigned) count), dim3(256), 0, sp, e->g, e->cfg, P,
+    hipLaunchKernelGGL(cck::k_prep, dim3((unsigned) ((per_stream + cck::PREP_POINTS_PER_BLOCK - 1) / cck::PREP_POINTS_PER_BLOCK), (unsigned) count), dim3(256), 0, sp,
+                       e->g, e->cfg, P,
                        d_xyz, d_pose, (long long) n, (long long) n_total, (long long) f0, skip_inserted ? (const StreamState*) e->d_states : nullptr,
                        first_stream);
     return CC_OK;
@@ -372,6 +374,17 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     CC_MARK(si); // ev2: insert
     CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
+    // k_table only needs what the insertion of this batch wrote. It is a latency-bound kernel (8 wavefronts per stream) that takes 0.8 ms
+    // when it shares the GPU with the throughput kernels — on the segmentation chain, which is the longest of the three, that is a
+    // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
+    const bool table_early = si != sb && e->table_on_insert_chain;
+    if (table_early)
+    {
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, e->P, e->d_states, first_stream, slot);
+        else
+            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, e->P, e->d_states, first_stream, slot);
+    }
     if (si != sb)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
@@ -379,10 +392,13 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     // ---- table + segmentation + window-scan chain ------------------------------------------------------------
     CC_MARK(sb); // ev3: start of the second chain
-    if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
-    else
-        hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
+    if (!table_early)
+    {
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
+        else
+            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
+    }
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0);
@@ -1393,6 +1409,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->allow_graphs = value != 0;
     else if (n == "sub_batch")
         e->sub_batch = value < 0 ? 0 : value;
+    else if (n == "table_on_insert_chain")
+        e->table_on_insert_chain = value != 0;
     else if (n == "publish_off_chain")
         e->publish_off_chain = value != 0;
     else if (n == "parallel_insert")

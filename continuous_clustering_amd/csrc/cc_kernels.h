@@ -308,33 +308,40 @@ __device__ __forceinline__ PreppedPoint prep_point(const float fx, const float f
     return o;
 }
 
-// grid = (points of one stream's sub-batch / 256, streams). The caller's buffers hold n_total firings per stream; this launch
+// grid = (points of one stream's sub-batch / PREP_POINTS_PER_BLOCK, streams). The caller's buffers hold n_total firings per stream; this launch
 // prepares firings [f0, f0 + m) of every stream into the compact staging planes (index [stream][m][row]). Firings that k_insert_par
 // has already inserted (below the stream's cursor) are skipped: nobody reads their staging cells.
+constexpr int PREP_POINTS_PER_BLOCK = 4096; // 16 rounds of 256 threads: few, fat blocks — when k_insert_par has taken the whole batch every
+                                             // block leaves after one test, and 9 k blocks do that faster than 140 k
 __global__ __launch_bounds__(256) void k_prep(Geometry g, cc_config cfg, Planes P, const float* __restrict__ xyz,
                                              const double* __restrict__ poses, long long m, long long n_total, long long f0,
                                              const StreamState* __restrict__ states, int first_stream)
 {
     const int R = g.num_rows;
-    const long long local = (long long) blockIdx.x * 256 + threadIdx.x; // [firing within the sub-batch][row]
-    if (local >= m * R)
-        return;
     const long long sl = blockIdx.y;
-    if (states && local / R < states[first_stream + sl].cursor)
-        return;
-    const long long src = (sl * n_total + f0) * R + local; // index into the caller's [stream][n_total][row] buffers
-    const long long firing = src / R;                      // [stream][firing] flattened
-    const long long i = sl * m * R + local;                // index into the staging planes
-    const PreppedPoint q = prep_point(xyz[src * 3 + 0], xyz[src * 3 + 1], xyz[src * 3 + 2], poses + firing * 12, cfg.sensor_is_clockwise != 0, g.az_width);
-    P.pp_cir[i] = q.cir;
-    if (q.cir == PP_SKIP)
-        return;
-    P.pp_x[i] = q.x;
-    P.pp_y[i] = q.y;
-    P.pp_z[i] = q.z;
-    P.pp_dist[i] = q.dist;
-    P.pp_incl[i] = q.incl;
-    P.pp_incaz[i] = q.incaz;
+    const long long cursor = states ? states[first_stream + sl].cursor : 0;
+    const long long block_first = (long long) blockIdx.x * PREP_POINTS_PER_BLOCK;
+    const long long total = m * R;
+    if (block_first >= total || (block_first + PREP_POINTS_PER_BLOCK - 1) / R < cursor)
+        return; // every firing of this block has been inserted already
+    for (long long local = block_first + threadIdx.x; local < block_first + PREP_POINTS_PER_BLOCK && local < total; local += 256)
+    {
+        if (local / R < cursor)
+            continue;
+        const long long src = (sl * n_total + f0) * R + local; // index into the caller's [stream][n_total][row] buffers
+        const long long firing = src / R;                      // [stream][firing] flattened
+        const long long i = sl * m * R + local;                // index into the staging planes
+        const PreppedPoint q = prep_point(xyz[src * 3 + 0], xyz[src * 3 + 1], xyz[src * 3 + 2], poses + firing * 12, cfg.sensor_is_clockwise != 0, g.az_width);
+        P.pp_cir[i] = q.cir;
+        if (q.cir == PP_SKIP)
+            continue;
+        P.pp_x[i] = q.x;
+        P.pp_y[i] = q.y;
+        P.pp_z[i] = q.z;
+        P.pp_dist[i] = q.dist;
+        P.pp_incl[i] = q.incl;
+        P.pp_incaz[i] = q.incaz;
+    }
 }
 
 // =====================================================================================================
@@ -1335,6 +1342,9 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     StreamState* st = &states[s];
+#ifdef CC_CHAIN2_PRIO
+    __builtin_amdgcn_s_setprio(CC_CHAIN2_PRIO);
+#endif
     if (threadIdx.x == 0)
         st->batch[slot].mode = st->assoc_mode; // one decision per batch and stream for every kernel behind this one (any value the
                                                // association chain of the previous batch is just writing is fine)
