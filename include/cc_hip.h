@@ -258,7 +258,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never
  * use the captured-hipGraph low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in
  * production), "parallel_insert" (1 (default): the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a
- * block-parallel kernel, the serial insertion kernel continues behind it; 0: serial kernel only), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
+ * block-parallel kernel, the serial insertion kernel continues behind it; 0: serial kernel only), "publish_off_chain" (1 (default): in the pipelined mode k_publish runs on a stream of its own instead of at the end of
+ * the association chain), "table_on_insert_chain" (1 (default): in the pipelined mode k_table runs at the end of the insertion chain instead of
+ * at the head of the segmentation chain), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
  * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
