@@ -1470,7 +1470,10 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
 
 // ---- k_seg_pre: everything of the segmentation that does not depend on the rows below. One wavefront per column,
 // lanes = rows (coalesced); blocks stride over the columns of the batch. grid = (SEGPRE_BLOCKS, streams), block = 64.
-constexpr int SEGPRE_BLOCKS = 256;
+#ifndef CC_SEGPRE_BLOCKS
+#define CC_SEGPRE_BLOCKS 256
+#endif
+constexpr int SEGPRE_BLOCKS = CC_SEGPRE_BLOCKS;
 
 template<int RPL>
 __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
@@ -2597,7 +2600,10 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
 // dimension: workgroups are dealt to the 8 XCDs round-robin by linear id, so with a multiple of 8 streams all blocks of one stream
 // run on one XCD and share its L2 (every candidate column is read by the scans of several later columns).
 // =====================================================================================================
-constexpr int SCAN_BLOCKS = 256;
+#ifndef CC_SCAN_BLOCKS
+#define CC_SCAN_BLOCKS 256
+#endif
+constexpr int SCAN_BLOCKS = CC_SCAN_BLOCKS;
 
 template<int RPL>
 __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
