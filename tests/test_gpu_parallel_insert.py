@@ -69,3 +69,32 @@ def test_counters_show_the_parallel_kernel_took_the_steady_part(oracle_lib):
     out = np.zeros(16, dtype=np.uint64)
     L.cc_engine_debug_counters(e.h, 0, out.ctypes.data)
     assert out[7] == 2 and out[6] == 2 * 2200      # not entered in the first call (ring not started), everything afterwards
+
+
+def test_device_call_longer_than_the_parallel_kernel_takes(oracle_lib):
+    """One cc_engine_add_firings_device call of 5000 firings per stream: k_insert_par considers at most IP_MAXF = 4608 of them, the serial
+    kernel the rest; two streams, events off (pipelined mode). State and the columns still in the ring must equal the oracle's."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    cfg = capi.Config.kitti()
+    N1, N2 = 2200, 5000
+    streams = [synth.make_stream(N1 + N2, seed=31 + s, motion=synth.Motion.translate()) for s in range(2)]
+    e = Engine(cfg, 64, 2)
+    e.record_events(False)
+    e.set_option("limit_columns", 8000)   # one pass per call: a continuation pass would clear what the first pass published (cc_hip.h)
+    for lo, hi in ((0, N1), (N1, N1 + N2)):
+        xyz = torch.from_numpy(np.stack([st.xyz[lo:hi] for st in streams])).cuda()
+        inten = torch.from_numpy(np.stack([st.intensity[lo:hi] for st in streams])).cuda()
+        poses = torch.from_numpy(np.stack([st.poses[lo:hi] for st in streams])).cuda()
+        torch.cuda.synchronize()
+        e.add_firings_device(hi - lo, xyz.data_ptr(), inten.data_ptr(), poses.data_ptr())
+        assert e.sync() == 0, e.last_error()
+    for s in range(2):
+        o = Oracle(cfg, 64)
+        assert o.add_firings(streams[s].xyz, streams[s].intensity, streams[s].poses) == 0
+        so, se = o.state(), e.state(s)
+        for k in util.STATE_FIELDS:
+            assert so[k] == se[k], (s, k)
+        hi = se["first_unpublished_global_column_index"] - 1
+        util.compare_columns(o.read_published(hi - 3000, hi), e.read_columns(hi - 3000, hi, stream=s), hi - 3000)
