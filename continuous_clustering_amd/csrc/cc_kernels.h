@@ -2698,12 +2698,15 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                         const int cont = (run && !(ccm::absf(ow - me.w) > mad)) ? 1 : 0;
                         const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
                         const int acc = (cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2) ? 1 : 0; // x = NaN: ignored / empty
-                        const unsigned long long cand = (unsigned long long) ((sb << 8) | (orow & 0xff));
-                        const int as_link = (acc && rooted && nlinks[0] < LINK_SLOTS) ? 1 : 0;
-                        overflow |= (acc && rooted && nlinks[0] >= LINK_SLOTS) ? 1 : 0;
-                        parent[0] = (acc && !rooted) ? (int) cand : parent[0];
-                        packed[0] |= as_link ? cand << (16 * nlinks[0]) : 0ull;
-                        nlinks[0] += as_link;
+                        const int cand = (sb << 8) | (orow & 0xff);
+                        parent[0] = (acc && !rooted) ? cand : parent[0];
+                        if (__any(acc && rooted)) // a second accepted candidate is a link (rare next to the visits: wave-uniform branch)
+                        {
+                            const int as_link = (acc && rooted && nlinks[0] < LINK_SLOTS) ? 1 : 0;
+                            overflow |= (acc && rooted && nlinks[0] >= LINK_SLOTS) ? 1 : 0;
+                            packed[0] |= as_link ? (unsigned long long) cand << (16 * nlinks[0]) : 0ull;
+                            nlinks[0] += as_link;
+                        }
                         rooted |= acc;
                         const int stop = (rooted && c.stop_enabled && d >= c.stop_min_steps) ? 1 : 0;
                         d++;
