@@ -84,6 +84,7 @@ struct StreamState
     int32_t n_events;
     int64_t error_a;
     int64_t error_b;
+    int64_t overrun_col; // lowest column found stale by the segmentation (CC_ERR_RING_OVERRUN), INT64_MAX = none
 };
 
 // All planes of an engine. Index of a cell inside a plane: stream * cells_per_stream + lcol * num_rows + row.

@@ -162,6 +162,16 @@ int free_all(cc_engine* e)
     e->view_bytes = 0;
     e->prep_capacity = 0;
     e->d_small = nullptr;
+    // the pinned staging of the small-call path is sized for the row count it was created with
+    if (e->h_small)
+    {
+        (void) hipHostFree(e->h_small);
+        (void) hipHostFree(e->h_small_state);
+        (void) hipHostFree(e->h_small_events);
+        e->h_small = nullptr;
+        e->h_small_state = nullptr;
+        e->h_small_events = nullptr;
+    }
     return CC_OK;
 }
 
@@ -230,6 +240,7 @@ int reset_state(cc_engine* e, bool keep_table)
         st.min_required = 0;
         st.finish_lower_bound = std::numeric_limits<double>::max();
         st.last_round_min_az = -1.0; // Point::visited_at_continuous_azimuth_angle{-1.} cc.hpp:158
+        st.overrun_col = std::numeric_limits<int64_t>::max();
         for (auto& d : st.batch)
             d.seg_begin = d.seg_end = d.acp_next = d.pub_begin = d.pub_end = -1, d.mode = 0;
         st.assoc_mode = e->cfg.max_steps_in_row > WIN_COLS - 2 ? 1 : 0;
@@ -679,6 +690,41 @@ int collect_events(cc_engine* e, int first_stream, int count)
     return CC_OK;
 }
 
+// CC_ERR_RING_OVERRUN: several columns of a batch can be stale and they are segmented in parallel; the reference throws at the lowest
+// one, at the first stale cell of its bottom-up row walk (cc.cpp:314-345). The kernel recorded the lowest column; read its cells.
+void fixup_overrun(cc_engine* e, int stream, StreamState& st)
+{
+    if (st.error != CC_ERR_RING_OVERRUN || st.overrun_col == std::numeric_limits<int64_t>::max())
+        return;
+    const int R = e->g.num_rows;
+    std::vector<int64_t> col((size_t) R);
+    const size_t off = (size_t) stream * (size_t) e->g.cells + (size_t) (st.overrun_col % e->g.ring_cols) * R;
+    if (hipMemcpy(col.data(), e->P.gcol + off, (size_t) R * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+        return;
+    for (int row = R - 1; row >= 0; row--)
+        if (col[(size_t) row] != st.overrun_col && col[(size_t) row] != -1)
+        {
+            st.error_a = col[(size_t) row];
+            st.error_b = st.overrun_col;
+            return;
+        }
+}
+
+// Text of a kernel-side error; CC_ERR_RING_OVERRUN carries the reference's wording and numbers (cc.cpp:337-342: stale global column
+// index found in the cell, column being segmented, ring size).
+void set_kernel_error(cc_engine* e, int stream, StreamState& st)
+{
+    fixup_overrun(e, stream, st);
+    char buf[320];
+    if (st.error == CC_ERR_RING_OVERRUN)
+        snprintf(buf, sizeof(buf), "stream %d: This column is not cleared (ring buffer full or written after clearing): %lld, %lld, %d", stream,
+                 (long long) st.error_a, (long long) st.error_b, e->g.ring_cols);
+    else
+        snprintf(buf, sizeof(buf), "stream %d: kernel-side error %d (%lld, %lld)", stream, st.error, (long long) st.error_a,
+                 (long long) st.error_b);
+    e->error = buf;
+}
+
 int first_stream_error(cc_engine* e, int first_stream, int count)
 {
     std::vector<StreamState> st(count);
@@ -687,10 +733,7 @@ int first_stream_error(cc_engine* e, int first_stream, int count)
     for (int i = 0; i < count; i++)
         if (st[i].error)
         {
-            char buf[256];
-            snprintf(buf, sizeof(buf), "stream %d: kernel-side error %d (%lld, %lld)", first_stream + i, st[i].error,
-                     (long long) st[i].error_a, (long long) st[i].error_b);
-            e->error = buf;
+            set_kernel_error(e, first_stream + i, st[i]);
             return st[i].error;
         }
     return CC_OK;
@@ -789,7 +832,7 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         int rc = finish_batch(e);
         return rc ? rc : first_stream_error(e, stream, 1);
     }
-    const StreamState& st = *e->h_small_state;
+    StreamState& st = *e->h_small_state;
     if (e->g.record_events && st.n_events > 0)
     {
         auto& dst = e->pending_events[stream];
@@ -805,10 +848,7 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     }
     if (st.error)
     {
-        char buf[256];
-        snprintf(buf, sizeof(buf), "stream %d: kernel-side error %d (%lld, %lld)", stream, st.error, (long long) st.error_a,
-                 (long long) st.error_b);
-        e->error = buf;
+        set_kernel_error(e, stream, st);
         return st.error;
     }
     return CC_OK;
@@ -953,13 +993,7 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamSynchronize(e->stream6);
     (void) hipStreamSynchronize(e->stream5);
     destroy_small_graphs(e);
-    if (e->h_small)
-    {
-        (void) hipHostFree(e->h_small);
-        (void) hipHostFree(e->h_small_state);
-        (void) hipHostFree(e->h_small_events);
-    }
-    free_all(e);
+    free_all(e); // also the pinned small-call staging
     for (int i = 0; i < 4; i++)
     {
         (void) hipEventDestroy(e->ev_ins[i]);
@@ -1226,6 +1260,7 @@ int cc_engine_stream_state(cc_engine* e, int stream, cc_stream_state* out)
         return rc;
     StreamState st;
     CC_HIP_CHECK(e, hipMemcpy(&st, e->d_states + stream, sizeof(st), hipMemcpyDeviceToHost));
+    fixup_overrun(e, stream, st);
     memset(out, 0, sizeof(*out));
     out->num_rows = e->g.num_rows;
     out->num_columns = e->g.num_columns;

@@ -1526,6 +1526,8 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
 
         float dist[RPL], incl[RPL], tabv[RPL];
         bool isnan_[RPL], empty_cell[RPL], overrun = false;
+        int overrun_row = -1;        // the reference walks the rows bottom-up and reports the first stale cell it meets (cc.cpp:314-345)
+        long long overrun_gcol = -1;
         double min_az = 1.7976931348623157e308;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
@@ -1539,7 +1541,11 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                 const size_t ci = base + row;
                 const long long cg = p.gcol[ci];
                 if (cg != gc && cg != -1)
+                {
                     overrun = true; // cc.cpp:320-345
+                    overrun_row = row;
+                    overrun_gcol = cg;
+                }
                 empty_cell[k] = cg != gc;
                 dist[k] = p.dist[ci];
                 incl[k] = p.incl[ci];
@@ -1551,8 +1557,14 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         }
         if (__any(overrun))
         {
-            if (lane == 0)
-                raise_error(st, CC_ERR_RING_OVERRUN, -2, gc);
+            // Columns are segmented in parallel here; the reference meets the lowest stale column first. Keep the minimum; the host
+            // fills in error_a / error_b from that column's cells (cc_engine.hip: fixup_overrun).
+            const int worst = -wave_min_i32(-overrun_row); // highest stale row = the first one of the reference's bottom-up walk
+            if (overrun_row == worst)
+            {
+                atomicMin((unsigned long long*) &st->overrun_col, (unsigned long long) gc);
+                raise_error(st, CC_ERR_RING_OVERRUN, overrun_gcol, gc);
+            }
             continue;
         }
         // NaN cells: inclination of the cell below (already supplemented) + the per-row step (cc.cpp:364-369); runs of NaN

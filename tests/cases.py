@@ -94,6 +94,21 @@ def build_case(name: str):
     if name == "s32_small_sensor":
         sen = SensorModel(num_rows=32, num_columns=512, incl_top_deg=10.0, incl_bottom_deg=-30.0)
         return synth.make_stream(512 * 3, seed=20, sensor=sen), _vls(512, max_distance=0.5), None
+    # ---- ring-wrap cases: >= 12 rotations through the 10-rotation ring (cc.cpp:17), small columns-per-rotation so the oracle stays fast
+    if name == "w_s64_240x13":
+        sc = SceneModel(n_objects=40, object_range=(4.0, 30.0))
+        return synth.make_stream(240 * 13, seed=41, sensor=_s64(240), scene=sc, motion=Motion.translate()), _kitti(240), None
+    if name == "w_s64_360x12_turn":
+        return synth.make_stream(360 * 12 + 100, seed=42, sensor=_s64(360), motion=Motion.turn(8.0, 0.5)), _kitti(360), ROBOT_TF_TILTED
+    if name == "w_s64_ring_wall_240x12":
+        # unbroken wall ring + objects: forced finishes (cluster wider than a rotation) on every rotation, across the ring wrap
+        sc = SceneModel(n_objects=25, wall_radius=14.0, wall_gaps_deg=(), object_range=(3.0, 11.0))
+        return synth.make_stream(240 * 12 + 60, seed=43, sensor=_s64(240), scene=sc, motion=Motion.translate(3.0)), _kitti(240), None
+    if name == "w_s128_offsets_340x12":
+        return synth.make_stream(340 * 12 + 80, seed=44, sensor=_s128(340), start_column=12, motion=Motion.translate()), _vls(340), None
+    if name == "w_s32_256x12":
+        sen = SensorModel(num_rows=32, num_columns=256, incl_top_deg=10.0, incl_bottom_deg=-30.0)
+        return synth.make_stream(256 * 12 + 40, seed=45, sensor=sen, motion=Motion.translate()), _vls(256, max_distance=0.5), None
     # ---- small variants kept as committed golden fixtures -------------------------------------------------------
     if name == "g_s64_translate":
         return synth.make_stream(800, seed=31, sensor=_s64(360), motion=Motion.translate()), _kitti(360), None
@@ -114,6 +129,8 @@ ALL_CASES = ["s64_static", "s64_translate", "s64_turn", "s64_full_2200", "s64_fo
              "s64_fog_and_ego", "s64_counterclockwise", "s64_every_2nd_column", "s64_no_early_stop", "s64_min_steps_3",
              "s64_wide_window_global_kernel", "s64_dropouts", "s64_no_supplement_no_incl_ignore", "s64_robot_tf_tilted", "s128_offsets",
              "s128_no_offsets_translate", "s128_full_1700", "s32_small_sensor"]
+
+RING_WRAP_CASES = ["w_s64_240x13", "w_s64_360x12_turn", "w_s64_ring_wall_240x12", "w_s128_offsets_340x12", "w_s32_256x12"]
 
 # cases stored as golden fixtures under tests/golden/ (inputs + expected outputs)
 GOLDEN_CASES = ["g_s64_translate", "g_s64_forced_finish_ring", "g_s128_offsets", "g_s64_fog_and_ego"]
