@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
     ("w_s64_240x13", [97]),
     ("w_s64_240x13", [1]),
     ("w_s64_360x12_turn", [360]),
-    ("w_s64_360x12_turn", [1000, 7, 333]),
+    ("w_s64_360x12_turn", [700, 7, 333]),
     ("w_s64_ring_wall_240x12", [97]),
     ("w_s128_offsets_340x12", [340]),
     ("w_s128_offsets_340x12", [97]),
@@ -81,12 +81,13 @@ def test_ring_wrap_pipelined_device_path(pipeline, sub_batch, F, oracle_lib):
     e.record_events(False)
     e.set_option("pipeline", pipeline)
     e.set_option("sub_batch", sub_batch)
-    xyz = torch.from_numpy(np.stack([st.xyz for st in streams])).cuda()
-    inten = torch.from_numpy(np.stack([st.intensity for st in streams])).cuda()
-    poses = torch.from_numpy(np.stack([st.poses for st in streams])).cuda()
+    # batch-major device buffers that stay alive until the engine has consumed them (the calls are asynchronous)
+    xyz = torch.from_numpy(np.stack([st.xyz[:NB * F].reshape(NB, F, 64, 3) for st in streams], axis=1)).cuda()
+    inten = torch.from_numpy(np.stack([st.intensity[:NB * F].reshape(NB, F, 64) for st in streams], axis=1)).cuda()
+    poses = torch.from_numpy(np.stack([st.poses[:NB * F].reshape(NB, F, 12) for st in streams], axis=1)).cuda()
+    torch.cuda.synchronize()
     for b in range(NB):
-        e.add_firings_device(F, xyz[:, b * F:(b + 1) * F].contiguous(), inten[:, b * F:(b + 1) * F].contiguous(),
-                             poses[:, b * F:(b + 1) * F].contiguous())
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
     assert e.sync() == 0, e.last_error()
     for s in range(S):
         o = Oracle(cfg, 64)
