@@ -10,13 +10,20 @@ One *step* = one pass of the hot path (insertion -> ground segmentation -> assoc
 finished-cluster check -> publish) over one batch = one rotation (2200 firings) of every stream. Inputs are
 generated directly in HBM before the timed region. value = published range-image cells per second (NaN cells
 included) over all GPUs, in Mpoints/s. Streams never interact, so ranks share nothing on the data path
-(weak scaling: 256 streams per GPU); the only collective is the gather of per-rank result counts at the end.
+(weak scaling: 256 streams per GPU); the only collective is the gather of per-rank result counts at the end
+(RCCL when launched under torch.distributed.run, also at world size 1: `rccl_world` in the JSON line).
 
 The JSON line also carries
-  roofline      dominant kernel vs the 8 TB/s HBM roof: algorithmic bytes per launch (19.5 B per cell at 64 rows,
-                SURVEY 8d) / its average duration measured with HIP events on the engine's stream
-  cpu_baseline  the CPU oracle (oracle/, a restatement of the reference's single-threaded path) timed on this box's
-                host cores on a bounded sample of the same workload: N independent single-threaded instances (mode C)
+  roofline          dominant kernel vs the 8 TB/s HBM roof: algorithmic bytes per launch (19.5 B per cell at 64 rows,
+                    SURVEY 8d) / its average duration measured with HIP events on the engine's stream
+  verified_streams  after the timed region (outside it) the whole input of a few of the 256 streams is replayed through the
+                    CPU oracle; stream state and the last 1500 published columns must be bit-equal or the bench fails
+  s128              the same measurement for BASELINE.json configs[3] (128 rows x 1700 columns, VLS-128 firing shape with
+                    per-laser azimuth offsets, library defaults), fewer steps; the headline stays S64
+  cpu_baseline      the CPU oracle (oracle/, a restatement of the reference's single-threaded path) timed on this box's
+                    host cores: BASELINE.md mode C = N independent single-threaded instances, one PROCESS each, pinned to
+                    distinct physical cores, oracle constructed inside the pinned worker, >= 20 rotations per instance,
+                    N swept over {1, 16, 64, all physical cores}; mode A = per-call addFiring latency p50/p99 on one core
 """
 from __future__ import annotations
 
@@ -24,7 +31,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -33,6 +39,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+STATE_FIELDS = ("reset_required", "ring_buffer_start_global_column_index", "ring_buffer_end_global_column_index",
+                "first_unfinished_global_column_index", "first_unpublished_global_column_index", "cluster_counter",
+                "firings_consumed", "cells_published", "clusters_finished", "n_unfinished_trees")
 
 
 def parse():
@@ -45,7 +55,11 @@ def parse():
     ap.add_argument("--sensor", default="s64", choices=["s64", "s128"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-s128", action="store_true")
+    ap.add_argument("--verify-streams", type=int, default=3)
+    ap.add_argument("--cpu-procs", type=int, default=0, help="largest instance count of the CPU sweep (0 = all physical cores)")
+    ap.add_argument("--cpu-rotations", type=int, default=20)
     return ap.parse_args()
 
 
@@ -65,34 +79,274 @@ def gen_inputs(torch, dev, sensor, n_streams, n_firings, n_batches, seed0):
     return xyz, inten, poses
 
 
-def cpu_baseline(cfg, sensor, xyz, inten, poses, n_threads, repeats):
-    """Mode C of BASELINE.md 3: n_threads independent single-threaded oracle instances, one stream each, every instance
-    replaying its sample `repeats` times from a fresh reset (only the addFiring loop is timed, like kitti_demo.cpp:421-424)."""
-    from oracle.pyoracle import Oracle, IDENTITY_TF
-    n_threads = max(1, n_threads)
-    R = sensor.num_rows
-    oracles = [Oracle(cfg, R, record=False) for _ in range(n_threads)]
-    times = [0.0] * n_threads
-    cells = [0] * n_threads
+# ---------------------------------------------------------------------------------------------------------------------------
+# verification against the oracle (outside the timed region)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _bits_equal(a, b):
+    if a.dtype.kind == "f":
+        an, bn = np.isnan(a), np.isnan(b)
+        if not np.array_equal(an, bn):
+            return False
+        it = np.uint32 if a.dtype == np.float32 else np.uint64
+        return np.array_equal(a[~an].view(it), b[~bn].view(it))
+    return np.array_equal(a, b)
 
-    def work(i):
-        for rep in range(repeats):
-            if rep:
-                oracles[i].reset()
-                oracles[i].set_robot_from_sensor(IDENTITY_TF)
-            times[i] += oracles[i].time_firings(xyz[i], inten[i], poses[i])
-            cells[i] += oracles[i].state()["cells_published"]
 
-    th = [threading.Thread(target=work, args=(i,)) for i in range(n_threads)]
+def verify_against_oracle(eng, cfg, R, xyz, inten, poses, which, tail_cols=1500):
+    """Replay the complete input of the streams `which` through the CPU oracle and require the engine's stream state and the last
+    `tail_cols` published columns (every field of the column view: geometry bit patterns, labels, ignore flags, tree roots, raw
+    cluster ids) to be equal. Raises SystemExit on any difference: a fast run with different results is not a result."""
+    from oracle.pyoracle import Oracle
+    nb, _, F = xyz.shape[0], xyz.shape[1], xyz.shape[2]
     t0 = time.perf_counter()
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    wall = time.perf_counter() - t0
-    single = cells[0] / times[0] if times[0] > 0 else 0.0
-    return {"value": sum(cells) / max(times) / 1e6, "wall_s": wall, "single_core": single / 1e6, "cells": sum(cells),
-            "cpu_seconds": sum(times)}
+    for s in which:
+        hx = xyz[:, s].reshape(nb * F, R, 3).cpu().numpy()
+        hi = inten[:, s].reshape(nb * F, R).cpu().numpy()
+        hp = poses[:, s].reshape(nb * F, 12).cpu().numpy()
+        o = Oracle(cfg, R, record=True)
+        o.keep_published_tail(tail_cols + 256)
+        rc = o.add_firings(hx, hi, hp)
+        if rc != 0:
+            raise SystemExit(f"verify: oracle rc {rc} on stream {s}: {o.last_error()}")
+        so, se = o.state(), eng.state(s)
+        for k in STATE_FIELDS:
+            if so[k] != se[k]:
+                raise SystemExit(f"verify: stream {s} state.{k}: oracle {so[k]} engine {se[k]}")
+        hi_col = se["first_unpublished_global_column_index"] - 1
+        lo_col = max(hi_col - tail_cols + 1, se["ring_buffer_start_global_column_index"], o.published_range()[0])
+        ao, ae = o.read_published(lo_col, hi_col), eng.read_columns(lo_col, hi_col, stream=s)
+        for f in ao:
+            if not _bits_equal(ao[f], ae[f]):
+                raise SystemExit(f"verify: stream {s} columns [{lo_col}, {hi_col}] field {f} differs from the oracle")
+    return {"streams": [int(s) for s in which], "columns_compared_per_stream": int(tail_cols), "rotations_replayed": int(nb * F // cfg.num_columns),
+            "seconds": round(time.perf_counter() - t0, 2)}
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# CPU baseline: BASELINE.md 3 modes A and C on the host cores of this box
+# ---------------------------------------------------------------------------------------------------------------------------
+def physical_cores():
+    """One logical CPU per physical core (first SMT sibling), restricted to what this process may run on."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, cores = set(), []
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            cores.append(c)
+    return cores
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_worker(idx, core, cfg, R, hx, hi, hp, barrier, conn, latency):
+    try:
+        os.sched_setaffinity(0, {core})
+        from oracle.pyoracle import Oracle
+        # private, first-touched-here copies of the inputs; the oracle's ring is allocated (and touched by reset) inside this pinned process
+        x, i, p = np.array(hx, copy=True), np.array(hi, copy=True), np.array(hp, copy=True)
+        o = Oracle(cfg, R, record=False)
+        buf_a, buf_b = np.ones(1 << 24, dtype=np.float64), np.zeros(1 << 24, dtype=np.float64)  # 128 MB each: beyond every cache
+        barrier.wait(timeout=600)
+        sec = o.time_firings(x, i, p)
+        cells = o.state()["cells_published"]
+        lat = None
+        if latency:
+            o2 = Oracle(cfg, R, record=False)
+            ns = o2.time_each_firing(x, i, p)[2 * cfg.num_columns:]  # steady state: skip the first two rotations
+            lat = (float(np.percentile(ns, 50)), float(np.percentile(ns, 99)), float(ns.mean()))
+        barrier.wait(timeout=600)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            np.copyto(buf_b, buf_a)
+        bw = 3 * 2 * buf_a.nbytes / (time.perf_counter() - t0) / 1e9  # read + write
+        conn.send((idx, cells, sec, lat, bw))
+    except Exception as ex:  # noqa: BLE001
+        try:
+            barrier.abort()
+        except Exception:  # noqa: BLE001
+            pass
+        conn.send((idx, 0, -1.0, None, 0.0, repr(ex)))
+    finally:
+        conn.close()
+
+
+def cpu_mode_c(cfg, R, hx, hi, hp, cores):
+    """len(cores) independent single-threaded oracle instances, one process each, pinned; all start their timed addFiring loop at one
+    barrier; aggregate rate = cells of all instances / slowest instance."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")  # children never touch HIP; they inherit the host arrays without a copy
+    n = len(cores)
+    barrier = ctx.Barrier(n)
+    procs, conns = [], []
+    for k, core in enumerate(cores):
+        a, b = ctx.Pipe(duplex=False)
+        pr = ctx.Process(target=_cpu_worker, args=(k, core, cfg, R, hx[k % len(hx)], hi[k % len(hi)], hp[k % len(hp)], barrier, b, k == 0 and n == 1))
+        pr.start()
+        b.close()
+        procs.append(pr)
+        conns.append(a)
+    res = [c.recv() for c in conns]
+    for pr in procs:
+        pr.join()
+    bad = [r for r in res if r[2] <= 0]
+    if bad:
+        raise RuntimeError(f"cpu baseline worker failed: {bad[0]}")
+    cells = sum(r[1] for r in res)
+    slowest = max(r[2] for r in res)
+    return {"value": cells / slowest / 1e6, "cells": cells, "cpu_seconds": sum(r[2] for r in res), "slowest_s": slowest,
+            "fastest_s": min(r[2] for r in res), "latency_ns": res[0][3], "membw_GBs": sum(r[4] for r in res)}
+
+
+def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args):
+    R = sensor.num_rows
+    cores = physical_cores()
+    nmax = min(args.cpu_procs or len(cores), len(cores))
+    nb = min(xyz.shape[0], args.cpu_rotations)
+    n_inputs = min(S, nmax, 16)  # distinct streams replayed (instances beyond that re-use them: same work per instance)
+    hx = [xyz[:nb, k].reshape(nb * F, R, 3).cpu().numpy() for k in range(n_inputs)]
+    hi = [inten[:nb, k].reshape(nb * F, R).cpu().numpy() for k in range(n_inputs)]
+    hp = [poses[:nb, k].reshape(nb * F, 12).cpu().numpy() for k in range(n_inputs)]
+    sweep, best, best_n, single, lat = {}, None, 1, None, None
+    for n in sorted({1, 16, 64, nmax}):
+        if n > nmax:
+            continue
+        r = cpu_mode_c(cfg, R, hx, hi, hp, cores[:n])
+        sweep[str(n)] = {"mpoints_per_s": round(r["value"], 2), "per_instance": round(r["value"] / n, 2),
+                         "slowest_s": round(r["slowest_s"], 3), "fastest_s": round(r["fastest_s"], 3),
+                         "concurrent_copy_GBs": round(r["membw_GBs"], 1)}
+        if n == 1:
+            single, lat = r["value"], r["latency_ns"]
+        if best is None or r["value"] > best["value"]:
+            best, best_n = r, n
+    out = {
+        "value": best["value"], "unit": "Mpoints/s", "cores": best_n, "kind": "port",
+        "sample": f"BASELINE.md mode C: {best_n} independent single-threaded oracle instances (one process each, pinned to distinct "
+                  f"physical cores, ring allocated inside the pinned worker), each replaying {nb} rotations ({nb * F} firings) of one of the "
+                  f"bench's own S{R} streams once; {best['cells']} published cells, {best['cpu_seconds']:.1f} CPU-seconds in the timed "
+                  f"addFiring loops; rate = all cells / slowest instance",
+        "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "physical_cores": len(cores), "rotations_per_instance": nb,
+        "single_core_value": single, "sweep": sweep,
+    }
+    if lat:
+        out["mode_a_latency_us_per_column"] = {"p50": lat[0] / 1e3, "p99": lat[1] / 1e3, "mean": lat[2] / 1e3,
+                                                "note": "one instance, one core: steady_clock around every addFiring call (1 firing = 1 column), "
+                                                        "first two rotations skipped"}
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# GPU throughput leg
+# ---------------------------------------------------------------------------------------------------------------------------
+def engine_options(eng):
+    for env, opt in (("CC_SUB_BATCH", "sub_batch"), ("CC_TABLE_EARLY", "table_on_insert_chain"), ("CC_PIPELINE", "pipeline"),
+                     ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert")):
+        if os.environ.get(env):
+            eng.set_option(opt, int(os.environ[env]))
+
+
+def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, cfg, S, F, steps, warmup, seed0, n_verify):
+    from continuous_clustering_amd import Engine
+    R = sensor.num_rows
+    n_batches = warmup + steps
+    xyz, inten, poses = gen_inputs(torch, dev, sensor, S, F, n_batches, seed0=seed0)
+    torch.cuda.synchronize()
+    eng = Engine(cfg, R, S, device=local_rank)
+    eng.record_events(False)
+    engine_options(eng)
+
+    for b in range(warmup):
+        eng.add_firings_device(F, xyz[b], inten[b], poses[b])
+    rc = eng.sync()
+    if rc != 0:
+        raise SystemExit(f"engine error {rc}: {eng.last_error()}")
+    before = eng.totals()
+    eng.enable_timing(True)
+
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for b in range(warmup, n_batches):
+        eng.add_firings_device(F, xyz[b], inten[b], poses[b])
+    rc = eng.sync()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if rc != 0:
+        raise SystemExit(f"engine error {rc}: {eng.last_error()}")
+    after = eng.totals()
+    ktimes = eng.kernel_times()
+    eng.enable_timing(False)
+
+    cells = after["cells_published"] - before["cells_published"]
+    clusters = after["clusters_finished"] - before["clusters_finished"]
+    # the one exchange step of the path: gather per-rank result counts (RCCL over xGMI), max of the elapsed times
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        cnt = torch.tensor([cells, clusters, after["serial_columns"]], dtype=torch.int64, device=dev)
+        gathered = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(gathered, cnt)
+        cells = int(sum(int(g[0]) for g in gathered))
+        clusters = int(sum(int(g[1]) for g in gathered))
+
+    verified = None
+    if n_verify > 0:
+        which = sorted({(k * (S - 1)) // max(1, n_verify - 1) for k in range(n_verify)}) if n_verify > 1 else [0]
+        verified = verify_against_oracle(eng, cfg, R, xyz, inten, poses, which)
+
+    alg_bytes_per_cell = 18.0 + 96.0 / R  # SURVEY 8d: 13 B read + 5 B written per cell + 96 B pose per column
+    batches = max(1, ktimes["batches"])  # kernel launches of each kind: the engine may cut a step into pipelined sub-batches
+    launches_per_step = batches / max(1, steps)
+    per_kernel = {k: v / max(1, steps) for k, v in ktimes.items() if k.endswith("_ms")}  # ms per step
+    # dominant single kernel (segment_ms is the sum of k_table + k_seg_pre + k_seg_scan, profiles/ lists them separately;
+    # prep_ms covers k_insert_par — preparation fused with the block-parallel insertion — plus k_prep of what it left over;
+    # insert_ms is the serial kernel k_insert2 behind it)
+    KERNEL_OF = {"prep_ms": "k_insert_par", "insert_ms": "k_insert2", "scan_ms": "k_scan", "assoc_lds_ms": "k_assoc2",
+                 "assoc_global_ms": "k_associate", "publish_ms": "k_publish"}
+    dom = max(KERNEL_OF, key=lambda k: per_kernel.get(k, 0.0))
+    cells_per_launch = float(S * F * R) / launches_per_step
+    achieved = cells_per_launch * alg_bytes_per_cell / (per_kernel[dom] / launches_per_step * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json" if R == 64 else "traffic_s128.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(KERNEL_OF[dom], {}).get("hbm_bytes_per_launch")
+        except Exception:  # noqa: BLE001
+            traffic = None
+    res = {
+        "value": cells / elapsed / 1e6,
+        "ms_per_step": elapsed / steps * 1e3,
+        "cells_published": cells,
+        "clusters_finished": clusters,
+        "serial_columns": after["serial_columns"],
+        "kernel_ms_per_step": per_kernel,
+        "roofline": {
+            "bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": cells_per_launch * alg_bytes_per_cell, "launches_per_step": launches_per_step,
+            "launch_ms": per_kernel[dom] / launches_per_step,
+            "step_frac": cells * alg_bytes_per_cell / world / elapsed / 1e9 / HBM_PEAK_GBS,
+            "note": "path is latency/dependency-bound (serial per-stream column recurrence), not bandwidth-bound; step_frac = "
+                    "algorithmic bytes of the whole step / step time / peak",
+        },
+        "verified": verified,
+    }
+    return res, eng, (xyz, inten, poses)
 
 
 def main():
@@ -119,93 +373,19 @@ def main():
     sensor = synth.SensorModel.s64() if args.sensor == "s64" else synth.SensorModel.s128()
     cfg = capi.Config.kitti() if args.sensor == "s64" else capi.Config.vls128()
     S, F, R = args.streams, args.firings, sensor.num_rows
-    n_batches = args.warmup + args.steps
-    xyz, inten, poses = gen_inputs(torch, dev, sensor, S, F, n_batches, seed0=1234 + rank * S)
-    torch.cuda.synchronize()
-
-    eng = Engine(cfg, R, S, device=local_rank)
-    eng.record_events(False)
-    if os.environ.get("CC_SUB_BATCH"):
-        eng.set_option("sub_batch", int(os.environ["CC_SUB_BATCH"]))
-    if os.environ.get("CC_TABLE_EARLY"):
-        eng.set_option("table_on_insert_chain", int(os.environ["CC_TABLE_EARLY"]))
-    if os.environ.get("CC_PIPELINE"):
-        eng.set_option("pipeline", int(os.environ["CC_PIPELINE"]))
-    if os.environ.get("CC_PUBLISH_OFF_CHAIN"):
-        eng.set_option("publish_off_chain", int(os.environ["CC_PUBLISH_OFF_CHAIN"]))
-    if os.environ.get("CC_PARALLEL_INSERT"):
-        eng.set_option("parallel_insert", int(os.environ["CC_PARALLEL_INSERT"]))
-
-    def step(b):
-        eng.add_firings_device(F, xyz[b], inten[b], poses[b])
-
-    for b in range(args.warmup):
-        step(b)
-    rc = eng.sync()
-    if rc != 0:
-        raise SystemExit(f"engine error {rc}: {eng.last_error()}")
-    before = eng.totals()
-    eng.enable_timing(True)
-
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for b in range(args.warmup, n_batches):
-        step(b)
-    rc = eng.sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if rc != 0:
-        raise SystemExit(f"engine error {rc}: {eng.last_error()}")
-    after = eng.totals()
-    ktimes = eng.kernel_times()
-    eng.enable_timing(False)
-
-    cells = after["cells_published"] - before["cells_published"]
-    clusters = after["clusters_finished"] - before["clusters_finished"]
-    # the one exchange step of the path: gather per-rank result counts (RCCL over xGMI), max of the elapsed times
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        cnt = torch.tensor([cells, clusters, after["serial_columns"]], dtype=torch.int64, device=dev)
-        gathered = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(gathered, cnt)
-        cells = int(sum(int(g[0]) for g in gathered))
-        clusters = int(sum(int(g[1]) for g in gathered))
-
+    n_verify = 0 if args.no_verify else (args.verify_streams if rank == 0 else 0)
+    res, eng, (xyz, inten, poses) = run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, cfg, S, F, args.steps,
+                                                   args.warmup, 1234 + rank * S, n_verify)
     out = None
     if rank == 0:
-        alg_bytes_per_cell = 18.0 + 96.0 / R  # 13 B read + 5 B written per cell + 96 B pose per column
-        batches = max(1, ktimes["batches"])  # kernel launches of each kind: the engine cuts a step into pipelined sub-batches
-        launches_per_step = batches / max(1, args.steps)
-        per_kernel = {k: v / max(1, args.steps) for k, v in ktimes.items() if k.endswith("_ms")}  # ms per step
-        # dominant single kernel (segment_ms is the sum of k_table + k_seg_pre + k_seg_scan, profiles/ lists them separately)
-        # (prep_ms covers k_insert_par — preparation fused with the block-parallel insertion — plus k_prep of what it left over;
-        # insert_ms is the serial kernel k_insert2 behind it)
-        KERNEL_OF = {"prep_ms": "k_insert_par", "insert_ms": "k_insert2", "scan_ms": "k_scan", "assoc_lds_ms": "k_assoc2",
-                     "assoc_global_ms": "k_associate", "publish_ms": "k_publish"}
-        dom = max(KERNEL_OF, key=lambda k: per_kernel.get(k, 0.0))
-        cells_per_launch = float(S * F * R) / launches_per_step
-        achieved = cells_per_launch * alg_bytes_per_cell / (per_kernel[dom] / launches_per_step * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(KERNEL_OF[dom], {}).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "Mpoints/s clustered (64-beam streams)" if R == 64 else f"Mpoints/s clustered ({R}-beam streams)",
-            "value": cells / elapsed / 1e6,
+            "value": res["value"],
             "unit": "Mpoints/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -218,17 +398,14 @@ def main():
                 "streams_per_gpu": S, "firings_per_step": F, "num_rows": R, "num_columns": cfg.num_columns,
                 "sharding": f"stream-per-wavefront, {world} rank(s) x {S} streams, no data-path collective",
             },
-            "cells_published": cells,
-            "clusters_finished": clusters,
-            "serial_columns": after["serial_columns"],
-            "kernel_ms_per_step": per_kernel,
-            "roofline": {
-                "bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "algorithmic_bytes_per_launch": cells_per_launch * alg_bytes_per_cell, "launches_per_step": launches_per_step,
-                "launch_ms": per_kernel[dom] / launches_per_step,
-                "note": "path is latency/dependency-bound (serial per-stream column recurrence), not bandwidth-bound",
-            },
+            "cells_published": res["cells_published"],
+            "clusters_finished": res["clusters_finished"],
+            "serial_columns": res["serial_columns"],
+            "kernel_ms_per_step": res["kernel_ms_per_step"],
+            "roofline": res["roofline"],
+            "verified_streams": len(res["verified"]["streams"]) if res["verified"] else 0,
+            "verify": res["verified"],
+            "rccl_world": world if use_dist else 0,
         }
 
     # ---- single-stream latency (BASELINE.json configs[1] shape): one firing per call through the host API --------
@@ -248,42 +425,35 @@ def main():
                                                       "mode": "1 firing per cc_engine_add_firings call (H2D + all kernels of the path + sync + event read-back)"}
         e1.close()
 
-    # ---- CPU baseline on this box's host cores ------------------------------------------------------------------
+    # ---- CPU baseline on this box's host cores (inputs: the bench's own streams, copied back from HBM) ------------
     if rank == 0 and not args.no_cpu_baseline:
-        ncpu = os.cpu_count() or 1
-        nmax = args.cpu_threads or min(ncpu, 64, S)
-        nb = min(n_batches, 4)
-        repeats = 3
-        hx = xyz[:nb, :nmax].permute(1, 0, 2, 3, 4).reshape(nmax, nb * F, R, 3).cpu().numpy()
-        hi = inten[:nb, :nmax].permute(1, 0, 2, 3).reshape(nmax, nb * F, R).cpu().numpy()
-        hp = poses[:nb, :nmax].permute(1, 0, 2, 3).reshape(nmax, nb * F, 12).cpu().numpy()
-        # the multi-instance CPU path does not scale linearly (allocator / memory-bound AoS ring): sweep the instance count and
-        # report the best aggregate, so that the baseline is the CPU's best case on this host
-        sweep = {}
-        cb, nthreads = None, 1
-        for nt in sorted({1, 4, 8, 16, 32, nmax}):
-            if nt > nmax:
-                continue
-            r = cpu_baseline(cfg, sensor, hx, hi, hp, nt, repeats)
-            sweep[nt] = round(r["value"], 2)
-            if cb is None or r["value"] > cb["value"]:
-                cb, nthreads = r, nt
-            if nt == 1:
-                single = r["value"]
-        cb["single_core"] = single
-        out["cpu_baseline"] = {
-            "value": cb["value"], "unit": "Mpoints/s", "cores": nthreads, "kind": "port",
-            "sample": f"{nthreads} of the {S} streams x {nb} rotations x {repeats} replays ({cb['cells']} published cells, "
-                      f"{cb['cpu_seconds']:.1f} CPU-seconds in the timed addFiring loops), one single-threaded oracle instance per host "
-                      f"thread (BASELINE.md mode C); single instance on 1 core: {cb['single_core']:.2f} Mpoints/s",
-            "host_cpus": ncpu, "wall_s": cb["wall_s"], "single_core_value": cb["single_core"], "sweep_instances_to_mpoints": sweep,
-        }
+        out["cpu_baseline"] = cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args)
     elif rank == 0:
         out["cpu_baseline"] = None
 
+    eng.close()
+    del xyz, inten, poses
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE.json configs[3]: 128-row VLS-128-shaped streams (same harness, fewer steps; the headline stays S64) ----
+    if args.sensor == "s64" and not args.no_s128:
+        sensor2, cfg2 = synth.SensorModel.s128(), capi.Config.vls128()
+        steps2, warm2 = max(4, min(args.steps, 10)), 3
+        r2, eng2, bufs2 = run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor2, cfg2, S, 1700, steps2, warm2,
+                                         5678 + rank * S, min(n_verify, 2))
+        eng2.close()
+        del bufs2
+        if rank == 0:
+            out["s128"] = {"metric": "Mpoints/s clustered (128-beam streams)", "value": r2["value"], "unit": "Mpoints/s",
+                           "ms_per_step": r2["ms_per_step"], "steps": steps2, "warmup": warm2,
+                           "workload": f"{S} concurrent synthetic S128 streams per GPU (128 rows x 1700 columns/rotation, per-laser azimuth "
+                                       f"offsets: every firing spans ~60 columns; library-default parameters), 1700 firings per stream per step",
+                           "kernel_ms_per_step": r2["kernel_ms_per_step"], "roofline": r2["roofline"],
+                           "verified_streams": len(r2["verified"]["streams"]) if r2["verified"] else 0,
+                           "serial_columns": r2["serial_columns"]}
+
     if rank == 0:
         print(json.dumps(out))
-    eng.close()
     if use_dist:
         dist.destroy_process_group()
 

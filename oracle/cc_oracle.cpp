@@ -170,6 +170,7 @@ struct Oracle
     std::vector<cc_event> events;
     std::vector<ColumnSnapshot> published; // snapshots taken inside the cluster-view column callback
     int64_t published_base{-1};            // gcol of published[0]
+    int64_t keep_tail{0};                  // > 0: only the most recent snapshots are kept (long verification runs of bench.py)
     uint64_t firings_consumed{0}, cells_published{0}, clusters_finished{0};
     uint64_t exceed_one_rotation{0};
     uint64_t max_unfinished{0};
@@ -890,6 +891,12 @@ struct Oracle
             }
         }
         published.push_back(std::move(s));
+        if (keep_tail > 0 && (int64_t) published.size() > 2 * keep_tail)
+        {
+            const int64_t drop = (int64_t) published.size() - keep_tail;
+            published.erase(published.begin(), published.begin() + drop);
+            published_base += drop;
+        }
     }
 
     // ---- cc.cpp:88-93 addFiring -----------------------------------------------------------------------
@@ -925,6 +932,12 @@ void orc_destroy(orc_handle* h)
 void orc_record(orc_handle* h, int enable)
 {
     h->o.record = enable != 0;
+}
+
+// keep only (at least) the last n published column snapshots; 0 = all
+void orc_keep_published_tail(orc_handle* h, int64_t n)
+{
+    h->o.keep_tail = n;
 }
 
 int orc_set_config(orc_handle* h, const cc_config* cfg)
@@ -988,6 +1001,36 @@ double orc_time_firings(orc_handle* h, int64_t n, const float* xyz, const uint8_
     auto t1 = std::chrono::steady_clock::now();
     o.record = rec;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// Mode A of BASELINE.md 3: per-call latency of addFiring (one firing = one column for KITTI-shaped streams). out_ns[i] = duration of
+// call i in nanoseconds (steady_clock around each call; ~25 ns of clock overhead per sample). Returns the total seconds, -1 on error.
+double orc_time_each_firing(orc_handle* h, int64_t n, const float* xyz, const uint8_t* intensity, const double* poses, double* out_ns)
+{
+    Oracle& o = h->o;
+    bool rec = o.record;
+    o.record = false;
+    double total = 0;
+    try
+    {
+        for (int64_t i = 0; i < n; i++)
+        {
+            auto t0 = std::chrono::steady_clock::now();
+            o.add_firing(xyz + (size_t) i * o.num_rows * 3, intensity + (size_t) i * o.num_rows, poses + (size_t) i * 12);
+            auto t1 = std::chrono::steady_clock::now();
+            const double ns = std::chrono::duration<double, std::nano>(t1 - t0).count();
+            out_ns[i] = ns;
+            total += ns;
+        }
+    }
+    catch (const std::runtime_error& e)
+    {
+        o.error = e.what();
+        o.record = rec;
+        return -1.0;
+    }
+    o.record = rec;
+    return total * 1e-9;
 }
 
 const char* orc_last_error(orc_handle* h)

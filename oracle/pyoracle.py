@@ -38,12 +38,16 @@ def lib():
         L.orc_create.argtypes = [C.POINTER(capi.Config), C.c_int]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_record.argtypes = [C.c_void_p, C.c_int]
+        L.orc_keep_published_tail.argtypes = [C.c_void_p, C.c_int64]
+        L.orc_keep_published_tail.restype = None
         L.orc_set_config.argtypes = [C.c_void_p, C.POINTER(capi.Config)]
         L.orc_reset.argtypes = [C.c_void_p, C.c_int]
         L.orc_set_robot_from_sensor.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_add_firings.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_time_firings.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_time_firings.restype = C.c_double
+        L.orc_time_each_firing.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_time_each_firing.restype = C.c_double
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
         L.orc_stream_state.argtypes = [C.c_void_p, C.POINTER(capi.StreamState)]
@@ -103,6 +107,10 @@ class Oracle:
         except Exception:
             pass
 
+    def keep_published_tail(self, n: int):
+        """Keep only (at least) the last ``n`` published column snapshots (long runs: bench.py's verify block)."""
+        self.L.orc_keep_published_tail(self.h, int(n))
+
     def set_robot_from_sensor(self, tf12):
         tf = np.ascontiguousarray(tf12, dtype=np.float64).reshape(12)
         self.L.orc_set_robot_from_sensor(self.h, tf.ctypes.data)
@@ -127,6 +135,16 @@ class Oracle:
         intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
         poses = np.ascontiguousarray(poses, dtype=np.float64)
         return self.L.orc_time_firings(self.h, xyz.shape[0], xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
+
+    def time_each_firing(self, xyz, intensity, poses) -> np.ndarray:
+        """Per-call addFiring latency in nanoseconds (BASELINE.md mode A)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        out = np.zeros(xyz.shape[0], dtype=np.float64)
+        if self.L.orc_time_each_firing(self.h, xyz.shape[0], xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data, out.ctypes.data) < 0:
+            raise RuntimeError(self.last_error())
+        return out
 
     def last_error(self) -> str:
         return self.L.orc_last_error(self.h).decode()
