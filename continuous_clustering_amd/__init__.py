@@ -83,6 +83,7 @@ def load_library():
     L.cc_engine_record_events.argtypes = [vp, i32]
     L.cc_engine_drain_events.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.cc_engine_pending_events.argtypes = [vp, i32, C.POINTER(i64)]
+    L.cc_engine_drain_links.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.cc_engine_stream_state.argtypes = [vp, i32, C.POINTER(capi.StreamState)]
     L.cc_engine_read_columns.argtypes = [vp, i32, i64, i64, C.POINTER(capi.ColumnView)]
     L.cc_engine_output_planes.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
@@ -197,6 +198,15 @@ class Engine:
         out = np.zeros(max(1, n.value), dtype=capi.EVENT_DTYPE)
         got = C.c_int64(0)
         self._check(self.L.cc_engine_drain_events(self.h, stream, out.ctypes.data, n.value, C.byref(got)))
+        return out[: got.value]
+
+    def drain_links(self, stream: int = 0) -> np.ndarray:
+        """Tree links made since the last drain: rows of (root gcol, root row, root gcol, root row)."""
+        n = C.c_int64(0)
+        self._check(self.L.cc_engine_drain_links(self.h, stream, None, 0, C.byref(n)))
+        out = np.zeros((max(1, n.value), 4), dtype=np.int64)
+        got = C.c_int64(0)
+        self._check(self.L.cc_engine_drain_links(self.h, stream, out.ctypes.data, n.value, C.byref(got)))
         return out[: got.value]
 
     def read_columns(self, frm: int, to: int, stream: int = 0, fields=None) -> dict:

@@ -157,6 +157,9 @@ class ColumnView(C.Structure):
         ("global_column_index", C.c_void_p), ("source_firing", C.c_void_p),
         ("ground_point_label", C.c_void_p), ("debug_ground_point_label", C.c_void_p), ("is_ignored", C.c_void_p),
         ("id", C.c_void_p), ("tree_root_global_column", C.c_void_p), ("tree_root_row", C.c_void_p),
+        ("finished_at_continuous_azimuth_angle", C.c_void_p), ("tree_num_points", C.c_void_p), ("cluster_width", C.c_void_p),
+        ("number_of_child_points", C.c_void_p), ("number_of_visited_neighbors", C.c_void_p),
+        ("belongs_to_finished_cluster", C.c_void_p), ("tree_parent_global_column", C.c_void_p), ("tree_parent_row", C.c_void_p),
     ]
 
 
@@ -165,6 +168,9 @@ COLUMN_FIELDS = {
     "continuous_azimuth_angle": np.float64, "global_column_index": np.int64, "source_firing": np.int64,
     "ground_point_label": np.uint8, "debug_ground_point_label": np.uint8, "is_ignored": np.uint8, "id": np.uint64,
     "tree_root_global_column": np.int64, "tree_root_row": np.int32,
+    "finished_at_continuous_azimuth_angle": np.float64, "tree_num_points": np.uint32, "cluster_width": np.uint32,
+    "number_of_child_points": np.uint32, "number_of_visited_neighbors": np.int32, "belongs_to_finished_cluster": np.uint8,
+    "tree_parent_global_column": np.int64, "tree_parent_row": np.int32,
 }
 
 

@@ -84,17 +84,30 @@ struct LdsTrees2
 // (non-negative doubles order like their bit patterns): two round trips instead of a 12-step cross-lane reduction.
 __device__ __forceinline__ bool cluster_may_finish2(LdsTrees2& T, int n_unf, double min_az, double& lower_bound)
 {
-    if (lane_id() == 0)
-        T.bcast_u64 = 0x7fefffffffffffffull; // DBL_MAX
-    wave_lds_fence();
-    for (int k = lane_id(); k < n_unf; k += 64)
+    double lb;
+    if (n_unf <= 64)
     {
-        const int i = T.alist[k];
-        if (lds_ld(&T.uf[i]) == i)
-            atomicMin(&T.bcast_u64, lds_ld(&T.c_fin[i]));
+        // the usual case: one tree per lane, minimum by DPP (two LDS round trips, no atomics)
+        const int k = lane_id();
+        const int i = T.alist[k < n_unf ? k : 0];
+        const int rep = lds_ld(&T.uf[i]);
+        const unsigned long long f = lds_ld(&T.c_fin[i]);
+        lb = uniform_f64(wave_min_f64((k < n_unf && rep == i) ? __longlong_as_double((long long) f) : 1.7976931348623157e308));
     }
-    wave_lds_fence();
-    const double lb = uniform_f64(__longlong_as_double((long long) lds_ld(&T.bcast_u64)));
+    else
+    {
+        if (lane_id() == 0)
+            T.bcast_u64 = 0x7fefffffffffffffull; // DBL_MAX
+        wave_lds_fence();
+        for (int k = lane_id(); k < n_unf; k += 64)
+        {
+            const int i = T.alist[k];
+            if (lds_ld(&T.uf[i]) == i)
+                atomicMin(&T.bcast_u64, lds_ld(&T.c_fin[i]));
+        }
+        wave_lds_fence();
+        lb = uniform_f64(__longlong_as_double((long long) lds_ld(&T.bcast_u64)));
+    }
     lower_bound = lb; // min over the clusters of (a lower bound of) their max finished_at
     return !(lb > min_az);
 }
@@ -102,7 +115,7 @@ __device__ __forceinline__ bool cluster_may_finish2(LdsTrees2& T, int n_unf, dou
 // exact single-lane replay of one column (rare): reference semantics with immediate attach / link; ids come from the free ring
 template<int RPL>
 __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, const Geometry& g, LdsTrees2& T, short* s_win, const int lc,
-                                   const long long gc, const int first_local, int& n_unf, double& L, long long& M, int& head, int& err)
+                                   const long long gc, const int first_local, int& n_unf, double& L, long long& M, int& head, int& err, StreamState* st)
 {
     const SP& p = c.p;
     const int R = c.R, RC = c.RC;
@@ -115,6 +128,9 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
         if (p.ignored[pi])
         {
             p.root[pi] = -1;
+            p.sc_parent[pi] = -2;
+            if (g.mirror_fields)
+                p.sc_visits[pi] = 0;
             continue;
         }
         const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[pi]);
@@ -124,6 +140,7 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
         needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
         int oc = lc;
         long long ogc = gc;
+        int visits = 0, parcode = -1; // Point::number_of_visited_neighbors; the candidate whose child list the point joins (cc.cpp:663)
         int pslot = -1; // tree id of the point (-1: none yet)
         for (int sb = 0; sb <= needed; sb++)
         {
@@ -136,6 +153,7 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
                 while (orow >= 0 && orow < R && sv <= c.max_steps_in_column)
                 {
                     const int oi = oc * R + orow;
+                    visits++; // cc.cpp:725
                     if (ccm::absf(p.incl[oi] - pincl) > mad)
                         break;
                     if (!p.ignored[oi])
@@ -160,6 +178,7 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
                                         if (nw <= (uint32_t) c.NC)
                                         {
                                             pslot = oslot;
+                                            parcode = (sb << 8) | orow;
                                             T.last[oslot] = gc;
                                             const unsigned long long cand = (unsigned long long) __double_as_longlong(pcaz + (double) mad);
                                             if (cand > T.fin[oslot])
@@ -170,7 +189,10 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
                                     }
                                 }
                                 else if (oslot >= 0 && oslot != pslot)
+                                {
+                                    log_link(g, st, p.link_log, T.cell[pslot], T.cell[oslot]);
                                     lds_union(T.uf, T.c_fin, pslot, oslot);
+                                }
                             }
                         }
                     }
@@ -215,6 +237,9 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
         }
         wcol[row] = (short) pslot;
         p.root[pi] = T.cell[pslot];
+        p.sc_parent[pi] = (int16_t) parcode; // the live scan's parent replaces the static one
+        if (g.mirror_fields)
+            p.sc_visits[pi] = sat_u16(visits);
     }
 }
 
@@ -437,6 +462,8 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     break;
                 if (cmd == A2_PARK)
                 {
+                    // (this wave's tree-root stores of the columns it resolved must have landed before wave B replays one of them)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (lane == 0)
                         lds_st(&T.a_parked, 1);
                     while (uniform_i32(lds_ld(&T.cmd)) == A2_PARK)
@@ -467,7 +494,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     }
                 }
             }
-            int term[RPL], nlk[RPL];
+            int term[RPL], nlk[RPL], parc[RPL];
             unsigned long long lk[RPL];
 #pragma unroll
             for (int k = 0; k < RPL; k++)
@@ -475,6 +502,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 term[k] = nx_term[k];
                 nlk[k] = nx_nl[k];
                 lk[k] = nx_link[k];
+                parc[k] = nx_par[k];
                 const int row = k * 64 + lane;
                 if (row < R) // stage what wave B needs of this column
                 {
@@ -523,6 +551,26 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 const int row = k * 64 + lane;
                 if (row < R)
                     wcol[row] = (short) ent[k];
+            }
+            // Tree root of every cell (Point::tree_root_, cc.cpp:661,814): the lane of a new root files its cell under the tree id, then
+            // every lane reads the root cell of its tree and writes the root plane — this wave has the time, wave B issues no global
+            // store per column. A column wave B replays exactly (stale speculation) is rewritten by the replay; what this wave
+            // resolves again after a restart is written again.
+            if (bad == 0)
+            {
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                    if (parc[k] == -1 && ent[k] >= 0)
+                        T.cell[ent[k] & A2_IDMASK] = lc * R + k * 64 + lane;
+                wave_lds_fence();
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    const int cell = T.cell[ent[k] >= 0 ? (ent[k] & A2_IDMASK) : 0];
+                    if (row < R)
+                        p.root[lc * R + row] = ent[k] >= 0 ? cell : -1;
+                }
             }
             // Links (further accepted candidates) only matter where they lead to another tree, which is rare (two trees of one
             // object meeting): this wave, which has the time, looks the targets up and tells wave B whether the column has any.
@@ -677,6 +725,9 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
         wave_lds_fence(); // ring entries are read after the flag
     };
 
+#ifdef CC_A2_STATS
+    unsigned long long st_full = 0, st_kill = 0, st_removed = 0, st_nunf = 0;
+#endif
     // finished-cluster check (cc.cpp:837-974) and publish bookkeeping (cc.cpp:1035-1092) of one column, exact tree state
     bool killed = false; // the last finished-cluster check retired trees
     auto finish_and_publish = [&](const long long gc, const double min_az)
@@ -786,6 +837,13 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                         const int cell = T.cell[i];
                         p.t_finished[cell] = 1;
                         p.t_cid[cell] = T.a_cid[j];
+                        if (g.mirror_fields)
+                        {
+                            // final per-tree values of Point (cc.cpp:666-671) for the host mirror; unfinished trees are persisted at the end
+                            p.t_fin[cell] = __longlong_as_double((long long) T.fin[i]);
+                            p.t_pts[cell] = T.pts[i];
+                            p.t_width[cell] = (unsigned) (T.last[i] - T.gcol[i] + 1);
+                        }
                         dead = true;
                     }
                     else
@@ -806,7 +864,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 {
                     const int pos = tail + removed + __popcll(dmask & lanes_below());
                     T.ring_id[pos & (TREE_SLOTS - 1)] = (short) i;
-                    T.ring_rel[pos & (TREE_SLOTS - 1)] = gc + WIN_COLS;
+                    T.ring_rel[pos & (TREE_SLOTS - 1)] = gc + WIN_COLS + G; // (+ G: the group-wide verification marks new ids early)
                     T.alive[i] = 0;
                 }
                 if (surv)
@@ -824,6 +882,11 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             M = min_surv;
             n_unf -= removed;
             killed = removed > 0;
+#ifdef CC_A2_STATS
+            st_full++;
+            st_kill += removed > 0;
+            st_removed += removed;
+#endif
             wave_lds_fence();
         }
         last_min_az = min_az;
@@ -858,11 +921,18 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             load_group(gc + gcount, lcn); // prefetch: nothing below depends on it
         }
 
-        int u0 = 0;          // first column of the group not yet processed
+        int u0 = 0;            // first column of the group not yet processed
         bool ids_stale = true; // ids of the columns >= u0 have to be (re)read from the ring
         bool verify = true;    // ... and checked against the tree state (again after trees were finished)
+        bool rewalk = true;    // the scalar walk has to be redone (false after a finished-cluster check that retired nothing: only L moved)
         unsigned badmask = 0;
         int v_abad = 0;
+        // results of the scalar walk, lane u = column gc + u; they stay valid across a check that retires nothing
+        int w_cnt = 0, w_flags = 0, w_maxd = 0, w_nafter = 0, w_nbefore = 0;
+        double w_L = 0., w_azprev = 0.;
+        long long gcu_l = 0, w_M = 0, w_Mbefore = 0, w_Mc = 0, w_fub = 0;
+        bool w_alias = false;
+        unsigned long long m_global = 0, m_live = 0, m_check = 0;
         while (u0 < gcount && err == 0 && !to_global)
         {
 #ifdef CC_A2_STATS
@@ -887,36 +957,51 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 verify = true;
             }
             A2_PH(0)
-            // ---- what wave A assumed: every tree joined from an earlier column is still unfinished (cc.cpp:658); trees that
-            // start in one of these columns count as unfinished for the columns after them --------------------------------------
+            // ---- what wave A assumed: every tree joined from an earlier column is still unfinished (cc.cpp:658). All columns of the
+            // group at once: the ids of the trees that start in these columns are marked unfinished first (a freed id stays in
+            // quarantine for WIN_COLS + G columns, so no entry of the group can still name its previous tree), then one gather of the
+            // flags for every entry of the group — two LDS round trips per group instead of three per column. -------------------------
             if (verify)
             {
                 verify = false;
+                rewalk = true;
                 badmask = 0;
-                for (int u = u0; u < gcount; u++)
+                int q_par[G][RPL], q_e[G][RPL];
+#pragma unroll
+                for (int u = 0; u < G; u++)
                 {
-                    const short* wc = s_win + (int) ((gc + u) & (WIN2_COLS - 1)) * R;
-                    bool bad = false;
+                    const bool on = u >= u0 && u < gcount;
 #pragma unroll
                     for (int k = 0; k < RPL; k++)
                     {
                         const int row = k * 64 + lane;
-                        if (row < R)
-                        {
-                            const int par = st_parent[(int) ((gc + u) & (A2_STAGE - 1)) * R + row];
-                            const int e = wc[row];
-                            if (par == -1 && e >= 0)
-                                T.alive[e & A2_IDMASK] = 1;
-                            else if (par >= 0)
-                            {
-                                if (e < 0)
-                                    bad = true;
-                                else if (!(e & A2_FRESH))
-                                    bad |= !T.alive[e & A2_IDMASK];
-                            }
-                        }
+                        const int rr = row < R ? row : 0;
+                        const int a = st_parent[(int) ((gc + u) & (A2_STAGE - 1)) * R + rr];
+                        const int b = s_win[(int) ((gc + u) & (WIN2_COLS - 1)) * R + rr];
+                        q_par[u][k] = (on && row < R) ? a : -2;
+                        q_e[u][k] = (on && row < R) ? b : -1;
                     }
-                    wave_lds_fence();
+                }
+#pragma unroll
+                for (int u = 0; u < G; u++)
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                        if (q_par[u][k] == -1 && q_e[u][k] >= 0)
+                            T.alive[q_e[u][k] & A2_IDMASK] = 1;
+                wave_lds_fence();
+                unsigned char q_al[G][RPL];
+#pragma unroll
+                for (int u = 0; u < G; u++)
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                        q_al[u][k] = T.alive[q_e[u][k] >= 0 ? (q_e[u][k] & A2_IDMASK) : 0];
+#pragma unroll
+                for (int u = 0; u < G; u++)
+                {
+                    bool bad = false;
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                        bad |= q_par[u][k] >= 0 && (q_e[u][k] < 0 || (!(q_e[u][k] & A2_FRESH) && !q_al[u][k]));
                     if (__any(bad))
                         badmask |= 1u << u;
                 }
@@ -933,47 +1018,90 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             };
             const int wu = lane;
             const bool inr = wu >= u0 && wu < gcount;
-            const int w_cnt = inr ? (v_info & 0xff) : 0;
-            const int w_flags = (v_info >> 8) & 0xff, w_maxd = v_info >> 16;
-            int ps = w_cnt; // inclusive prefix sums / minima over the columns u0 .. u
-            ps += dpp_shr_i32<1>(ps, 0);
-            ps += dpp_shr_i32<2>(ps, 0);
-            ps += dpp_shr_i32<4>(ps, 0);
             const double inf = 1.7976931348623157e308;
-            double pm = (inr && w_cnt > 0) ? v_newfin : inf;
+            if (rewalk)
             {
-                double o = dpp_shr_f64<1>(pm, inf);
-                pm = o < pm ? o : pm;
-                o = dpp_shr_f64<2>(pm, inf);
-                pm = o < pm ? o : pm;
-                o = dpp_shr_f64<4>(pm, inf);
-                pm = o < pm ? o : pm;
+                rewalk = false;
+                w_cnt = inr ? (v_info & 0xff) : 0;
+                w_flags = (v_info >> 8) & 0xff;
+                w_maxd = (v_info >> 16) & 0xff;
+                const int w_reach = g.mirror_fields ? (v_info >> 24) & 0x7f : 0; // (mirror mode) deepest column any scan of the column looked at
+                int ps = w_cnt; // inclusive prefix sums / minima over the columns u0 .. u
+                ps += dpp_shr_i32<1>(ps, 0);
+                ps += dpp_shr_i32<2>(ps, 0);
+                ps += dpp_shr_i32<4>(ps, 0);
+                if (G > 8)
+                    ps += dpp_shr_i32<8>(ps, 0);
+                double pm = (inr && w_cnt > 0) ? v_newfin : inf;
+                {
+                    double o = dpp_shr_f64<1>(pm, inf);
+                    pm = o < pm ? o : pm;
+                    o = dpp_shr_f64<2>(pm, inf);
+                    pm = o < pm ? o : pm;
+                    o = dpp_shr_f64<4>(pm, inf);
+                    pm = o < pm ? o : pm;
+                    if (G > 8)
+                    {
+                        o = dpp_shr_f64<8>(pm, inf);
+                        pm = o < pm ? o : pm;
+                    }
+                }
+                w_nafter = n_unf + ps;
+                w_nbefore = w_nafter - w_cnt;
+                w_L = pm < L ? pm : L;
+                gcu_l = gc + wu;
+                // the oldest root column: set by the first new tree while there is none (cc.cpp:1035-1050 keeps the minimum)
+                int firstnew = 64;
+                if (n_unf == 0)
+                {
+                    const unsigned long long nm = __ballot(inr && w_cnt > 0);
+                    firstnew = nm ? (int) __ffsll((long long) nm) - 1 : 64;
+                }
+                w_M = (n_unf == 0 && wu >= firstnew) ? gc + firstnew : M;
+                w_Mbefore = (n_unf == 0 && wu > firstnew) ? gc + firstnew : M;
+                w_Mc = w_nafter == 0 ? gcu_l + 1 : w_M; // first unpublished column after this column, nothing finishing
+                w_fub = dpp_shr_i64<1>(w_Mc, first_unpub);
+                w_fub = wu == u0 ? first_unpub : w_fub;
+                w_azprev = dpp_shr_f64<1>(v_minaz, last_min_az);
+                w_azprev = wu == u0 ? last_min_az : w_azprev;
+                const bool w_badbit = (badmask >> wu) & 1u;
+                const bool c_global = inr && (w_nafter > tree_limit || (v_abad & 3) == 2);
+                const bool c_live = inr && (w_badbit || (w_flags & 1) || (v_abad & 3) == 1 ||
+                                            (w_nbefore > 0 && (uint32_t) (gcu_l - w_Mbefore + 1) > (uint32_t) NC) // cc.cpp:657
+                                            || gcu_l - w_maxd < w_fub                                              // cc.cpp:762-763
+                                            || gcu_l - w_reach < w_fub); // static visit counts (cc.cpp:725) need the whole window
+                w_alias = w_nafter > 0 && v_minaz == w_azprev;
+                const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || v_minaz >= w_L);
+                m_global = __ballot(c_global);
+                m_live = __ballot(c_live);
+                m_check = __ballot(c_check);
             }
-            const int w_nafter = n_unf + ps, w_nbefore = w_nafter - w_cnt;
-            const double w_L = pm < L ? pm : L;
-            const long long gcu_l = gc + wu;
-            // the oldest root column: set by the first new tree while there is none (cc.cpp:1035-1050 keeps the minimum)
-            int firstnew = 64;
-            if (n_unf == 0)
+            else
             {
-                const unsigned long long nm = __ballot(inr && w_cnt > 0);
-                firstnew = nm ? (int) __ffsll((long long) nm) - 1 : 64;
+                // A finished-cluster check ran with the exact tree state and retired nothing: tree count, oldest root, first unpublished
+                // column of the later columns are what the walk said; only the bound L was refreshed. The prefix minimum over the new
+                // roots' finished_at restarts behind the checked column (the earlier ones are part of L now).
+                double pm = (inr && w_cnt > 0) ? v_newfin : inf;
+                {
+                    double o = dpp_shr_f64<1>(pm, inf);
+                    pm = o < pm ? o : pm;
+                    o = dpp_shr_f64<2>(pm, inf);
+                    pm = o < pm ? o : pm;
+                    o = dpp_shr_f64<4>(pm, inf);
+                    pm = o < pm ? o : pm;
+                    if (G > 8)
+                    {
+                        o = dpp_shr_f64<8>(pm, inf);
+                        pm = o < pm ? o : pm;
+                    }
+                }
+                w_L = pm < L ? pm : L;
+                const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || v_minaz >= w_L);
+                m_check = __ballot(c_check);
+                const unsigned long long keep = ~((1ull << u0) - 1ull);
+                m_global &= keep;
+                m_live &= keep;
             }
-            const long long w_M = (n_unf == 0 && wu >= firstnew) ? gc + firstnew : M;
-            const long long w_Mbefore = (n_unf == 0 && wu > firstnew) ? gc + firstnew : M;
-            const long long w_Mc = w_nafter == 0 ? gcu_l + 1 : w_M; // first unpublished column after this column, nothing finishing
-            long long w_fub = dpp_shr_i64<1>(w_Mc, first_unpub);
-            w_fub = wu == u0 ? first_unpub : w_fub;
-            double w_azprev = dpp_shr_f64<1>(v_minaz, last_min_az);
-            w_azprev = wu == u0 ? last_min_az : w_azprev;
-            const bool w_badbit = (badmask >> wu) & 1u;
-            const bool c_global = inr && (w_nafter > tree_limit || (v_abad & 3) == 2);
-            const bool c_live = inr && (w_badbit || (w_flags & 1) || (v_abad & 3) == 1 ||
-                                        (w_nbefore > 0 && (uint32_t) (gcu_l - w_Mbefore + 1) > (uint32_t) NC) // cc.cpp:657
-                                        || gcu_l - w_maxd < w_fub);                                            // cc.cpp:762-763
-            const bool w_alias = w_nafter > 0 && v_minaz == w_azprev;
-            const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || v_minaz >= w_L);
-            const unsigned long long m_global = __ballot(c_global), m_live = __ballot(c_live), m_check = __ballot(c_check);
             const unsigned long long m_cut = m_global | m_live | m_check;
             const int ucut = m_cut ? (int) __ffsll((long long) m_cut) - 1 : gcount;
             int cut = CUT_NONE;
@@ -1043,10 +1171,11 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             // ---- the batch [u0, u1), column by column: new trees (list order = column, then row), then the point and link
             // updates. Point updates are run-length aggregated per row: consecutive columns of a row mostly join the same tree, so
             // a lane keeps (tree, points, max finished_at, last column) in registers and touches the tree state only when its
-            // tree changes and at the end of the batch. -------------------------------------------------------------------------
+            // tree changes and at the end of the batch. The column's inputs are read one column ahead (no LDS wait in the loop); the
+            // root plane was written by wave A. ---------------------------------------------------------------------------------
             if (u1 > u0)
             {
-                int cur[RPL], curcell[RPL];
+                int cur[RPL];
                 unsigned rcnt[RPL];
                 unsigned long long rfin[RPL];
                 long long rlast[RPL];
@@ -1054,7 +1183,6 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                 for (int k = 0; k < RPL; k++)
                 {
                     cur[k] = -1;
-                    curcell[k] = -1;
                     rcnt[k] = 0;
                     rfin[k] = 0;
                     rlast[k] = 0;
@@ -1068,12 +1196,30 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     atomicMax(&T.c_fin[rep], rfin[k]);
                     atomicAdd(&T.pts[i], rcnt[k]);
                 };
+                int n_par[RPL], n_e[RPL];
+                double n_fc[RPL];
+                auto load_col = [&](int u)
+                {
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                    {
+                        const int row = k * 64 + lane;
+                        const int rr = row < R ? row : 0;
+                        const int so = (int) ((gc + u) & (A2_STAGE - 1)) * R + rr;
+                        const int a = st_parent[so];
+                        const double f = st_fin[so];
+                        const int b = s_win[(int) ((gc + u) & (WIN2_COLS - 1)) * R + rr];
+                        n_par[k] = row < R ? a : -2;
+                        n_fc[k] = f;
+                        n_e[k] = row < R ? b : -1;
+                    }
+                };
+                load_col(u0);
                 int lcu = lc0 + u0;
                 lcu = lcu >= RC ? lcu - RC : lcu;
                 for (int u = u0; u < u1; u++, lcu = (lcu + 1 == RC ? 0 : lcu + 1))
                 {
                     const long long gcu = gc + u;
-                    const int wcu = (int) (gcu & (WIN2_COLS - 1));
                     const int info = lane_i32(v_info, u);
                     const bool has_new = (info & 0xff) != 0, has_links = (lane_i32(v_abad, u) >> 4) & 1; // links to other trees
                     int par[RPL], e[RPL];
@@ -1081,17 +1227,12 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
 #pragma unroll
                     for (int k = 0; k < RPL; k++)
                     {
-                        const int row = k * 64 + lane;
-                        par[k] = -2;
-                        e[k] = -1;
-                        fc[k] = 0.;
-                        if (row < R)
-                        {
-                            par[k] = st_parent[(int) (gcu & (A2_STAGE - 1)) * R + row];
-                            fc[k] = st_fin[(int) (gcu & (A2_STAGE - 1)) * R + row];
-                            e[k] = s_win[wcu * R + row];
-                        }
+                        par[k] = n_par[k];
+                        e[k] = n_e[k];
+                        fc[k] = n_fc[k];
                     }
+                    if (u + 1 < u1)
+                        load_col(u + 1);
                     if (has_new)
                     {
                         const int nb = lane_i32(w_nbefore, u);
@@ -1122,19 +1263,15 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
 #pragma unroll
                     for (int k = 0; k < RPL; k++)
                     {
-                        const int row = k * 64 + lane;
                         const int i = e[k] & A2_IDMASK;
                         if (e[k] >= 0 && i != cur[k])
                         {
                             if (rcnt[k] > 0)
                                 flush(k);
                             cur[k] = i;
-                            curcell[k] = T.cell[i];
                             rcnt[k] = 0;
                             rfin[k] = 0;
                         }
-                        if (row < R)
-                            p.root[lcu * R + row] = e[k] >= 0 ? curcell[k] : -1;
                         if (par[k] >= 0)
                         {
                             const unsigned long long fb = (unsigned long long) __double_as_longlong(fc[k]);
@@ -1149,6 +1286,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                         for (int k = 0; k < RPL; k++)
                         {
                             const int row = k * 64 + lane;
+                            const int wcu = (int) (gcu & (WIN2_COLS - 1));
                             const int nlk = (par[k] >= 0 && row < R) ? (int) p.sc_nlinks[lcu * R + row] : 0; // (rare path: straight from HBM)
                             if (nlk > 0)
                             {
@@ -1160,7 +1298,10 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                                     const int v = s_win[((wcu - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
                                     const int vv = v & A2_IDMASK;
                                     if (v >= 0 && vv != i && T.alive[vv])
+                                    {
+                                        log_link(g, st, p.link_log, T.cell[i], T.cell[vv]);
                                         lds_union(T.uf, T.c_fin, i, vv);
+                                    }
                                 }
                             }
                         }
@@ -1176,6 +1317,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             A2_PH(3)
             // ---- the cut column ----------------------------------------------------------------------------------------------
 #ifdef CC_A2_STATS
+            st_nunf += n_unf;
             st_sub++;
             st_check += cut == CUT_CHECK;
             st_live += cut == CUT_LIVE;
@@ -1206,7 +1348,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     int nn = n_unf, e = 0, hd = info_head;
                     double LL = L;
                     long long MM = M;
-                    assoc_column_live2<RPL>(c, cfg, g, T, s_win, lcu, gcu, (int) (first_unpub % RC), nn, LL, MM, hd, e); // (64-bit modulo: rare path)
+                    assoc_column_live2<RPL>(c, cfg, g, T, s_win, lcu, gcu, (int) (first_unpub % RC), nn, LL, MM, hd, e, st); // (64-bit modulo: rare path)
                     T.bcast_i[0] = nn;
                     T.bcast_i[1] = e;
                     T.bcast_i[3] = hd;
@@ -1265,6 +1407,10 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
         st->dbg[11] += st_live;
         st->dbg[12] += (unsigned long long) (gc - col_begin);
         st->dbg[13] += st_wait_g;
+        st->dbg[14] += st_full;
+        st->dbg[15] += st_kill;
+        st->dbg[5] += st_removed;
+        st->dbg[6] += st_nunf;
         for (int i = 0; i < 5; i++)
             st->dbg[i] += st_ph[i];
     }

@@ -84,6 +84,8 @@ struct StreamState
     int32_t n_events;
     int64_t error_a;
     int64_t error_b;
+    int32_t n_links;     // entries of the link log written in the current call
+    int32_t pad2;
     int64_t overrun_col; // lowest column found stale by the segmentation (CC_ERR_RING_OVERRUN), INT64_MAX = none
 };
 
@@ -156,6 +158,9 @@ struct Planes
     uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS
     unsigned long long* sc_links; // LINK_SLOTS x 16-bit candidate codes packed into one word per cell
     double* sc_fin;      // continuous azimuth + max angle diff of the point (its contribution to finished_at)
+    uint16_t* sc_visits; // Point::number_of_visited_neighbors (cc.cpp:725), only with Geometry::mirror_fields
+    int2* link_log;      // [stream][link_capacity] (root cell, root cell) of every tree link made in the current call (cc.cpp:693-694), only
+                         // with Geometry::mirror_fields: the host rebuilds Point::associated_trees from it
     float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
 };
 
@@ -174,6 +179,9 @@ struct Geometry
     int32_t limit_columns;   // a launch stops consuming firings of a stream once it emitted this many columns
     int32_t debug_flags;     // experiment switches (cc_engine_set_option "debug_flags"); 0 in production
     int32_t lds_tree_limit;  // unfinished trees kept in LDS before a stream falls back to the global-memory kernel (<= TREE_SLOTS)
+    int32_t mirror_fields;   // also produce the per-point fields only the host mirror of range_image_ shows (visited-neighbour counts, the
+                             // parent of live-replayed points, per-tree values of finished trees, the tree-link log)
+    int32_t link_capacity;
 };
 
 } // namespace ccd

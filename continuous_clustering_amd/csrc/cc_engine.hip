@@ -76,6 +76,7 @@ struct cc_engine
     void* d_view{nullptr};
     size_t view_bytes{0};
     std::vector<std::vector<cc_event>> pending_events; // per stream, drained from the device after each batch
+    std::vector<std::vector<int64_t>> pending_links;   // per stream: (root gcol, root row, root gcol, root row) per logged tree link
     // pending continuation of the last device batch (kernel stopped early for some stream)
     const float* last_xyz{nullptr};
     const uint8_t* last_int{nullptr};
@@ -197,6 +198,8 @@ int allocate(cc_engine* e)
     A(sc_term, C) A(col_newfin, L) A(col_info, L);
     A(sg_x2, C) A(sg_uz, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
+    A(sc_visits, C);
+    A(link_log, S * (size_t) g.link_capacity);
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
         return rc;
@@ -241,6 +244,7 @@ int reset_state(cc_engine* e, bool keep_table)
         st.finish_lower_bound = std::numeric_limits<double>::max();
         st.last_round_min_az = -1.0; // Point::visited_at_continuous_azimuth_angle{-1.} cc.hpp:158
         st.overrun_col = std::numeric_limits<int64_t>::max();
+        st.n_links = 0;
         for (auto& d : st.batch)
             d.seg_begin = d.seg_end = d.acp_next = d.pub_begin = d.pub_end = -1, d.mode = 0;
         st.assoc_mode = e->cfg.max_steps_in_row > WIN_COLS - 2 ? 1 : 0;
@@ -248,6 +252,8 @@ int reset_state(cc_engine* e, bool keep_table)
     CC_HIP_CHECK(e, hipMemcpyAsync(e->d_states, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice, e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     for (auto& v : e->pending_events)
+        v.clear();
+    for (auto& v : e->pending_links)
         v.clear();
     e->batch_open = false;
     for (bool& b : e->assoc_pending)
@@ -427,10 +433,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     CC_MARK(sc); // ev4: table + segment (start of the window scan)
     const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
-    if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_scan<1>, scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    if (rpl == 1 && !g.mirror_fields)
+        hipLaunchKernelGGL((cck::k_scan<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    else if (rpl == 1)
+        hipLaunchKernelGGL((cck::k_scan<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    else if (!g.mirror_fields)
+        hipLaunchKernelGGL((cck::k_scan<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_scan<2>, scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        hipLaunchKernelGGL((cck::k_scan<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
     CC_MARK(sc); // ev5: scan
     if (sc != sa)
     {
@@ -488,6 +498,7 @@ __global__ void k_begin_batch(StreamState* states, int first_stream, int count, 
     {
         states[first_stream + i].cursor = 0;
         states[first_stream + i].n_events = 0; // every event of the previous call has been collected
+        states[first_stream + i].n_links = 0;
         states[first_stream + i].clear_allowed = unlimited_clear ? 0x7fffffffffffffffll : states[first_stream + i].ring_start;
     }
     if (i == 0)
@@ -503,10 +514,14 @@ __global__ void k_clear_events(StreamState* states, int first_stream, int count)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count)
+    {
         states[first_stream + i].n_events = 0;
+        states[first_stream + i].n_links = 0;
+    }
 }
 
 int collect_events(cc_engine* e, int first_stream, int count);
+int collect_links(cc_engine* e, int stream, const StreamState& st);
 
 int resolve_timing(cc_engine* e)
 {
@@ -670,6 +685,38 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
     return CC_OK;
 }
 
+// Tree links logged by the association kernels during the last call (Geometry::mirror_fields): root cells -> (global column, row)
+int collect_links(cc_engine* e, int stream, const StreamState& st)
+{
+    if (!e->g.mirror_fields || st.n_links <= 0)
+        return CC_OK;
+    if (st.n_links > e->g.link_capacity)
+    {
+        e->error = "tree-link log overflow (more than " + std::to_string(e->g.link_capacity) + " links in one call)";
+        return CC_ERR_CAPACITY;
+    }
+    std::vector<int2> raw((size_t) st.n_links);
+    CC_HIP_CHECK(e, hipMemcpy(raw.data(), e->P.link_log + (size_t) stream * e->g.link_capacity, raw.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    const int R = e->g.num_rows, RC = e->g.ring_cols;
+    // a root cell's column is the latest global column <= the last segmented one that maps to its ring slot
+    const int64_t last = st.first_unfinished - 1;
+    auto gcol_of = [&](int cell)
+    {
+        const int64_t lc = cell / R;
+        int64_t g = last - (((last % RC) - lc + RC) % RC);
+        return g;
+    };
+    auto& dst = e->pending_links[stream];
+    for (const int2& l : raw)
+    {
+        dst.push_back(gcol_of(l.x));
+        dst.push_back(l.x % R);
+        dst.push_back(gcol_of(l.y));
+        dst.push_back(l.y % R);
+    }
+    return CC_OK;
+}
+
 int collect_events(cc_engine* e, int first_stream, int count)
 {
     std::vector<StreamState> st(count);
@@ -684,6 +731,12 @@ int collect_events(cc_engine* e, int first_stream, int count)
         dst.resize(old + n);
         CC_HIP_CHECK(e, hipMemcpy(dst.data() + old, e->P.events + (size_t) (first_stream + i) * e->g.event_capacity,
                                   n * sizeof(cc_event), hipMemcpyDeviceToHost));
+    }
+    for (int i = 0; i < count; i++)
+    {
+        int rc = collect_links(e, first_stream + i, st[i]);
+        if (rc)
+            return rc;
     }
     hipLaunchKernelGGL(k_clear_events, dim3((count + 255) / 256), dim3(256), 0, e->stream, e->d_states, first_stream, count);
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
@@ -846,6 +899,12 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
                                       (size_t) (st.n_events - SMALL_EVENTS) * sizeof(cc_event), hipMemcpyDeviceToHost));
         }
     }
+    if (e->g.record_events)
+    {
+        int rcl = collect_links(e, stream, st);
+        if (rcl)
+            return rcl;
+    }
     if (st.error)
     {
         set_kernel_error(e, stream, st);
@@ -953,9 +1012,12 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     e->g.num_streams = num_streams;
     e->g.tree_capacity = 1 << 15;
     e->g.record_events = num_streams == 1 ? 1 : 0;
+    e->g.mirror_fields = e->g.record_events; // the host mirror's extra per-point fields: on where a host reads columns back (1 stream)
+    e->g.link_capacity = 8192;
     fill_geometry(e, num_rows);
     e->g.event_capacity = e->g.record_events ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
     e->pending_events.resize(num_streams);
+    e->pending_links.resize(num_streams);
     (void) hipFuncSetAttribute((const void*) cck::k_seg_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1210,6 +1272,7 @@ int cc_engine_record_events(cc_engine* e, int enable)
     if (want == e->g.record_events)
         return CC_OK;
     e->g.record_events = want;
+    e->g.mirror_fields = want;
     const int cap = want ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
     if (cap > e->g.event_capacity)
     {
@@ -1235,6 +1298,23 @@ int cc_engine_drain_events(cc_engine* e, int stream, cc_event* out, int64_t capa
         memcpy(out, q.data(), (size_t) k * sizeof(cc_event));
     q.erase(q.begin(), q.begin() + k);
     *n = k;
+    return CC_OK;
+}
+
+int cc_engine_drain_links(cc_engine* e, int stream, int64_t* out, int64_t capacity, int64_t* n)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !n || capacity < 0 || (capacity > 0 && !out))
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    auto& q = e->pending_links[stream];
+    const int64_t k = std::min<int64_t>(capacity, (int64_t) q.size() / 4);
+    if (k > 0)
+        memcpy(out, q.data(), (size_t) k * 4 * sizeof(int64_t));
+    q.erase(q.begin(), q.begin() + k * 4);
+    *n = capacity == 0 ? (int64_t) q.size() / 4 : k;
     return CC_OK;
 }
 
@@ -1290,8 +1370,9 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     if (rc)
         return rc;
     const size_t n = (size_t) (to - from + 1) * e->g.num_rows;
-    // one staging block: 5 float + 1 double + 3 int64 + 3 u8 + 1 u64 + 1 i32 planes
-    const size_t bytes = n * (5 * 4 + 8 + 3 * 8 + 3 + 8 + 4) + 256;
+    // one staging block: 5 float + 1 double + 3 int64 + 3 u8 + 1 u64 + 1 i32 planes, + 1 double + 1 int64 + 5 x 4-byte + 1 u8 of the
+    // remaining clustering fields
+    const size_t bytes = n * (5 * 4 + 8 + 3 * 8 + 3 + 8 + 4 + 8 + 8 + 5 * 4 + 1) + 256;
     if (e->view_bytes < bytes)
     {
         void* p = nullptr;
@@ -1308,19 +1389,32 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     o.src = (int64_t*) (base + n * 16);
     o.root_gcol = (int64_t*) (base + n * 24);
     o.id = (uint64_t*) (base + n * 32);
-    char* b4 = base + n * 40;
+    o.fin = (double*) (base + n * 40);
+    o.par_gcol = (int64_t*) (base + n * 48);
+    char* b4 = base + n * 56;
     o.x = (float*) b4;
     o.y = (float*) (b4 + n * 4);
     o.z = (float*) (b4 + n * 8);
     o.dist = (float*) (b4 + n * 12);
     o.incl = (float*) (b4 + n * 16);
     o.root_row = (int32_t*) (b4 + n * 20);
-    char* b1 = b4 + n * 24;
+    o.tpts = (uint32_t*) (b4 + n * 24);
+    o.width = (uint32_t*) (b4 + n * 28);
+    o.nchild = (uint32_t*) (b4 + n * 32);
+    o.visits = (int32_t*) (b4 + n * 36);
+    o.par_row = (int32_t*) (b4 + n * 40);
+    char* b1 = b4 + n * 44;
     o.ground = (uint8_t*) b1;
     o.debug = (uint8_t*) (b1 + n);
     o.ignored = (uint8_t*) (b1 + 2 * n);
+    o.finished = (uint8_t*) (b1 + 3 * n);
+    // the optional fields cost a child-count pass and extra copies: only when the caller asked for one of them
+    if (!v->number_of_child_points)
+        o.nchild = nullptr;
+    int max_back = e->cfg.max_steps_in_row < e->g.ring_cols - 1 ? e->cfg.max_steps_in_row : e->g.ring_cols - 1;
+    max_back = max_back < 0 ? 0 : (max_back > 255 ? 255 : max_back);
     hipLaunchKernelGGL(cck::k_view, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, e->d_states, stream,
-                       (long long) from, o);
+                       (long long) from, o, max_back);
     CC_HIP_CHECK(e, hipGetLastError());
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
 #define COPY(dst, srcp, T)                                                                        \
@@ -1330,6 +1424,11 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     COPY(continuous_azimuth_angle, o.caz, double) COPY(global_column_index, o.gcol, int64_t) COPY(source_firing, o.src, int64_t);
     COPY(ground_point_label, o.ground, uint8_t) COPY(debug_ground_point_label, o.debug, uint8_t) COPY(is_ignored, o.ignored, uint8_t);
     COPY(id, o.id, uint64_t) COPY(tree_root_global_column, o.root_gcol, int64_t) COPY(tree_root_row, o.root_row, int32_t);
+    COPY(finished_at_continuous_azimuth_angle, o.fin, double) COPY(tree_num_points, o.tpts, uint32_t) COPY(cluster_width, o.width, uint32_t);
+    COPY(number_of_visited_neighbors, o.visits, int32_t) COPY(belongs_to_finished_cluster, o.finished, uint8_t);
+    COPY(tree_parent_global_column, o.par_gcol, int64_t) COPY(tree_parent_row, o.par_row, int32_t);
+    if (v->number_of_child_points)
+        CC_HIP_CHECK(e, hipMemcpy(v->number_of_child_points, o.nchild, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
 #undef COPY
     return CC_OK;
 }
@@ -1454,6 +1553,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")
         e->assoc_waves = value == 1 ? 1 : 2;
+    else if (n == "mirror_fields")
+        e->g.mirror_fields = value != 0;
     else if (n == "limit_columns")
         e->g.limit_columns = (int32_t) (value < 1 ? 1 : value);
     else

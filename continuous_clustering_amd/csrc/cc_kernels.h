@@ -169,6 +169,22 @@ __device__ __forceinline__ void raise_error(StreamState* st, int code, long long
     }
 }
 
+// Point::associated_trees (cc.cpp:693-694) is an unordered union here; with Geometry::mirror_fields every link that is made is also
+// logged as a pair of root cells, so that the host mirror can walk the tree graph in the reference's order (cc.cpp:851-910).
+__device__ __forceinline__ void log_link(const Geometry& g, StreamState* st, int2* log, int cell_a, int cell_b)
+{
+    if (!g.mirror_fields)
+        return;
+    const int k = atomicAdd(&st->n_links, 1);
+    if (k < g.link_capacity)
+        log[k] = make_int2(cell_a, cell_b);
+}
+
+__device__ __forceinline__ uint16_t sat_u16(int v)
+{
+    return (uint16_t) (v > 65535 ? 65535 : v);
+}
+
 // Pointers of one stream (planes offset to the stream's first cell / column / pool slot).
 struct SP
 {
@@ -203,6 +219,8 @@ struct SP
     float *sg_x2, *sg_uz;
     uint8_t* sg_flags;
     float4* sc_rec;
+    uint16_t* sc_visits;
+    int2* link_log;
 };
 
 __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, int s)
@@ -258,6 +276,8 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.sg_uz = P.sg_uz + co;
     p.sg_flags = P.sg_flags + co;
     p.sc_rec = P.sc_rec + co;
+    p.sc_visits = P.sc_visits + co;
+    p.link_log = P.link_log + (size_t) s * (size_t) g.link_capacity;
     return p;
 }
 
@@ -2024,7 +2044,8 @@ __device__ __forceinline__ void tree_init(const SP& p, int cell, double fin)
 template<bool LIVE, bool CODE = false, bool REC = false>
 __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, const long long gc, const int row, const int first_local,
                                            const float mad, const double pcaz, int& p_root, int& parent, int* links, int& nlinks,
-                                           bool& overflow, const int max_links = LINK_SLOTS_V1)
+                                           bool& overflow, const int max_links = LINK_SLOTS_V1, int* visits = nullptr, StreamState* st = nullptr,
+                                           const Geometry* geo = nullptr, int* reach = nullptr)
 {
     const SP& p = c.p;
     const int R = c.R;
@@ -2060,6 +2081,10 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
             while (orow >= 0 && orow < R && sv <= c.max_steps_in_column)
             {
                 const int oi = oc * R + orow;
+                if (visits)
+                    ++*visits; // cc.cpp:725
+                if (reach)
+                    *reach = sb;
                 float4 orec;
                 unsigned char oign = 0;
                 if (REC)
@@ -2094,6 +2119,7 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                                     if (nw <= (uint32_t) c.NC && !p.t_finished[oroot])
                                     {
                                         p_root = oroot;
+                                        parent = (sb << 8) | orow; // the point joins other's child list (cc.cpp:663)
                                         p.t_width[oroot] = nw;
                                         const double cand = pcaz + (double) mad;
                                         const double cur = ld_agent(&p.t_fin[oroot]);
@@ -2106,7 +2132,11 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                                 {
                                     // associatePointTreeToPointTree cc.cpp:675-696
                                     if (!p.t_finished[p_root] && !p.t_finished[oroot] && p_root != oroot)
+                                    {
+                                        if (geo)
+                                            log_link(*geo, st, p.link_log, p_root, oroot);
                                         uf_union(p.t_uf, p_root, oroot);
+                                    }
                                 }
                             }
                             else
@@ -2238,11 +2268,26 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                     active[k] = true;
                     mad[k] = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
                     pcaz[k] = p.caz[ci];
-                    int dummy_root = -1;
+                    int dummy_root = -1, vis = 0;
                     scan_point<false>(c, lc, gc, row, first_local, mad[k], pcaz[k], dummy_root, parent[k], s_links[row], nlinks[k],
-                                      overflow);
+                                      overflow, LINK_SLOTS_V1, &vis);
+                    if (g.mirror_fields)
+                        p.sc_visits[ci] = sat_u16(vis);
                 }
                 s_parent[row] = active[k] ? parent[k] : -2;
+                // this kernel takes its candidates as cell indices; the planes keep the (columns back, row) code of k_scan
+                {
+                    int code = active[k] ? -1 : -2;
+                    if (parent[k] >= 0)
+                    {
+                        int back = lc - parent[k] / R;
+                        back = back < 0 ? back + RC : back;
+                        code = (back << 8) | (parent[k] % R);
+                    }
+                    p.sc_parent[ci] = (int16_t) code;
+                    if (!active[k] && g.mirror_fields)
+                        p.sc_visits[ci] = 0;
+                }
             }
         }
         __syncthreads();
@@ -2349,7 +2394,10 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                     {
                         const int rq = p.root[s_links[row][j]];
                         if (rq != rp && rq >= 0 && !p.t_finished[rp] && !p.t_finished[rq])
+                        {
+                            log_link(g, st, p.link_log, rp, rq);
                             uf_union(p.t_uf, rp, rq);
+                        }
                     }
                 }
             }
@@ -2371,13 +2419,19 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                     if (p.ignored[ci])
                     {
                         p.root[ci] = -1;
+                        p.sc_parent[ci] = -2;
+                        if (g.mirror_fields)
+                            p.sc_visits[ci] = 0;
                         continue;
                     }
                     const float m = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
                     const double caz = p.caz[ci];
-                    int proot = -1, par = -1, nl = 0;
+                    int proot = -1, par = -1, nl = 0, vis = 0;
                     bool ov = false;
-                    scan_point<true>(c, lc, gc, row, first_local, m, caz, proot, par, nullptr, nl, ov);
+                    scan_point<true>(c, lc, gc, row, first_local, m, caz, proot, par, nullptr, nl, ov, LINK_SLOTS_V1, &vis, st, &g);
+                    p.sc_parent[ci] = (int16_t) par; // the live scan's parent replaces the static one
+                    if (g.mirror_fields)
+                        p.sc_visits[ci] = sat_u16(vis);
                     if (proot == -1)
                     {
                         if (nn + 1 > g.tree_capacity)
@@ -2617,7 +2671,9 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
 #endif
 constexpr int SCAN_BLOCKS = CC_SCAN_BLOCKS;
 
-template<int RPL>
+// MIRROR: also count Point::number_of_visited_neighbors (cc.cpp:725) and how far back the scan looked (the live scan stops at the first
+// unpublished column, cc.cpp:762-763, so a count is only right if it did not look past it: the association kernels replay such columns).
+template<int RPL, bool MIRROR>
 __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
@@ -2651,6 +2707,7 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
         int parent[RPL], nlinks[RPL];
         double fin[RPL];
         unsigned long long packed[RPL];
+        int reach = 0; // deepest column (steps back) any visit of this lane went to
         if (RPL == 1)
         {
             // Rows = lanes: the scan of all 64 points of the column runs in lock step. Every lane visits the same relative cell
@@ -2680,7 +2737,7 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
             }
             // per-lane state as 0/1 integers in VGPRs: booleans carried through the loops as lane masks cost three scalar
             // instructions per variable at every loop exit
-            int rooted = 0, overflow = 0, live_i = live ? 1 : 0;
+            int rooted = 0, overflow = 0, live_i = live ? 1 : 0, visits = 0;
             int oc = lc;
             for (int sb = 0;; sb++)
             {
@@ -2707,6 +2764,11 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                         const float ox = __shfl(cr.x, src), oy = __shfl(cr.y, src), oz = __shfl(cr.z, src), ow = __shfl(cr.w, src);
                         // branch-free: cc.cpp:721 inclination window, :729 ignored cell, :738 distance, :745-757 parent / link,
                         // :759 early stop
+                        if (MIRROR)
+                        {
+                            visits += run; // cc.cpp:725
+                            reach = run ? sb : reach;
+                        }
                         const int cont = (run && !(ccm::absf(ow - me.w) > mad)) ? 1 : 0;
                         const float dx = me.x - ox, dy = me.y - oy, dz = me.z - oz;
                         const int acc = (cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2) ? 1 : 0; // x = NaN: ignored / empty
@@ -2741,6 +2803,8 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 p.sc_fin[ci] = fin[0];
                 if (nlinks[0] > 0)
                     p.sc_links[ci] = packed[0];
+                if (MIRROR)
+                    p.sc_visits[ci] = sat_u16(visits);
             }
         }
         else
@@ -2762,11 +2826,19 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                     const double caz = p.caz[ci];
                     fin[k] = caz + (double) mad;
                     bool overflow = false;
-                    int dummy_root = -1;
-                    scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent[k], s_links[row], nlinks[k], overflow, LINK_SLOTS);
+                    int dummy_root = -1, vis = 0, rch = 0;
+                    scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent[k], s_links[row], nlinks[k], overflow, LINK_SLOTS,
+                                                  MIRROR ? &vis : nullptr, nullptr, nullptr, MIRROR ? &rch : nullptr);
                     if (overflow)
                         nlinks[k] = 255;
+                    if (MIRROR)
+                    {
+                        p.sc_visits[ci] = sat_u16(vis);
+                        reach = rch > reach ? rch : reach;
+                    }
                 }
+                else if (MIRROR)
+                    p.sc_visits[ci] = 0;
                 p.sc_parent[ci] = (int16_t) parent[k];
                 p.sc_nlinks[ci] = (uint8_t) nlinks[k];
                 p.sc_fin[ci] = fin[k];
@@ -2848,12 +2920,14 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 p.sc_term[lc * R + row] = (int16_t) term;
         }
         max_delta = -wave_min_i32(-max_delta); // DPP reductions, ballots: no LDS round trips
+        if (MIRROR)
+            reach = -wave_min_i32(-reach);
         flags = (__any(flags & 1) ? 1 : 0) | (__any(flags & 2) ? 2 : 0);
         newfin = wave_min_f64(newfin);
         if (lane == 0)
         {
             p.col_newfin[lc] = newfin;
-            p.col_info[lc] = cnt_new | (flags << 8) | (max_delta << 16);
+            p.col_info[lc] = cnt_new | (flags << 8) | (max_delta << 16) | ((MIRROR ? reach : 0) << 24);
         }
     }
 }
@@ -2941,7 +3015,7 @@ __device__ __forceinline__ bool cluster_may_finish(LdsTrees& T, int n_unf, doubl
 // exact single-lane replay of one column (rare): reference semantics with immediate attach / link, LDS tree state
 template<int RPL>
 __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const Geometry& g, LdsTrees& T, int* s_win, const int lc,
-                                  const long long gc, const int first_local, int& n_unf, double& L, long long& M, int& err)
+                                  const long long gc, const int first_local, int& n_unf, double& L, long long& M, int& err, StreamState* st)
 {
     const SP& p = c.p;
     const int R = c.R, RC = c.RC;
@@ -2954,6 +3028,9 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
         if (p.ignored[pi])
         {
             p.root[pi] = -1;
+            p.sc_parent[pi] = -2;
+            if (g.mirror_fields)
+                p.sc_visits[pi] = 0;
             continue;
         }
         const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[pi]);
@@ -2963,6 +3040,7 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
         needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
         int oc = lc;
         long long ogc = gc;
+        int visits = 0, parcode = -1; // Point::number_of_visited_neighbors; the candidate whose child list the point joins (cc.cpp:663)
         int pslot = -1; // tree slot of the point (-1: none yet)
         for (int sb = 0; sb <= needed; sb++)
         {
@@ -2975,6 +3053,7 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
                 while (orow >= 0 && orow < R && sv <= c.max_steps_in_column)
                 {
                     const int oi = oc * R + orow;
+                    visits++; // cc.cpp:725
                     if (ccm::absf(p.incl[oi] - pincl) > mad)
                         break;
                     if (!p.ignored[oi])
@@ -2996,6 +3075,7 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
                                         if (nw <= (uint32_t) c.NC)
                                         {
                                             pslot = oslot;
+                                            parcode = (sb << 8) | orow;
                                             T.last[oslot] = (unsigned) gc;
                                             const unsigned long long cand = (unsigned long long) __double_as_longlong(pcaz + (double) mad);
                                             if (cand > T.fin[oslot])
@@ -3006,7 +3086,10 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
                                     }
                                 }
                                 else if (oslot >= 0 && oslot != pslot)
+                                {
+                                    log_link(g, st, p.link_log, T.cell[pslot], T.cell[oslot]);
                                     lds_union(T.uf, T.c_fin, pslot, oslot);
+                                }
                             }
                         }
                     }
@@ -3050,6 +3133,9 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
         rootcell = T.cell[pslot];
         wcol[row] = pslot;
         p.root[pi] = rootcell;
+        p.sc_parent[pi] = (int16_t) parcode; // the live scan's parent replaces the static one
+        if (g.mirror_fields)
+            p.sc_visits[pi] = sat_u16(visits);
     }
 }
 
@@ -3425,6 +3511,9 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 }
             }
         }
+        // (mirror mode) the static visit counts are only right if no scan looked past the first unpublished column
+        if (g.mirror_fields && gc - ((p.col_info[lc] >> 24) & 0x7f) < first_unpub)
+            bad = true;
         const bool column_live = __any(bad);
         CC_SEC(3)
 
@@ -3483,7 +3572,10 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                             const int code = (int) ((link[k] >> (16 * j)) & 0xffff);
                             const int v = s_win[((wcur - (code >> 8)) & (WIN_COLS - 1)) * R + (code & 0xff)];
                             if (v >= 0 && v != i)
+                            {
+                                log_link(g, st, p.link_log, T.cell[i], T.cell[v]);
                                 lds_union(T.uf, T.c_fin, i, v);
+                            }
                         }
                 }
             }
@@ -3497,7 +3589,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 int nn = n_unf, e = 0;
                 double LL = L;
                 long long MM = M;
-                assoc_column_live<RPL>(c, cfg, g, T, s_win, lc, gc, first_local, nn, LL, MM, e);
+                assoc_column_live<RPL>(c, cfg, g, T, s_win, lc, gc, first_local, nn, LL, MM, e, st);
                 s_bi[0] = nn;
                 s_bi[1] = e;
                 s_bd[0] = LL;
@@ -3625,6 +3717,13 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                     {
                         p.t_finished[cell] = 1;
                         p.t_cid[cell] = T.a_cid[j];
+                        if (g.mirror_fields)
+                        {
+                            // final per-tree values of Point (cc.cpp:666-671) for the host mirror
+                            p.t_fin[cell] = __longlong_as_double((long long) fin);
+                            p.t_pts[cell] = pts;
+                            p.t_width[cell] = (unsigned) (width - (unsigned) tg) + 1u;
+                        }
                     }
                     else
                     {
@@ -3848,9 +3947,15 @@ struct ViewOut
     uint8_t *ground, *debug, *ignored;
     uint64_t* id;
     int32_t* root_row;
+    // the remaining clustering fields of Point (include/cc_hip.h), any of them may be null
+    double* fin;
+    uint32_t *tpts, *width, *nchild;
+    int32_t *visits, *par_row;
+    uint8_t* finished;
+    int64_t* par_gcol;
 };
 
-__global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamState* states, int s, long long from, ViewOut o)
+__global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamState* states, int s, long long from, ViewOut o, int max_back)
 {
     const StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
@@ -3881,6 +3986,50 @@ __global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamS
         o.id[oi] = r >= 0 ? (uint64_t) p.t_cid[r] : 0ull;
         o.root_gcol[oi] = r >= 0 ? p.colg[r / R] : -1;
         o.root_row[oi] = r >= 0 ? r % R : 0;
+        // per-tree values live at the root cell (cc.cpp:666-671, 818-822, 933); everything else keeps its cleared value
+        const bool is_root = r >= 0 && (size_t) r == ci;
+        if (o.fin)
+            o.fin[oi] = is_root ? p.t_fin[ci] : 0.;
+        if (o.tpts)
+            o.tpts[oi] = is_root ? p.t_pts[ci] : 0u;
+        if (o.width)
+            o.width[oi] = is_root ? p.t_width[ci] : 0u;
+        if (o.finished)
+            o.finished[oi] = is_root ? p.t_finished[ci] : (uint8_t) 0;
+        if (o.visits)
+            o.visits[oi] = (segmented && g.mirror_fields) ? (int32_t) p.sc_visits[ci] : 0;
+        const int code = (segmented && r >= 0) ? (int) p.sc_parent[ci] : -1; // (columns back << 8) | row of the point whose child list holds this one
+        if (o.par_gcol)
+            o.par_gcol[oi] = code >= 0 ? gc - (code >> 8) : -1;
+        if (o.par_row)
+            o.par_row[oi] = code >= 0 ? (code & 0xff) : 0;
+    }
+    if (o.nchild)
+    {
+        // Point::child_points.size(): the points of this and the following columns whose parent is a cell of this column
+        __shared__ unsigned s_cnt[WAVE * MAX_ROWS_PER_LANE];
+        for (int row = lane_id(); row < R; row += 64)
+            s_cnt[row] = 0;
+        __syncthreads();
+        if (segmented)
+            for (int d = 0; d <= max_back; d++)
+            {
+                const long long gd = gc + d;
+                if (gd >= st->first_unfinished)
+                    break;
+                int ld = lc + d;
+                ld = ld >= RC ? ld - RC : ld;
+                for (int row = lane_id(); row < R; row += 64)
+                {
+                    const size_t cj = (size_t) ld * R + row;
+                    const int code = p.root[cj] >= 0 ? (int) p.sc_parent[cj] : -1;
+                    if (code >= 0 && (code >> 8) == d)
+                        atomicAdd(&s_cnt[code & 0xff], 1u);
+                }
+            }
+        __syncthreads();
+        for (int row = lane_id(); row < R; row += 64)
+            o.nchild[(size_t) blockIdx.x * R + row] = s_cnt[row];
     }
 }
 

@@ -176,6 +176,17 @@ typedef struct cc_column_view
     uint64_t* id;                    /* Point::id — cluster id, reference numbering (cc.cpp:939), 0 = none */
     int64_t* tree_root_global_column;/* global column of Point::tree_root_, -1 = none */
     int32_t* tree_root_row;          /* row of Point::tree_root_ */
+    /* The remaining clustering fields of Point that the reference's ROS packers read (ros_utils.cpp:289-295) and that
+     * collectPointsForCusterAndPublish walks (cc.cpp:996-1016). Final once the point's tree is finished, i.e. for every
+     * published column. Produced when the engine option "mirror_fields" is on (default for 1 stream). */
+    double* finished_at_continuous_azimuth_angle; /* Point::finished_at_continuous_azimuth_angle: tree roots, 0 elsewhere (cc.cpp:669,818) */
+    uint32_t* tree_num_points;       /* Point::tree_num_points: tree roots, 0 elsewhere (cc.cpp:671,822) */
+    uint32_t* cluster_width;         /* Point::cluster_width: tree roots, 0 elsewhere (cc.cpp:666,819) */
+    uint32_t* number_of_child_points;/* Point::child_points.size() (cc.cpp:663) */
+    int32_t* number_of_visited_neighbors; /* Point::number_of_visited_neighbors (cc.cpp:725) */
+    uint8_t* belongs_to_finished_cluster; /* Point::belongs_to_finished_cluster: set on tree roots only (cc.cpp:933) */
+    int64_t* tree_parent_global_column;   /* the point whose child_points list holds this point (cc.cpp:663); -1 = tree root / no tree */
+    int32_t* tree_parent_row;
 } cc_column_view;
 
 typedef struct cc_engine cc_engine;
@@ -227,6 +238,12 @@ int cc_engine_record_events(cc_engine* e, int enable);
 /* Move up to `capacity` queued events of `stream` into `out`; *n = number written. Implies sync. */
 int cc_engine_drain_events(cc_engine* e, int stream, cc_event* out, int64_t capacity, int64_t* n);
 
+/* Tree links made since the last drain (cc.cpp:693-694, associatePointTreeToPointTree), each as four int64:
+ * (global column, row) of the one tree root, (global column, row) of the other. Only recorded while events are (option
+ * "mirror_fields"); a host mirror rebuilds Point::associated_trees from them to walk a finished cluster's trees in the
+ * reference's order (cc.cpp:851-910). capacity = 0: *n = number of queued links, nothing is removed. Implies sync. */
+int cc_engine_drain_links(cc_engine* e, int stream, int64_t* out, int64_t capacity, int64_t* n);
+
 /* Number of queued events of `stream`. Implies sync. */
 int cc_engine_pending_events(cc_engine* e, int stream, int64_t* n);
 
@@ -260,7 +277,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * production), "parallel_insert" (1 (default): the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a
  * block-parallel kernel, the serial insertion kernel continues behind it; 0: serial kernel only), "publish_off_chain" (1 (default): in the pipelined mode k_publish runs on a stream of its own instead of at the end of
  * the association chain), "table_on_insert_chain" (1 (default): in the pipelined mode k_table runs at the end of the insertion chain instead of
- * at the head of the segmentation chain), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
+ * at the head of the segmentation chain), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
+ * number_of_visited_neighbors, per-tree values of finished trees, the tree-link log; 0 in throughput mode), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
  * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 

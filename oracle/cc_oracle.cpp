@@ -123,6 +123,7 @@ struct Cell
     std::list<Ref> children;
     std::set<Ref> links;
     Ref root;
+    Ref parent; // the cell whose child list holds this point (bookkeeping of the checker: the reference only keeps the child lists)
     uint32_t tree_points, width;
     uint64_t tree_id, id;
     double visited_at;
@@ -139,6 +140,11 @@ struct ColumnSnapshot
     std::vector<int32_t> root_row;
     std::vector<uint8_t> ground, debug, ignored;
     std::vector<uint64_t> id;
+    std::vector<double> finished_at;
+    std::vector<uint32_t> tree_points, width, n_children;
+    std::vector<int32_t> visited, parent_row;
+    std::vector<uint8_t> finished;
+    std::vector<int64_t> parent_gcol;
 };
 
 struct Oracle
@@ -170,6 +176,7 @@ struct Oracle
     std::vector<cc_event> events;
     std::vector<ColumnSnapshot> published; // snapshots taken inside the cluster-view column callback
     int64_t published_base{-1};            // gcol of published[0]
+    std::vector<std::vector<std::pair<int64_t, int32_t>>> cluster_members; // per CC_EV_CLUSTER event, in event order (record only)
     int64_t keep_tail{0};                  // > 0: only the most recent snapshots are kept (long verification runs of bench.py)
     uint64_t firings_consumed{0}, cells_published{0}, clusters_finished{0};
     uint64_t exceed_one_rotation{0};
@@ -209,6 +216,8 @@ struct Oracle
                 c.links.clear();
                 c.root.row = 0;
                 c.root.col = -1;
+                c.parent.row = 0;
+                c.parent.col = -1;
                 c.tree_points = 0;
                 c.width = 0;
                 c.tree_id = 0;
@@ -244,6 +253,7 @@ struct Oracle
         incl_steps.resize(rows, std::nanf(""));
         events.clear();
         published.clear();
+        cluster_members.clear();
         published_base = -1;
         firings_consumed = cells_published = clusters_finished = 0;
     }
@@ -624,6 +634,7 @@ struct Oracle
             p.root = other.root;
             p.tree_id = root.gcol * num_rows + root.row;
             other.children.push_back(Ref{p.lcol, static_cast<uint16_t>(p.row)});
+            p.parent = Ref{other.lcol, static_cast<uint16_t>(other.row)};
             root.width = new_width;
             root.finished_at = std::max(root.finished_at, p.cont_az + max_angle_diff);
             root.tree_points++;
@@ -810,6 +821,7 @@ struct Oracle
             uint32_t n = 0;
             int64_t cmin = std::numeric_limits<int64_t>::max(), cmax = -1;
             std::list<Ref> q;
+            std::vector<std::pair<int64_t, int32_t>> members; // (global column, row) in the order cluster_points is filled
             for (const Ref& t : *it_trees)
             {
                 q.clear();
@@ -820,6 +832,8 @@ struct Oracle
                     q.pop_front();
                     Cell& c = at(cur.col, cur.row);
                     c.id = cid;
+                    if (record)
+                        members.emplace_back(c.gcol, (int32_t) cur.row);
                     n++;
                     cmin = std::min(cmin, c.gcol);
                     cmax = std::max(cmax, c.gcol);
@@ -828,6 +842,8 @@ struct Oracle
                 }
             }
             clusters_finished++;
+            if (record)
+                cluster_members.push_back(std::move(members));
             emit(CC_EV_CLUSTER, cmin, cmax, (uint32_t) cid, n, gcol);
             ++it_trees;
         }
@@ -879,6 +895,22 @@ struct Oracle
             s.debug.push_back(c.debug);
             s.ignored.push_back(c.ignored ? 1 : 0);
             s.id.push_back(c.id);
+            s.finished_at.push_back(c.finished_at);
+            s.tree_points.push_back(c.tree_points);
+            s.width.push_back(c.width);
+            s.n_children.push_back((uint32_t) c.children.size());
+            s.visited.push_back(c.visited_neighbors);
+            s.finished.push_back(c.finished ? 1 : 0);
+            if (c.parent.col >= 0)
+            {
+                s.parent_gcol.push_back(at(c.parent.col, c.parent.row).gcol);
+                s.parent_row.push_back(c.parent.row);
+            }
+            else
+            {
+                s.parent_gcol.push_back(-1);
+                s.parent_row.push_back(0);
+            }
             if (c.root.col >= 0)
             {
                 s.root_gcol.push_back(at(c.root.col, c.root.row).gcol);
@@ -1103,9 +1135,34 @@ int orc_read_published(orc_handle* h, int64_t from, int64_t to, const cc_column_
             if (v->id) v->id[off + r] = s.id[r];
             if (v->tree_root_global_column) v->tree_root_global_column[off + r] = s.root_gcol[r];
             if (v->tree_root_row) v->tree_root_row[off + r] = s.root_row[r];
+            if (v->finished_at_continuous_azimuth_angle) v->finished_at_continuous_azimuth_angle[off + r] = s.finished_at[r];
+            if (v->tree_num_points) v->tree_num_points[off + r] = s.tree_points[r];
+            if (v->cluster_width) v->cluster_width[off + r] = s.width[r];
+            if (v->number_of_child_points) v->number_of_child_points[off + r] = s.n_children[r];
+            if (v->number_of_visited_neighbors) v->number_of_visited_neighbors[off + r] = s.visited[r];
+            if (v->belongs_to_finished_cluster) v->belongs_to_finished_cluster[off + r] = s.finished[r];
+            if (v->tree_parent_global_column) v->tree_parent_global_column[off + r] = s.parent_gcol[r];
+            if (v->tree_parent_row) v->tree_parent_row[off + r] = s.parent_row[r];
         }
     }
     return CC_OK;
+}
+
+// Member points of the idx-th cluster that received an id since reset (the order of its CC_EV_CLUSTER event), in the order the reference
+// fills cluster_points (cc.cpp:996-1016: trees in BFS order of the tree graph, points of a tree in BFS order of the child lists).
+int64_t orc_cluster_members(orc_handle* h, int64_t idx, int64_t capacity, int64_t* gcol, int32_t* row)
+{
+    Oracle& o = h->o;
+    if (idx < 0 || idx >= (int64_t) o.cluster_members.size())
+        return -1;
+    const auto& m = o.cluster_members[(size_t) idx];
+    const int64_t n = std::min<int64_t>(capacity, (int64_t) m.size());
+    for (int64_t i = 0; i < n; i++)
+    {
+        gcol[i] = m[(size_t) i].first;
+        row[i] = m[(size_t) i].second;
+    }
+    return (int64_t) m.size();
 }
 
 int64_t orc_published_base(orc_handle* h)

@@ -55,6 +55,8 @@ def lib():
         L.orc_num_events.argtypes = [C.c_void_p]
         L.orc_drain_events.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_read_published.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(capi.ColumnView)]
+        L.orc_cluster_members.restype = C.c_int64
+        L.orc_cluster_members.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_published_base.restype = C.c_int64
         L.orc_published_base.argtypes = [C.c_void_p]
         L.orc_published_count.restype = C.c_int64
@@ -160,6 +162,15 @@ class Oracle:
         got = C.c_int64(0)
         self.L.orc_drain_events(self.h, out.ctypes.data, n, C.byref(got))
         return out[: got.value]
+
+    def cluster_members(self, idx: int):
+        """(global column, row) of the idx-th id-carrying cluster since reset, in the reference's cluster_points order."""
+        n = self.L.orc_cluster_members(self.h, idx, 0, None, None)
+        if n < 0:
+            raise IndexError(idx)
+        g, r = np.zeros(max(1, n), dtype=np.int64), np.zeros(max(1, n), dtype=np.int32)
+        self.L.orc_cluster_members(self.h, idx, n, g.ctypes.data, r.ctypes.data)
+        return g[:n], r[:n]
 
     def published_range(self):
         base = self.L.orc_published_base(self.h)

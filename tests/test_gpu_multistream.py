@@ -99,7 +99,7 @@ def test_full_size_properties_256_streams():
         hi = states[s]["first_unpublished_global_column_index"] - 1
         lo = hi - 1500
         for s2 in (s, s + distinct * 7):
-            util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo)
+            util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo, mirror=False)
     g_ptr, id_ptr = e.output_planes(0)
     assert g_ptr and id_ptr
 
@@ -134,4 +134,4 @@ def test_pipelined_throughput_path_matches_oracle(pipeline, sub_batch, oracle_li
             assert so[k] == se[k], (s, k)
         hi = se["first_unpublished_global_column_index"] - 1
         lo = max(hi - 600, se["ring_buffer_start_global_column_index"])
-        util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo)
+        util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
