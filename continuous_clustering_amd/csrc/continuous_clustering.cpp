@@ -116,6 +116,10 @@ void ContinuousClustering::reset(int num_rows)
     buf_int_.clear();
     buf_pose_.clear();
     col_min_src_.assign(static_cast<size_t>(ring_buffer_max_columns), -1);
+    mirror_stage_.assign(range_image_.size(), 0);
+    tree_links_.clear();
+    v_from_ = 0;
+    v_to_ = -1;
 }
 
 // ---- continuous_clustering.cpp:66-81 ----------------------------------------------------------------------------------
@@ -234,82 +238,205 @@ void ContinuousClustering::clearMirrorColumns(int64_t from, int64_t to)
             Point& p = range_image_[lc * num_rows_ + r];
             p = Point{};
             p.ground_point_label = GP_UNKNOWN;
+            mirror_stage_[lc * num_rows_ + r] = 0;
         }
     }
 }
 
-void ContinuousClustering::refreshColumns(int64_t from, int64_t to)
+int64_t ContinuousClustering::globalColumnOfLocal(int64_t local_column) const
 {
+    // the latest global column <= the ring's end that maps to this ring slot
+    const int64_t end = ring_buffer_end_global_column_index;
+    const int64_t rc = ring_buffer_max_columns;
+    return end - (((end % rc) - local_column + rc) % rc);
+}
+
+// One read of the columns [from, to] into the v_* arrays (every field of cc_column_view).
+void ContinuousClustering::fetchColumns(int64_t from, int64_t to)
+{
+    v_from_ = from;
+    v_to_ = to;
     if (to < from)
         return;
+    const size_t n = static_cast<size_t>(to - from + 1) * static_cast<size_t>(num_rows_);
+    v_x_.resize(n), v_y_.resize(n), v_z_.resize(n), v_d_.resize(n), v_i_.resize(n), v_caz_.resize(n), v_src_.resize(n);
+    v_rootc_.resize(n), v_rootr_.resize(n), v_g_.resize(n), v_dbg_.resize(n), v_ign_.resize(n), v_id_.resize(n);
+    v_fin_.resize(n), v_tpts_.resize(n), v_width_.resize(n), v_nchild_.resize(n), v_visits_.resize(n), v_parr_.resize(n);
+    v_finished_.resize(n), v_parc_.resize(n);
     const size_t R = static_cast<size_t>(num_rows_);
     const int64_t step = 4096;
     for (int64_t c0 = from; c0 <= to; c0 += step)
     {
         const int64_t c1 = std::min(to, c0 + step - 1);
-        const size_t n = static_cast<size_t>(c1 - c0 + 1) * R;
-        v_x_.resize(n), v_y_.resize(n), v_z_.resize(n), v_d_.resize(n), v_i_.resize(n), v_caz_.resize(n), v_src_.resize(n);
-        v_rootc_.resize(n), v_rootr_.resize(n), v_g_.resize(n), v_dbg_.resize(n), v_ign_.resize(n), v_id_.resize(n);
+        const size_t o = static_cast<size_t>(c0 - from) * R;
         cc_column_view v{};
-        v.x = v_x_.data(), v.y = v_y_.data(), v.z = v_z_.data(), v.distance = v_d_.data(), v.inclination_angle = v_i_.data();
-        v.continuous_azimuth_angle = v_caz_.data(), v.source_firing = v_src_.data();
-        v.ground_point_label = v_g_.data(), v.debug_ground_point_label = v_dbg_.data(), v.is_ignored = v_ign_.data();
-        v.id = v_id_.data(), v.tree_root_global_column = v_rootc_.data(), v.tree_root_row = v_rootr_.data();
+        v.x = v_x_.data() + o, v.y = v_y_.data() + o, v.z = v_z_.data() + o, v.distance = v_d_.data() + o;
+        v.inclination_angle = v_i_.data() + o, v.continuous_azimuth_angle = v_caz_.data() + o, v.source_firing = v_src_.data() + o;
+        v.ground_point_label = v_g_.data() + o, v.debug_ground_point_label = v_dbg_.data() + o, v.is_ignored = v_ign_.data() + o;
+        v.id = v_id_.data() + o, v.tree_root_global_column = v_rootc_.data() + o, v.tree_root_row = v_rootr_.data() + o;
+        v.finished_at_continuous_azimuth_angle = v_fin_.data() + o, v.tree_num_points = v_tpts_.data() + o;
+        v.cluster_width = v_width_.data() + o, v.number_of_visited_neighbors = v_visits_.data() + o;
+        v.belongs_to_finished_cluster = v_finished_.data() + o, v.tree_parent_global_column = v_parc_.data() + o;
+        v.tree_parent_row = v_parr_.data() + o;
         check(cc_engine_read_columns(engine_, 0, c0, c1, &v));
-        for (int64_t g = c0; g <= c1; g++)
+    }
+}
+
+// Bring the mirror cells of the columns [from, to] (inside the fetched range) to `stage`. STAGE_GROUND: range-image and ground
+// segmentation fields, clustering fields as clearColumns left them (the ground-view callback runs before the column is associated,
+// cc.cpp:618-623). STAGE_ASSOC: tree root, visited-neighbour count, and the point enters its parent's child list (cc.cpp:663) —
+// columns reach this stage in ascending order and rows ascend inside a column, which is the order the reference attaches points in.
+// STAGE_FULL: cluster id and the per-tree values of root points.
+void ContinuousClustering::applyColumns(int64_t from, int64_t to, MirrorStage stage)
+{
+    from = std::max(from, v_from_);
+    to = std::min(to, v_to_);
+    const size_t R = static_cast<size_t>(num_rows_);
+    for (int64_t g = from; g <= to; g++)
+    {
+        const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
+        int64_t min_src = -1;
+        for (size_t r = 0; r < R; r++)
         {
-            const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
-            int64_t min_src = -1;
-            for (size_t r = 0; r < R; r++)
-            {
-                const size_t i = static_cast<size_t>(g - c0) * R + r;
-                if (v_src_[i] >= 0 && (min_src < 0 || v_src_[i] < min_src))
-                    min_src = v_src_[i];
-                Point& p = range_image_[lc * R + r];
-                p.xyz = Point3D(v_x_[i], v_y_[i], v_z_[i]);
-                p.distance = v_d_[i];
-                p.inclination_angle = v_i_[i];
-                p.continuous_azimuth_angle = v_caz_[i];
-                p.global_column_index = g; // refilled for every cell of a segmented column (cc.cpp:348-350)
-                p.local_column_index = static_cast<int>(lc);
-                p.ground_point_label = v_g_[i];
-                p.debug_ground_point_label = v_dbg_[i];
-                p.is_ignored = v_ign_[i] != 0;
-                p.id = v_id_[i];
-                if (v_rootc_[i] >= 0)
-                {
-                    p.tree_root_ = RangeImageIndex(static_cast<uint16_t>(v_rootr_[i]), v_rootc_[i] % ring_buffer_max_columns);
-                    p.tree_id = static_cast<uint64_t>(v_rootc_[i]) * R + static_cast<uint64_t>(v_rootr_[i]);
-                }
-                else
-                {
-                    p.tree_root_ = RangeImageIndex(0, -1);
-                    p.tree_id = 0;
-                }
-                p.belongs_to_finished_cluster = p.id != 0;
-                const int64_t src = v_src_[i];
-                if (src >= static_cast<int64_t>(firing_log_base_) && src < static_cast<int64_t>(firing_log_base_ + firing_log_.size()))
-                {
-                    const RawPoint& raw = firing_log_[static_cast<size_t>(src - firing_log_base_)]->points[r];
-                    p.row_index = static_cast<int>(r);
-                    p.firing_index = raw.firing_index;
-                    p.intensity = raw.intensity;
-                    p.stamp = raw.stamp;
-                    p.globally_unique_point_index = raw.globally_unique_point_index;
-                    p.azimuth_angle = std::atan2(raw.y, raw.x); // cc.cpp:142 (sensor frame)
-                }
-                else
-                {
-                    p.row_index = -1;
-                    p.firing_index = 0;
-                    p.intensity = 0;
-                    p.stamp = 0;
-                    p.globally_unique_point_index = static_cast<uint64_t>(-1);
-                    p.azimuth_angle = std::nanf("");
-                }
-            }
-            col_min_src_[lc] = min_src;
+            const size_t i = static_cast<size_t>(g - v_from_) * R + r;
+            if (v_src_[i] >= 0 && (min_src < 0 || v_src_[i] < min_src))
+                min_src = v_src_[i];
+            applyCell(g, static_cast<int>(r), stage);
         }
+        col_min_src_[lc] = min_src;
+    }
+}
+
+void ContinuousClustering::applyCell(int64_t g, int row, MirrorStage stage)
+{
+    if (g < v_from_ || g > v_to_)
+        return;
+    const size_t R = static_cast<size_t>(num_rows_), r = static_cast<size_t>(row);
+    const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
+    const size_t i = static_cast<size_t>(g - v_from_) * R + r;
+    const size_t ci = lc * R + r;
+    Point& p = range_image_[ci];
+    if (mirror_stage_[ci] < 1)
+    {
+        p.xyz = Point3D(v_x_[i], v_y_[i], v_z_[i]);
+        p.distance = v_d_[i];
+        p.inclination_angle = v_i_[i];
+        p.continuous_azimuth_angle = v_caz_[i];
+        p.global_column_index = g; // refilled for every cell of a segmented column (cc.cpp:348-350)
+        p.local_column_index = static_cast<int>(lc);
+        p.ground_point_label = v_g_[i];
+        p.debug_ground_point_label = v_dbg_[i];
+        p.is_ignored = v_ign_[i] != 0;
+        const int64_t src = v_src_[i];
+        if (src >= static_cast<int64_t>(firing_log_base_) && src < static_cast<int64_t>(firing_log_base_ + firing_log_.size()))
+        {
+            const RawPoint& raw = firing_log_[static_cast<size_t>(src - firing_log_base_)]->points[r];
+            p.row_index = static_cast<int>(r);
+            p.firing_index = raw.firing_index;
+            p.intensity = raw.intensity;
+            p.stamp = raw.stamp;
+            p.globally_unique_point_index = raw.globally_unique_point_index;
+            p.azimuth_angle = std::atan2(raw.y, raw.x); // cc.cpp:142 (sensor frame)
+        }
+        else
+        {
+            p.row_index = -1;
+            p.firing_index = 0;
+            p.intensity = 0;
+            p.stamp = 0;
+            p.globally_unique_point_index = static_cast<uint64_t>(-1);
+            p.azimuth_angle = std::nanf("");
+        }
+        mirror_stage_[ci] = 1;
+    }
+    if (stage >= STAGE_ASSOC && mirror_stage_[ci] < 2)
+    {
+        // what associatePointsInColumn leaves in the point (cc.cpp:661-663, 725, 814-815): final once the column is associated
+        if (v_rootc_[i] >= 0)
+        {
+            p.tree_root_ = RangeImageIndex(static_cast<uint16_t>(v_rootr_[i]), v_rootc_[i] % ring_buffer_max_columns);
+            p.tree_id = static_cast<uint64_t>(v_rootc_[i]) * R + static_cast<uint64_t>(v_rootr_[i]); // cc.cpp:662,815
+        }
+        else
+        {
+            p.tree_root_ = RangeImageIndex(0, -1);
+            p.tree_id = 0;
+        }
+        p.number_of_visited_neighbors = v_visits_[i];
+        if (v_parc_[i] >= 0)
+        {
+            const size_t plc = static_cast<size_t>(v_parc_[i] % ring_buffer_max_columns);
+            Point& q = range_image_[plc * R + static_cast<size_t>(v_parr_[i])];
+            if (q.global_column_index == v_parc_[i]) // (the parent's column is still in the mirror)
+                q.child_points.emplace_back(static_cast<uint16_t>(r), static_cast<int64_t>(lc));
+        }
+        mirror_stage_[ci] = 2;
+    }
+    if (stage == STAGE_FULL && mirror_stage_[ci] < 3)
+    {
+        // values that keep changing until the point's tree is finished: the cluster id (cc.cpp:1005) and, in the root point, the
+        // per-tree values (cc.cpp:666-671, 818-822) and belongs_to_finished_cluster (:933). Final for every published column.
+        p.id = v_id_[i];
+        p.finished_at_continuous_azimuth_angle = v_fin_[i];
+        p.tree_num_points = v_tpts_[i];
+        p.cluster_width = v_width_[i];
+        p.belongs_to_finished_cluster = v_finished_[i] != 0;
+        mirror_stage_[ci] = 3;
+    }
+}
+
+// cluster_points of collectPointsForCusterAndPublish (cc.cpp:985-1016) for one finished cluster: its member cells (gathered on the
+// device in column-then-row order) are brought to the full stage, then the trees are walked in the order of cc.cpp:851-910 (breadth
+// first over Point::associated_trees from the cluster's oldest tree) and the points of each tree breadth first over the child lists.
+void ContinuousClustering::collectClusterPoints(const cc_event& e, const int64_t* gcol, const int32_t* row, size_t cnt)
+{
+    cluster_points_.clear();
+    const size_t R = static_cast<size_t>(num_rows_);
+    const int64_t rc = ring_buffer_max_columns;
+    std::vector<RangeImageIndex> roots; // in creation order (column, then row)
+    for (size_t k = 0; k < cnt; k++)
+    {
+        applyCell(gcol[k], row[k], STAGE_FULL); // members only, in column-then-row order: the order their parents' child lists grow in
+        const Point& p = range_image_[static_cast<size_t>(gcol[k] % rc) * R + static_cast<size_t>(row[k])];
+        if (p.tree_root_.column_index == gcol[k] % rc && p.tree_root_.row_index == row[k])
+            roots.emplace_back(static_cast<uint16_t>(row[k]), gcol[k] % rc);
+    }
+    std::list<RangeImageIndex> trees_to_visit, trees;
+    std::set<RangeImageIndex> visited;
+    if (!roots.empty())
+        trees_to_visit.push_back(roots.front());
+    while (!trees_to_visit.empty())
+    {
+        const RangeImageIndex t = trees_to_visit.front();
+        trees_to_visit.pop_front();
+        if (!visited.insert(t).second)
+            continue;
+        trees.push_back(t);
+        auto it = tree_links_.find(t);
+        if (it != tree_links_.end())
+            for (const RangeImageIndex& o : it->second)
+                if (!visited.count(o))
+                    trees_to_visit.push_back(o);
+    }
+    for (const RangeImageIndex& r : roots) // (a root the link walk did not reach would mean a lost log entry: keep its points)
+        if (!visited.count(r))
+            trees.push_back(r);
+    std::list<RangeImageIndex> points_to_visit;
+    for (const RangeImageIndex& t : trees)
+    {
+        points_to_visit.clear();
+        points_to_visit.push_back(t);
+        while (!points_to_visit.empty())
+        {
+            const RangeImageIndex cur = points_to_visit.front();
+            points_to_visit.pop_front();
+            Point& p = range_image_[static_cast<size_t>(cur.column_index) * R + cur.row_index];
+            p.id = e.c; // cc.cpp:1005
+            cluster_points_.push_back(p);
+            for (const RangeImageIndex& ch : p.child_points)
+                points_to_visit.push_back(ch);
+        }
+        tree_links_.erase(t);
     }
 }
 
@@ -336,11 +463,29 @@ void ContinuousClustering::process()
         check(cc_engine_drain_events(engine_, 0, events_.data(), pending, &got));
     events_.resize(static_cast<size_t>(got));
 
-    // bring the mirror up to date for every column an event of this batch refers to
+    // tree links made during this call -> Point::associated_trees of the roots (cc.cpp:693-694)
+    int64_t n_links = 0;
+    check(cc_engine_drain_links(engine_, 0, nullptr, 0, &n_links));
+    if (n_links > 0)
+    {
+        link_buf_.resize(static_cast<size_t>(n_links) * 4);
+        check(cc_engine_drain_links(engine_, 0, link_buf_.data(), n_links, &got));
+        for (int64_t k = 0; k < got; k++)
+        {
+            const RangeImageIndex a(static_cast<uint16_t>(link_buf_[4 * k + 1]), link_buf_[4 * k + 0] % ring_buffer_max_columns);
+            const RangeImageIndex b(static_cast<uint16_t>(link_buf_[4 * k + 3]), link_buf_[4 * k + 2] % ring_buffer_max_columns);
+            tree_links_[a].insert(b);
+            tree_links_[b].insert(a);
+        }
+    }
+
+    // one read of every column an event of this call refers to; the mirror is then brought up to date in callback order
     int64_t lo = std::numeric_limits<int64_t>::max(), hi = -1;
     for (const cc_event& e : events_)
     {
         if (e.type == CC_EV_PUBLISH_COLUMNS && e.b < e.a)
+            continue;
+        if (e.type == CC_EV_CLUSTER && !(e.d > 20 && finished_cluster_callback_))
             continue;
         lo = std::min(lo, e.a);
         hi = std::max(hi, e.b);
@@ -348,11 +493,12 @@ void ContinuousClustering::process()
     if (hi >= 0)
     {
         lo = std::max(lo, hi - ring_buffer_max_columns + 1);
-        refreshColumns(lo, hi);
+        fetchColumns(lo, hi);
     }
+    else
+        fetchColumns(0, -1);
 
-    // member points of the clusters that get a callback: gathered and compacted on the device (cc_engine_gather_cluster_points),
-    // in column-then-row order; the mirror supplies the Point payload
+    // member points of the clusters that get a callback: gathered and compacted on the device (cc_engine_gather_cluster_points)
     std::vector<uint32_t> g_cid, g_cnt;
     std::vector<int64_t> g_from, g_to, g_col;
     std::vector<int32_t> g_row;
@@ -385,24 +531,23 @@ void ContinuousClustering::process()
             case CC_EV_GROUND_COLUMN:
                 if (ring_buffer_start_global_column_index == -1)
                     ring_buffer_start_global_column_index = e.a; // cc.cpp:274-278
+                applyColumns(e.a, e.a, STAGE_GROUND);
                 if (finished_column_callback_)
                     finished_column_callback_(e.a, e.a, true);
+                applyColumns(e.a, e.a, STAGE_ASSOC); // the reference associates the column right after the callback (cc.cpp:622-623)
                 break;
             case CC_EV_CLUSTER:
                 if (e.d > 20 && finished_cluster_callback_) // cc.cpp:1023
                 {
-                    cluster_points_.clear();
-                    uint64_t min_stamp = std::numeric_limits<uint64_t>::max(), max_stamp = 0;
                     const size_t cnt = g_cnt[g_next++];
-                    for (size_t k = g_pos; k < g_pos + cnt; k++)
+                    collectClusterPoints(e, g_col.data() + g_pos, g_row.data() + g_pos, cnt);
+                    g_pos += cnt;
+                    uint64_t min_stamp = std::numeric_limits<uint64_t>::max(), max_stamp = 0;
+                    for (const Point& p : cluster_points_)
                     {
-                        const size_t lc = static_cast<size_t>(g_col[k] % ring_buffer_max_columns);
-                        const Point& p = range_image_[lc * num_rows_ + static_cast<size_t>(g_row[k])];
-                        cluster_points_.push_back(p);
                         min_stamp = std::min(min_stamp, p.stamp);
                         max_stamp = std::max(max_stamp, p.stamp);
                     }
-                    g_pos += cnt;
                     const uint64_t stamp = config_.clustering.use_last_point_for_cluster_stamp ?
                                                max_stamp :
                                                min_stamp + (max_stamp - min_stamp) / 2; // cc.cpp:1025-1028
@@ -413,6 +558,7 @@ void ContinuousClustering::process()
             {
                 const int64_t old_start = ring_buffer_start_global_column_index;
                 ring_buffer_start_global_column_index = std::max<int64_t>(0, (e.b + 1) - num_columns_); // cc.cpp:1079
+                applyColumns(e.a, e.b, STAGE_FULL);
                 if (finished_column_callback_)
                     finished_column_callback_(e.a, e.b, false);
                 clearMirrorColumns(old_start, ring_buffer_start_global_column_index - 1); // cc.cpp:1091
@@ -422,6 +568,16 @@ void ContinuousClustering::process()
                 break;
         }
     }
+    // links of trees that finished in a cluster without callback (<= 20 points) or without id: drop what points behind the ring start
+    if (!tree_links_.empty() && ring_buffer_start_global_column_index > 0)
+        for (auto it = tree_links_.begin(); it != tree_links_.end();)
+        {
+            const int64_t g = globalColumnOfLocal(it->first.column_index);
+            if (g < ring_buffer_start_global_column_index)
+                it = tree_links_.erase(it);
+            else
+                ++it;
+        }
 
     // firings older than anything still in the ring are no longer needed for the pass-through metadata
     int64_t oldest_needed = -1;

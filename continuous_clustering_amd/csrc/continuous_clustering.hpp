@@ -27,6 +27,7 @@
 #include <functional>
 #include <limits>
 #include <list>
+#include <map>
 #include <memory>
 #include <set>
 #include <stdexcept>
@@ -264,8 +265,19 @@ class ContinuousClustering
     void setRobotTransformImpl();
     void process();
     void check(int rc);
-    void refreshColumns(int64_t from, int64_t to);
+    // mirror of range_image_: the columns a call touched are fetched once (fetchColumns) and applied in callback order, stage by stage
+    enum MirrorStage
+    {
+        STAGE_GROUND = 0, // what the reference's range image holds when the ground-view callback runs (cc.cpp:618-620)
+        STAGE_ASSOC = 1,  // ... after associatePointsInColumn of the column (cc.cpp:773-835), which follows that callback directly
+        STAGE_FULL = 2    // ... when the cluster-view callback publishes the column (cc.cpp:1087-1089)
+    };
+    void fetchColumns(int64_t from, int64_t to);
+    void applyColumns(int64_t from, int64_t to, MirrorStage stage);
+    void applyCell(int64_t global_column, int row, MirrorStage stage);
     void clearMirrorColumns(int64_t from, int64_t to);
+    void collectClusterPoints(const cc_event& e, const int64_t* gcol, const int32_t* row, size_t cnt);
+    int64_t globalColumnOfLocal(int64_t local_column) const;
     void toPod(const Configuration& c, cc_config& out) const;
 
     Configuration config_;
@@ -295,6 +307,16 @@ class ContinuousClustering
     std::vector<int32_t> v_rootr_;
     std::vector<uint8_t> v_g_, v_dbg_, v_ign_;
     std::vector<uint64_t> v_id_;
+    std::vector<double> v_fin_;
+    std::vector<uint32_t> v_tpts_, v_width_, v_nchild_;
+    std::vector<int32_t> v_visits_, v_parr_;
+    std::vector<uint8_t> v_finished_;
+    std::vector<int64_t> v_parc_;
+    int64_t v_from_{0}, v_to_{-1}; // global columns held by the v_* arrays
+    std::vector<uint8_t> mirror_stage_; // per ring cell: 0 cleared, 1 ground stage applied, 2 association stage, 3 full
+    // Point::associated_trees of the unfinished trees, rebuilt from the engine's tree-link log: root (row, local column) -> linked roots
+    std::map<RangeImageIndex, std::set<RangeImageIndex>> tree_links_;
+    std::vector<int64_t> link_buf_;
     std::vector<int64_t> col_min_src_; // per ring column: oldest firing that still has a point in it (-1 unknown)
     std::list<size_t> num_pending_jobs_;
 };

@@ -5,7 +5,7 @@
 // it with the CPU oracle.
 //
 //   dropin_demo <in.bin> <out.bin> [batch]
-// in.bin : int32 rows, cols, n, kitti(1)/default(0); then n*rows*3 float xyz, n*rows uint8 intensity, n*12 double poses
+// in.bin : int32 rows, cols, n, kitti(1)/default(0)/default + ego box(2); then n*rows*3 float xyz, n*rows uint8 intensity, n*12 double poses
 // out.bin: records, see the writer below
 #include <cstdio>
 #include <cstdlib>
@@ -37,11 +37,21 @@ int main(int argc, char** argv)
 
     ContinuousClustering clustering;
     Configuration config; // kitti_demo.cpp:279-294
-    if (kitti)
+    if (kitti == 1)
     {
         config.general.is_single_threaded = true;
         config.clustering.ignore_points_in_chessboard_pattern = false;
         config.clustering.max_distance = 0.5;
+        config.ground_segmentation.height_ref_to_maximum_ = 0.5;
+        config.ground_segmentation.height_ref_to_ground_ = -1.7;
+        config.ground_segmentation.length_ref_to_front_end_ = 3;
+        config.ground_segmentation.length_ref_to_rear_end_ = -3;
+        config.ground_segmentation.width_ref_to_left_mirror_ = 1.5;
+        config.ground_segmentation.width_ref_to_right_mirror_ = -1.5;
+    }
+    else if (kitti == 2) // library defaults + an ego box (tests/cases.py `_vls`)
+    {
+        config.general.is_single_threaded = true;
         config.ground_segmentation.height_ref_to_maximum_ = 0.5;
         config.ground_segmentation.height_ref_to_ground_ = -1.7;
         config.ground_segmentation.length_ref_to_front_end_ = 3;
@@ -56,13 +66,22 @@ int main(int argc, char** argv)
     clustering.setBatchSize(batch);
 
     FILE* out = fopen(argv[2], "wb");
-    long long n_ground_cb = 0, n_cluster_cb = 0;
+    long long n_ground_cb = 0, n_cluster_cb = 0, n_ground_view_violations = 0;
     clustering.setFinishedColumnCallback(
         [&](int64_t from, int64_t to, bool ground_points_only)
         {
             if (ground_points_only)
             {
                 n_ground_cb++;
+                // the ground view runs before the column is associated (cc.cpp:618-623): clustering fields still as clearColumns left them
+                int lc = static_cast<int>(from % clustering.ring_buffer_max_columns);
+                for (int r = 0; r < clustering.num_rows_; r++)
+                {
+                    const Point& p = clustering.range_image_[lc * clustering.num_rows_ + r];
+                    if (p.global_column_index != from || p.tree_root_.column_index != -1 || p.id != 0 || !p.child_points.empty() ||
+                        p.number_of_visited_neighbors != 0 || p.ground_point_label == 0)
+                        n_ground_view_violations++;
+                }
                 return;
             }
             // record type 1: published range, then per cell what kitti_demo reads (kitti_demo.cpp:192-216) + a few more fields
@@ -84,6 +103,14 @@ int main(int argc, char** argv)
                     fwrite(&stamp, 8, 1, out);
                     fwrite(lab, 1, 3, out);
                     fwrite(geo, 4, 3, out);
+                    // what the ROS packers read of the clustering stage (ros_utils.cpp:289-295)
+                    double fin = p.finished_at_continuous_azimuth_angle;
+                    int32_t more[6] = {(int32_t) p.child_points.size(), (int32_t) p.tree_root_.row_index, (int32_t) p.tree_root_.column_index,
+                                       p.number_of_visited_neighbors, (int32_t) p.belongs_to_finished_cluster, (int32_t) p.tree_num_points};
+                    uint64_t tree_id = p.tree_id;
+                    fwrite(&fin, 8, 1, out);
+                    fwrite(more, 4, 6, out);
+                    fwrite(&tree_id, 8, 1, out);
                 }
             }
         });
@@ -97,6 +124,15 @@ int main(int argc, char** argv)
             fwrite(&id, 8, 1, out);
             fwrite(&cnt, 8, 1, out);
             fwrite(&stamp, 8, 1, out);
+            // the member points in the order of the vector (cc.cpp:996-1016), and whether every copy carries the cluster id (cc.cpp:1005)
+            for (const Point& p : pts)
+            {
+                int64_t g = p.global_column_index;
+                int32_t r = p.row_index, ok = p.id == id ? 1 : 0;
+                fwrite(&g, 8, 1, out);
+                fwrite(&r, 4, 1, out);
+                fwrite(&ok, 4, 1, out);
+            }
         });
 
     for (int k = 0; k < n; k++)
@@ -125,6 +161,7 @@ int main(int argc, char** argv)
     fwrite(&tag, 4, 1, out);
     fwrite(&n_ground_cb, 8, 1, out);
     fwrite(&n_cluster_cb, 8, 1, out);
+    fwrite(&n_ground_view_violations, 8, 1, out);
     fclose(out);
     // error behaviour: wrong firing size must throw like continuous_clustering.cpp:90-91
     try

@@ -23,7 +23,9 @@ def parse(path, rows):
     data = open(path, "rb").read()
     pos = 0
     ranges, cells, clusters, counts = [], {}, [], None
-    rec = np.dtype([("id", "<u8"), ("uidx", "<u8"), ("stamp", "<u8"), ("lab", "u1", 3), ("geo", "<f4", 3)])
+    rec = np.dtype([("id", "<u8"), ("uidx", "<u8"), ("stamp", "<u8"), ("lab", "u1", 3), ("geo", "<f4", 3), ("fin", "<f8"),
+                    ("more", "<i4", 6), ("tree_id", "<u8")])
+    mem = np.dtype([("gcol", "<i8"), ("row", "<i4"), ("ok", "<i4")])
     while pos < len(data):
         (tag,) = struct.unpack_from("<i", data, pos)
         pos += 4
@@ -37,24 +39,27 @@ def parse(path, rows):
             for k in range(max(0, to - frm + 1)):
                 cells[frm + k] = arr[k]
         elif tag == 2:
-            clusters.append(struct.unpack_from("<QQQ", data, pos))
+            cid, cnt, stamp = struct.unpack_from("<QQQ", data, pos)
             pos += 24
+            members = np.frombuffer(data, dtype=mem, count=cnt, offset=pos)
+            pos += cnt * mem.itemsize
+            clusters.append((cid, cnt, stamp, members))
         elif tag == 3:
-            counts = struct.unpack_from("<qq", data, pos)
-            pos += 16
+            counts = struct.unpack_from("<qqq", data, pos)
+            pos += 24
         else:
             raise AssertionError(f"bad tag {tag}")
     return ranges, cells, clusters, counts
 
 
-@pytest.mark.parametrize("batch", [1, 97])
-def test_dropin_class_matches_oracle(tmp_path, batch, oracle_lib):
+@pytest.mark.parametrize("case,batch", [("g_s64_translate", 1), ("g_s64_translate", 97), ("s64_dropouts", 1), ("s64_dropouts", 61), ("s128_offsets", 170)])
+def test_dropin_class_matches_oracle(tmp_path, case, batch, oracle_lib):
     build_demo()
-    stream, cfg, tf = cases.build_case("g_s64_translate")
+    stream, cfg, tf = cases.build_case(case)
     rows = stream.sensor.num_rows
     inp, outp = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     with open(inp, "wb") as f:
-        f.write(struct.pack("<iiii", rows, cfg.num_columns, stream.n_firings, 1))
+        f.write(struct.pack("<iiii", rows, cfg.num_columns, stream.n_firings, 2 if rows == 128 else 1))
         f.write(stream.xyz.astype(np.float32).tobytes())
         f.write(stream.intensity.astype(np.uint8).tobytes())
         f.write(stream.poses.astype(np.float64).tobytes())
@@ -90,11 +95,35 @@ def test_dropin_class_matches_oracle(tmp_path, batch, oracle_lib):
     exp_az = az[src[has], rowidx[has]]
     assert np.allclose(got["geo"][..., 2][has], exp_az, atol=1e-6)
     # cluster callbacks: clusters with more than 20 points (cc.cpp:1023), in order, with the reference's stamp rule
+    # the clustering-stage fields the ROS packers read (ros_utils.cpp:289-295), as the cluster-view callback sees them
+    util.assert_float_equal("finished_at", got["fin"].copy(), ref["finished_at_continuous_azimuth_angle"])
+    assert np.array_equal(got["more"][..., 0], ref["number_of_child_points"].astype(np.int32))
+    has_root = ref["tree_root_global_column"] >= 0
+    assert np.array_equal(got["more"][..., 1][has_root], ref["tree_root_row"][has_root])
+    assert np.array_equal(got["more"][..., 2][has_root], (ref["tree_root_global_column"][has_root] % (10 * cfg.num_columns)).astype(np.int32))
+    assert (got["more"][..., 2][~has_root] == -1).all()
+    assert np.array_equal(got["more"][..., 3], ref["number_of_visited_neighbors"])
+    assert np.array_equal(got["more"][..., 4], ref["belongs_to_finished_cluster"].astype(np.int32))
+    assert np.array_equal(got["more"][..., 5], ref["tree_num_points"].astype(np.int32))
+    assert np.array_equal(got["tree_id"][has_root], (ref["tree_root_global_column"][has_root] * rows + ref["tree_root_row"][has_root]).astype(np.uint64))
+    assert counts[2] == 0, "a ground-view callback saw clustering-stage values"
+    all_cl = ev[ev["type"] == 2]
+    cl_index = {int(e["c"]): k for k, e in enumerate(all_cl)}
+    multi_tree = 0
     cl = ev[(ev["type"] == 2) & (ev["d"] > 20)]
     assert len(clusters) == len(cl) == counts[1]
-    for (cid, cnt, stamp), e in zip(clusters, cl):
+    for (cid, cnt, stamp, members), e in zip(clusters, cl):
         assert cid == e["c"] and cnt == e["d"]
+        # the vector handed to finished_cluster_callback_ lists the points in the reference's order (cc.cpp:996-1016) with the id set
+        og, orow = o.cluster_members(cl_index[int(cid)])
+        assert np.array_equal(members["gcol"], og) and np.array_equal(members["row"], orow), f"cluster {cid}: member order differs"
+        assert members["ok"].all()
+        roots = set(zip(ref["tree_root_global_column"][(ref["id"] == cid)].tolist(), ref["tree_root_row"][(ref["id"] == cid)].tolist()))
+        multi_tree += len(roots) > 1
         m = ref["id"] == cid
         if m.sum() == cnt:  # every point of the cluster is in a published column (not true for the very last clusters)
             st = 1000000 + 45 * src[m]
             assert stamp == int(st.min()) + (int(st.max()) - int(st.min())) // 2
+    if case != "g_s64_translate":
+        assert multi_tree > 10, "the case was chosen to contain clusters made of several linked trees"
+
