@@ -35,6 +35,21 @@ def _s128(cols, offsets=True):
     return s
 
 
+def jitter_azimuth(stream, seed, amp_columns=0.8):
+    """Rotate every firing about the sensor's z axis by a random fraction of a column: firings then repeat columns (cell collisions,
+    the shift-to-the-next-column rule cc.cpp:188-202, refusals cc.cpp:204-206), skip columns (empty columns) and step backwards
+    (returns behind the first unfinished column, cc.cpp:209-219) — what the evenly stepping synthetic sensor never does."""
+    rng = np.random.default_rng(seed)
+    w = 2 * np.pi / stream.sensor.num_columns
+    a = rng.uniform(-amp_columns, amp_columns, stream.n_firings) * w
+    ca, sa = np.cos(a)[:, None], np.sin(a)[:, None]
+    x, y = stream.xyz[..., 0].astype(np.float64), stream.xyz[..., 1].astype(np.float64)
+    xyz = stream.xyz.copy()
+    xyz[..., 0] = (ca * x - sa * y).astype(np.float32)
+    xyz[..., 1] = (sa * x + ca * y).astype(np.float32)
+    return synth.Stream(xyz=xyz, intensity=stream.intensity, poses=stream.poses, sensor=stream.sensor, hit=stream.hit)
+
+
 ROBOT_TF_TILTED = np.array([0.9961946980917455, 0.0, 0.08715574274765817, 1.2,
                             0.0, 1.0, 0.0, 0.1,
                             -0.08715574274765817, 0.0, 0.9961946980917455, 0.3], dtype=np.float64)
@@ -94,6 +109,16 @@ def build_case(name: str):
     if name == "s32_small_sensor":
         sen = SensorModel(num_rows=32, num_columns=512, incl_top_deg=10.0, incl_bottom_deg=-30.0)
         return synth.make_stream(512 * 3, seed=20, sensor=sen), _vls(512, max_distance=0.5), None
+    # ---- jittered firing azimuths: collisions, shifts, refusals, skipped and revisited columns in the insertion
+    if name == "j_s64_jitter":
+        st = synth.make_stream(720 * 2 + 50, seed=51, sensor=_s64(720), motion=Motion.translate())
+        return jitter_azimuth(st, 151, 0.8), _kitti(720), None
+    if name == "j_s64_jitter_wide":
+        st = synth.make_stream(360 * 3, seed=52, sensor=_s64(360), motion=Motion.turn(8.0, 0.4), scene=SceneModel(dropout=0.15))
+        return jitter_azimuth(st, 152, 2.5), _kitti(360), ROBOT_TF_TILTED
+    if name == "j_s128_offsets_jitter":
+        st = synth.make_stream(680 * 2, seed=53, sensor=_s128(680), start_column=20, motion=Motion.translate())
+        return jitter_azimuth(st, 153, 1.2), _vls(680), None
     # ---- ring-wrap cases: >= 12 rotations through the 10-rotation ring (cc.cpp:17), small columns-per-rotation so the oracle stays fast
     if name == "w_s64_240x13":
         sc = SceneModel(n_objects=40, object_range=(4.0, 30.0))
@@ -128,7 +153,7 @@ def build_case(name: str):
 ALL_CASES = ["s64_static", "s64_translate", "s64_turn", "s64_full_2200", "s64_forced_finish_ring", "s64_ring_with_objects",
              "s64_fog_and_ego", "s64_counterclockwise", "s64_every_2nd_column", "s64_no_early_stop", "s64_min_steps_3",
              "s64_wide_window_global_kernel", "s64_dropouts", "s64_no_supplement_no_incl_ignore", "s64_robot_tf_tilted", "s128_offsets",
-             "s128_no_offsets_translate", "s128_full_1700", "s32_small_sensor"]
+             "s128_no_offsets_translate", "s128_full_1700", "s32_small_sensor", "j_s64_jitter", "j_s64_jitter_wide", "j_s128_offsets_jitter"]
 
 RING_WRAP_CASES = ["w_s64_240x13", "w_s64_360x12_turn", "w_s64_ring_wall_240x12", "w_s128_offsets_340x12", "w_s32_256x12"]
 

@@ -38,7 +38,7 @@ def test_struct_layouts_match_header(lib):
     assert ctypes.sizeof(capi.Config) == 33 * 4
     assert ctypes.sizeof(capi.Event) == 40
     assert ctypes.sizeof(capi.StreamState) == 16 + 32 + 32 + 8 + 16
-    assert ctypes.sizeof(capi.ColumnView) == 14 * 8
+    assert ctypes.sizeof(capi.ColumnView) == 22 * 8  # 14 fields of ABI 0.1 + the 8 clustering fields the ROS packers read
     c = capi.Config()
     lib.cc_config_default(ctypes.byref(c))
     assert bytes(c) == bytes(capi.Config.default())
