@@ -3,6 +3,7 @@
 // cc_engine_create fails with CC_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -75,6 +76,13 @@ struct cc_engine
     // staging for cc_engine_read_columns
     void* d_view{nullptr};
     size_t view_bytes{0};
+    bool idle{false}; // nothing has been enqueued on any of the engine's HIP streams since they were last synchronised
+    std::vector<StreamState> state_cache; // per stream: the state as the last small (graph) call copied it back, if still current
+    std::vector<char> state_cached;
+    char* d_gather{nullptr}; // scratch of cc_engine_gather_cluster_points
+    size_t gather_bytes{0};
+    char* h_view{nullptr}; // pinned mirror of d_view: one D2H copy per read, the fields are split on the host
+    size_t h_view_bytes{0};
     std::vector<std::vector<cc_event>> pending_events; // per stream, drained from the device after each batch
     std::vector<std::vector<int64_t>> pending_links;   // per stream: (root gcol, root row, root gcol, root row) per logged tree link
     // pending continuation of the last device batch (kernel stopped early for some stream)
@@ -162,6 +170,8 @@ int free_all(cc_engine* e)
     e->d_view = nullptr;
     e->view_bytes = 0;
     e->prep_capacity = 0;
+    e->d_gather = nullptr;
+    e->gather_bytes = 0;
     e->d_small = nullptr;
     // the pinned staging of the small-call path is sized for the row count it was created with
     if (e->h_small)
@@ -212,6 +222,7 @@ int allocate(cc_engine* e)
 // sc_inclination_angles_between_lasers_ values when the size does not change (cc.cpp:46).
 int reset_state(cc_engine* e, bool keep_table)
 {
+    std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     const Geometry& g = e->g;
     const size_t S = (size_t) g.num_streams;
     const size_t C = S * (size_t) g.cells;
@@ -329,6 +340,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                  const double* d_pose, bool first_pass, int slot, hipStream_t si, hipStream_t sb, hipStream_t sa,
                  hipStream_t sc = nullptr, hipStream_t sp = nullptr, bool prep_done = false)
 {
+    e->idle = false;
     if (!sc)
         sc = sb; // window scan on the segmentation chain unless the four-stage pipeline gives it its own stream
     if (!sp)
@@ -551,6 +563,8 @@ int resolve_timing(cc_engine* e)
 
 int sync_all(cc_engine* e)
 {
+    if (e->idle)
+        return CC_OK;
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
@@ -559,6 +573,7 @@ int sync_all(cc_engine* e)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream6));
     for (bool& b : e->assoc_pending)
         b = false;
+    e->idle = true;
     return CC_OK;
 }
 
@@ -594,6 +609,7 @@ int finish_batch(cc_engine* e)
 int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose,
            bool pipeline, int64_t n_total = 0, int64_t f0 = 0)
 {
+    std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     if (n_total <= 0)
     {
         n_total = n;
@@ -867,8 +883,11 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     memcpy(e->h_small, xyz, (size_t) n * R * 3 * sizeof(float));
     memcpy(e->h_small + b_xyz, intensity, (size_t) n * R);
     memcpy(e->h_small + b_xyz + b_int, poses, (size_t) n * 12 * sizeof(double));
+    std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
+    const bool was_idle = e->idle;
     CC_HIP_CHECK(e, hipGraphLaunch(exec, e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    e->idle = was_idle; // (capturing the graph went through launch_batch; replaying it only touches `stream`, which is drained again)
     if (*e->h_remaining != 0)
     {
         // the kernels stopped early (limit_columns): continue on the general path, which also collects the events
@@ -910,6 +929,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         set_kernel_error(e, stream, st);
         return st.error;
     }
+    e->state_cache[stream] = st; // (n_events / n_links are not part of what cc_engine_stream_state reports)
+    e->state_cached[stream] = 1;
     return CC_OK;
 }
 } // namespace
@@ -1018,6 +1039,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     e->g.event_capacity = e->g.record_events ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
     e->pending_events.resize(num_streams);
     e->pending_links.resize(num_streams);
+    e->state_cache.resize(num_streams);
+    e->state_cached.assign(num_streams, 0);
     (void) hipFuncSetAttribute((const void*) cck::k_seg_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1056,6 +1079,8 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamSynchronize(e->stream5);
     destroy_small_graphs(e);
     free_all(e); // also the pinned small-call staging
+    if (e->h_view)
+        (void) hipHostFree(e->h_view);
     for (int i = 0; i < 4; i++)
     {
         (void) hipEventDestroy(e->ev_ins[i]);
@@ -1113,6 +1138,7 @@ int cc_engine_set_config(cc_engine* e, const cc_config* cfg)
                 s.assoc_mode = 1;
         }
         CC_HIP_CHECK(e, hipMemcpy(e->d_states, st.data(), st.size() * sizeof(StreamState), hipMemcpyHostToDevice));
+        std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     }
     return CC_OK;
 }
@@ -1165,6 +1191,7 @@ int cc_engine_set_robot_from_sensor(cc_engine* e, int stream, const double tf[12
         s.has_robot_tf = 1;
     }
     CC_HIP_CHECK(e, hipMemcpy(e->d_states + first, st.data(), count * sizeof(StreamState), hipMemcpyHostToDevice));
+    std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     return CC_OK;
 }
 
@@ -1339,7 +1366,10 @@ int cc_engine_stream_state(cc_engine* e, int stream, cc_stream_state* out)
     if (rc)
         return rc;
     StreamState st;
-    CC_HIP_CHECK(e, hipMemcpy(&st, e->d_states + stream, sizeof(st), hipMemcpyDeviceToHost));
+    if (e->state_cached[stream])
+        st = e->state_cache[stream];
+    else
+        CC_HIP_CHECK(e, hipMemcpy(&st, e->d_states + stream, sizeof(st), hipMemcpyDeviceToHost));
     fixup_overrun(e, stream, st);
     memset(out, 0, sizeof(*out));
     out->num_rows = e->g.num_rows;
@@ -1381,6 +1411,15 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
         e->d_view = p;
         e->view_bytes = bytes;
     }
+    if (e->h_view_bytes < bytes)
+    {
+        if (e->h_view)
+            (void) hipHostFree(e->h_view);
+        e->h_view = nullptr;
+        e->h_view_bytes = 0;
+        CC_HIP_CHECK(e, hipHostMalloc((void**) &e->h_view, bytes));
+        e->h_view_bytes = bytes;
+    }
     char* base = (char*) e->d_view;
     cck::ViewOut o;
     // 8-byte planes first to keep alignment
@@ -1416,10 +1455,13 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     hipLaunchKernelGGL(cck::k_view, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, e->d_states, stream,
                        (long long) from, o, max_back);
     CC_HIP_CHECK(e, hipGetLastError());
+    // one copy of the whole staging block (a call per field costs more than the bytes for the few columns a live mirror reads)
+    const size_t used = (size_t) ((char*) o.finished + n - base);
+    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_view, base, used, hipMemcpyDeviceToHost, e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
 #define COPY(dst, srcp, T)                                                                        \
     if (v->dst)                                                                                   \
-        CC_HIP_CHECK(e, hipMemcpy(v->dst, srcp, n * sizeof(T), hipMemcpyDeviceToHost));
+        memcpy(v->dst, e->h_view + ((const char*) (srcp) - base), n * sizeof(T));
     COPY(x, o.x, float) COPY(y, o.y, float) COPY(z, o.z, float) COPY(distance, o.dist, float) COPY(inclination_angle, o.incl, float);
     COPY(continuous_azimuth_angle, o.caz, double) COPY(global_column_index, o.gcol, int64_t) COPY(source_firing, o.src, int64_t);
     COPY(ground_point_label, o.ground, uint8_t) COPY(debug_ground_point_label, o.debug, uint8_t) COPY(is_ignored, o.ignored, uint8_t);
@@ -1428,7 +1470,7 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     COPY(number_of_visited_neighbors, o.visits, int32_t) COPY(belongs_to_finished_cluster, o.finished, uint8_t);
     COPY(tree_parent_global_column, o.par_gcol, int64_t) COPY(tree_parent_row, o.par_row, int32_t);
     if (v->number_of_child_points)
-        CC_HIP_CHECK(e, hipMemcpy(v->number_of_child_points, o.nchild, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        memcpy(v->number_of_child_points, e->h_view + (b4 + n * 32 - base), n * sizeof(uint32_t));
 #undef COPY
     return CC_OK;
 }
@@ -1455,13 +1497,17 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
         return CC_ERR_INVALID_ARGUMENT;
     // one device block: descriptors (cid, n_points: u32; from, to, offset: i64), mismatch counter, outputs
     const size_t desc = (size_t) n * (4 + 4 + 8 + 8 + 8) + 64, outb = (size_t) total * (8 + 4) + 64;
-    char* d = nullptr;
-    CC_HIP_CHECK(e, hipMalloc((void**) &d, desc + outb));
-    auto fail = [&](int code)
+    // grow-only scratch owned by the engine (a hipMalloc / hipFree pair per call costs more than the gather)
+    if (e->gather_bytes < desc + outb)
     {
-        (void) hipFree(d);
-        return code;
-    };
+        void* p = nullptr;
+        CC_HIP_CHECK(e, hipMalloc(&p, (desc + outb) * 2));
+        e->allocations.push_back(p);
+        e->d_gather = (char*) p;
+        e->gather_bytes = (desc + outb) * 2;
+    }
+    char* d = e->d_gather;
+    auto fail = [&](int code) { return code; };
     cck::ClusterQuery q;
     char* b = d;
     q.col_from = (const long long*) b;
@@ -1500,7 +1546,6 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
         e->error = "cc_engine_gather_cluster_points: launch / copy failed";
         return fail(CC_ERR_HIP);
     }
-    (void) hipFree(d);
     if (mismatch != 0)
     {
         e->error = "cc_engine_gather_cluster_points: " + std::to_string(mismatch) + " cluster descriptor(s) do not match the engine state";

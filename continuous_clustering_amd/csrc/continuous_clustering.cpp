@@ -2,6 +2,7 @@
 #include "continuous_clustering.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 namespace continuous_clustering
@@ -184,7 +185,20 @@ void ContinuousClustering::recordJobQueueWorkload(size_t num_jobs_sensor_input)
 void ContinuousClustering::setBatchSize(int firings_per_launch)
 {
     flush();
-    batch_size_ = std::max(1, firings_per_launch);
+    adaptive_ = firings_per_launch <= 0;
+    batch_size_ = adaptive_ ? 8 : firings_per_launch; // 8 = what one captured-graph launch of the engine takes (cc_engine_add_firings)
+}
+
+// Adaptive batching (setBatchSize(0)): a firing is handed to the engine together with the firings that arrived while the previous
+// call was running — at most 8 per call (one graph launch, ~0.1 ms) and never later than `max_wait_us` after the oldest buffered
+// firing arrived. A sensor that delivers 22 000 firings per second is then followed in real time (a call per firing takes longer
+// than the firing period); the callbacks' order is the reference's, they are only delivered a few firings later.
+void ContinuousClustering::setAdaptiveBatching(int max_firings, int max_wait_us)
+{
+    flush();
+    adaptive_ = true;
+    batch_size_ = std::max(1, std::min(8, max_firings));
+    max_wait_us_ = std::max(0, max_wait_us);
 }
 
 void ContinuousClustering::setDevice(int hip_device)
@@ -218,6 +232,22 @@ void ContinuousClustering::addFiringImpl(const RawPoints::ConstPtr& firing, cons
     buffered_++;
     // never pass more than 2 * num_columns firings per engine call: everything a call publishes stays readable until the
     // next call (include/cc_hip.h, cc_engine_add_firings)
+    if (adaptive_)
+    {
+        const auto now = std::chrono::steady_clock::now();
+        if (buffered_ == 1)
+            first_buffered_at_ = now;
+        // flush when the call is full, when the oldest firing has waited long enough, or when the caller is not ahead of us (the previous
+        // call returned more than a firing period ago: nothing is queued behind this firing)
+        const double waited_us = std::chrono::duration<double, std::micro>(now - first_buffered_at_).count();
+        const double idle_us = std::chrono::duration<double, std::micro>(now - last_process_end_).count();
+        if (buffered_ >= batch_size_ || waited_us >= max_wait_us_ || idle_us >= max_wait_us_)
+        {
+            process();
+            last_process_end_ = std::chrono::steady_clock::now();
+        }
+        return;
+    }
     if (buffered_ >= batch_size_ || buffered_ >= 2 * num_columns_)
         process();
 }

@@ -21,6 +21,7 @@
 //  * is_single_threaded is accepted but the call order is always the single-threaded one.
 #pragma once
 
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <deque>
@@ -247,7 +248,10 @@ class ContinuousClustering
     void recordJobQueueWorkload(size_t num_jobs_sensor_input);
 
     // ---- extensions of the MI355X build -----------------------------------------------------------------------------
-    void setBatchSize(int firings_per_launch); // default 1: callbacks fire inside addFiring like the reference
+    void setBatchSize(int firings_per_launch); // default 1: callbacks fire inside addFiring like the reference; 0 = adaptive (below)
+    // hand firings to the engine as they queue up behind a running call: at most max_firings (<= 8) per call, none waits longer than
+    // max_wait_us for company. Keeps up with a real-time sensor (a call per firing does not: DESIGN.md section 6).
+    void setAdaptiveBatching(int max_firings = 8, int max_wait_us = 150);
     void flush();                              // process buffered firings now
     void setDevice(int hip_device);            // before the first reset(); default 0
 
@@ -284,6 +288,9 @@ class ContinuousClustering
     cc_engine* engine_{nullptr};
     int device_{0};
     int batch_size_{1};
+    bool adaptive_{false};
+    int max_wait_us_{150};
+    std::chrono::steady_clock::time_point first_buffered_at_{}, last_process_end_{};
     bool reset_required_{false};
     bool has_robot_tf_{false};
     double robot_from_sensor_[12]{1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};

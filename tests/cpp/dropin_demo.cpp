@@ -7,8 +7,11 @@
 //   dropin_demo <in.bin> <out.bin> [batch]
 // in.bin : int32 rows, cols, n, kitti(1)/default(0)/default + ego box(2); then n*rows*3 float xyz, n*rows uint8 intensity, n*12 double poses
 // out.bin: records, see the writer below
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../continuous_clustering_amd/csrc/continuous_clustering.hpp"
@@ -33,7 +36,8 @@ int main(int argc, char** argv)
         fread(poses.data(), 8, poses.size(), f) != poses.size())
         return 2;
     fclose(f);
-    const int batch = argc > 3 ? atoi(argv[3]) : 1;
+    const int batch = argc > 3 ? atoi(argv[3]) : 1;      // 0 = adaptive batching (setAdaptiveBatching)
+    const double rate_hz = argc > 4 ? atof(argv[4]) : 0.;  // > 0: feed the firings paced like a live sensor (firings per second)
 
     ContinuousClustering clustering;
     Configuration config; // kitti_demo.cpp:279-294
@@ -63,10 +67,14 @@ int main(int argc, char** argv)
     clustering.setConfiguration(config);
     clustering.reset(rows);
     clustering.setTransformRobotFrameFromSensorFrame(Pose3d::Identity());
-    clustering.setBatchSize(batch);
+    if (batch <= 0)
+        clustering.setAdaptiveBatching();
+    else
+        clustering.setBatchSize(batch);
 
+    const bool dump = std::string(argv[2]) != "/dev/null"; // timing runs: callbacks installed, nothing written
     FILE* out = fopen(argv[2], "wb");
-    long long n_ground_cb = 0, n_cluster_cb = 0, n_ground_view_violations = 0;
+    long long n_ground_cb = 0, n_cluster_cb = 0, n_ground_view_violations = 0, n_published = 0;
     clustering.setFinishedColumnCallback(
         [&](int64_t from, int64_t to, bool ground_points_only)
         {
@@ -82,6 +90,11 @@ int main(int argc, char** argv)
                         p.number_of_visited_neighbors != 0 || p.ground_point_label == 0)
                         n_ground_view_violations++;
                 }
+                return;
+            }
+            if (!dump)
+            {
+                n_published += to >= from ? to - from + 1 : 0;
                 return;
             }
             // record type 1: published range, then per cell what kitti_demo reads (kitti_demo.cpp:192-216) + a few more fields
@@ -118,6 +131,8 @@ int main(int argc, char** argv)
         [&](const std::vector<Point>& pts, uint64_t stamp)
         {
             n_cluster_cb++;
+            if (!dump)
+                return;
             int32_t tag = 2;
             uint64_t cnt = pts.size(), id = pts.empty() ? 0 : pts[0].id;
             fwrite(&tag, 4, 1, out);
@@ -135,8 +150,24 @@ int main(int argc, char** argv)
             }
         });
 
+    // real-time feed: firing k is due at t0 + k / rate; its latency is measured from that instant to the moment its ground-view callback
+    // has run (the column it finishes has been segmented and handed on) — 0 pacing = as fast as the class takes them
+    using clk = std::chrono::steady_clock;
+    std::vector<double> due_us((size_t) n, 0.), seen_us((size_t) n, -1.);
+    long long delivered_upto = 0; // firings [0, delivered_upto) have been through the engine
+    const auto t0 = clk::now();
+    auto now_us = [&]() { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
     for (int k = 0; k < n; k++)
     {
+        if (rate_hz > 0)
+        {
+            due_us[(size_t) k] = 1e6 * k / rate_hz;
+            while (now_us() < due_us[(size_t) k])
+            {
+            }
+        }
+        else
+            due_us[(size_t) k] = now_us();
         RawPoints::Ptr firing(new RawPoints);
         firing->stamp = 1000000ull + 45ull * k;
         firing->points.resize(rows);
@@ -154,9 +185,30 @@ int main(int argc, char** argv)
         Pose3d pose;
         for (int i = 0; i < 12; i++)
             pose.m[i] = poses[(size_t) k * 12 + i];
+        const long long before = n_ground_cb;
         clustering.addFiring(firing, pose);
+        if (n_ground_cb != before || batch == 1)
+        {
+            // the call went through the engine: every firing fed so far has been delivered
+            const double t = now_us();
+            for (long long j = delivered_upto; j <= k; j++)
+                seen_us[(size_t) j] = t;
+            delivered_upto = k + 1;
+        }
     }
     clustering.flush();
+    {
+        const double t = now_us();
+        for (long long j = delivered_upto; j < n; j++)
+            seen_us[(size_t) j] = t;
+        std::vector<double> lat;
+        for (int k = n / 10; k < n; k++) // skip the start-up (ring not started, graph capture)
+            lat.push_back(seen_us[(size_t) k] - due_us[(size_t) k]);
+        std::sort(lat.begin(), lat.end());
+        const double total_s = t * 1e-6;
+        printf("feed rate_hz=%.0f batch=%d firings=%d seconds=%.4f firings_per_s=%.0f latency_us_p50=%.1f p99=%.1f max=%.1f\n", rate_hz, batch, n,
+               total_s, n / total_s, lat[lat.size() / 2], lat[(size_t) (lat.size() * 0.99)], lat.back());
+    }
     int32_t tag = 3;
     fwrite(&tag, 4, 1, out);
     fwrite(&n_ground_cb, 8, 1, out);

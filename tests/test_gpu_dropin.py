@@ -52,7 +52,8 @@ def parse(path, rows):
     return ranges, cells, clusters, counts
 
 
-@pytest.mark.parametrize("case,batch", [("g_s64_translate", 1), ("g_s64_translate", 97), ("s64_dropouts", 1), ("s64_dropouts", 61), ("s128_offsets", 170)])
+@pytest.mark.parametrize("case,batch", [("g_s64_translate", 1), ("g_s64_translate", 97), ("g_s64_translate", 0), ("s64_dropouts", 1), ("s64_dropouts", 61),
+                                        ("s128_offsets", 170)])
 def test_dropin_class_matches_oracle(tmp_path, case, batch, oracle_lib):
     build_demo()
     stream, cfg, tf = cases.build_case(case)
@@ -127,3 +128,30 @@ def test_dropin_class_matches_oracle(tmp_path, case, batch, oracle_lib):
     if case != "g_s64_translate":
         assert multi_tree > 10, "the case was chosen to contain clusters made of several linked trees"
 
+
+
+def test_adaptive_batching_follows_a_live_sensor(tmp_path):
+    """An HDL-64E delivers 22 000 firings per second (10 Hz x 2200 columns). One engine call per firing takes ~0.1 ms and falls behind;
+    with setAdaptiveBatching() the class hands over the firings that queued up behind the running call and keeps up. The demo paces the
+    feed with a busy-wait clock and reports the latency from a firing's due time to the return of the call that delivered it."""
+    import re
+    build_demo()
+    from continuous_clustering_amd import capi, synth
+    cfg = capi.Config.kitti()
+    stream = synth.make_stream(2200 * 3, seed=77, motion=synth.Motion.translate())
+    inp = str(tmp_path / "in.bin")
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<iiii", 64, cfg.num_columns, stream.n_firings, 1))
+        f.write(stream.xyz.astype(np.float32).tobytes())
+        f.write(stream.intensity.astype(np.uint8).tobytes())
+        f.write(stream.poses.astype(np.float64).tobytes())
+    out = {}
+    for batch, rate in ((0, 22000), (0, 0), (1, 0)):
+        r = subprocess.run([DEMO, inp, "/dev/null", str(batch), str(rate)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        m = re.search(r"firings_per_s=(\d+) latency_us_p50=([\d.]+) p99=([\d.]+) max=([\d.]+)", r.stdout)
+        out[(batch, rate)] = tuple(float(v) for v in m.groups())
+        print("feed", batch, rate, out[(batch, rate)])
+    assert out[(0, 22000)][0] >= 21800, "the adaptive mode did not keep up with 22 000 firings per second"
+    assert out[(0, 22000)][2] < 2000, "p99 delivery latency above 2 ms"
+    assert out[(0, 0)][0] > 22000, "free-running adaptive feed slower than the sensor"
