@@ -62,6 +62,9 @@ struct cc_engine
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
+    int scan_packed{-1};                // option "scan_packed": 1 = k_scan2 (active points packed into the lanes), 0 = k_scan (rows as lanes, lock
+                                        // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch;
+                                        // at 64 rows the lock-step kernel is 3 % ahead inside the pipeline although it issues 1.5 x the instructions)
     int assoc_waves{2};                 // option "assoc_waves": 2 = k_assoc2 (front / back wavefronts), 1 = k_assoc_lds
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
@@ -445,7 +448,18 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     CC_MARK(sc); // ev4: table + segment (start of the window scan)
     const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
-    if (rpl == 1 && !g.mirror_fields)
+    if (e->scan_packed == 1 || (e->scan_packed < 0 && rpl > 1))
+    {
+        if (rpl == 1 && !g.mirror_fields)
+            hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else if (rpl == 1)
+            hipLaunchKernelGGL((cck::k_scan2<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else if (!g.mirror_fields)
+            hipLaunchKernelGGL((cck::k_scan2<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else
+            hipLaunchKernelGGL((cck::k_scan2<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    }
+    else if (rpl == 1 && !g.mirror_fields)
         hipLaunchKernelGGL((cck::k_scan<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else if (rpl == 1)
         hipLaunchKernelGGL((cck::k_scan<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -1598,6 +1612,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")
         e->assoc_waves = value == 1 ? 1 : 2;
+    else if (n == "scan_packed")
+        e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (n == "mirror_fields")
         e->g.mirror_fields = value != 0;
     else if (n == "limit_columns")

@@ -1972,7 +1972,12 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 p.ground[ci] = (unsigned char) (GV >> (8 * (o & 7)));
                 p.debug[ci] = (unsigned char) (dcode < 8 ? (DV0 >> (8 * dcode)) : (unsigned long long) (DV1 >> (8 * (dcode - 8))));
                 // cc.cpp:567-616: everything that is not an obstacle is ignored, and so are the filtered obstacles
-                p.ignored[ci] = ((o & 7) != SG_G_OBSTACLE || (o & 0x80)) ? 1 : 0;
+                const bool ign = (o & 7) != SG_G_OBSTACLE || (o & 0x80);
+                p.ignored[ci] = ign ? 1 : 0;
+                // the window scan reads one 16-byte record per visited cell: an ignored cell is marked there as x = NaN (cells without a
+                // return have it already), so that the distance test of cc.cpp:638-641 fails without a second load
+                if (ign && (o & 7) != SG_G_UNKNOWN)
+                    ((float*) &p.sc_rec[ci])[0] = __builtin_nanf("");
             }
             lc = lc + 1 == RC ? 0 : lc + 1;
         }
@@ -2657,6 +2662,94 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
 }
 
 
+// ---- column epilogue of the window scan: everything about the column that does not depend on the tree state, so that the serial
+// association kernel finds it precomputed. (1) where every point's chain of same-column parents ends; (2) the column summary. One
+// wavefront, lanes = rows; `parent` = (columns back << 8) | row of the first accepted candidate, -1 new root, -2 ignored cell.
+template<int RPL, bool MIRROR>
+__device__ __forceinline__ void scan_column_epilogue(const SP& p, const int R, const int lc, const int lane, const int (&parent)[RPL],
+                                                     const int (&nlinks)[RPL], const double (&fin)[RPL], const unsigned long long (&packed)[RPL],
+                                                     int reach)
+{
+    int t[RPL]; // row at the top of the chain so far
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        const bool same_col = parent[k] >= 0 && (parent[k] >> 8) == 0;
+        t[k] = same_col ? (parent[k] & 0xff) : row;
+    }
+    for (int it = 0; it < 7; it++) // pointer jumping: rows <= 128, chains shorter than 2^7
+    {
+        int nt[RPL];
+        bool changed = false;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int src = t[k];
+            const int lo = __shfl(t[0], src & 63);
+            const int hi = RPL > 1 ? __shfl(t[RPL - 1], src & 63) : lo;
+            nt[k] = src < 64 ? lo : hi;
+            changed |= nt[k] != t[k];
+        }
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+            t[k] = nt[k];
+        if (!__any(changed))
+            break;
+    }
+    int cnt_new = 0, mine[RPL];
+    int max_delta = 0;
+    int flags = 0;
+    double newfin = 1.7976931348623157e308;
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const bool is_new = parent[k] == -1;
+        const unsigned long long mask = __ballot(is_new);
+        const int newidx = cnt_new + __popcll(mask & lanes_below());
+        cnt_new += __popcll(mask);
+        mine[k] = is_new ? newidx : (parent[k] >= 0 ? parent[k] : -1);
+        if (is_new && fin[k] < newfin)
+            newfin = fin[k];
+        if (parent[k] >= 0)
+        {
+            int d = parent[k] >> 8;
+            const int nl = nlinks[k] == 255 ? LINK_SLOTS : nlinks[k];
+            for (int j = 0; j < nl; j++)
+            {
+                const int dj = (int) ((packed[k] >> (16 * j + 8)) & 0xff);
+                d = dj > d ? dj : d;
+            }
+            max_delta = d > max_delta ? d : max_delta;
+        }
+        if (nlinks[k] == 255)
+            flags |= 1;
+        else if (nlinks[k] > 0)
+            flags |= 2;
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        const int src = t[k];
+        const int lo = __shfl(mine[0], src & 63);
+        const int hi = RPL > 1 ? __shfl(mine[RPL - 1], src & 63) : lo;
+        const int term = parent[k] < -1 ? -1 : (src < 64 ? lo : hi);
+        if (row < R)
+            p.sc_term[lc * R + row] = (int16_t) term;
+    }
+    max_delta = -wave_min_i32(-max_delta); // DPP reductions, ballots: no LDS round trips
+    if (MIRROR)
+        reach = -wave_min_i32(-reach);
+    flags = (__any(flags & 1) ? 1 : 0) | (__any(flags & 2) ? 2 : 0);
+    newfin = wave_min_f64(newfin);
+    if (lane == 0)
+    {
+        p.col_newfin[lc] = newfin;
+        p.col_info[lc] = cnt_new | (flags << 8) | (max_delta << 16) | ((MIRROR ? reach : 0) << 24);
+    }
+}
+
 // =====================================================================================================
 // k_scan — the window scan of traverseFieldOfView (cc.cpp:698-771) for every point of the batch's columns, as a pure
 // function of static per-cell data (SURVEY.md 8a "derived fact"): first accepted candidate = parent, later accepted
@@ -2849,86 +2942,228 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                     p.sc_links[ci] = packed[k];
             }
         }
-        // ---- column epilogue: everything about the column that does not depend on the tree state, so that the serial association
-        // kernel finds it precomputed. (1) where every point's chain of same-column parents ends; (2) the column summary.
-        int t[RPL]; // row at the top of the chain so far
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
+        scan_column_epilogue<RPL, MIRROR>(p, R, lc, lane, parent, nlinks, fin, packed, reach);
+    }
+}
+
+// =====================================================================================================
+// k_scan2 — the same window scan with the ACTIVE points packed into the lanes. Only every fourth cell reaches the association (ground,
+// ego, empty and filtered cells are ignored) and nearly every scan is over after four visits (cc.cpp:746-758), so a wavefront whose
+// lanes are the rows of one column runs its lock-step visit loop for the slowest of ~16 busy lanes while 48 idle ones ride along. Here a
+// wavefront takes a tile of SCAN_TILE_CELLS / num_rows columns, compacts the non-ignored cells of the tile into a list, and every lane
+// scans ONE point of the list with its own little state machine (one visit per iteration, the candidate's 16-byte record by a gather
+// that hits L2: k_seg_pre / k_seg_scan wrote the records just before). Results go through LDS back into rows-as-lanes order for the
+// column epilogue (same-column parent chains, column summary) and the coalesced stores. Same outputs as k_scan, bit for bit.
+// grid = (streams, SCAN_BLOCKS), block = 64.
+// =====================================================================================================
+constexpr int SCAN_TILE_CELLS = 256;
+
+template<int RPL, bool MIRROR>
+__global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+{
+    const int s = first_stream + blockIdx.x;
+    const int lane = lane_id();
+    const StreamState* st = &states[s];
+    if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->batch[slot].mode != 0)
+        return;
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    const float maxd2 = g.max_distance_squared;
+    const int max_row_steps = cfg.max_steps_in_row, max_col_steps = cfg.max_steps_in_column;
+    const bool stop_enabled = cfg.stop_after_association_enabled != 0;
+    const int stop_min = cfg.stop_after_association_min_steps;
+    const int TC = SCAN_TILE_CELLS / (RPL * 64); // columns per tile: 4 at <= 64 rows, 2 at <= 128
+    __shared__ unsigned short s_list[SCAN_TILE_CELLS];  // tile-local cell (column in tile * RPL * 64 + row) of every active point
+    __shared__ short s_parent[SCAN_TILE_CELLS];
+    __shared__ unsigned char s_nlinks[SCAN_TILE_CELLS];
+    __shared__ unsigned short s_visits[SCAN_TILE_CELLS];
+    __shared__ unsigned char s_reach[SCAN_TILE_CELLS];
+    __shared__ double s_fin[SCAN_TILE_CELLS];
+    __shared__ unsigned long long s_links[SCAN_TILE_CELLS];
+    const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
+    const int first_lc = (int) (first_column % RC);
+    const long long n_tiles = (col_end - col_begin + TC - 1) / TC;
+    for (long long tile = blockIdx.y; tile < n_tiles; tile += gridDim.y)
+    {
+        const long long gc0 = col_begin + tile * TC;
+        const int ncols = (int) (col_end - gc0 < TC ? col_end - gc0 : TC);
+        const int lc0 = (int) (gc0 % RC);
+        // ---- A: the tile's active cells --------------------------------------------------------------------------------------
+        int n_act = 0;
+        for (int j = 0; j < TC * RPL; j++)
         {
-            const int row = k * 64 + lane;
-            const bool same_col = parent[k] >= 0 && (parent[k] >> 8) == 0;
-            t[k] = same_col ? (parent[k] & 0xff) : row;
-        }
-        for (int it = 0; it < 7; it++) // pointer jumping: rows <= 128, chains shorter than 2^7
-        {
-            int nt[RPL];
-            bool changed = false;
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
+            const int tc = j / RPL, row = (j % RPL) * 64 + lane;
+            const int tl = tc * RPL * 64 + row;
+            bool act = false;
+            if (tc < ncols && row < R)
             {
-                const int src = t[k];
-                const int lo = __shfl(t[0], src & 63);
-                const int hi = RPL > 1 ? __shfl(t[RPL - 1], src & 63) : lo;
-                nt[k] = src < 64 ? lo : hi;
-                changed |= nt[k] != t[k];
+                int lc = lc0 + tc;
+                lc = lc >= RC ? lc - RC : lc;
+                act = p.ignored[lc * R + row] == 0;
             }
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-                t[k] = nt[k];
-            if (!__any(changed))
-                break;
-        }
-        int cnt_new = 0, mine[RPL];
-        int max_delta = 0;
-        int flags = 0;
-        double newfin = 1.7976931348623157e308;
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            const bool is_new = parent[k] == -1;
-            const unsigned long long mask = __ballot(is_new);
-            const int newidx = cnt_new + __popcll(mask & lanes_below());
-            cnt_new += __popcll(mask);
-            mine[k] = is_new ? newidx : (parent[k] >= 0 ? parent[k] : -1);
-            if (is_new && fin[k] < newfin)
-                newfin = fin[k];
-            if (parent[k] >= 0)
+            s_parent[tl] = -2;
+            s_nlinks[tl] = 0;
+            s_fin[tl] = 0.;
+            s_links[tl] = 0;
+            if (MIRROR)
             {
-                int d = parent[k] >> 8;
-                const int nl = nlinks[k] == 255 ? LINK_SLOTS : nlinks[k];
-                for (int j = 0; j < nl; j++)
+                s_visits[tl] = 0;
+                s_reach[tl] = 0;
+            }
+            const unsigned long long m = __ballot(act);
+            if (act)
+                s_list[n_act + __popcll(m & lanes_below())] = (unsigned short) tl;
+            n_act += __popcll(m);
+        }
+        wave_lds_fence();
+        // ---- B: one point per lane ---------------------------------------------------------------------------------------------
+        for (int base = 0; base < n_act; base += 64)
+        {
+            const bool have = base + lane < n_act;
+            const int tl = have ? (int) s_list[base + lane] : 0;
+            const int tc = tl / (RPL * 64), row = tl % (RPL * 64);
+            const long long gc = gc0 + tc;
+            int lc = lc0 + tc;
+            lc = lc >= RC ? lc - RC : lc;
+            const int ci = lc * R + row;
+            float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
+            float mad = 0.f;
+            double fin = 0.;
+            int needed = -1;
+            if (have)
+            {
+                me = p.sc_rec[ci];
+                mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                fin = p.caz[ci] + (double) mad;
+                needed = f2i_x86(__builtin_ceilf(mad / g.az_width));
+                needed = needed < max_row_steps ? needed : max_row_steps;
+            }
+            // never look at columns older than the first column ever segmented (their planes are uninitialised)
+            const int bound = (gc - first_column) <= (long long) max_row_steps + 1 ? first_lc : -1;
+            // state of the scan (cc.cpp:706-769): column offset sb, direction (0 = rows above, 1 = rows below), vertical step d
+            int sb = 0, down = 0, d = 1, oc = lc, orow = row - 1;
+            int rooted = 0, parent = -1, nlinks = 0, overflow = 0, visits = 0, reach = 0;
+            unsigned long long packed = 0;
+            // position on the first cell that passes the while-condition of cc.cpp:718-719, or finish
+            bool run = have;
+            auto next_column = [&]() // the end of a column's visits: cc.cpp:756-769
+            {
+                if ((rooted && stop_enabled && sb >= stop_min) || oc == bound || sb + 1 > needed)
+                    run = false;
+                else
                 {
-                    const int dj = (int) ((packed[k] >> (16 * j + 8)) & 0xff);
-                    d = dj > d ? dj : d;
+                    sb++;
+                    oc = oc == 0 ? RC - 1 : oc - 1;
+                    down = 0;
+                    d = 0;
+                    orow = row; // (the cell in the same row always passes the loop condition: d = 0, row inside the image)
                 }
-                max_delta = d > max_delta ? d : max_delta;
+            };
+            auto next_direction = [&]() // a direction ended (break or loop condition false)
+            {
+                if (down == 0 && sb > 0)
+                {
+                    down = 1;
+                    d = 1;
+                    orow = row + 1;
+                    if (!(orow < R && d <= max_col_steps))
+                        next_column();
+                }
+                else
+                    next_column();
+            };
+            if (run && !(orow >= 0 && d <= max_col_steps))
+                next_direction(); // row 0 has nothing above it in its own column
+            while (__any(run))
+            {
+                if (run)
+                {
+                    const float4 o = p.sc_rec[oc * R + orow];
+                    if (MIRROR)
+                    {
+                        visits++; // cc.cpp:725
+                        reach = sb;
+                    }
+                    if (ccm::absf(o.w - me.w) > mad) // cc.cpp:728: the inclination window is left
+                        next_direction();
+                    else
+                    {
+                        const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+                        if (o.x == o.x && dx * dx + dy * dy + dz * dz < maxd2) // (x = NaN: ignored or empty cell)
+                        {
+                            const int cand = (sb << 8) | orow;
+                            if (!rooted)
+                                parent = cand;
+                            else if (nlinks < LINK_SLOTS)
+                            {
+                                packed |= (unsigned long long) cand << (16 * nlinks);
+                                nlinks++;
+                            }
+                            else
+                                overflow = 1;
+                            rooted = 1;
+                        }
+                        if (rooted && stop_enabled && d >= stop_min) // cc.cpp:746-749
+                            next_direction();
+                        else
+                        {
+                            d++;
+                            orow = down ? orow + 1 : orow - 1;
+                            if (!(orow >= 0 && orow < R && d <= max_col_steps))
+                                next_direction();
+                        }
+                    }
+                }
             }
-            if (nlinks[k] == 255)
-                flags |= 1;
-            else if (nlinks[k] > 0)
-                flags |= 2;
+            if (have)
+            {
+                s_parent[tl] = (short) parent;
+                s_nlinks[tl] = (unsigned char) (overflow ? 255 : nlinks);
+                s_fin[tl] = fin;
+                s_links[tl] = packed;
+                if (MIRROR)
+                {
+                    s_visits[tl] = sat_u16(visits);
+                    s_reach[tl] = (unsigned char) reach;
+                }
+            }
         }
+        wave_lds_fence();
+        // ---- C: back to rows-as-lanes: stores and the column epilogue ------------------------------------------------------------
+        for (int tc = 0; tc < ncols; tc++)
+        {
+            int lc = lc0 + tc;
+            lc = lc >= RC ? lc - RC : lc;
+            int parent[RPL], nlinks[RPL];
+            double fin[RPL];
+            unsigned long long packed[RPL];
+            int reach = 0;
 #pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            const int row = k * 64 + lane;
-            const int src = t[k];
-            const int lo = __shfl(mine[0], src & 63);
-            const int hi = RPL > 1 ? __shfl(mine[RPL - 1], src & 63) : lo;
-            const int term = parent[k] < -1 ? -1 : (src < 64 ? lo : hi);
-            if (row < R)
-                p.sc_term[lc * R + row] = (int16_t) term;
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                const int tl = tc * RPL * 64 + row;
+                parent[k] = s_parent[tl];
+                nlinks[k] = s_nlinks[tl];
+                fin[k] = s_fin[tl];
+                packed[k] = s_links[tl];
+                if (MIRROR)
+                    reach = (int) s_reach[tl] > reach ? (int) s_reach[tl] : reach;
+                if (row < R)
+                {
+                    const int ci = lc * R + row;
+                    p.sc_parent[ci] = (int16_t) parent[k];
+                    p.sc_nlinks[ci] = (uint8_t) nlinks[k];
+                    p.sc_fin[ci] = fin[k];
+                    if (nlinks[k] > 0)
+                        p.sc_links[ci] = packed[k];
+                    if (MIRROR)
+                        p.sc_visits[ci] = s_visits[tl];
+                }
+            }
+            scan_column_epilogue<RPL, MIRROR>(p, R, lc, lane, parent, nlinks, fin, packed, reach);
         }
-        max_delta = -wave_min_i32(-max_delta); // DPP reductions, ballots: no LDS round trips
-        if (MIRROR)
-            reach = -wave_min_i32(-reach);
-        flags = (__any(flags & 1) ? 1 : 0) | (__any(flags & 2) ? 2 : 0);
-        newfin = wave_min_f64(newfin);
-        if (lane == 0)
-        {
-            p.col_newfin[lc] = newfin;
-            p.col_info[lc] = cnt_new | (flags << 8) | (max_delta << 16) | ((MIRROR ? reach : 0) << 24);
-        }
+        wave_lds_fence(); // the tile's LDS arrays are rewritten by the next tile
     }
 }
 
