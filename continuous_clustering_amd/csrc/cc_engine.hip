@@ -47,6 +47,7 @@ struct cc_engine
     bool allow_pipeline{true};    // option "pipeline"
     bool publish_off_chain{true}; // option "publish_off_chain"
     bool table_on_insert_chain{true}; // option "table_on_insert_chain"
+    bool parallel_insert_multi{true}; // option "parallel_insert" = 1: k_insert_multi behind / instead of k_insert_par; 2: k_insert_par only
     bool parallel_insert{true};   // option "parallel_insert": k_insert_par takes the single-column-firing head of every batch
     // low-latency path of cc_engine_add_firings for small calls: one captured hipGraph per (stream, n), pinned staging
     struct SmallGraph
@@ -373,13 +374,24 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (par)
         sp = si;
     CC_MARK(sp); // ev0
-    if (par)
+    if (par && rpl == 1) // (two rows per lane = sensors with per-laser azimuth offsets in practice: straight to k_insert_multi)
     {
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_insert_par<1>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                                d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
         else
             hipLaunchKernelGGL(cck::k_insert_par<2>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
+                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
+    }
+    // multi-column firings (per-laser azimuth offsets) and whatever single-column head k_insert_par did not take: block-parallel as well,
+    // with the per-row collision rule checked instead of assumed (option "parallel_insert" = 2 restricts this to the first kernel)
+    if (par && e->parallel_insert_multi)
+    {
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_insert_multi<1>, dim3(count), dim3(64 * cck::IM_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
+                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
+        else
+            hipLaunchKernelGGL(cck::k_insert_multi<2>, dim3(count), dim3(64 * cck::IM_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                                d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
     }
     if (first_pass && !prep_done) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
@@ -1607,7 +1619,10 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "publish_off_chain")
         e->publish_off_chain = value != 0;
     else if (n == "parallel_insert")
+    {
         e->parallel_insert = value != 0;
+        e->parallel_insert_multi = value == 1;
+    }
     else if (n == "input_on_engine_stream")
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")

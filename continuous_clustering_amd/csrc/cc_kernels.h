@@ -1347,6 +1347,332 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
 }
 
 // =====================================================================================================
+// k_insert_multi — the block-parallel insertion for MULTI-COLUMN firings (sensors whose lasers carry individual azimuth offsets: a
+// VLS-128 firing spans ~60 columns; cc.cpp:105-292), and for whatever single-column head k_insert_par left over.
+//
+// What makes the insertion serial is (1) the column of every return relative to the previous rearmost laser (cc.cpp:152-175) and (2) the
+// per-row collision rule (cc.cpp:188-206). With r_f the column-in-rotation of the REARMOST laser of firing f, (1) is again a prefix sum
+// while the rearmost laser advances by >= 1 column per firing: rear column G_f = G_(f-1) + unwrap(r_f - r_(f-1)), and a return whose
+// column-in-rotation lies o columns ahead of r_f lands in column G_f + o. (2) never fires while every ROW's target columns increase
+// strictly from firing to firing (a cell of row i can only have been written by an earlier return of row i: rows never share cells) and
+// the previous tenant of the ring slot has been cleared. Both conditions are CHECKED, per firing and per row, before anything is written;
+// the first firing that violates one (empty firing, rearmost laser not advancing, a row revisiting or falling behind one of its earlier
+// columns, span of half a rotation, ring slot not provably clear, emission limit) ends the run and the serial kernel continues there,
+// with exactly the state it would have at that firing. No roll-back is needed: nothing of a firing is written before it is accepted.
+//
+// One block per stream, IM_WAVES wavefronts, chunks of IM_WAVES firings: every wavefront prepares one firing (rigid transform, range,
+// bit-exact atan2f / asinf: prep_point) and keeps its points in registers, the chunk's rear columns and per-row target columns meet in LDS
+// (two barriers per chunk), then every accepted firing writes its cells. grid = streams, block = 64 * IM_WAVES.
+// =====================================================================================================
+constexpr int IM_WAVES = 8;
+
+template<int RPL>
+__global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+                                                              const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
+                                                              const double* __restrict__ poses, long long n, long long n_total, long long fbase)
+{
+    const int sl = blockIdx.x;
+    const int s = first_stream + sl;
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    StreamState* st = &states[s];
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
+    constexpr int NR = 64 * RPL;
+    __shared__ int s_rear_cir[IM_WAVES]; // column-in-rotation of the firing's rearmost laser, -1 = empty firing
+    __shared__ int s_span[IM_WAVES];     // foremost - rearmost column of the firing
+    __shared__ int s_col[IM_WAVES][NR];  // per row: columns ahead of the firing's rearmost laser, -1 = no return
+    __shared__ int s_rowmax[NR];         // per row: last column written (relative to prev_rearmost at entry), INT_MIN = none in reach
+    __shared__ int s_stop;               // first firing of the chunk whose rows clash with earlier returns
+    __shared__ long long s_ring_start;
+
+    const long long cursor0 = st->cursor;
+    if (cursor0 >= n)
+        return;
+    const long long prev_rear0 = st->prev_rearmost, prev_fore0 = st->prev_foremost, first_unf0 = st->first_unfinished;
+    const long long ring_end0 = st->ring_end;
+    if (tid == 0)
+        s_ring_start = __hip_atomic_load(&st->ring_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const long long ring_start = s_ring_start;
+    // deferred clearColumns (cc.cpp:1094-1145), spread over the wavefronts (as in k_insert_par; nothing left to do when that kernel ran)
+    long long clear_done = st->clear_done;
+    if (clear_done >= 0)
+    {
+        const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
+        for (long long c = clear_done + wave; c < clear_to; c += IM_WAVES)
+        {
+            const int clc = (int) (c % RC);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const size_t ci = (size_t) clc * R + row;
+                    p.dist[ci] = __builtin_nanf("");
+                    p.incl[ci] = __builtin_nanf("");
+                    p.gcol[ci] = -1;
+                }
+            }
+        }
+        if (clear_to > clear_done)
+            clear_done = clear_to;
+    }
+    const bool steady = ring_start != -1 && first_unf0 > 0 && first_unf0 == prev_rear0 && prev_fore0 >= prev_rear0 && st->reset_required == 0 &&
+                        clear_done >= 0 && prev_fore0 - prev_rear0 < NC / 2;
+    __syncthreads(); // the cleared cells are ordered before everything this block writes from here on
+    if (!steady)
+    {
+        if (tid == 0)
+            st->clear_done = clear_done;
+        return;
+    }
+    // what the rows have written ahead of the rearmost laser so far: the last occupied column of every row in [prev_rear0, prev_fore0]
+    for (int r = tid; r < NR; r += 64 * IM_WAVES)
+        s_rowmax[r] = (int) 0x80000000;
+    __syncthreads();
+    {
+        const int ahead = (int) (prev_fore0 - prev_rear0);
+        const int lc_base = (int) (prev_rear0 % RC);
+        for (int c = wave; c <= ahead; c += IM_WAVES)
+        {
+            int lc = lc_base + c;
+            lc = lc >= RC ? lc - RC : lc;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const float d = p.dist[(size_t) lc * R + row];
+                    if (d == d)
+                        atomicMax(&s_rowmax[row], c);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int half = NC / 2;
+    const bool clockwise = cfg.sensor_is_clockwise != 0;
+    const size_t fglob = (size_t) sl * (size_t) n_total + (size_t) fbase;
+    const long long seq0 = (long long) st->firings_consumed;
+    const long long rot0 = prev_rear0 / NC;
+    const int cir0 = (int) (prev_rear0 - rot0 * NC);
+    const int lc0 = (int) (prev_rear0 % RC);
+    // carried from chunk to chunk (every thread keeps the same values)
+    int carry_rel = 0;    // rear column of the last accepted firing, relative to prev_rear0
+    int carry_cir = cir0; // its column-in-rotation
+    int fore_rel = (int) (prev_fore0 - prev_rear0);
+    long long done = cursor0;
+    for (long long f0 = cursor0; f0 < n; f0 += IM_WAVES)
+    {
+        const long long f = f0 + wave;
+        const bool mine = f < n;
+        PreppedPoint q[RPL];
+        int oc[RPL];
+        // ---- prepare this wavefront's firing ------------------------------------------------------------------------------------
+        int rear_cir = -1, span = 0;
+        if (mine)
+        {
+            const size_t fi = fglob + (size_t) f;
+            const double* T = poses + fi * 12;
+            int c0 = -1;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                q[k].cir = PP_SKIP;
+                if (row < R)
+                {
+                    const size_t src = (fi * R + row) * 3;
+                    q[k] = prep_point(xyz[src], xyz[src + 1], xyz[src + 2], T, clockwise, g.az_width);
+                }
+                const unsigned long long m = __ballot(q[k].cir != PP_SKIP && q[k].cir >= 0 && q[k].cir < NC);
+                if (c0 < 0 && m)
+                    c0 = __builtin_amdgcn_readlane(q[k].cir, (int) __ffsll((long long) m) - 1);
+            }
+            if (c0 >= 0)
+            {
+                // columns relative to the first valid return, unwrapped into (-half, half]; rearmost = minimum, foremost = maximum
+                int lo = 0x7fffffff, hi = -0x7fffffff; // (neutral for the negated minimum below)
+                bool odd = false; // a return outside [0, NC): leave it to the serial kernel
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    oc[k] = (int) 0x80000000;
+                    if (q[k].cir != PP_SKIP)
+                    {
+                        odd |= q[k].cir < 0 || q[k].cir >= NC;
+                        int rel = q[k].cir - c0;
+                        rel = rel > half ? rel - NC : (rel < -half ? rel + NC : rel);
+                        oc[k] = rel;
+                        lo = rel < lo ? rel : lo;
+                        hi = rel > hi ? rel : hi;
+                    }
+                }
+                lo = wave_min_i32(lo);
+                hi = -wave_min_i32(-hi);
+                if (!__any(odd))
+                {
+                    rear_cir = c0 + lo;
+                    rear_cir = rear_cir < 0 ? rear_cir + NC : (rear_cir >= NC ? rear_cir - NC : rear_cir);
+                    span = hi - lo;
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                        oc[k] = q[k].cir != PP_SKIP ? oc[k] - lo : -1;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+            s_col[wave][k * 64 + lane] = (mine && rear_cir >= 0) ? oc[k] : -1;
+        if (lane == 0)
+        {
+            s_rear_cir[wave] = rear_cir;
+            s_span[wave] = span;
+            if (wave == 0)
+                s_stop = IM_WAVES;
+        }
+        __syncthreads();
+        // ---- rear column of every firing of the chunk (every thread the same scalar walk), first firing that ends the run -------------
+        int my_rel = 0, my_prev_rel = 0, stop = IM_WAVES;
+        {
+            int rel = carry_rel, cir = carry_cir, fmax = fore_rel;
+            for (int j = 0; j < IM_WAVES; j++)
+            {
+                if (f0 + j >= n)
+                {
+                    stop = stop < j ? stop : j;
+                    break;
+                }
+                const int rc = s_rear_cir[j], sp = s_span[j];
+                const int diff = rc - cir;
+                const bool ok = rc >= 0 && ((diff > 0 && diff <= half) || diff < -half) && sp < half; // strictly forward, also across the wrap
+                const int delta = ok ? (diff < -half ? diff + NC : diff) : 0;
+                const int nrel = rel + delta;
+                // taken only while the batch has emitted fewer than limit_columns columns before it (k_insert2's loop head), and while the
+                // previous tenant of every ring slot it touches is known to be cleared
+                if (!ok || (prev_rear0 + rel) - first_unf0 >= g.limit_columns || prev_rear0 + nrel + sp - RC >= clear_done)
+                {
+                    stop = stop < j ? stop : j;
+                    break;
+                }
+                if (j == wave)
+                {
+                    my_rel = nrel;
+                    my_prev_rel = rel;
+                }
+                rel = nrel;
+                cir = rc;
+                fmax = nrel + sp > fmax ? nrel + sp : fmax;
+            }
+        }
+        // ---- per-row collision rule: this firing's cell of a row must lie ahead of everything the row has written -----------------
+        if (mine && wave < stop)
+        {
+            bool clash = false;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (oc[k] >= 0)
+                {
+                    int last = s_rowmax[row];
+                    int rel = carry_rel, cir = carry_cir;
+                    for (int j = 0; j < wave; j++) // (the rear columns of the earlier firings of the chunk, recomputed: a handful of adds)
+                    {
+                        const int rc = s_rear_cir[j];
+                        const int diff = rc - cir;
+                        rel += diff < -half ? diff + NC : diff;
+                        cir = rc;
+                        const int o = s_col[j][row];
+                        if (o >= 0)
+                            last = rel + o > last ? rel + o : last;
+                    }
+                    clash |= my_rel + oc[k] <= last;
+                }
+            }
+            if (__any(clash) && lane == 0)
+                atomicMin(&s_stop, wave);
+        }
+        __syncthreads();
+        {
+            const int st2 = s_stop;
+            stop = st2 < stop ? st2 : stop;
+        }
+        // ---- accepted firings write their cells ------------------------------------------------------------------------------------
+        if (mine && wave < stop)
+        {
+            const size_t fi = fglob + (size_t) f;
+            const uint8_t* si = inten + fi * R;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (oc[k] >= 0)
+                {
+                    const int crel = my_rel + oc[k];
+                    const int lc = (int) ((unsigned) (lc0 + crel) % (unsigned) RC);
+                    const long long rot = rot0 + (long long) ((unsigned) (cir0 + crel) / (unsigned) NC);
+                    const size_t ci = (size_t) lc * R + row;
+                    p.x[ci] = q[k].x;
+                    p.y[ci] = q[k].y;
+                    p.z[ci] = q[k].z;
+                    p.inten[ci] = si[row];
+                    p.src[ci] = seq0 + (f - cursor0);
+                    p.dist[ci] = q[k].dist;
+                    p.incl[ci] = q[k].incl;
+                    p.caz[ci] = CC_2PI_D * (double) rot + (double) q[k].incaz;
+                    p.gcol[ci] = prev_rear0 + crel;
+                    atomicMax(&s_rowmax[row], crel);
+                }
+            }
+            // columns [G_(f-1), G_f) (rearmost columns) are finished by this firing and carry its pose (cc.cpp:289-291)
+            const int cnt = my_rel - my_prev_rel;
+            for (int jj = lane; jj < cnt; jj += 64)
+                p.trig[(int) ((unsigned) (lc0 + my_prev_rel + jj) % (unsigned) RC)] = (int) f;
+        }
+        // ---- carry (the same walk over the accepted firings, in every thread) -------------------------------------------------------
+        for (int j = 0; j < stop; j++)
+        {
+            const int rc = s_rear_cir[j], sp = s_span[j];
+            const int diff = rc - carry_cir;
+            carry_rel += diff < -half ? diff + NC : diff;
+            carry_cir = rc;
+            fore_rel = carry_rel + sp > fore_rel ? carry_rel + sp : fore_rel;
+        }
+        done = f0 + stop;
+        if (stop < IM_WAVES)
+            break;
+        __syncthreads(); // this chunk's LDS reads and s_rowmax updates are complete before the next chunk rewrites the hand-off arrays
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        st->clear_done = clear_done;
+        st->dbg[6] += (unsigned long long) (done - cursor0);
+        st->dbg[7] += 1;
+        if (done > cursor0)
+        {
+            const long long G = prev_rear0 + carry_rel;
+            const long long F = prev_rear0 + fore_rel;
+            st->prev_rearmost = G;
+            st->prev_foremost = F > prev_fore0 ? F : prev_fore0;
+            st->first_unfinished = G;
+            if (F > ring_end0)
+                st->ring_end = F;
+            st->cursor = done;
+            st->firings_consumed = (unsigned long long) (seq0 + (done - cursor0));
+            if (st->pre_seg_begin == 0)
+                st->pre_seg_begin = first_unf0;
+        }
+    }
+}
+
+// =====================================================================================================
 // k_table — sc_inclination_angles_between_lasers_ (cc.cpp:353-357): per row the last non-NaN inclination step over the
 // emitted columns, in column order = a per-row "last valid value" scan along the columns. One block of TABLE_WAVES wavefronts
 // per stream, lanes = rows: every wavefront owns a contiguous chunk of the batch's columns; phase 1 finds the last valid step

@@ -106,3 +106,35 @@ def test_two_wave_kernel_rolls_back_speculation(oracle_lib):
     stream, cfg, tf = cases.build_case("s64_forced_finish_ring")
     summary = util.run_and_compare(stream, cfg, chunks=[37, 5, 211], robot_tf=tf)
     assert summary["engine_state"]["error_b"] > 0
+
+
+@pytest.mark.parametrize("name,option,value", [
+    ("s64_translate", "scan_packed", 1), ("s64_dropouts", "scan_packed", 1), ("j_s64_jitter_wide", "scan_packed", 1),
+    ("s128_offsets", "scan_packed", 0), ("s32_small_sensor", "scan_packed", 1),
+    ("s128_offsets", "parallel_insert", 2), ("s128_full_1700", "parallel_insert", 0), ("j_s128_offsets_jitter", "parallel_insert", 2),
+    ("j_s64_jitter", "parallel_insert", 0), ("s64_full_2200", "parallel_insert", 2),
+])
+def test_kernel_variants_give_the_same_result(name, option, value, oracle_lib):
+    """The window scan has two kernels (rows as lanes in lock step / active points packed into the lanes) and the insertion three
+    (block-parallel single-column, block-parallel multi-column with the collision rule checked, serial): every selection must reproduce the
+    oracle. The defaults are covered by test_engine_matches_oracle; here the other choice of each option."""
+    stream, cfg, tf = cases.build_case(name)
+    util.run_and_compare(stream, cfg, chunks=[stream.sensor.num_columns, 211], robot_tf=tf, engine_setup=lambda e: e.set_option(option, value))
+
+
+def test_multi_column_insertion_takes_the_steady_part(oracle_lib):
+    """VLS-128-shaped stream (every firing spans ~60 columns): after the ring has started, k_insert_multi takes whole calls (debug
+    counter 6 = firings taken by the block-parallel kernels)."""
+    import ctypes as C
+    from continuous_clustering_amd import Engine, load_library
+    stream, cfg, tf = cases.build_case("s128_full_1700")
+    e = Engine(cfg, 128, 1)
+    n = 0
+    for b in range(2):
+        sl = slice(b * 1700, (b + 1) * 1700)
+        assert e.add_firings(stream.xyz[sl], stream.intensity[sl], stream.poses[sl]) == 0
+    L = load_library()
+    L.cc_engine_debug_counters.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    out = np.zeros(16, dtype=np.uint64)
+    L.cc_engine_debug_counters(e.h, 0, out.ctypes.data)
+    assert out[6] >= 1700, out[6]  # the whole second call (the first one starts the ring in the serial kernel)
