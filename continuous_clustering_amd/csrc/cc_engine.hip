@@ -80,6 +80,9 @@ struct cc_engine
     // staging for cc_engine_read_columns
     void* d_view{nullptr};
     size_t view_bytes{0};
+    double* d_ego[4]{nullptr, nullptr, nullptr, nullptr}; // k_ego output per batch-descriptor slot: [streams in launch][n][12]
+    size_t ego_capacity{0};
+    bool small_graphs_stale{false}; // a buffer a captured graph points at was re-allocated
     bool idle{false}; // nothing has been enqueued on any of the engine's HIP streams since they were last synchronised
     std::vector<StreamState> state_cache; // per stream: the state as the last small (graph) call copied it back, if still current
     std::vector<char> state_cached;
@@ -174,6 +177,7 @@ int free_all(cc_engine* e)
     e->d_view = nullptr;
     e->view_bytes = 0;
     e->prep_capacity = 0;
+    e->ego_capacity = 0;
     e->d_gather = nullptr;
     e->gather_bytes = 0;
     e->d_small = nullptr;
@@ -289,6 +293,7 @@ int ensure_prep(cc_engine* e, size_t points)
             (rc = alloc_plane(e, &q.incaz, points)) || (rc = alloc_plane(e, &q.cir, points)))
             return rc;
     e->prep_capacity = points;
+    e->small_graphs_stale = true; // captured small-call graphs bake the old staging pointers
     return CC_OK;
 }
 
@@ -345,6 +350,22 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                  hipStream_t sc = nullptr, hipStream_t sp = nullptr, bool prep_done = false)
 {
     e->idle = false;
+    {
+        const size_t need = (size_t) count * (size_t) n;
+        if (e->ego_capacity < need)
+        {
+            // (old blocks stay in `allocations`; captured small-call graphs hold the old pointers and are dropped)
+            const size_t cap = need < 4096 ? 4096 : need;
+            for (int i = 0; i < 4; i++)
+            {
+                int rce = alloc_plane(e, &e->d_ego[i], cap * 12);
+                if (rce)
+                    return rce;
+            }
+            e->ego_capacity = cap;
+            e->small_graphs_stale = true;
+        }
+    }
     if (!sc)
         sc = sb; // window scan on the segmentation chain unless the four-stage pipeline gives it its own stream
     if (!sp)
@@ -443,12 +464,16 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         else
             hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
     }
+    // per-firing ego transforms of this batch (one buffer per descriptor slot: up to three batches are in flight)
+    double* d_ego = e->d_ego[slot];
+    hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
+                       d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
-                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0);
+                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
     else
         hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
-                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0);
+                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
         hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -868,6 +893,19 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     const float* d_xyz = (const float*) e->d_small;
     const uint8_t* d_int = e->d_small + b_xyz;
     const double* d_pose = (const double*) (e->d_small + b_xyz + b_int);
+    if (e->ego_capacity < 4096)
+    {
+        for (int i = 0; i < 4; i++)
+            if (alloc_plane(e, &e->d_ego[i], (size_t) 4096 * 12) != CC_OK)
+                return -1;
+        e->ego_capacity = 4096;
+        e->small_graphs_stale = true;
+    }
+    if (e->small_graphs_stale)
+    {
+        destroy_small_graphs(e);
+        e->small_graphs_stale = false;
+    }
     hipGraphExec_t exec = nullptr;
     for (auto& g : e->small_graphs)
         if (g.stream == stream && g.n == n && g.record == e->g.record_events)

@@ -1814,6 +1814,33 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
     }
 }
 
+// ---- k_ego: ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1 (cc.cpp:300-301) once per FIRING of the batch (one
+// thread each) instead of once per column and wavefront in k_seg_pre, where all 64 lanes evaluated the same ~80 double-precision
+// operations. Same expressions, same order. out[(stream in launch * n + firing) * 12] = {R (3x3, row major), t}. grid = (n / 256, streams).
+__global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ states, int first_stream, const double* __restrict__ poses, long long n,
+                                             long long n_total, long long fbase, double* __restrict__ out)
+{
+    const int sl = blockIdx.y;
+    const long long f = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (f >= n)
+        return;
+    const double* A = states[first_stream + sl].robot_from_sensor;
+    const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) f) * 12;
+    double ir[9], it[3];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            ir[i * 3 + j] = T[j * 4 + i];
+    for (int i = 0; i < 3; i++)
+        it[i] = ((-ir[i * 3 + 0]) * T[3] + (-ir[i * 3 + 1]) * T[7]) + (-ir[i * 3 + 2]) * T[11];
+    double* o = out + ((size_t) sl * (size_t) n + (size_t) f) * 12;
+    for (int i = 0; i < 3; i++)
+    {
+        for (int j = 0; j < 3; j++)
+            o[i * 3 + j] = (A[i * 4 + 0] * ir[0 * 3 + j] + A[i * 4 + 1] * ir[1 * 3 + j]) + A[i * 4 + 2] * ir[2 * 3 + j];
+        o[9 + i] = ((A[i * 4 + 0] * it[0] + A[i * 4 + 1] * it[1]) + A[i * 4 + 2] * it[2]) + A[i * 4 + 3];
+    }
+}
+
 // ---- k_seg_pre: everything of the segmentation that does not depend on the rows below. One wavefront per column,
 // lanes = rows (coalesced); blocks stride over the columns of the batch. grid = (SEGPRE_BLOCKS, streams), block = 64.
 #ifndef CC_SEGPRE_BLOCKS
@@ -1823,7 +1850,8 @@ constexpr int SEGPRE_BLOCKS = CC_SEGPRE_BLOCKS;
 
 template<int RPL>
 __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                const double* __restrict__ poses, long long n_total, long long fbase)
+                                                const double* __restrict__ poses, long long n_total, long long fbase,
+                                                const double* __restrict__ ego, long long n_batch)
 {
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
@@ -1853,21 +1881,15 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     {
         const size_t base = (size_t) lc * R;
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
-        const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) p.trig[lc]) * 12;
-        // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301)
-        double ir[9], it[3];
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++)
-                ir[i * 3 + j] = T[j * 4 + i];
-        for (int i = 0; i < 3; i++)
-            it[i] = ((-ir[i * 3 + 0]) * T[3] + (-ir[i * 3 + 1]) * T[7]) + (-ir[i * 3 + 2]) * T[11];
+        const int trig = uniform_i32(p.trig[lc]); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
+        const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) trig) * 12;
+        // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301), prepared per firing by k_ego
+        const double* E = ego + ((size_t) sl * (size_t) n_batch + (size_t) trig) * 12;
         double er[9], et[3];
+        for (int i = 0; i < 9; i++)
+            er[i] = E[i];
         for (int i = 0; i < 3; i++)
-        {
-            for (int j = 0; j < 3; j++)
-                er[i * 3 + j] = (A[i * 4 + 0] * ir[0 * 3 + j] + A[i * 4 + 1] * ir[1 * 3 + j]) + A[i * 4 + 2] * ir[2 * 3 + j];
-            et[i] = ((A[i * 4 + 0] * it[0] + A[i * 4 + 1] * it[1]) + A[i * 4 + 2] * it[2]) + A[i * 4 + 3];
-        }
+            et[i] = E[9 + i];
         const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
 
         float dist[RPL], incl[RPL], tabv[RPL];
