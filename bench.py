@@ -438,6 +438,7 @@ def main():
         import struct
         import subprocess
         import tempfile
+        n_batches = int(xyz.shape[0])
         nrt = min(n_batches, 3) * F
         with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as tf_:
             tf_.write(struct.pack("<iiii", R, cfg.num_columns, nrt, 1))

@@ -182,6 +182,7 @@ struct Geometry
     int32_t mirror_fields;   // also produce the per-point fields only the host mirror of range_image_ shows (visited-neighbour counts, the
                              // parent of live-replayed points, per-tree values of finished trees, the tree-link log)
     int32_t link_capacity;
+    int32_t mark_ignored_in_rec; // k_seg_scan also marks ignored cells in the scan records (x = NaN): what k_scan2 reads instead of the flag plane
 };
 
 } // namespace ccd

@@ -154,6 +154,7 @@ int validate(cc_engine* e, const cc_config* cfg, int num_rows, int num_streams)
 void fill_geometry(cc_engine* e, int num_rows)
 {
     Geometry& g = e->g;
+    g.mark_ignored_in_rec = (e->scan_packed == 1 || (e->scan_packed < 0 && num_rows > WAVE)) ? 1 : 0;
     g.num_rows = num_rows;
     g.num_columns = e->cfg.num_columns;
     g.az_width = static_cast<float>((2 * M_PI)) / static_cast<float>(g.num_columns); // cc.cpp:16
@@ -1666,7 +1667,10 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "assoc_waves")
         e->assoc_waves = value == 1 ? 1 : 2;
     else if (n == "scan_packed")
+    {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);
+        e->g.mark_ignored_in_rec = (e->scan_packed == 1 || (e->scan_packed < 0 && e->g.num_rows > WAVE)) ? 1 : 0;
+    }
     else if (n == "mirror_fields")
         e->g.mirror_fields = value != 0;
     else if (n == "limit_columns")

@@ -2324,7 +2324,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 p.ignored[ci] = ign ? 1 : 0;
                 // the window scan reads one 16-byte record per visited cell: an ignored cell is marked there as x = NaN (cells without a
                 // return have it already), so that the distance test of cc.cpp:638-641 fails without a second load
-                if (ign && (o & 7) != SG_G_UNKNOWN)
+                if (g.mark_ignored_in_rec && ign && (o & 7) != SG_G_UNKNOWN) // (only k_scan2 relies on it; k_scan reads the flag plane)
                     ((float*) &p.sc_rec[ci])[0] = __builtin_nanf("");
             }
             lc = lc + 1 == RC ? 0 : lc + 1;

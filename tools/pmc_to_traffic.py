@@ -9,8 +9,10 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
+round_tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+out_name = sys.argv[3] if len(sys.argv) > 3 else "traffic.json"
 src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
-ALIAS = {"k_prep": "prep", "k_insert_par": "insert_parallel", "k_insert2": "insert", "k_seg_pre": "segment_pre", "k_seg_scan": "segment", "k_scan": "scan",
+ALIAS = {"k_insert_multi": "insert_multi", "k_scan2": "scan_packed", "k_ego": "ego", "k_prep": "prep", "k_insert_par": "insert_parallel", "k_insert2": "insert", "k_seg_pre": "segment_pre", "k_seg_scan": "segment", "k_scan": "scan",
          "k_assoc_lds": "assoc_lds_1wave", "k_assoc2": "assoc_lds", "k_associate": "assoc_global", "k_publish": "publish", "k_table": "table"}
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -22,17 +24,17 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
                 acc[m.group(1)].append(float(row["Counter_Value"]))
     # the first launch of every kernel processes a cold ring; use the median launch
     vals[ctr] = {k: sorted(v)[len(v) // 2] for k, v in acc.items()}
-    shutil.copy(os.path.join(src, ctr + ".csv"), os.path.join(ROOT, "profiles", f"r01_pmc_{ctr}.csv"))
+    shutil.copy(os.path.join(src, ctr + ".csv"), os.path.join(ROOT, "profiles", f"{round_tag}_pmc_{ctr}{'' if out_name == 'traffic.json' else '_s128'}.csv"))
 out = {}
 note = ("FETCH_SIZE doubled (gfx950 wide-read correction of MI355X_MICROARCH.md); separate --pmc passes; median launch; "
-        "256 streams x 2200 firings per launch")
+        "256 streams x one rotation of firings per launch")
 for k in sorted(vals["FETCH_SIZE"]):
     f, w = vals["FETCH_SIZE"][k], vals["WRITE_SIZE"].get(k, 0.0)
     rec = {"kernel": k, "fetch_size_kb_raw": f, "write_size_kb": w, "hbm_bytes_per_launch": (2 * f + w) * 1024.0, "note": note}
     out[k] = rec
     if k in ALIAS:
         out[ALIAS[k]] = rec
-json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", out_name), "w"), indent=1)
 tot = sum(r["hbm_bytes_per_launch"] for k, r in out.items() if k.startswith("k_"))
 for k, r in out.items():
     if k.startswith("k_"):

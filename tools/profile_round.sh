@@ -1,0 +1,25 @@
+#!/bin/bash
+# usage: tools/profile_round.sh <tag>   (GPU box, through gpurun)  — every measurement the round's profiles/ entries come from, in one call:
+#  1 default bench line   2 rocprofv3 --kernel-trace --stats of the same S64 leg   3 TCC FETCH_SIZE / WRITE_SIZE passes (S64 and S128)
+#  4 SQ / LDS / L2 counter passes on tools/solo_run.py   5 bench under torch.distributed.run at world size 1 (RCCL)
+tag=$1
+repo=${GRAFT_REPO_ROOT:-/root/repo}
+out=$repo/gpurun_out/round_$tag
+mkdir -p $out
+cd $repo
+python bench.py > $out/bench_line.json 2> $out/bench.err
+tools/prof.sh $tag --steps 40 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof.log 2>&1
+tools/prof.sh ${tag}_s128 --sensor s128 --firings 1700 --steps 10 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof_s128.log 2>&1
+tools/pmc.sh $tag > $out/pmc.log 2>&1
+tools/pmc.sh ${tag}_s128 --sensor s128 --firings 1700 > $out/pmc_s128.log 2>&1
+tools/pmc_sq.sh $tag "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+                     "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+                     "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC" \
+                     "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" > $out/sq.log 2>&1
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 3 \
+  --no-cpu-baseline --no-latency --no-s128 > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
+cp $repo/gpurun_out/prof_$tag/*kernel_stats.csv $out/kernel_stats_s64.csv 2>/dev/null
+cp $repo/gpurun_out/prof_${tag}_s128/*kernel_stats.csv $out/kernel_stats_s128.csv 2>/dev/null
+cp $repo/gpurun_out/prof_$tag/bench_line.json $out/prof_bench_line.json 2>/dev/null
+cp $repo/gpurun_out/prof_${tag}_s128/bench_line.json $out/prof_bench_line_s128.json 2>/dev/null
+ls -la $out; tail -3 $out/bench.err; grep -E "^k_" $out/sq.log | head -60
