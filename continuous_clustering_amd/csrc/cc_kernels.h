@@ -1364,7 +1364,10 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
 // bit-exact atan2f / asinf: prep_point) and keeps its points in registers, the chunk's rear columns and per-row target columns meet in LDS
 // (two barriers per chunk), then every accepted firing writes its cells. grid = streams, block = 64 * IM_WAVES.
 // =====================================================================================================
-constexpr int IM_WAVES = 8;
+#ifndef CC_IM_WAVES
+#define CC_IM_WAVES 8
+#endif
+constexpr int IM_WAVES = CC_IM_WAVES;
 
 template<int RPL>
 __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
