@@ -162,7 +162,7 @@ def _cpu_worker(idx, core, cfg, R, hx, hi, hp, barrier, conn, latency):
         # private, first-touched-here copies of the inputs; the oracle's ring is allocated (and touched by reset) inside this pinned process
         x, i, p = np.array(hx, copy=True), np.array(hi, copy=True), np.array(hp, copy=True)
         o = Oracle(cfg, R, record=False)
-        buf_a, buf_b = np.ones(1 << 24, dtype=np.float64), np.zeros(1 << 24, dtype=np.float64)  # 128 MB each: beyond every cache
+        buf_a, buf_b = np.ones(1 << 24, dtype=np.float64), np.ones(1 << 24, dtype=np.float64)  # 128 MB each, touched here: beyond every cache
         barrier.wait(timeout=600)
         sec = o.time_firings(x, i, p)
         cells = o.state()["cells_published"]
