@@ -66,7 +66,7 @@ struct cc_engine
     int scan_packed{-1};                // option "scan_packed": 1 = k_scan2 (active points packed into the lanes), 0 = k_scan (rows as lanes, lock
                                         // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch;
                                         // at 64 rows the lock-step kernel is 3 % ahead inside the pipeline although it issues 1.5 x the instructions)
-    int assoc_waves{2};                 // option "assoc_waves": 2 = k_assoc2 (front / back wavefronts), 1 = k_assoc_lds
+    int assoc_waves{3};                 // option "assoc_waves": 2 = k_assoc2 (front / back wavefronts), 1 = k_assoc_lds
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
     std::string error;
@@ -514,7 +514,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // ---- association + publish chain -------------------------------------------------------------------------
     CC_MARK(sa); // ev6: start of the third chain
     // k_assoc2 walks the finished-cluster checks of several columns at once and assumes one check per column
-    if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
+    if (e->assoc_waves == 3 && e->cfg.cluster_point_trees_every_nth_column == 1)
+    {
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), dim3(192), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else
+            hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), dim3(192), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    }
+    else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_assoc2<1>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -1665,7 +1672,7 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "input_on_engine_stream")
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")
-        e->assoc_waves = value == 1 ? 1 : 2;
+        e->assoc_waves = value == 1 ? 1 : (value == 2 ? 2 : 3);
     else if (n == "scan_packed")
     {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);
