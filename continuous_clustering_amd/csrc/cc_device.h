@@ -26,7 +26,10 @@ constexpr int PP_SKIP = 0x7fffffff;
 #endif
 constexpr int INS_WIN = CC_INS_WIN;          // columns of `distance` kept in LDS by the insertion kernel
 constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLOSE = 16;
-constexpr int TREE_SLOTS = 256;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
+#ifndef CC_TREE_SLOTS
+#define CC_TREE_SLOTS 256
+#endif
+constexpr int TREE_SLOTS = CC_TREE_SLOTS;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
 
 // Scalar state of one sensor stream: the srig_*/sgps_*/sc_* members of the reference class
 // (continuous_clustering.hpp:244-275) plus engine bookkeeping.
