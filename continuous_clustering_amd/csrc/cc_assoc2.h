@@ -122,6 +122,7 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
     short* wcol = s_win + (int) (gc & (WIN2_COLS - 1)) * R;
     for (int row = 0; row < R; row++)
         wcol[row] = -1;
+    const CazBase cb = caz_base_of_column(gc, c.NC);
     for (int row = 0; row < R; row++)
     {
         const int pi = lc * R + row;
@@ -134,8 +135,9 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
             continue;
         }
         const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[pi]);
-        const double pcaz = p.caz[pi];
-        const float pincl = p.incl[pi], px = p.x[pi], py = p.y[pi], pz = p.z[pi];
+        const double pcaz = cell_caz(cb, p.incaz[pi]);
+        const float4 me = p.sc_rec[pi];
+        const float pincl = me.w, px = me.x, py = me.y, pz = me.z;
         int needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
         needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
         int oc = lc;
@@ -154,7 +156,8 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
                 {
                     const int oi = oc * R + orow;
                     visits++; // cc.cpp:725
-                    if (ccm::absf(p.incl[oi] - pincl) > mad)
+                    const float4 orec = p.sc_rec[oi];
+                    if (ccm::absf(orec.w - pincl) > mad)
                         break;
                     if (!p.ignored[oi])
                     {
@@ -167,7 +170,7 @@ __device__ void assoc_column_live2(const AssocCtx& c, const cc_config& cfg, cons
                         const bool same = pslot >= 0 && oslot == pslot;
                         if (!same)
                         {
-                            const float dx = px - p.x[oi], dy = py - p.y[oi], dz = pz - p.z[oi];
+                            const float dx = px - orec.x, dy = py - orec.y, dz = pz - orec.z;
                             if (dx * dx + dy * dy + dz * dz < c.maxd2)
                             {
                                 if (pslot == -1)

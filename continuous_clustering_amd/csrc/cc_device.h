@@ -95,13 +95,12 @@ struct StreamState
 // All planes of an engine. Index of a cell inside a plane: stream * cells_per_stream + lcol * num_rows + row.
 struct Planes
 {
-    // geometry written by the insertion kernel
-    float* x;
-    float* y;
-    float* z;
+    // geometry written by the insertion kernel (x, y, z live in sc_rec below: one 16-byte record per cell)
     float* dist;
     float* incl;
-    double* caz;      // continuous azimuth angle
+    float* incaz;     // increasing azimuth angle of the return (cc.cpp:146-148). Its continuous azimuth angle (cc.cpp:184-186) is
+                      // 2 pi * rotation + incaz, where the rotation is that of the cell's column — or one less when the sign bit is set
+                      // (a return moved on to the first column of the next rotation, cc.cpp:188-202)
     int64_t* gcol;    // per-cell global column index (-1 = cleared)
     int64_t* src;     // sequence number of the firing that filled the cell
     uint8_t* inten;
@@ -149,8 +148,9 @@ struct Planes
     float* sg_x2;       // ||xy|| of the point relative to the sensor (to2dInAzimuthPlane(...).x, cc.hpp:229-232)
     float* sg_uz;       // z of the point relative to the sensor
     uint8_t* sg_flags;  // SG_* bits
-    // one 16-byte record per cell for the window scan: {x, y, z, inclination}; x = NaN for ignored cells, so that the
-    // distance test of cc.cpp:638-641 fails for them without a separate is_ignored load
+    // one 16-byte record per cell: {x, y, z, inclination} of the return in the odom frame, written by the insertion kernels (the only
+    // copy of x, y, z); cells without a return get {NaN, NaN, NaN, supplemented inclination} from k_seg_pre. What the window scan
+    // reads per visited cell.
     float4* sc_rec;
     // candidates are coded as (columns back << 8) | row
     int16_t* sc_parent;  // first accepted candidate, -1 = none, -2 = point is ignored
@@ -185,7 +185,6 @@ struct Geometry
     int32_t mirror_fields;   // also produce the per-point fields only the host mirror of range_image_ shows (visited-neighbour counts, the
                              // parent of live-replayed points, per-tree values of finished trees, the tree-link log)
     int32_t link_capacity;
-    int32_t mark_ignored_in_rec; // k_seg_scan also marks ignored cells in the scan records (x = NaN): what k_scan2 reads instead of the flag plane
 };
 
 } // namespace ccd

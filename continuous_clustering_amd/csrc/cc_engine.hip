@@ -154,7 +154,6 @@ int validate(cc_engine* e, const cc_config* cfg, int num_rows, int num_streams)
 void fill_geometry(cc_engine* e, int num_rows)
 {
     Geometry& g = e->g;
-    g.mark_ignored_in_rec = (e->scan_packed == 1 || (e->scan_packed < 0 && num_rows > WAVE)) ? 1 : 0;
     g.num_rows = num_rows;
     g.num_columns = e->cfg.num_columns;
     g.az_width = static_cast<float>((2 * M_PI)) / static_cast<float>(g.num_columns); // cc.cpp:16
@@ -207,7 +206,7 @@ int allocate(cc_engine* e)
 #define A(field, count)                                \
     if ((rc = alloc_plane(e, &P.field, (count))) != 0) \
         return rc;
-    A(x, C) A(y, C) A(z, C) A(dist, C) A(incl, C) A(caz, C) A(gcol, C) A(src, C) A(inten, C) A(tab, C);
+    A(dist, C) A(incl, C) A(incaz, C) A(gcol, C) A(src, C) A(inten, C) A(tab, C);
     A(trig, L) A(colg, L) A(colminaz, L);
     A(ground, C) A(debug, C) A(ignored, C) A(root, C) A(id, C);
     A(t_fin, C) A(t_width, C) A(t_pts, C) A(t_uf, C) A(t_cid, C) A(t_pos, C) A(t_finished, C);
@@ -1676,7 +1675,6 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "scan_packed")
     {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);
-        e->g.mark_ignored_in_rec = (e->scan_packed == 1 || (e->scan_packed < 0 && e->g.num_rows > WAVE)) ? 1 : 0;
     }
     else if (n == "mirror_fields")
         e->g.mirror_fields = value != 0;

@@ -185,11 +185,44 @@ __device__ __forceinline__ uint16_t sat_u16(int v)
     return (uint16_t) (v > 65535 ? 65535 : v);
 }
 
+// ---- continuous azimuth angle of a cell (cc.cpp:184-186): 2 pi * rotation index + increasing azimuth angle, in double. The cell keeps the
+// f32 increasing azimuth (Planes::incaz); the rotation index is that of the cell's global column, or one less when the sign bit is set.
+// Same expression as the reference, so the same bits — at half the bytes of a stored double.
+__device__ __forceinline__ float pack_incaz(const float inc_az, const bool previous_rotation)
+{
+    return previous_rotation ? __uint_as_float(__float_as_uint(inc_az) | 0x80000000u) : inc_az; // (inc_az >= +0: atan2f + pi)
+}
+struct CazBase
+{
+    double b0, b1; // 2 pi * rotation of the column, 2 pi * (rotation - 1)
+};
+__device__ __forceinline__ CazBase caz_base_of_rotation(const long long rot)
+{
+    CazBase b;
+    b.b0 = CC_2PI_D * (double) rot;
+    b.b1 = CC_2PI_D * (double) (rot - 1);
+    return b;
+}
+__device__ __forceinline__ CazBase caz_base_of_column(const long long gc, const int num_columns)
+{
+    return caz_base_of_rotation(gc / num_columns); // (64-bit division: once per column, never per cell)
+}
+__device__ __forceinline__ double cell_caz(const CazBase& b, const float packed)
+{
+    const unsigned u = __float_as_uint(packed);
+    return ((u >> 31) ? b.b1 : b.b0) + (double) __uint_as_float(u & 0x7fffffffu);
+}
+// a cell without a return: middle of its column (cc.cpp:371-372)
+__device__ __forceinline__ double empty_cell_caz(const long long gc, const float az_width)
+{
+    return ((double) gc + 0.5) * (double) az_width;
+}
+
 // Pointers of one stream (planes offset to the stream's first cell / column / pool slot).
 struct SP
 {
-    float *x, *y, *z, *dist, *incl, *tab;
-    double* caz;
+    float *dist, *incl, *tab;
+    float* incaz;
     int64_t *gcol, *src;
     uint8_t *inten, *ground, *debug, *ignored;
     int32_t* trig;
@@ -229,13 +262,10 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     const size_t co = (size_t) s * (size_t) g.cells;
     const size_t lo = (size_t) s * (size_t) g.ring_cols;
     const size_t to = (size_t) s * (size_t) g.tree_capacity;
-    p.x = P.x + co;
-    p.y = P.y + co;
-    p.z = P.z + co;
     p.dist = P.dist + co;
     p.incl = P.incl + co;
     p.tab = P.tab + co;
-    p.caz = P.caz + co;
+    p.incaz = P.incaz + co;
     p.gcol = P.gcol + co;
     p.src = P.src + co;
     p.inten = P.inten + co;
@@ -698,7 +728,6 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     lc += RC;
                 else if (lc >= RC)
                     lc -= RC;
-                const double caz_base = CC_2PI_D * (double) prev_rot;
 #pragma unroll
                 for (int k = 0; k < RPL; k++)
                 {
@@ -708,14 +737,12 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                         const int so = slot * R + row;
                         const size_t ci = (size_t) lc * R + row;
                         const float d = r_d[so];
-                        p.x[ci] = r_x[so];
-                        p.y[ci] = r_y[so];
-                        p.z[ci] = r_z[so];
+                        p.sc_rec[ci] = make_float4(r_x[so], r_y[so], r_z[so], r_i[so]);
                         p.inten[ci] = (uint8_t) r_t[so];
                         p.src[ci] = seq0 + (f - cursor0);
                         p.dist[ci] = d;
                         p.incl[ci] = r_i[so];
-                        p.caz[ci] = caz_base + (double) r_a[so];
+                        p.incaz[ci] = pack_incaz(r_a[so], c0 >= NC); // (rotation of the return: prev_rot, the column's unless c0 == NC)
                         p.gcol[ci] = gc0;
                         w_dist[wcol + row] = d;
                     }
@@ -921,13 +948,12 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                 {
                     const size_t ci = (size_t) lc * R + row;
 #ifndef CC_EXP_NOSTORE
-                    p.x[ci] = r_x[so];
-                    p.y[ci] = r_y[so];
-                    p.z[ci] = r_z[so];
+                    p.sc_rec[ci] = make_float4(r_x[so], r_y[so], r_z[so], r_i[so]);
                     p.inten[ci] = (uint8_t) r_t[so];
                     p.src[ci] = seq0 + (f - cursor0);
                     p.incl[ci] = r_i[so];
-                    p.caz[ci] = CC_2PI_D * (double) (prev_rot + rot_off[k]) + (double) r_a[so];
+                    // rotation of the return = prev_rot + rot_off (cc.cpp:184-186) = that of its column gc = gcv (+ 1 if moved on), or one less
+                    p.incaz[ci] = pack_incaz(r_a[so], cir[k] + (int) (gc - gcv[k]) >= NC);
                     p.gcol[ci] = gc;
 #endif
                     p.dist[ci] = d;
@@ -1272,8 +1298,6 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
         const long long rel_prev = f > 0 ? s_off[f - 1] : 0; // G_(f-1) - prev_rear0
         const long long G = prev_rear0 + rel;
         const int lc = (int) ((unsigned) (lc0 + (int) rel) % (unsigned) RC);
-        const long long rot = rot0 + (long long) ((unsigned) (cir0 + (int) rel) / (unsigned) NC);
-        const double caz_base = CC_2PI_D * (double) rot;
         const uint8_t* si = inten + fi * R;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
@@ -1282,14 +1306,12 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
             if (q[k].cir != PP_SKIP)
             {
                 const size_t ci = (size_t) lc * R + row;
-                p.x[ci] = q[k].x;
-                p.y[ci] = q[k].y;
-                p.z[ci] = q[k].z;
+                p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
                 p.inten[ci] = si[row];
                 p.src[ci] = seq0 + f;
                 p.dist[ci] = q[k].dist;
                 p.incl[ci] = q[k].incl;
-                p.caz[ci] = caz_base + (double) q[k].incaz;
+                p.incaz[ci] = q[k].incaz; // (c0 < num_columns and nothing moves on: the return's rotation is its column's)
                 p.gcol[ci] = G;
             }
         }
@@ -1619,16 +1641,13 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                 {
                     const int crel = my_rel + oc[k];
                     const int lc = (int) ((unsigned) (lc0 + crel) % (unsigned) RC);
-                    const long long rot = rot0 + (long long) ((unsigned) (cir0 + crel) / (unsigned) NC);
                     const size_t ci = (size_t) lc * R + row;
-                    p.x[ci] = q[k].x;
-                    p.y[ci] = q[k].y;
-                    p.z[ci] = q[k].z;
+                    p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
                     p.inten[ci] = si[row];
                     p.src[ci] = seq0 + (f - cursor0);
                     p.dist[ci] = q[k].dist;
                     p.incl[ci] = q[k].incl;
-                    p.caz[ci] = CC_2PI_D * (double) rot + (double) q[k].incaz;
+                    p.incaz[ci] = q[k].incaz; // (the return's rotation, rot0 + (cir0 + crel) / num_columns, is that of its column)
                     p.gcol[ci] = prev_rear0 + crel;
                     atomicMax(&s_rowmax[row], crel);
                 }
@@ -1877,12 +1896,19 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     const float height_sensor_to_ground = -(float) A[11] + cfg.height_ref_to_ground_;
     (void) height_sensor_to_ground;
 
-    // (ring column advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
+    // (ring column and rotation index advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
     int lc = (int) ((seg_begin + blockIdx.y) % RC);
     const int lc_step = (int) (gridDim.y % (unsigned) RC);
-    for (long long gc = seg_begin + blockIdx.y; gc < seg_end; gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
+    const int NC = g.num_columns;
+    long long rot = (seg_begin + blockIdx.y) / NC;
+    int cir = (int) ((seg_begin + blockIdx.y) - rot * NC);
+    const int cir_step = (int) (gridDim.y % (unsigned) NC);
+    const long long rot_step = (long long) (gridDim.y / (unsigned) NC);
+    for (long long gc = seg_begin + blockIdx.y; gc < seg_end; gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step),
+                   rot += rot_step + (cir + cir_step >= NC ? 1 : 0), cir = (cir + cir_step >= NC ? cir + cir_step - NC : cir + cir_step))
     {
         const size_t base = (size_t) lc * R;
+        const CazBase cb = caz_base_of_rotation(rot);
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
         const int trig = uniform_i32(p.trig[lc]); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
         const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) trig) * 12;
@@ -1896,6 +1922,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
 
         float dist[RPL], incl[RPL], tabv[RPL];
+        float4 rec[RPL];
         bool isnan_[RPL], empty_cell[RPL], overrun = false;
         int overrun_row = -1;        // the reference walks the rows bottom-up and reports the first stale cell it meets (cc.cpp:314-345)
         long long overrun_gcol = -1;
@@ -1919,7 +1946,11 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                 }
                 empty_cell[k] = cg != gc;
                 dist[k] = p.dist[ci];
-                incl[k] = p.incl[ci];
+                // a cell that received a return carries its record; a cleared cell has inclination = NaN (cc.cpp:1110-1119) and nothing else
+                rec[k] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                if (!empty_cell[k])
+                    rec[k] = p.sc_rec[ci];
+                incl[k] = rec[k].w;
                 tabv[k] = p.tab[ci];
                 isnan_[k] = dist[k] != dist[k];
                 s_incl[row] = incl[k];
@@ -2015,26 +2046,23 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                 p.gcol[ci] = gc; // cells that received a return already carry the column index (k_insert2)
             int flags = 0;
             float x2 = 0.f, uz = 0.f;
-            float4 rec = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), incl[k]);
             if (isnan_[k])
             {
                 flags = SG_NAN;
                 if (cfg.supplement_inclination_angle_for_nan_cells && row < R - 1)
                     p.incl[ci] = incl[k];
-                const double caz = ((double) gc + 0.5) * (double) g.az_width; // cc.cpp:371-372
-                p.caz[ci] = caz;
+                // (the window scan leaves its inclination window by this value, and never accepts the cell: x = NaN)
+                p.sc_rec[ci] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), incl[k]);
+                const double caz = empty_cell_caz(gc, g.az_width); // cc.cpp:371-372 (not stored: every reader knows the cell's column)
                 if (caz < min_az)
                     min_az = caz;
             }
             else
             {
-                const double caz = p.caz[ci];
+                const double caz = cell_caz(cb, p.incaz[ci]);
                 if (caz < min_az)
                     min_az = caz;
-                const float cx = p.x[ci], cy = p.y[ci], cz = p.z[ci];
-                rec.x = cx;
-                rec.y = cy;
-                rec.z = cz;
+                const float cx = rec[k].x, cy = rec[k].y, cz = rec[k].z;
                 if (cfg.fog_filtering_enabled && p.inten[ci] < (uint8_t) cfg.fog_filtering_intensity_below &&
                     dist[k] < cfg.fog_filtering_distance_below && incl[k] > cfg.fog_filtering_inclination_above)
                     flags |= SG_FOG;
@@ -2056,7 +2084,6 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             p.sg_x2[ci] = x2;
             p.sg_uz[ci] = uz;
             p.sg_flags[ci] = (uint8_t) flags;
-            p.sc_rec[ci] = rec;
         }
         min_az = wave_min_f64(min_az);
         if (lane == 0)
@@ -2325,10 +2352,6 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 // cc.cpp:567-616: everything that is not an obstacle is ignored, and so are the filtered obstacles
                 const bool ign = (o & 7) != SG_G_OBSTACLE || (o & 0x80);
                 p.ignored[ci] = ign ? 1 : 0;
-                // the window scan reads one 16-byte record per visited cell: an ignored cell is marked there as x = NaN (cells without a
-                // return have it already), so that the distance test of cc.cpp:638-641 fails without a second load
-                if (g.mark_ignored_in_rec && ign && (o & 7) != SG_G_UNKNOWN) // (only k_scan2 relies on it; k_scan reads the flag plane)
-                    ((float*) &p.sc_rec[ci])[0] = __builtin_nanf("");
             }
             lc = lc + 1 == RC ? 0 : lc + 1;
         }
@@ -2406,22 +2429,8 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
     const SP& p = c.p;
     const int R = c.R;
     const int pi = lc * R + row;
-    float pincl, px, py, pz;
-    if (REC)
-    {
-        const float4 me = p.sc_rec[pi]; // the point itself is not ignored: x is the real coordinate
-        px = me.x;
-        py = me.y;
-        pz = me.z;
-        pincl = me.w;
-    }
-    else
-    {
-        pincl = p.incl[pi];
-        px = p.x[pi];
-        py = p.y[pi];
-        pz = p.z[pi];
-    }
+    const float4 me = p.sc_rec[pi]; // (REC only says how the visited cells are read: the records are the one copy of x, y, z)
+    const float pincl = me.w, px = me.x, py = me.y, pz = me.z;
     int needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
     needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
     int oc = lc;
@@ -2441,14 +2450,11 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                     ++*visits; // cc.cpp:725
                 if (reach)
                     *reach = sb;
-                float4 orec;
+                const float4 orec = p.sc_rec[oi];
                 unsigned char oign = 0;
                 if (REC)
-                {
-                    orec = p.sc_rec[oi]; // both loads are issued before the first use: one round trip per visit
-                    oign = p.ignored[oi];
-                }
-                const float oincl = REC ? orec.w : p.incl[oi];
+                    oign = p.ignored[oi]; // both loads are issued before the first use: one round trip per visit
+                const float oincl = orec.w;
                 if (ccm::absf(oincl - pincl) > mad)
                     break;
                 if (REC ? !oign : !p.ignored[oi])
@@ -2462,7 +2468,7 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                     }
                     if (consider)
                     {
-                        const float dx = px - (REC ? orec.x : p.x[oi]), dy = py - (REC ? orec.y : p.y[oi]), dz = pz - (REC ? orec.z : p.z[oi]);
+                        const float dx = px - orec.x, dy = py - orec.y, dz = pz - orec.z;
                         if (dx * dx + dy * dy + dz * dz < c.maxd2)
                         {
                             if (LIVE)
@@ -2599,6 +2605,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
     {
         const int lc = (int) (gc % RC);
         const int first_local = (int) (first_unpub % RC);
+        const CazBase cb = caz_base_of_column(gc, g.num_columns);
         emit(CC_EV_GROUND_COLUMN, gc, gc, 0, 0, gc);
 
         // ------------------------------------------------------------------ association (cc.cpp:773-835)
@@ -2623,7 +2630,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 {
                     active[k] = true;
                     mad[k] = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                    pcaz[k] = p.caz[ci];
+                    pcaz[k] = cell_caz(cb, p.incaz[ci]);
                     int dummy_root = -1, vis = 0;
                     scan_point<false>(c, lc, gc, row, first_local, mad[k], pcaz[k], dummy_root, parent[k], s_links[row], nlinks[k],
                                       overflow, LINK_SLOTS_V1, &vis);
@@ -2781,7 +2788,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                         continue;
                     }
                     const float m = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                    const double caz = p.caz[ci];
+                    const double caz = cell_caz(cb, p.incaz[ci]);
                     int proot = -1, par = -1, nl = 0, vis = 0;
                     bool ov = false;
                     scan_point<true>(c, lc, gc, row, first_local, m, caz, proot, par, nullptr, nl, ov, LINK_SLOTS_V1, &vis, st, &g);
@@ -3143,11 +3150,18 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
     const int first_lc = (int) (first_column % RC);
     int lc = (int) ((st->batch[slot].acp_next + blockIdx.y) % RC);
     const int lc_step = (int) (gridDim.y % (unsigned) RC);
+    const int NC = g.num_columns;
+    long long rot = (st->batch[slot].acp_next + blockIdx.y) / NC; // rotation index / column within the rotation, advanced the same way
+    int cir = (int) ((st->batch[slot].acp_next + blockIdx.y) - rot * NC);
+    const int cir_step = (int) (gridDim.y % (unsigned) NC);
+    const long long rot_step = (long long) (gridDim.y / (unsigned) NC);
     for (long long gc = st->batch[slot].acp_next + blockIdx.y; gc < col_end;
-         gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step))
+         gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step), rot += rot_step + (cir + cir_step >= NC ? 1 : 0),
+                   cir = (cir + cir_step >= NC ? cir + cir_step - NC : cir + cir_step))
     {
         // never look at columns older than the first column ever segmented (their planes are uninitialised)
         const int bound = (gc - first_column) <= (long long) cfg.max_steps_in_row + 1 ? first_lc : -1;
+        const CazBase cb = caz_base_of_rotation(rot);
         int parent[RPL], nlinks[RPL];
         double fin[RPL];
         unsigned long long packed[RPL];
@@ -3175,7 +3189,7 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 parent[0] = -1;
                 me = p.sc_rec[ci]; // the point itself is not ignored: x is the real coordinate
                 mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                fin[0] = p.caz[ci] + (double) mad;
+                fin[0] = cell_caz(cb, p.incaz[ci]) + (double) mad;
                 needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
                 needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
             }
@@ -3267,7 +3281,7 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
                 {
                     parent[k] = -1;
                     const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                    const double caz = p.caz[ci];
+                    const double caz = cell_caz(cb, p.incaz[ci]);
                     fin[k] = caz + (double) mad;
                     bool overflow = false;
                     int dummy_root = -1, vis = 0, rch = 0;
@@ -3339,6 +3353,8 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
         const long long gc0 = col_begin + tile * TC;
         const int ncols = (int) (col_end - gc0 < TC ? col_end - gc0 : TC);
         const int lc0 = (int) (gc0 % RC);
+        const long long rot0 = gc0 / g.num_columns; // rotation index and column within the rotation of the tile's first column
+        const int cir0 = (int) (gc0 - rot0 * g.num_columns);
         // ---- A: the tile's active cells --------------------------------------------------------------------------------------
         int n_act = 0;
         for (int j = 0; j < TC * RPL; j++)
@@ -3385,7 +3401,7 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
             {
                 me = p.sc_rec[ci];
                 mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                fin = p.caz[ci] + (double) mad;
+                fin = cell_caz(caz_base_of_rotation(rot0 + (cir0 + tc >= g.num_columns ? 1 : 0)), p.incaz[ci]) + (double) mad;
                 needed = f2i_x86(__builtin_ceilf(mad / g.az_width));
                 needed = needed < max_row_steps ? needed : max_row_steps;
             }
@@ -3430,6 +3446,7 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
                 if (run)
                 {
                     const float4 o = p.sc_rec[oc * R + orow];
+                    const unsigned char oign = p.ignored[oc * R + orow]; // (issued with the record: one round trip per visit)
                     if (MIRROR)
                     {
                         visits++; // cc.cpp:725
@@ -3440,7 +3457,7 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
                     else
                     {
                         const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-                        if (o.x == o.x && dx * dx + dy * dy + dz * dz < maxd2) // (x = NaN: ignored or empty cell)
+                        if (!oign && dx * dx + dy * dy + dz * dz < maxd2) // (a cell without a return is ignored, and its x is NaN)
                         {
                             const int cand = (sb << 8) | orow;
                             if (!rooted)
@@ -3608,6 +3625,7 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
     int* wcol = s_win + (int) (gc % WIN_COLS) * R;
     for (int row = 0; row < R; row++)
         wcol[row] = -1;
+    const CazBase cb = caz_base_of_column(gc, c.NC);
     for (int row = 0; row < R; row++)
     {
         const int pi = lc * R + row;
@@ -3620,8 +3638,9 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
             continue;
         }
         const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[pi]);
-        const double pcaz = p.caz[pi];
-        const float pincl = p.incl[pi], px = p.x[pi], py = p.y[pi], pz = p.z[pi];
+        const double pcaz = cell_caz(cb, p.incaz[pi]);
+        const float4 me = p.sc_rec[pi];
+        const float pincl = me.w, px = me.x, py = me.y, pz = me.z;
         int needed = f2i_x86(__builtin_ceilf(mad / c.az_width));
         needed = needed < c.max_steps_in_row ? needed : c.max_steps_in_row;
         int oc = lc;
@@ -3640,7 +3659,8 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
                 {
                     const int oi = oc * R + orow;
                     visits++; // cc.cpp:725
-                    if (ccm::absf(p.incl[oi] - pincl) > mad)
+                    const float4 orec = p.sc_rec[oi];
+                    if (ccm::absf(orec.w - pincl) > mad)
                         break;
                     if (!p.ignored[oi])
                     {
@@ -3650,7 +3670,7 @@ __device__ void assoc_column_live(const AssocCtx& c, const cc_config& cfg, const
                         const bool same = pslot >= 0 && oslot == pslot;
                         if (!same)
                         {
-                            const float dx = px - p.x[oi], dy = py - p.y[oi], dz = pz - p.z[oi];
+                            const float dx = px - orec.x, dy = py - orec.y, dz = pz - orec.z;
                             if (dx * dx + dy * dy + dz * dz < c.maxd2)
                             {
                                 if (pslot == -1)
@@ -4551,6 +4571,7 @@ __global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamS
     const int lc = (int) (((gc % RC) + RC) % RC);
     const bool in_ring = st->ring_end >= 0 && gc >= 0 && gc >= st->clear_done && gc <= st->ring_end;
     const bool segmented = in_ring && st->first_column >= 0 && gc >= st->first_column && gc < st->first_unfinished;
+    const CazBase cb = caz_base_of_column(gc >= 0 ? gc : 0, g.num_columns);
     for (int row = lane_id(); row < R; row += 64)
     {
         const size_t ci = (size_t) lc * R + row;
@@ -4558,12 +4579,14 @@ __global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamS
         const float nanf_ = __builtin_nanf("");
         const bool filled = in_ring && (segmented ? true : p.gcol[ci] == gc);
         const bool has_point = filled && !(p.dist[ci] != p.dist[ci]) && p.gcol[ci] == gc;
-        o.x[oi] = has_point ? p.x[ci] : nanf_;
-        o.y[oi] = has_point ? p.y[ci] : nanf_;
-        o.z[oi] = has_point ? p.z[ci] : nanf_;
+        const float4 rec = has_point ? p.sc_rec[ci] : make_float4(nanf_, nanf_, nanf_, nanf_);
+        o.x[oi] = rec.x;
+        o.y[oi] = rec.y;
+        o.z[oi] = rec.z;
         o.dist[oi] = has_point ? p.dist[ci] : nanf_;
         o.incl[oi] = (has_point || segmented) ? p.incl[ci] : nanf_;
-        o.caz[oi] = (has_point || segmented) ? p.caz[ci] : __builtin_nan("");
+        // (a segmented cell without a return sits in the middle of its column, cc.cpp:371-372)
+        o.caz[oi] = has_point ? cell_caz(cb, p.incaz[ci]) : (segmented ? empty_cell_caz(gc, g.az_width) : __builtin_nan(""));
         o.gcol[oi] = segmented ? gc : (has_point ? gc : -1);
         o.src[oi] = has_point ? p.src[ci] : -1;
         o.ground[oi] = segmented ? p.ground[ci] : (uint8_t) CC_GP_UNKNOWN;
