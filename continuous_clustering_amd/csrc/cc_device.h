@@ -101,8 +101,8 @@ struct Planes
     float* incaz;     // increasing azimuth angle of the return (cc.cpp:146-148). Its continuous azimuth angle (cc.cpp:184-186) is
                       // 2 pi * rotation + incaz, where the rotation is that of the cell's column — or one less when the sign bit is set
                       // (a return moved on to the first column of the next rotation, cc.cpp:188-202)
-    int64_t* gcol;    // per-cell global column index (-1 = cleared)
-    int64_t* src;     // sequence number of the firing that filled the cell
+    uint16_t* gtag;   // which pass over the ring filled the cell (Point::global_column_index in two bytes; 0 = cleared): cc_kernels.h cell_tag
+    uint32_t* src;    // sequence number of the firing that filled the cell (low 32 bits)
     uint8_t* inten;
     float* tab;       // sc_inclination_angles_between_lasers_[row] as of this column
     // per column [stream][lcol]

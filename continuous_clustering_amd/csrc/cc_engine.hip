@@ -206,7 +206,7 @@ int allocate(cc_engine* e)
 #define A(field, count)                                \
     if ((rc = alloc_plane(e, &P.field, (count))) != 0) \
         return rc;
-    A(dist, C) A(incl, C) A(incaz, C) A(gcol, C) A(src, C) A(inten, C) A(tab, C);
+    A(dist, C) A(incl, C) A(incaz, C) A(gtag, C) A(src, C) A(inten, C) A(tab, C);
     A(trig, L) A(colg, L) A(colminaz, L);
     A(ground, C) A(debug, C) A(ignored, C) A(root, C) A(id, C);
     A(t_fin, C) A(t_width, C) A(t_pts, C) A(t_uf, C) A(t_cid, C) A(t_pos, C) A(t_finished, C);
@@ -235,10 +235,10 @@ int reset_state(cc_engine* e, bool keep_table)
     const size_t S = (size_t) g.num_streams;
     const size_t C = S * (size_t) g.cells;
     Planes& P = e->P;
-    // cleared cell: distance = inclination = NaN, global column index = -1 (cc.cpp:1110-1119); 0xFF bytes give both
+    // cleared cell: distance = inclination = NaN (0xFF bytes), global column index = -1 (tag 0) (cc.cpp:1110-1119)
     CC_HIP_CHECK(e, hipMemsetAsync(P.dist, 0xFF, C * sizeof(float), e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.incl, 0xFF, C * sizeof(float), e->stream));
-    CC_HIP_CHECK(e, hipMemsetAsync(P.gcol, 0xFF, C * sizeof(int64_t), e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.gtag, 0, C * sizeof(uint16_t), e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.id, 0, C * sizeof(uint32_t), e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.ground, CC_GP_UNKNOWN, C, e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.debug, CC_DBG_WHITE, C, e->stream));
@@ -824,14 +824,17 @@ void fixup_overrun(cc_engine* e, int stream, StreamState& st)
     if (st.error != CC_ERR_RING_OVERRUN || st.overrun_col == std::numeric_limits<int64_t>::max())
         return;
     const int R = e->g.num_rows;
-    std::vector<int64_t> col((size_t) R);
-    const size_t off = (size_t) stream * (size_t) e->g.cells + (size_t) (st.overrun_col % e->g.ring_cols) * R;
-    if (hipMemcpy(col.data(), e->P.gcol + off, (size_t) R * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess)
+    std::vector<uint16_t> col((size_t) R);
+    const int64_t RC = e->g.ring_cols;
+    const size_t off = (size_t) stream * (size_t) e->g.cells + (size_t) (st.overrun_col % RC) * R;
+    if (hipMemcpy(col.data(), e->P.gtag + off, (size_t) R * sizeof(uint16_t), hipMemcpyDeviceToHost) != hipSuccess)
         return;
+    // cells carry the pass over the ring that filled them (cc_kernels.h: cell_tag); 0 = cleared
+    const unsigned tag = 0x8000u | ((unsigned) (st.overrun_col / RC) & 0x7fffu);
     for (int row = R - 1; row >= 0; row--)
-        if (col[(size_t) row] != st.overrun_col && col[(size_t) row] != -1)
+        if (col[(size_t) row] != tag && col[(size_t) row] != 0)
         {
-            st.error_a = col[(size_t) row];
+            st.error_a = st.overrun_col - (int64_t) ((tag - (unsigned) col[(size_t) row]) & 0x7fffu) * RC; // the stale global column index
             st.error_b = st.overrun_col;
             return;
         }

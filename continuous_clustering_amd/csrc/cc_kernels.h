@@ -218,12 +218,23 @@ __device__ __forceinline__ double empty_cell_caz(const long long gc, const float
     return ((double) gc + 0.5) * (double) az_width;
 }
 
+// ---- which pass over the ring a cell belongs to (Planes::gtag). The reference keeps the 64-bit global column index in every cell
+// (Point::global_column_index, cleared to -1: cc.cpp:1110-1119) and compares it with the column being segmented (cc.cpp:320-345). A cell
+// of ring column lc can only ever hold a global column lc + pass * ring_cols, so the pass index says the same in two bytes:
+// 0 = cleared, else 0x8000 | (pass mod 2^15). A stale cell is met (and reported) on the very next pass, long before a tag could repeat.
+constexpr uint16_t CELL_CLEARED = 0;
+__device__ __forceinline__ uint16_t cell_tag(const long long pass)
+{
+    return (uint16_t) (0x8000u | ((unsigned) pass & 0x7fffu));
+}
+
 // Pointers of one stream (planes offset to the stream's first cell / column / pool slot).
 struct SP
 {
     float *dist, *incl, *tab;
     float* incaz;
-    int64_t *gcol, *src;
+    uint16_t* gtag;
+    uint32_t* src;
     uint8_t *inten, *ground, *debug, *ignored;
     int32_t* trig;
     int64_t* colg;
@@ -266,7 +277,7 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.incl = P.incl + co;
     p.tab = P.tab + co;
     p.incaz = P.incaz + co;
-    p.gcol = P.gcol + co;
+    p.gtag = P.gtag + co;
     p.src = P.src + co;
     p.inten = P.inten + co;
     p.ground = P.ground + co;
@@ -559,7 +570,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     const size_t ci = (size_t) clc * R + row;
                     p.dist[ci] = __builtin_nanf("");
                     p.incl[ci] = __builtin_nanf("");
-                    p.gcol[ci] = -1;
+                    p.gtag[ci] = CELL_CLEARED;
                 }
             }
         }
@@ -626,6 +637,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     long long prev_rot = prev_rear / NC;
     int prev_cir = (int) (prev_rear - prev_rot * NC);
     int rear_lc = (int) (prev_rear % RC);
+    long long rear_pass = prev_rear / RC; // pass over the ring the previous rearmost laser is in (cell_tag)
     long long tracked_rear = prev_rear;
 #ifdef CC_PROFILE_SECTIONS
     unsigned long long isec[6] = {0, 0, 0, 0, 0, 0};
@@ -654,13 +666,17 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                 }
                 rear_lc += (int) dlt;
                 if (rear_lc >= RC)
+                {
                     rear_lc -= RC;
+                    rear_pass++;
+                }
             }
             else
             {
                 prev_rot = prev_rear / NC;
                 prev_cir = (int) (prev_rear - prev_rot * NC);
                 rear_lc = (int) (prev_rear % RC);
+                rear_pass = prev_rear / RC;
             }
             tracked_rear = prev_rear;
         }
@@ -724,10 +740,18 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                 if (__any(occupied))
                     break;
                 int lc = rear_lc + (int) (gc0 - prev_rear);
+                long long pass = rear_pass;
                 if (lc < 0)
+                {
                     lc += RC;
+                    pass--;
+                }
                 else if (lc >= RC)
+                {
                     lc -= RC;
+                    pass++;
+                }
+                const uint16_t tag0 = cell_tag(pass);
 #pragma unroll
                 for (int k = 0; k < RPL; k++)
                 {
@@ -739,11 +763,11 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                         const float d = r_d[so];
                         p.sc_rec[ci] = make_float4(r_x[so], r_y[so], r_z[so], r_i[so]);
                         p.inten[ci] = (uint8_t) r_t[so];
-                        p.src[ci] = seq0 + (f - cursor0);
+                        p.src[ci] = (uint32_t) (seq0 + (f - cursor0));
                         p.dist[ci] = d;
                         p.incl[ci] = r_i[so];
                         p.incaz[ci] = pack_incaz(r_a[so], c0 >= NC); // (rotation of the return: prev_rot, the column's unless c0 == NC)
-                        p.gcol[ci] = gc0;
+                        p.gtag[ci] = tag0;
                         w_dist[wcol + row] = d;
                     }
                 }
@@ -760,7 +784,10 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     }
                     rear_lc += dlt;
                     if (rear_lc >= RC)
+                    {
                         rear_lc -= RC;
+                        rear_pass++;
+                    }
                     tracked_rear = prev_rear;
                 }
                 if (gc0 > prev_fore)
@@ -821,13 +848,17 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                 }
                 rear_lc += (int) dlt;
                 if (rear_lc >= RC)
+                {
                     rear_lc -= RC;
+                    rear_pass++;
+                }
             }
             else
             {
                 prev_rot = prev_rear / NC;
                 prev_cir = (int) (prev_rear - prev_rot * NC);
                 rear_lc = (int) (prev_rear % RC);
+                rear_pass = prev_rear / RC;
             }
             tracked_rear = prev_rear;
         }
@@ -909,10 +940,17 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                 long long gc = gcv[k];
                 // ring column: offset from the previous rearmost laser's ring column (|offset| < one rotation < RC)
                 int lc = rear_lc + (int) (gc - prev_rear);
+                long long pass = rear_pass; // pass over the ring of column gc (cell_tag)
                 if (lc < 0)
+                {
                     lc += RC;
+                    pass--;
+                }
                 else if (lc >= RC)
+                {
                     lc -= RC;
+                    pass++;
+                }
                 const int so = slot * R + row;
                 const float d = r_d[so];
                 const bool res = gc >= wbase && gc + 1 < wbase + WINC; // both candidate columns resident in LDS
@@ -937,6 +975,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
                     if (nd != nd)
                     {
                         gc++;
+                        pass += lc + 1 >= RC ? 1 : 0;
                         lc = lc + 1 >= RC ? 0 : lc + 1;
                         cd = nd;
                     }
@@ -950,11 +989,11 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 #ifndef CC_EXP_NOSTORE
                     p.sc_rec[ci] = make_float4(r_x[so], r_y[so], r_z[so], r_i[so]);
                     p.inten[ci] = (uint8_t) r_t[so];
-                    p.src[ci] = seq0 + (f - cursor0);
+                    p.src[ci] = (uint32_t) (seq0 + (f - cursor0));
                     p.incl[ci] = r_i[so];
                     // rotation of the return = prev_rot + rot_off (cc.cpp:184-186) = that of its column gc = gcv (+ 1 if moved on), or one less
                     p.incaz[ci] = pack_incaz(r_a[so], cir[k] + (int) (gc - gcv[k]) >= NC);
-                    p.gcol[ci] = gc;
+                    p.gtag[ci] = cell_tag(pass);
 #endif
                     p.dist[ci] = d;
                     if (gc >= wbase && gc < wbase + WINC)
@@ -1172,7 +1211,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
                     const size_t ci = (size_t) clc * R + row;
                     p.dist[ci] = __builtin_nanf("");
                     p.incl[ci] = __builtin_nanf("");
-                    p.gcol[ci] = -1;
+                    p.gtag[ci] = CELL_CLEARED;
                 }
             }
         }
@@ -1201,6 +1240,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     const long long rot0 = prev_rear0 / NC;
     const int cir0 = (int) (prev_rear0 - rot0 * NC);
     const int lc0 = (int) (prev_rear0 % RC);
+    const long long pass0 = prev_rear0 / RC; // pass over the ring of the previous rearmost laser (cell_tag)
 
     // ---- 0: the column of every firing from its first valid return (prep_point's column arithmetic, nothing else of it)
     for (int f = tid; f < nn; f += 64 * IP_WAVES)
@@ -1297,7 +1337,9 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
         const long long rel = s_off[f];                    // G_f - prev_rear0
         const long long rel_prev = f > 0 ? s_off[f - 1] : 0; // G_(f-1) - prev_rear0
         const long long G = prev_rear0 + rel;
-        const int lc = (int) ((unsigned) (lc0 + (int) rel) % (unsigned) RC);
+        const unsigned lcq = (unsigned) (lc0 + (int) rel) / (unsigned) RC; // (one division: quotient = passes over the ring since lc0)
+        const int lc = (int) ((unsigned) (lc0 + (int) rel) - lcq * (unsigned) RC);
+        const uint16_t tag = cell_tag(pass0 + (long long) lcq);
         const uint8_t* si = inten + fi * R;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
@@ -1308,11 +1350,11 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
                 const size_t ci = (size_t) lc * R + row;
                 p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
                 p.inten[ci] = si[row];
-                p.src[ci] = seq0 + f;
+                p.src[ci] = (uint32_t) (seq0 + f);
                 p.dist[ci] = q[k].dist;
                 p.incl[ci] = q[k].incl;
                 p.incaz[ci] = q[k].incaz; // (c0 < num_columns and nothing moves on: the return's rotation is its column's)
-                p.gcol[ci] = G;
+                p.gtag[ci] = tag;
             }
         }
         // columns [G_(f-1), G_f) are finished by this firing and carry its pose (cc.cpp:289-291)
@@ -1342,7 +1384,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
                         const size_t ci = (size_t) lc * R + row;
                         p.dist[ci] = __builtin_nanf("");
                         p.incl[ci] = __builtin_nanf("");
-                        p.gcol[ci] = -1;
+                        p.gtag[ci] = CELL_CLEARED;
                     }
                 }
             }
@@ -1438,7 +1480,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                     const size_t ci = (size_t) clc * R + row;
                     p.dist[ci] = __builtin_nanf("");
                     p.incl[ci] = __builtin_nanf("");
-                    p.gcol[ci] = -1;
+                    p.gtag[ci] = CELL_CLEARED;
                 }
             }
         }
@@ -1487,6 +1529,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     const long long rot0 = prev_rear0 / NC;
     const int cir0 = (int) (prev_rear0 - rot0 * NC);
     const int lc0 = (int) (prev_rear0 % RC);
+    const long long pass0 = prev_rear0 / RC; // pass over the ring of the previous rearmost laser (cell_tag)
     // carried from chunk to chunk (every thread keeps the same values)
     int carry_rel = 0;    // rear column of the last accepted firing, relative to prev_rear0
     int carry_cir = cir0; // its column-in-rotation
@@ -1640,15 +1683,16 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                 if (oc[k] >= 0)
                 {
                     const int crel = my_rel + oc[k];
-                    const int lc = (int) ((unsigned) (lc0 + crel) % (unsigned) RC);
+                    const unsigned lcq = (unsigned) (lc0 + crel) / (unsigned) RC;
+                    const int lc = (int) ((unsigned) (lc0 + crel) - lcq * (unsigned) RC);
                     const size_t ci = (size_t) lc * R + row;
                     p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
                     p.inten[ci] = si[row];
-                    p.src[ci] = seq0 + (f - cursor0);
+                    p.src[ci] = (uint32_t) (seq0 + (f - cursor0));
                     p.dist[ci] = q[k].dist;
                     p.incl[ci] = q[k].incl;
                     p.incaz[ci] = q[k].incaz; // (the return's rotation, rot0 + (cir0 + crel) / num_columns, is that of its column)
-                    p.gcol[ci] = prev_rear0 + crel;
+                    p.gtag[ci] = cell_tag(pass0 + (long long) lcq);
                     atomicMax(&s_rowmax[row], crel);
                 }
             }
@@ -1904,11 +1948,15 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     int cir = (int) ((seg_begin + blockIdx.y) - rot * NC);
     const int cir_step = (int) (gridDim.y % (unsigned) NC);
     const long long rot_step = (long long) (gridDim.y / (unsigned) NC);
-    for (long long gc = seg_begin + blockIdx.y; gc < seg_end; gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step),
-                   rot += rot_step + (cir + cir_step >= NC ? 1 : 0), cir = (cir + cir_step >= NC ? cir + cir_step - NC : cir + cir_step))
+    long long pass = (seg_begin + blockIdx.y) / RC; // pass over the ring (cell_tag)
+    const long long pass_step = (long long) (gridDim.y / (unsigned) RC);
+    for (long long gc = seg_begin + blockIdx.y; gc < seg_end; gc += gridDim.y, pass += pass_step + (lc + lc_step >= RC ? 1 : 0),
+                   lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step), rot += rot_step + (cir + cir_step >= NC ? 1 : 0),
+                   cir = (cir + cir_step >= NC ? cir + cir_step - NC : cir + cir_step))
     {
         const size_t base = (size_t) lc * R;
         const CazBase cb = caz_base_of_rotation(rot);
+        const uint16_t tag = cell_tag(pass);
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
         const int trig = uniform_i32(p.trig[lc]); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
         const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) trig) * 12;
@@ -1937,14 +1985,15 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             if (row < R)
             {
                 const size_t ci = base + row;
-                const long long cg = p.gcol[ci];
-                if (cg != gc && cg != -1)
+                const uint16_t tg = p.gtag[ci];
+                if (tg != tag && tg != CELL_CLEARED)
                 {
                     overrun = true; // cc.cpp:320-345
                     overrun_row = row;
-                    overrun_gcol = cg;
+                    // the stale global column index: this ring column in the latest earlier pass that carries the cell's tag
+                    overrun_gcol = gc - (long long) ((((unsigned) tag - (unsigned) tg) & 0x7fffu)) * RC;
                 }
-                empty_cell[k] = cg != gc;
+                empty_cell[k] = tg != tag;
                 dist[k] = p.dist[ci];
                 // a cell that received a return carries its record; a cleared cell has inclination = NaN (cc.cpp:1110-1119) and nothing else
                 rec[k] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
@@ -2043,7 +2092,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                 continue;
             const size_t ci = base + row;
             if (empty_cell[k])
-                p.gcol[ci] = gc; // cells that received a return already carry the column index (k_insert2)
+                p.gtag[ci] = tag; // cells that received a return already carry it (insertion kernels)
             int flags = 0;
             float x2 = 0.f, uz = 0.f;
             if (isnan_[k])
@@ -4572,13 +4621,15 @@ __global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamS
     const bool in_ring = st->ring_end >= 0 && gc >= 0 && gc >= st->clear_done && gc <= st->ring_end;
     const bool segmented = in_ring && st->first_column >= 0 && gc >= st->first_column && gc < st->first_unfinished;
     const CazBase cb = caz_base_of_column(gc >= 0 ? gc : 0, g.num_columns);
+    const uint16_t tag = cell_tag((gc >= 0 ? gc : 0) / RC);
     for (int row = lane_id(); row < R; row += 64)
     {
         const size_t ci = (size_t) lc * R + row;
         const size_t oi = (size_t) blockIdx.x * R + row;
         const float nanf_ = __builtin_nanf("");
-        const bool filled = in_ring && (segmented ? true : p.gcol[ci] == gc);
-        const bool has_point = filled && !(p.dist[ci] != p.dist[ci]) && p.gcol[ci] == gc;
+        const bool mine = p.gtag[ci] == tag; // the cell belongs to this pass over the ring (Point::global_column_index == gc)
+        const bool filled = in_ring && (segmented ? true : mine);
+        const bool has_point = filled && !(p.dist[ci] != p.dist[ci]) && mine;
         const float4 rec = has_point ? p.sc_rec[ci] : make_float4(nanf_, nanf_, nanf_, nanf_);
         o.x[oi] = rec.x;
         o.y[oi] = rec.y;
@@ -4588,7 +4639,8 @@ __global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamS
         // (a segmented cell without a return sits in the middle of its column, cc.cpp:371-372)
         o.caz[oi] = has_point ? cell_caz(cb, p.incaz[ci]) : (segmented ? empty_cell_caz(gc, g.az_width) : __builtin_nan(""));
         o.gcol[oi] = segmented ? gc : (has_point ? gc : -1);
-        o.src[oi] = has_point ? p.src[ci] : -1;
+        // (the firing's sequence number, kept as its low 32 bits: it is one of the last 2^32 firings the stream consumed)
+        o.src[oi] = has_point ? (long long) (st->firings_consumed - (unsigned long long) (uint32_t) ((uint32_t) st->firings_consumed - p.src[ci])) : -1;
         o.ground[oi] = segmented ? p.ground[ci] : (uint8_t) CC_GP_UNKNOWN;
         o.debug[oi] = segmented ? p.debug[ci] : (uint8_t) CC_DBG_WHITE;
         o.ignored[oi] = segmented ? p.ignored[ci] : 0;
