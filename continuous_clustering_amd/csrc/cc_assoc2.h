@@ -264,25 +264,6 @@ __device__ __forceinline__ double dpp_shr_f64(double v, double fill)
 {
     return __longlong_as_double(dpp_shr_i64<N>(__double_as_longlong(v), __double_as_longlong(fill)));
 }
-__device__ __forceinline__ long long lane_i64(long long v, int u)
-{
-    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (unsigned long long) v, u);
-    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) v >> 32), u);
-    return (long long) (((unsigned long long) hi << 32) | lo);
-}
-
-// helpers: lane-indexed per-column scalars of a group (lane u holds column u's value)
-__device__ __forceinline__ int lane_i32(int v, int u)
-{
-    return __builtin_amdgcn_readlane(v, u);
-}
-__device__ __forceinline__ double lane_f64(double v, int u)
-{
-    const long long b = __double_as_longlong(v);
-    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (unsigned long long) b, u);
-    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) b >> 32), u);
-    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
-}
 
 template<int RPL>
 __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)

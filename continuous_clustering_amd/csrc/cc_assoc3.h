@@ -168,9 +168,10 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         int lc = (int) (col_begin % RC);
         long long b_seen = col_begin;
         int nx_term[RPL], nx_info = 0, nx_nl[RPL], nx_par[RPL];
+        int nxx_info = 0; // col_info of the column after the one in nx_*: says whether that column's link words are worth loading
         unsigned long long nx_link[RPL];
         double nx_fin[RPL];
-        auto load_a = [&](long long gcx, int lcx)
+        auto load_a = [&](long long gcx, int lcx, bool with_links)
         {
 #pragma unroll
             for (int k = 0; k < RPL; k++)
@@ -187,13 +188,17 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     nx_fin[k] = p.sc_fin[lcx * R + row];
                     nx_term[k] = p.sc_term[lcx * R + row];
                     nx_nl[k] = p.sc_nlinks[lcx * R + row];
-                    nx_link[k] = p.sc_links[lcx * R + row]; // (stale where the point has no links: never looked at)
+                    if (with_links) // (8 of the 21 bytes per cell; k_scan only writes the word where a point has links)
+                        nx_link[k] = p.sc_links[lcx * R + row];
                 }
             }
             if (lane == 0 && gcx < col_end)
+            {
                 nx_info = p.col_info[lcx];
+                nxx_info = gcx + 1 < col_end ? p.col_info[lcx + 1 == RC ? 0 : lcx + 1] : 0;
+            }
         };
-        load_a(gcA, lc);
+        load_a(gcA, lc, true);
         bool wait_park = false; // a column could not be resolved: wave B will park us when it gets there
         int poll = 0;
         while (true)
@@ -218,7 +223,7 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     lc = (int) (gcA % RC);
                     b_seen = gcA;
                     wait_park = false;
-                    load_a(gcA, lc);
+                    load_a(gcA, lc, true);
                     continue;
                 }
                 if (wait_park || gcA >= col_end)
@@ -257,7 +262,8 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
             const bool col_links = (uniform_i32(nx_info) >> 8) & 2;
             {
                 const int lc1 = lc + 1 == RC ? 0 : lc + 1;
-                load_a(gcA + 1, lc1); // prefetch
+                const bool next_links = (uniform_i32(nxx_info) >> 8) & 2; // (arrived with this column's inputs)
+                load_a(gcA + 1, lc1, next_links); // prefetch
             }
             const int wcur = (int) (gcA & (WIN2_COLS - 1));
             int bad = 0;

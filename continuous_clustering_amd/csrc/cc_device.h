@@ -30,6 +30,17 @@ constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLO
 #define CC_TREE_SLOTS 256
 #endif
 constexpr int TREE_SLOTS = CC_TREE_SLOTS;      // unfinished point trees per stream kept in LDS (more -> global-memory kernel)
+// k_table / k_seg_pre: the columns a batch segments are cut into TABLE_WAVES ranges of SEGPRE_BLOCKS / TABLE_WAVES chunks (cc_kernels.h)
+#ifndef CC_TABLE_WAVES
+#define CC_TABLE_WAVES 8
+#endif
+constexpr int TABLE_WAVES = CC_TABLE_WAVES;
+#ifndef CC_SEGPRE_BLOCKS
+#define CC_SEGPRE_BLOCKS 256
+#endif
+constexpr int SEGPRE_BLOCKS = CC_SEGPRE_BLOCKS; // chunks per stream and batch
+static_assert(SEGPRE_BLOCKS % TABLE_WAVES == 0, "chunks are distributed evenly over the table wavefronts");
+constexpr int BATCH_SLOTS = 4;                  // batch descriptors in flight (StreamState::batch)
 
 // Scalar state of one sensor stream: the srig_*/sgps_*/sc_* members of the reference class
 // (continuous_clustering.hpp:244-275) plus engine bookkeeping.
@@ -104,7 +115,6 @@ struct Planes
     uint16_t* gtag;   // which pass over the ring filled the cell (Point::global_column_index in two bytes; 0 = cleared): cc_kernels.h cell_tag
     uint32_t* src;    // sequence number of the firing that filled the cell (low 32 bits)
     uint8_t* inten;
-    float* tab;       // sc_inclination_angles_between_lasers_[row] as of this column
     // per column [stream][lcol]
     int32_t* trig;    // batch-relative index of the firing that finished the column (its pose is the job's pose)
     int64_t* colg;    // global column index of a segmented column
@@ -165,6 +175,9 @@ struct Planes
     int2* link_log;      // [stream][link_capacity] (root cell, root cell) of every tree link made in the current call (cc.cpp:693-694), only
                          // with Geometry::mirror_fields: the host rebuilds Point::associated_trees from it
     float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
+    // what k_table leaves for k_seg_pre (one set per batch-descriptor slot; the engine passes the slot's pointers):
+    float* tabc;      // [stream][SEGPRE_BLOCKS][num_rows] last valid inclination step before each chunk of columns (NaN: none in its range)
+    float* tabw;      // [stream][TABLE_WAVES][num_rows] the table at the start of each range of chunks
 };
 
 struct Geometry

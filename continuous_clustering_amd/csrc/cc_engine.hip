@@ -206,7 +206,7 @@ int allocate(cc_engine* e)
 #define A(field, count)                                \
     if ((rc = alloc_plane(e, &P.field, (count))) != 0) \
         return rc;
-    A(dist, C) A(incl, C) A(incaz, C) A(gtag, C) A(src, C) A(inten, C) A(tab, C);
+    A(dist, C) A(incl, C) A(incaz, C) A(gtag, C) A(src, C) A(inten, C);
     A(trig, L) A(colg, L) A(colminaz, L);
     A(ground, C) A(debug, C) A(ignored, C) A(root, C) A(id, C);
     A(t_fin, C) A(t_width, C) A(t_pts, C) A(t_uf, C) A(t_cid, C) A(t_pos, C) A(t_finished, C);
@@ -216,6 +216,7 @@ int allocate(cc_engine* e)
     A(sc_term, C) A(col_newfin, L) A(col_info, L);
     A(sg_x2, C) A(sg_uz, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
+    A(tabc, (size_t) BATCH_SLOTS * S * SEGPRE_BLOCKS * (size_t) g.num_rows) A(tabw, (size_t) BATCH_SLOTS * S * TABLE_WAVES * (size_t) g.num_rows);
     A(sc_visits, C);
     A(link_log, S * (size_t) g.link_capacity);
 #undef A
@@ -442,13 +443,17 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // k_table only needs what the insertion of this batch wrote. It is a latency-bound kernel (8 wavefronts per stream) that takes 0.8 ms
     // when it shares the GPU with the throughput kernels — on the segmentation chain, which is the longest of the three, that is a
     // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
+    // k_table -> k_seg_pre scratch of this batch-descriptor slot (up to BATCH_SLOTS batches are in flight)
+    Planes Pt = e->P;
+    Pt.tabc += (size_t) slot * (size_t) g.num_streams * cck::SEGPRE_BLOCKS * (size_t) g.num_rows;
+    Pt.tabw += (size_t) slot * (size_t) g.num_streams * cck::TABLE_WAVES * (size_t) g.num_rows;
     const bool table_early = si != sb && e->table_on_insert_chain;
     if (table_early)
     {
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, Pt, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, Pt, e->d_states, first_stream, slot);
     }
     if (si != sb)
     {
@@ -460,19 +465,19 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (!table_early)
     {
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
     }
     // per-firing ego transforms of this batch (one buffer per descriptor slot: up to three batches are in flight)
     double* d_ego = e->d_ego[slot];
     hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
                        d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
     if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
+        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
     else
-        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states,
+        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);

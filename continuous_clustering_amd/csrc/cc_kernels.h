@@ -148,6 +148,27 @@ __device__ __forceinline__ double uniform_f64(double v)
     return __longlong_as_double(uniform_i64(__double_as_longlong(v)));
 }
 
+// the value lane u holds, as a wave-uniform scalar (v_readlane)
+__device__ __forceinline__ long long lane_i64(long long v, int u)
+{
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (unsigned long long) v, u);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) v >> 32), u);
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+
+// helpers: lane-indexed per-column scalars of a group (lane u holds column u's value)
+__device__ __forceinline__ int lane_i32(int v, int u)
+{
+    return __builtin_amdgcn_readlane(v, u);
+}
+__device__ __forceinline__ double lane_f64(double v, int u)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) (unsigned long long) b, u);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) b >> 32), u);
+    return __longlong_as_double((long long) (((unsigned long long) hi << 32) | lo));
+}
+
 __device__ __forceinline__ unsigned long long lanes_below()
 {
     return (1ull << lane_id()) - 1ull;
@@ -231,7 +252,7 @@ __device__ __forceinline__ uint16_t cell_tag(const long long pass)
 // Pointers of one stream (planes offset to the stream's first cell / column / pool slot).
 struct SP
 {
-    float *dist, *incl, *tab;
+    float *dist, *incl, *tabc, *tabw;
     float* incaz;
     uint16_t* gtag;
     uint32_t* src;
@@ -275,7 +296,6 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     const size_t to = (size_t) s * (size_t) g.tree_capacity;
     p.dist = P.dist + co;
     p.incl = P.incl + co;
-    p.tab = P.tab + co;
     p.incaz = P.incaz + co;
     p.gtag = P.gtag + co;
     p.src = P.src + co;
@@ -305,6 +325,8 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.agg_first = P.agg_first + to;
     p.agg_flag = P.agg_flag + to;
     p.curtab = P.curtab + (size_t) s * g.num_rows;
+    p.tabc = P.tabc + (size_t) s * SEGPRE_BLOCKS * g.num_rows;
+    p.tabw = P.tabw + (size_t) s * TABLE_WAVES * g.num_rows;
     p.events = P.events + (size_t) s * g.event_capacity;
     p.sc_parent = P.sc_parent + co;
     p.sc_term = P.sc_term + co;
@@ -1306,13 +1328,56 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     if (tid == 0)
         s_bad = upto;
     __syncthreads();
-    // ---- D: the cells and the columns each firing finishes; wavefronts run independently
+    // ---- D: the cells and the columns each firing finishes; wavefronts run independently. A wavefront's firings are latency chains
+    // (load the returns -> ~300 instructions of arithmetic -> store the cells) and there are only two wavefronts per SIMD to hide
+    // them, so the inputs of the wavefront's NEXT firing (returns, intensities, pose: one lane per matrix element) are loaded before
+    // the current one is worked on.
+    float nx_x[RPL], nx_y[RPL], nx_z[RPL];
+    uint8_t nx_i[RPL];
+    double nx_pose = 0.;
+    auto load_firing = [&](const int f)
+    {
+        const size_t fi = fglob + (size_t) f;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            nx_x[k] = nx_y[k] = nx_z[k] = __builtin_nanf("");
+            nx_i[k] = 0;
+            if (row < R && f < upto)
+            {
+                const size_t src = (fi * R + row) * 3;
+                nx_x[k] = xyz[src];
+                nx_y[k] = xyz[src + 1];
+                nx_z[k] = xyz[src + 2];
+                nx_i[k] = inten[fi * R + row];
+            }
+        }
+        if (f < upto)
+            nx_pose = poses[fi * 12 + (size_t) (lane < 12 ? lane : 0)];
+    };
+    if (wave < upto)
+        load_firing(wave);
     for (int f = wave; f < upto; f += IP_WAVES)
     {
+        float cx[RPL], cy[RPL], cz[RPL];
+        uint8_t cint[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            cx[k] = nx_x[k];
+            cy[k] = nx_y[k];
+            cz[k] = nx_z[k];
+            cint[k] = nx_i[k];
+        }
+        double T[12]; // (wave-uniform: the matrix travels in SGPRs)
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            T[i] = lane_f64(nx_pose, i);
+        load_firing(f + IP_WAVES);
         if (f > lds_ld(&s_bad)) // some earlier firing left the shape: nothing behind it is wanted (wave-uniform)
             break;
         const size_t fi = fglob + (size_t) f;
-        const double* T = poses + fi * 12;
         const int c0 = s_c[f];
         PreppedPoint q[RPL];
         bool differs = false;
@@ -1322,10 +1387,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
             const int row = k * 64 + lane;
             q[k].cir = PP_SKIP;
             if (row < R)
-            {
-                const size_t src = (fi * R + row) * 3;
-                q[k] = prep_point(xyz[src], xyz[src + 1], xyz[src + 2], T, clockwise, g.az_width);
-            }
+                q[k] = prep_point(cx[k], cy[k], cz[k], T, clockwise, g.az_width);
             differs |= q[k].cir != PP_SKIP && q[k].cir != c0;
         }
         if (__any(differs))
@@ -1340,7 +1402,6 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
         const unsigned lcq = (unsigned) (lc0 + (int) rel) / (unsigned) RC; // (one division: quotient = passes over the ring since lc0)
         const int lc = (int) ((unsigned) (lc0 + (int) rel) - lcq * (unsigned) RC);
         const uint16_t tag = cell_tag(pass0 + (long long) lcq);
-        const uint8_t* si = inten + fi * R;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -1349,7 +1410,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
             {
                 const size_t ci = (size_t) lc * R + row;
                 p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
-                p.inten[ci] = si[row];
+                p.inten[ci] = cint[k];
                 p.src[ci] = (uint32_t) (seq0 + f);
                 p.dist[ci] = q[k].dist;
                 p.incl[ci] = q[k].incl;
@@ -1740,15 +1801,28 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
 
 // =====================================================================================================
 // k_table — sc_inclination_angles_between_lasers_ (cc.cpp:353-357): per row the last non-NaN inclination step over the
-// emitted columns, in column order = a per-row "last valid value" scan along the columns. One block of TABLE_WAVES wavefronts
-// per stream, lanes = rows: every wavefront owns a contiguous chunk of the batch's columns; phase 1 finds the last valid step
-// of each chunk, the chunk carries are combined through LDS, phase 2 re-walks the chunk and writes the table plane.
-// grid = streams, block = 64 * TABLE_WAVES.
+// emitted columns, in column order = a per-row "last valid value" scan along the columns. k_seg_pre needs the table as of every column.
+// The batch's columns are cut into TABLE_WAVES contiguous ranges (one wavefront each, lanes = rows) of SEGPRE_BLOCKS / TABLE_WAVES
+// chunks; k_seg_pre handles one chunk per wavefront, in column order, and carries the table through its chunk in registers. This
+// kernel reads every column once and leaves what a chunk needs to start:
+//   tabc[chunk][row]  the last valid step between the start of the wavefront's range and the start of the chunk (NaN: none), and
+//   tabw[wave][row]   the table at the start of the wavefront's range (earlier ranges' last valid step, else the stream's table),
+// and the table after the last column of the batch (Planes::curtab). grid = streams, block = 64 * TABLE_WAVES.
 // =====================================================================================================
-#ifndef CC_TABLE_WAVES
-#define CC_TABLE_WAVES 8
-#endif
-constexpr int TABLE_WAVES = CC_TABLE_WAVES;
+
+// the columns [lo, hi) of chunk `chunk` (0 .. SEGPRE_BLOCKS - 1) of a batch that segments [seg_begin, seg_end); wave = chunk / CPW
+struct TableChunks
+{
+    long long per_wave, chunk_len;
+    __device__ __forceinline__ TableChunks(const long long seg_begin, const long long seg_end)
+    {
+        const long long total = seg_end - seg_begin;
+        per_wave = (total + TABLE_WAVES - 1) / TABLE_WAVES;
+        constexpr int CPW = SEGPRE_BLOCKS / TABLE_WAVES;
+        chunk_len = (per_wave + CPW - 1) / CPW;
+        chunk_len = chunk_len < 1 ? 1 : chunk_len;
+    }
+};
 
 template<int RPL>
 __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
@@ -1769,113 +1843,101 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
     const int R = g.num_rows, RC = g.ring_cols;
     __shared__ float s_last[TABLE_WAVES][WAVE * RPL];
     __shared__ int s_has[TABLE_WAVES][WAVE * RPL];
-    const long long total = seg_end - seg_begin;
-    const long long per = (total + TABLE_WAVES - 1) / TABLE_WAVES;
-    const long long c_lo = seg_begin + per * wave, c_hi = (c_lo + per < seg_end ? c_lo + per : seg_end);
+    constexpr int CPW = SEGPRE_BLOCKS / TABLE_WAVES;
+    const TableChunks tc(seg_begin, seg_end);
+    const long long c_lo = seg_begin + tc.per_wave * wave, c_hi = (c_lo + tc.per_wave < seg_end ? c_lo + tc.per_wave : seg_end);
+    float* tabc = p.tabc + (size_t) wave * CPW * R; // this wavefront's chunks
     constexpr int U = 16;
-    // phase 1: last valid step of this chunk per row
-    float last[RPL];
-    bool has[RPL];
+    float last[RPL]; // NaN = no valid step in this range so far
 #pragma unroll
     for (int k = 0; k < RPL; k++)
+        last[k] = __builtin_nanf("");
+    int lc = c_lo < c_hi ? (int) (c_lo % RC) : 0;
+    long long in_chunk = 0; // columns of the current chunk already walked
+    int chunk = 0;
+    for (long long c0 = c_lo; c0 < c_hi; c0 += U)
     {
-        last[k] = 0.f;
-        has[k] = false;
-    }
-    for (int pass = 0; pass < 2; pass++)
-    {
-        float carry[RPL];
-        if (pass == 1)
+        float cur[U][RPL], below[U][RPL];
+#pragma unroll
+        for (int u = 0; u < U; u++)
         {
-            // carry-in of this chunk: the last valid step of the nearest earlier chunk that has one, else the stream's table
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 const int row = k * 64 + lane;
-                carry[k] = row < R ? p.curtab[row] : 0.f;
-                if (row < R)
-                    for (int w = 0; w < wave; w++)
-                        if (s_has[w][row])
-                            carry[k] = s_last[w][row];
-            }
-        }
-        int lc = c_lo < c_hi ? (int) (c_lo % RC) : 0;
-        for (long long c0 = c_lo; c0 < c_hi; c0 += U)
-        {
-            float cur[U][RPL], below[U][RPL];
-            int lcs[U];
-#pragma unroll
-            for (int u = 0; u < U; u++)
-            {
-                lcs[u] = lc;
-                lc = lc + 1 == RC ? 0 : lc + 1;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
+                cur[u][k] = below[u][k] = 0.f;
+                if (row < R && c0 + u < c_hi)
                 {
-                    const int row = k * 64 + lane;
-                    cur[u][k] = below[u][k] = 0.f;
-                    if (row < R && c0 + u < c_hi)
-                    {
-                        const size_t ci = (size_t) lcs[u] * R + row;
-                        cur[u][k] = p.incl[ci];
-                        below[u][k] = row + 1 < R ? p.incl[ci + 1] : 0.f;
-                    }
+                    const size_t ci = (size_t) lc * R + row;
+                    cur[u][k] = p.incl[ci];
+                    below[u][k] = row + 1 < R ? p.incl[ci + 1] : 0.f;
                 }
             }
+            lc = lc + 1 == RC ? 0 : lc + 1;
+        }
 #pragma unroll
-            for (int u = 0; u < U; u++)
+        for (int u = 0; u < U; u++)
+        {
+            if (c0 + u >= c_hi)
+                break;
+            if (in_chunk == 0)
             {
-                if (c0 + u >= c_hi)
-                    break;
+                // the table state a chunk starts from
 #pragma unroll
                 for (int k = 0; k < RPL; k++)
                 {
                     const int row = k * 64 + lane;
                     if (row < R)
-                    {
-                        const float diff = cur[u][k] - below[u][k];
-                        if (pass == 0)
-                        {
-                            if (!(diff != diff))
-                            {
-                                last[k] = diff;
-                                has[k] = true;
-                            }
-                        }
-                        else
-                        {
-                            if (!(diff != diff))
-                                carry[k] = diff;
-                            p.tab[(size_t) lcs[u] * R + row] = carry[k];
-                        }
-                    }
+                        tabc[(size_t) chunk * R + row] = last[k];
                 }
+                chunk++;
             }
-        }
-        if (pass == 0)
-        {
+            in_chunk = in_chunk + 1 == tc.chunk_len ? 0 : in_chunk + 1;
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
-                const int row = k * 64 + lane;
-                if (row < R)
-                {
-                    s_last[wave][row] = last[k];
-                    s_has[wave][row] = has[k] ? 1 : 0;
-                }
+                const float diff = cur[u][k] - below[u][k];
+                if (!(diff != diff))
+                    last[k] = diff;
             }
-            __syncthreads();
         }
-        else if (wave == TABLE_WAVES - 1)
-        {
-            // table after the last emitted column = carry of the last chunk (chunks may be empty: then it is the carry-in)
+    }
 #pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (row < R)
-                    p.curtab[row] = carry[k];
-            }
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        if (row < R)
+        {
+            s_last[wave][row] = last[k];
+            s_has[wave][row] = (last[k] != last[k]) ? 0 : 1;
+        }
+    }
+    __syncthreads();
+    // the table at the start of this range: the last valid step of the nearest earlier range that has one, else the stream's table
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        if (row < R)
+        {
+            float carry = p.curtab[row];
+            for (int w = 0; w < wave; w++)
+                if (s_has[w][row])
+                    carry = s_last[w][row];
+            p.tabw[(size_t) wave * R + row] = carry;
+            last[k] = (last[k] != last[k]) ? carry : last[k];
+        }
+    }
+    __syncthreads(); // every wavefront has read the stream's table before it is replaced
+    if (wave == TABLE_WAVES - 1)
+    {
+        // table after the last emitted column (ranges may be empty: then it is the carry-in)
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row < R)
+                p.curtab[row] = last[k];
         }
     }
 }
@@ -1907,12 +1969,9 @@ __global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ sta
     }
 }
 
-// ---- k_seg_pre: everything of the segmentation that does not depend on the rows below. One wavefront per column,
-// lanes = rows (coalesced); blocks stride over the columns of the batch. grid = (SEGPRE_BLOCKS, streams), block = 64.
-#ifndef CC_SEGPRE_BLOCKS
-#define CC_SEGPRE_BLOCKS 256
-#endif
-constexpr int SEGPRE_BLOCKS = CC_SEGPRE_BLOCKS;
+// ---- k_seg_pre: everything of the segmentation that does not depend on the rows below. Lanes = rows (coalesced); one wavefront per
+// chunk of consecutive columns (TableChunks), which it walks in column order carrying sc_inclination_angles_between_lasers_ in
+// registers. grid = (streams, SEGPRE_BLOCKS), block = 64.
 
 template<int RPL>
 __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
@@ -1940,25 +1999,114 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     const float height_sensor_to_ground = -(float) A[11] + cfg.height_ref_to_ground_;
     (void) height_sensor_to_ground;
 
-    // (ring column and rotation index advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
-    int lc = (int) ((seg_begin + blockIdx.y) % RC);
-    const int lc_step = (int) (gridDim.y % (unsigned) RC);
+    // this wavefront's chunk of the batch's columns (the partition k_table prepared the table for), in column order
+    constexpr int CPW = SEGPRE_BLOCKS / TABLE_WAVES;
+    const TableChunks tc(seg_begin, seg_end);
+    const int tw = (int) blockIdx.y / CPW, tj = (int) blockIdx.y % CPW;
+    const long long w_lo = seg_begin + tc.per_wave * tw, w_hi = (w_lo + tc.per_wave < seg_end ? w_lo + tc.per_wave : seg_end);
+    const long long c_lo = w_lo + tc.chunk_len * tj, c_hi = (c_lo + tc.chunk_len < w_hi ? c_lo + tc.chunk_len : w_hi);
+    if (c_lo >= c_hi)
+        return;
+    // sc_inclination_angles_between_lasers_ (cc.cpp:353-357) as of the chunk's first column: the last valid step since the start of the
+    // table wavefront's range, else the table at the start of that range (k_table); carried through the chunk in registers
+    float tabv[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        tabv[k] = 0.f;
+        if (row < R)
+        {
+            const float t = p.tabc[(size_t) blockIdx.y * R + row];
+            tabv[k] = (t != t) ? p.tabw[(size_t) tw * R + row] : t;
+        }
+    }
+    // (ring column, rotation index and ring pass advanced incrementally: a 64-bit division per column costs ~100 scalar instructions)
     const int NC = g.num_columns;
-    long long rot = (seg_begin + blockIdx.y) / NC;
-    int cir = (int) ((seg_begin + blockIdx.y) - rot * NC);
-    const int cir_step = (int) (gridDim.y % (unsigned) NC);
-    const long long rot_step = (long long) (gridDim.y / (unsigned) NC);
-    long long pass = (seg_begin + blockIdx.y) / RC; // pass over the ring (cell_tag)
-    const long long pass_step = (long long) (gridDim.y / (unsigned) RC);
-    for (long long gc = seg_begin + blockIdx.y; gc < seg_end; gc += gridDim.y, pass += pass_step + (lc + lc_step >= RC ? 1 : 0),
-                   lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step), rot += rot_step + (cir + cir_step >= NC ? 1 : 0),
-                   cir = (cir + cir_step >= NC ? cir + cir_step - NC : cir + cir_step))
+    int lc = (int) (c_lo % RC);
+    long long rot = c_lo / NC;
+    int cir = (int) (c_lo - rot * NC);
+    long long pass = c_lo / RC; // pass over the ring (cell_tag)
+    // The columns of a chunk are latency chains (cells -> LDS recurrence -> stores): the cells of the NEXT column are loaded before
+    // the current one is worked on, and the ring-pass tags (which say which cells hold a record at all) one column before that.
+    uint16_t a_tg[RPL];            // tags of column gc + 1 (two columns ahead when they are loaded)
+    uint16_t n_tg[RPL];            // column gc's tags ...
+    float n_dist[RPL], n_incaz[RPL];
+    float4 n_rec[RPL];             // ... and cells, loaded one column ahead
+    uint8_t n_inten[RPL];
+    int n_trig = 0;
+    auto load_tags = [&](const long long gcx, const int lcx)
+    {
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            a_tg[k] = CELL_CLEARED;
+            if (row < R && gcx < c_hi)
+                a_tg[k] = p.gtag[(size_t) lcx * R + row];
+        }
+    };
+    auto load_cells = [&](const long long gcx, const int lcx, const uint16_t tagx)
+    {
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            n_dist[k] = n_incaz[k] = 0.f;
+            n_inten[k] = 0;
+            // a cell that received a return carries its record; a cleared cell has inclination = NaN (cc.cpp:1110-1119) and nothing else
+            n_rec[k] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            if (row < R && gcx < c_hi)
+            {
+                const size_t ci = (size_t) lcx * R + row;
+                n_dist[k] = p.dist[ci];
+                if (n_tg[k] == tagx)
+                {
+                    n_rec[k] = p.sc_rec[ci];
+                    n_incaz[k] = p.incaz[ci];
+                    n_inten[k] = p.inten[ci];
+                }
+            }
+        }
+        if (gcx < c_hi)
+            n_trig = p.trig[lcx];
+    };
+    {
+        load_tags(c_lo, lc);
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+            n_tg[k] = a_tg[k];
+        load_cells(c_lo, lc, cell_tag(pass));
+        load_tags(c_lo + 1, lc + 1 == RC ? 0 : lc + 1);
+    }
+    for (long long gc = c_lo; gc < c_hi; gc++, pass += (lc + 1 == RC ? 1 : 0), lc = (lc + 1 == RC ? 0 : lc + 1), rot += (cir + 1 == NC ? 1 : 0),
+                   cir = (cir + 1 == NC ? 0 : cir + 1))
     {
         const size_t base = (size_t) lc * R;
         const CazBase cb = caz_base_of_rotation(rot);
         const uint16_t tag = cell_tag(pass);
+        // this column's inputs (arrived during the previous column), then the loads of the next one
+        uint16_t c_tg[RPL];
+        float c_dist[RPL], c_incaz[RPL];
+        float4 c_rec[RPL];
+        uint8_t c_inten[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            c_tg[k] = n_tg[k];
+            c_dist[k] = n_dist[k];
+            c_incaz[k] = n_incaz[k];
+            c_rec[k] = n_rec[k];
+            c_inten[k] = n_inten[k];
+            n_tg[k] = a_tg[k];
+        }
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
-        const int trig = uniform_i32(p.trig[lc]); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
+        const int trig = uniform_i32(n_trig); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
+        {
+            const int lc1 = lc + 1 == RC ? 0 : lc + 1, lc2 = lc1 + 1 == RC ? 0 : lc1 + 1;
+            load_cells(gc + 1, lc1, cell_tag(pass + (lc + 1 == RC ? 1 : 0)));
+            load_tags(gc + 2, lc2);
+        }
         const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) trig) * 12;
         // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301), prepared per firing by k_ego
         const double* E = ego + ((size_t) sl * (size_t) n_batch + (size_t) trig) * 12;
@@ -1969,7 +2117,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             et[i] = E[9 + i];
         const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
 
-        float dist[RPL], incl[RPL], tabv[RPL];
+        float dist[RPL], incl[RPL];
         float4 rec[RPL];
         bool isnan_[RPL], empty_cell[RPL], overrun = false;
         int overrun_row = -1;        // the reference walks the rows bottom-up and reports the first stale cell it meets (cc.cpp:314-345)
@@ -1979,13 +2127,12 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         for (int k = 0; k < RPL; k++)
         {
             const int row = k * 64 + lane;
-            dist[k] = incl[k] = tabv[k] = 0.f;
+            dist[k] = incl[k] = 0.f;
             isnan_[k] = true;
             empty_cell[k] = false;
             if (row < R)
             {
-                const size_t ci = base + row;
-                const uint16_t tg = p.gtag[ci];
+                const uint16_t tg = c_tg[k];
                 if (tg != tag && tg != CELL_CLEARED)
                 {
                     overrun = true; // cc.cpp:320-345
@@ -1994,13 +2141,9 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                     overrun_gcol = gc - (long long) ((((unsigned) tag - (unsigned) tg) & 0x7fffu)) * RC;
                 }
                 empty_cell[k] = tg != tag;
-                dist[k] = p.dist[ci];
-                // a cell that received a return carries its record; a cleared cell has inclination = NaN (cc.cpp:1110-1119) and nothing else
-                rec[k] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
-                if (!empty_cell[k])
-                    rec[k] = p.sc_rec[ci];
+                dist[k] = c_dist[k];
+                rec[k] = c_rec[k];
                 incl[k] = rec[k].w;
-                tabv[k] = p.tab[ci];
                 isnan_[k] = dist[k] != dist[k];
                 s_incl[row] = incl[k];
                 s_done[row] = (!isnan_[k] || !cfg.supplement_inclination_angle_for_nan_cells || row == R - 1) ? 1 : 0;
@@ -2018,9 +2161,21 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             }
             continue;
         }
+        wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
+        // the column's valid inclination steps enter the table before it is used (cc.cpp:353-357; the raw inclinations, NaN where empty)
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row < R)
+            {
+                const float diff = incl[k] - (row + 1 < R ? s_incl[row + 1] : 0.f);
+                if (!(diff != diff))
+                    tabv[k] = diff;
+            }
+        }
         // NaN cells: inclination of the cell below (already supplemented) + the per-row step (cc.cpp:364-369); runs of NaN
         // cells resolve bottom-up, one row per iteration
-        wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
         while (true)
         {
             bool pending = false;
@@ -2108,11 +2263,11 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             }
             else
             {
-                const double caz = cell_caz(cb, p.incaz[ci]);
+                const double caz = cell_caz(cb, c_incaz[k]);
                 if (caz < min_az)
                     min_az = caz;
                 const float cx = rec[k].x, cy = rec[k].y, cz = rec[k].z;
-                if (cfg.fog_filtering_enabled && p.inten[ci] < (uint8_t) cfg.fog_filtering_intensity_below &&
+                if (cfg.fog_filtering_enabled && c_inten[k] < (uint8_t) cfg.fog_filtering_intensity_below &&
                     dist[k] < cfg.fog_filtering_distance_below && incl[k] > cfg.fog_filtering_inclination_above)
                     flags |= SG_FOG;
                 const double dx = cx, dy = cy, dz = cz;
