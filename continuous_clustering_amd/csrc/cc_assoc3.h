@@ -163,6 +163,9 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         // Per column: one look-up in the id ring per point (k_scan already followed the same-column parent chains), ids from the
         // free ring for the new roots, the column's ids into the ring. Every flag read is made wave-uniform (readfirstlane): a
         // divergent loop condition would drag all of the wave's scalar bookkeeping into VGPRs.
+#ifdef CC_A2_STATS
+        unsigned long long st_acyc = 0, st_acols = 0; // busy cycles (s_memtime) and columns of this wave
+#endif
         int head = 0;
         long long gcA = col_begin;
         int lc = (int) (col_begin % RC);
@@ -241,6 +244,9 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     }
                 }
             }
+#ifdef CC_A2_STATS
+            const unsigned long long st_ta = __builtin_amdgcn_s_memtime();
+#endif
             int term[RPL], nlk[RPL], parc[RPL];
             unsigned long long lk[RPL];
 #pragma unroll
@@ -342,7 +348,18 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                 head += cnt_new;
             gcA++;
             lc = lc + 1 == RC ? 0 : lc + 1;
+#ifdef CC_A2_STATS
+            st_acyc += __builtin_amdgcn_s_memtime() - st_ta;
+            st_acols++;
+#endif
         }
+#ifdef CC_A2_STATS
+        if (lane == 0)
+        {
+            atomicAdd((unsigned long long*) &st->dbg[6], st_acyc);
+            atomicAdd((unsigned long long*) &st->dbg[7], st_acols);
+        }
+#endif
         return;
     }
 
@@ -353,6 +370,9 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         // number of points and the largest finished_at contribution (a handful of wave-wide reductions: a column touches 1-3 trees);
         // Point::tree_root_ of every cell (cc.cpp:661,814): a new root's lane files its cell under the tree id, every lane gathers its
         // tree's root cell and writes the root plane. Wave B then never looks at a point: it applies these records.
+#ifdef CC_A2_STATS
+        unsigned long long st_rcyc = 0;
+#endif
         long long gcR = col_begin, a_seen = col_begin;
         int lcR = (int) (col_begin % RC);
         int poll = 0;
@@ -395,6 +415,9 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     wave_lds_fence(); // ring entries and staged inputs are read after the flag
                 }
             }
+#ifdef CC_A2_STATS
+            const unsigned long long st_tr = __builtin_amdgcn_s_memtime();
+#endif
             const int sc = (int) (gcR & (A2_STAGE - 1));
             const int abad = uniform_i32(lds_ld(&T.info_bad[(int) (gcR & (A2_INFO - 1))]));
             if ((abad & 3) == 0)
@@ -505,7 +528,14 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                 lds_st(&r_done, gcR + 1);
             gcR++;
             lcR = lcR + 1 == RC ? 0 : lcR + 1;
+#ifdef CC_A2_STATS
+            st_rcyc += __builtin_amdgcn_s_memtime() - st_tr;
+#endif
         }
+#ifdef CC_A2_STATS
+        if (lane == 0)
+            atomicAdd((unsigned long long*) &st->dbg[5], st_rcyc);
+#endif
         return;
     }
 
@@ -863,7 +893,10 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                 const bool on = ru >= u0 && ru < gcount;
                 const int nbu = on ? (int) bt_n[rsc] : 0, nru = on ? (int) rc_n[rsc] : 0;
                 if (nbu != 255 && rk < nbu)
+                {
                     T.alive[bt_id[rsc][rk]] = 1;
+                    T.comp[bt_id[rsc][rk]] = -1; // (not in the list of unfinished trees yet: see the exact finish prediction below)
+                }
                 wave_lds_fence();
                 const unsigned char al = T.alive[(nru != 255 && rk < nru) ? (int) rc_id[rsc][rk] : 0];
                 const bool bad = on && (nru == 255 || nbu == 255 || (rk < nru && !al));
@@ -887,6 +920,55 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
             const int wu = lane;
             const bool inr = wu >= u0 && wu < gcount;
             const double inf = 1.7976931348623157e308;
+            // ---- which columns can let an EXISTING cluster through the finished-cluster check (cc.cpp:884-885: the cluster's largest
+            // finished_at is not ahead of the column's smallest azimuth)? The scalar bound L (minimum over the clusters, as of the last
+            // exact check) goes stale as soon as the cluster it came from receives points, and four of five checks it asked for retired
+            // nothing. With at most 64 unfinished trees the prediction is made per cluster instead: the records of the group's columns
+            // (one lane per (column, record)) raise their cluster's value column by column in a [column][list position] table (the
+            // scratch of the finish pass), then one lane per tree walks its cluster's running maximum against the columns' azimuths.
+            // Trees born inside the group are covered by the prefix minimum over the new roots' finished_at below, links only merge
+            // clusters (never lower a maximum): a column that is not flagged cannot finish anything. -----------------------------
+            unsigned long long m_alarm = 0;
+            const bool exact = n_unf <= 64;
+            if (exact && n_unf > 0)
+            {
+                static_assert(2 * TREE_SLOTS >= G * 64, "a_fin + a_min hold the [column][list position] table");
+                unsigned long long* cf = &T.a_fin[0]; // [G][64], runs on into a_min (both are scratch of the finish pass)
+#pragma unroll
+                for (int u = 0; u < G; u++)
+                    cf[u * 64 + lane] = 0ull;
+                if (lane < n_unf)
+                    T.comp[T.alist[lane]] = lane; // list position of every unfinished tree
+                wave_lds_fence();
+                {
+                    const bool on = ru >= u0 && ru < gcount;
+                    const int nru = on ? (int) rc_n[rsc] : 0;
+                    if (nru != 255 && rk < nru)
+                    {
+                        const int id = rc_id[rsc][rk];
+                        const int pos0 = T.comp[id];
+                        if (T.alive[id] && pos0 >= 0) // (an id born in this group has no list position yet; a dead one makes its column a cut)
+                            atomicMax(&cf[ru * 64 + T.comp[lds_find(T.uf, id)]], (unsigned long long) rc_fin[rsc][rk]);
+                    }
+                }
+                wave_lds_fence();
+                const int ti = T.alist[lane < n_unf ? lane : 0];
+                const bool isrep = lane < n_unf && T.uf[ti] == ti;
+                unsigned long long run = T.c_fin[ti];
+                unsigned long long cfv[G];
+#pragma unroll
+                for (int u = 0; u < G; u++)
+                    cfv[u] = cf[u * 64 + lane];
+#pragma unroll
+                for (int u = 0; u < G; u++)
+                    if (u >= u0 && u < gcount)
+                    {
+                        run = cfv[u] > run ? cfv[u] : run;
+                        const double mz = lane_f64(v_minaz, u);
+                        if (__ballot(isrep && !(__longlong_as_double((long long) run) > mz)))
+                            m_alarm |= 1ull << u;
+                    }
+            }
             if (rewalk)
             {
                 rewalk = false;
@@ -939,7 +1021,8 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                                             || gcu_l - w_maxd < w_fub                                              // cc.cpp:762-763
                                             || gcu_l - w_reach < w_fub); // static visit counts (cc.cpp:725) need the whole window
                 w_alias = w_nafter > 0 && v_minaz == w_azprev;
-                const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || v_minaz >= w_L);
+                const bool c_fin_hit = exact ? (((m_alarm >> wu) & 1ull) != 0 || v_minaz >= pm) : v_minaz >= w_L;
+                const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || c_fin_hit);
                 m_global = __ballot(c_global);
                 m_live = __ballot(c_live);
                 m_check = __ballot(c_check);
@@ -964,7 +1047,8 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     }
                 }
                 w_L = pm < L ? pm : L;
-                const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || v_minaz >= w_L);
+                const bool c_fin_hit = exact ? (((m_alarm >> wu) & 1ull) != 0 || v_minaz >= pm) : v_minaz >= w_L;
+                const bool c_check = inr && w_nafter > 0 && !w_alias && ((gcu_l + 1 - w_M) >= NC || c_fin_hit);
                 m_check = __ballot(c_check);
                 const unsigned long long keep = ~((1ull << u0) - 1ull);
                 m_global &= keep;
@@ -1209,8 +1293,6 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         st->dbg[13] += st_wait_g;
         st->dbg[14] += st_full;
         st->dbg[15] += st_kill;
-        st->dbg[5] += st_removed;
-        st->dbg[6] += st_nunf;
         for (int i = 0; i < 5; i++)
             st->dbg[i] += st_ph[i];
     }

@@ -1454,8 +1454,10 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     if (tid == 0)
     {
         st->clear_done = clear_done;
+#ifndef CC_A2_STATS
         st->dbg[6] += (unsigned long long) done; // firings taken by this kernel / batches it saw (cc_engine_debug_counters)
         st->dbg[7] += 1;
+#endif
         if (done > 0)
         {
             const long long G = prev_rear0 + s_off[done - 1];
@@ -1780,8 +1782,10 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     if (tid == 0)
     {
         st->clear_done = clear_done;
+#ifndef CC_A2_STATS
         st->dbg[6] += (unsigned long long) (done - cursor0);
         st->dbg[7] += 1;
+#endif
         if (done > cursor0)
         {
             const long long G = prev_rear0 + carry_rel;

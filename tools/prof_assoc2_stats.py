@@ -20,6 +20,7 @@ tot /= (S / 8)
 cols = tot[12]
 print(f"columns {cols:.0f}  sub-batches/col {tot[8]/cols:.3f}  check cuts/col {tot[9]/cols:.3f}  live cuts/col {tot[11]/cols:.4f}  "
       f"B cycles/col {tot[10]/cols:.0f}  B waits for A /col {tot[13]/cols:.3f}")
-print(f"  full finish passes/col {tot[14]/cols:.3f}  passes that retired trees/col {tot[15]/cols:.3f}  trees retired/col {tot[5]/cols:.3f}  mean unfinished trees {tot[6]/max(tot[8],1):.1f}")
+print(f"  full finish passes/col {tot[14]/cols:.3f}  passes that retired trees/col {tot[15]/cols:.3f}")
+print(f"  k_assoc3 only: wave A busy cycles/col {tot[6]/max(tot[7],1):.0f} (over {tot[7]:.0f} columns incl. re-resolved ones)  wave R busy cycles/col {tot[5]/cols:.0f}")
 names = ["ids (re)load", "verification", "scalar walk", "batch apply", "cut column + b_done"]
 for i, n in enumerate(names): print(f"  {n:22s} {tot[i]/cols:8.0f} cycles/col   {tot[i]/max(tot[8],1):8.0f} per sub-batch")
