@@ -11,10 +11,11 @@
 #pragma once
 
 constexpr int A3_REC = 8;   // records (trees receiving points) per column
+constexpr int A3_THREADS = 256; // four wavefronts: A (resolve ids), B (apply + finish), R (records + roots), L (links)
 constexpr int A3_BIRTH = 8; // new roots per column kept inline (must equal A3_REC: one lane per (column, slot))
 
 template<int RPL>
-__global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     constexpr int G = RPL == 1 ? 8 : 4; // columns wave B handles per pass
     constexpr int A2_LEAD = a2_lead(RPL), A2_STAGE = a2_stage(RPL);
@@ -57,6 +58,10 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
     __shared__ unsigned char rc_n[A2_STAGE], bt_n[A2_STAGE];  // counts; 255 = more than fit (the column is replayed exactly)
     __shared__ long long r_done;                              // columns < r_done have their records
     __shared__ int r_parked;
+    // the links wave: per column whether a link candidate (an accepted candidate after the first, cc.cpp:693-694) leads to another tree
+    __shared__ long long l_done;                              // columns < l_done have their flag
+    __shared__ int l_parked;
+    __shared__ unsigned char l_foreign[A2_INFO];
 
     const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
     const int n_unf0 = st->n_unfinished;
@@ -74,7 +79,7 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
     }
 
     // ---- load the persistent tree state (global planes indexed by root cell): id = list position ------------------------------
-    for (int i = threadIdx.x; i < TREE_SLOTS; i += 192)
+    for (int i = threadIdx.x; i < TREE_SLOTS; i += A3_THREADS)
     {
         T.alive[i] = 0;
         if (i < n_unf0)
@@ -101,6 +106,8 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
     {
         r_done = col_begin;
         r_parked = 0;
+        l_done = col_begin;
+        l_parked = 0;
         T.a_done = col_begin;
         T.b_done = col_begin;
         T.restart_col = col_begin;
@@ -110,19 +117,19 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         T.tail = TREE_SLOTS - n_unf0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_unf0; i += 192)
+    for (int i = threadIdx.x; i < n_unf0; i += A3_THREADS)
         atomicMax(&T.c_fin[lds_find(T.uf, i)], T.fin[i]);
     {
         // ring of tree ids for the WIN2_COLS columns before col_begin (only the last WIN_COLS can be looked at): two dependent
         // gathers per cell (root plane, then the tree planes at the root), 8 cells at a time
         constexpr int B = 8;
-        for (int i0 = threadIdx.x; i0 < WIN2_COLS * R; i0 += 192 * B)
+        for (int i0 = threadIdx.x; i0 < WIN2_COLS * R; i0 += A3_THREADS * B)
         {
             int rr[B];
 #pragma unroll
             for (int u = 0; u < B; u++)
             {
-                const int i = i0 + u * 192;
+                const int i = i0 + u * A3_THREADS;
                 rr[u] = -1;
                 if (i < WIN2_COLS * R)
                 {
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
 #pragma unroll
             for (int u = 0; u < B; u++)
             {
-                const int i = i0 + u * 192;
+                const int i = i0 + u * A3_THREADS;
                 if (i < WIN2_COLS * R)
                     s_win[i] = (short) (rr[u] < 0 ? -1 : (fin_[u] ? -2 : pos_[u]));
             }
@@ -170,19 +177,15 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         long long gcA = col_begin;
         int lc = (int) (col_begin % RC);
         long long b_seen = col_begin;
-        int nx_term[RPL], nx_info = 0, nx_nl[RPL], nx_par[RPL];
-        int nxx_info = 0; // col_info of the column after the one in nx_*: says whether that column's link words are worth loading
-        unsigned long long nx_link[RPL];
+        int nx_term[RPL], nx_info = 0, nx_par[RPL];
         double nx_fin[RPL];
-        auto load_a = [&](long long gcx, int lcx, bool with_links)
+        auto load_a = [&](long long gcx, int lcx)
         {
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 const int row = k * 64 + lane;
                 nx_term[k] = -1;
-                nx_nl[k] = 0;
-                nx_link[k] = 0;
                 nx_par[k] = -2;
                 nx_fin[k] = 0.;
                 if (row < R && gcx < col_end)
@@ -190,18 +193,12 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     nx_par[k] = p.sc_parent[lcx * R + row];
                     nx_fin[k] = p.sc_fin[lcx * R + row];
                     nx_term[k] = p.sc_term[lcx * R + row];
-                    nx_nl[k] = p.sc_nlinks[lcx * R + row];
-                    if (with_links) // (8 of the 21 bytes per cell; k_scan only writes the word where a point has links)
-                        nx_link[k] = p.sc_links[lcx * R + row];
                 }
             }
             if (lane == 0 && gcx < col_end)
-            {
                 nx_info = p.col_info[lcx];
-                nxx_info = gcx + 1 < col_end ? p.col_info[lcx + 1 == RC ? 0 : lcx + 1] : 0;
-            }
         };
-        load_a(gcA, lc, true);
+        load_a(gcA, lc);
         bool wait_park = false; // a column could not be resolved: wave B will park us when it gets there
         int poll = 0;
         while (true)
@@ -226,7 +223,7 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     lc = (int) (gcA % RC);
                     b_seen = gcA;
                     wait_park = false;
-                    load_a(gcA, lc, true);
+                    load_a(gcA, lc);
                     continue;
                 }
                 if (wait_park || gcA >= col_end)
@@ -247,14 +244,11 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
 #ifdef CC_A2_STATS
             const unsigned long long st_ta = __builtin_amdgcn_s_memtime();
 #endif
-            int term[RPL], nlk[RPL], parc[RPL];
-            unsigned long long lk[RPL];
+            int term[RPL], parc[RPL];
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 term[k] = nx_term[k];
-                nlk[k] = nx_nl[k];
-                lk[k] = nx_link[k];
                 parc[k] = nx_par[k];
                 const int row = k * 64 + lane;
                 if (row < R) // stage what wave B needs of this column
@@ -265,11 +259,9 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                 }
             }
             const int cnt_new = uniform_i32(nx_info) & 0xff;
-            const bool col_links = (uniform_i32(nx_info) >> 8) & 2;
             {
                 const int lc1 = lc + 1 == RC ? 0 : lc + 1;
-                const bool next_links = (uniform_i32(nxx_info) >> 8) & 2; // (arrived with this column's inputs)
-                load_a(gcA + 1, lc1, next_links); // prefetch
+                load_a(gcA + 1, lc1); // prefetch
             }
             const int wcur = (int) (gcA & (WIN2_COLS - 1));
             int bad = 0;
@@ -306,38 +298,10 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                 if (row < R)
                     wcol[row] = (short) ent[k];
             }
-            // Links (further accepted candidates) only matter where they lead to another tree, which is rare (two trees of one
-            // object meeting): this wave, which has the time, looks the targets up and tells wave B whether the column has any.
-            int foreign = 0;
-            if (col_links && bad == 0)
-            {
-                wave_lds_fence(); // same-column targets: read what was just written
-                bool f = false;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                {
-                    const int mine = ent[k] & A2_IDMASK;
-                    int v[LINK_SLOTS];
-#pragma unroll
-                    for (int j = 0; j < LINK_SLOTS; j++)
-                    {
-                        v[j] = -1;
-                        if (term[k] >= 0 && j < nlk[k])
-                        {
-                            const int code = (int) ((lk[k] >> (16 * j)) & 0xffff);
-                            v[j] = s_win[((wcur - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < LINK_SLOTS; j++)
-                        f |= v[j] >= 0 && (v[j] & A2_IDMASK) != mine;
-                }
-                foreign = __any(f) ? 16 : 0;
-            }
             if (lane == 0)
             {
                 T.info_head[(int) (gcA & (A2_INFO - 1))] = head;
-                T.info_bad[(int) (gcA & (A2_INFO - 1))] = bad | foreign;
+                T.info_bad[(int) (gcA & (A2_INFO - 1))] = bad;
             }
             wave_lds_fence();
             if (lane == 0)
@@ -492,7 +456,7 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                         const unsigned long long v = mine ? fb[k] : 0ull;
                         mx = v > mx ? v : mx;
                     }
-                    mx = (unsigned long long) wave_max_i64((long long) mx); // (bit patterns of non-negative doubles order like the doubles)
+                    mx = wave_max_f64_bits(mx); // (finished_at contributions: non-negative doubles)
                     if (lane == 0 && nr < A3_REC)
                     {
                         rc_id[sc][nr] = (short) X;
@@ -536,6 +500,138 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         if (lane == 0)
             atomicAdd((unsigned long long*) &st->dbg[5], st_rcyc);
 #endif
+        return;
+    }
+
+    if (wave == 3)
+    {
+        // ============================================================================================= wave L: links
+        // Behind wave A, ahead of wave B. Links (further accepted candidates, cc.cpp:693-694) only matter where they lead to another
+        // tree, which is rare (two trees of one object meeting) — but nine columns of ten have link candidates, and looking their
+        // targets up in the id ring was 40 % of wave A's column. This wave does nothing else: it reads the link words itself (two
+        // columns ahead), looks the targets up and tells wave B per column whether any of them is foreign.
+        long long gcL = col_begin, a_seen = col_begin;
+        int lcL = (int) (col_begin % RC);
+        int poll = 0;
+        // inputs of columns gcL (c_*) and gcL + 1 (n_*)
+        int c_nl[RPL], n_nl[RPL], c_info = 0, n_info = 0;
+        unsigned long long c_lk[RPL], n_lk[RPL];
+        auto load_l = [&](long long gcx, int lcx, int* nl, unsigned long long* lk, int& info)
+        {
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                nl[k] = 0;
+                lk[k] = 0;
+                if (row < R && gcx < col_end)
+                {
+                    nl[k] = p.sc_nlinks[lcx * R + row];
+                    lk[k] = p.sc_links[lcx * R + row]; // (stale where the point has no links: never looked at)
+                }
+            }
+            info = 0;
+            if (gcx < col_end)
+                info = p.col_info[lcx];
+        };
+        auto reload = [&]()
+        {
+            load_l(gcL, lcL, c_nl, c_lk, c_info);
+            load_l(gcL + 1, lcL + 1 == RC ? 0 : lcL + 1, n_nl, n_lk, n_info);
+        };
+        reload();
+        while (true)
+        {
+            if (gcL >= col_end || gcL >= a_seen || (++poll & 7) == 0)
+            {
+                const int cmd = uniform_i32(lds_ld(&T.cmd));
+                if (cmd == A2_EXIT)
+                    break;
+                if (cmd == A2_PARK)
+                {
+                    if (lane == 0)
+                        lds_st(&l_parked, 1);
+                    while (uniform_i32(lds_ld(&T.cmd)) == A2_PARK)
+                        __builtin_amdgcn_s_sleep(1);
+                    if (uniform_i32(lds_ld(&T.cmd)) == A2_EXIT)
+                        break;
+                    wave_lds_fence();
+                    gcL = uniform_i64(lds_ld(&T.restart_col));
+                    lcL = (int) (gcL % RC);
+                    a_seen = gcL;
+                    reload();
+                    continue;
+                }
+                if (gcL >= col_end)
+                {
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                if (gcL >= a_seen)
+                {
+                    a_seen = uniform_i64(lds_ld(&T.a_done));
+                    if (gcL >= a_seen)
+                    {
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    wave_lds_fence(); // ring entries are read after the flag
+                }
+            }
+            int nlk[RPL];
+            unsigned long long lk[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                nlk[k] = c_nl[k];
+                lk[k] = c_lk[k];
+                c_nl[k] = n_nl[k];
+                c_lk[k] = n_lk[k];
+            }
+            const bool col_links = (uniform_i32(c_info) >> 8) & 2;
+            c_info = n_info;
+            {
+                int lc2 = lcL + 2;
+                lc2 = lc2 >= RC ? lc2 - RC : lc2;
+                load_l(gcL + 2, lc2, n_nl, n_lk, n_info); // two columns ahead
+            }
+            const int abad = uniform_i32(lds_ld(&T.info_bad[(int) (gcL & (A2_INFO - 1))]));
+            int foreign = 0;
+            if (col_links && (abad & 3) == 0)
+            {
+                const int wcur = (int) (gcL & (WIN2_COLS - 1));
+                bool f = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    const int e = row < R ? (int) s_win[wcur * R + row] : -1; // the point's tree (>= 0: the point has one)
+                    const int mine = e & A2_IDMASK;
+                    int v[LINK_SLOTS];
+#pragma unroll
+                    for (int j = 0; j < LINK_SLOTS; j++)
+                    {
+                        v[j] = -1;
+                        if (e >= 0 && j < nlk[k])
+                        {
+                            const int code = (int) ((lk[k] >> (16 * j)) & 0xffff);
+                            v[j] = s_win[((wcur - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < LINK_SLOTS; j++)
+                        f |= v[j] >= 0 && (v[j] & A2_IDMASK) != mine;
+                }
+                foreign = __any(f) ? 1 : 0;
+            }
+            if (lane == 0)
+                l_foreign[(int) (gcL & (A2_INFO - 1))] = (unsigned char) foreign;
+            wave_lds_fence();
+            if (lane == 0)
+                lds_st(&l_done, gcL + 1);
+            gcL++;
+            lcL = lcL + 1 == RC ? 0 : lcL + 1;
+        }
         return;
     }
 
@@ -598,7 +694,7 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         if (lane == 0)
             lds_st(&T.cmd, (int) A2_PARK);
         int spins = 0;
-        while (uniform_i32(lds_ld(&T.a_parked)) == 0 || uniform_i32(lds_ld(&r_parked)) == 0)
+        while (uniform_i32(lds_ld(&T.a_parked)) == 0 || uniform_i32(lds_ld(&r_parked)) == 0 || uniform_i32(lds_ld(&l_parked)) == 0)
         {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > A2_SPIN_LIMIT)
@@ -619,6 +715,8 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
             T.a_parked = 0;
             r_done = restart;
             r_parked = 0;
+            l_done = restart;
+            l_parked = 0;
         }
         wave_lds_fence();
         if (lane == 0)
@@ -629,7 +727,11 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
     {
         for (int spins = 0; a_seen < upto;)
         {
-            a_seen = uniform_i64(lds_ld(&r_done)); // (records ready = resolved by wave A and summarised by wave R)
+            a_seen = uniform_i64(lds_ld(&r_done)); // (records ready = resolved by wave A and summarised by wave R ...
+            {
+                const long long l_seen = uniform_i64(lds_ld(&l_done)); // ... and the links looked at by wave L)
+                a_seen = l_seen < a_seen ? l_seen : a_seen;
+            }
             if (a_seen < upto)
             {
 #ifdef CC_A2_STATS
@@ -849,6 +951,8 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
         bool verify = true;    // ... and checked against the tree state (again after trees were finished)
         bool rewalk = true;    // the scalar walk has to be redone (false after a finished-cluster check that retired nothing: only L moved)
         unsigned badmask = 0;
+        int q_id = -1;                 // this lane's record of the group (tree id, -1: none), kept from the verification for the walks
+        unsigned long long q_fin = 0;  // ... and its finished_at contribution
         int v_abad = 0;
         // results of the scalar walk, lane u = column gc + u; they stay valid across a check that retires nothing
         int w_cnt = 0, w_flags = 0, w_maxd = 0, w_nafter = 0, w_nbefore = 0;
@@ -875,7 +979,7 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                 if (err)
                     break;
                 if (lane < G)
-                    v_abad = T.info_bad[(int) ((gc + lane) & (A2_INFO - 1))];
+                    v_abad = T.info_bad[(int) ((gc + lane) & (A2_INFO - 1))] | (l_foreign[(int) ((gc + lane) & (A2_INFO - 1))] ? 16 : 0);
                 ids_stale = false;
                 verify = true;
             }
@@ -898,8 +1002,11 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
                     T.comp[bt_id[rsc][rk]] = -1; // (not in the list of unfinished trees yet: see the exact finish prediction below)
                 }
                 wave_lds_fence();
-                const unsigned char al = T.alive[(nru != 255 && rk < nru) ? (int) rc_id[rsc][rk] : 0];
+                q_id = (nru != 255 && rk < nru) ? (int) rc_id[rsc][rk] : -1;
+                q_fin = rc_fin[rsc][rk];
+                const unsigned char al = T.alive[q_id >= 0 ? q_id : 0];
                 const bool bad = on && (nru == 255 || nbu == 255 || (rk < nru && !al));
+                q_id = al ? q_id : -1; // (a record of a dead tree makes its column a cut: nothing behind it is looked at)
                 const unsigned long long bm = __ballot(bad);
                 badmask = 0;
 #pragma unroll
@@ -937,24 +1044,25 @@ __global__ __launch_bounds__(192) void k_assoc3(Geometry g, cc_config cfg, Plane
 #pragma unroll
                 for (int u = 0; u < G; u++)
                     cf[u * 64 + lane] = 0ull;
+                const int ti = T.alist[lane < n_unf ? lane : 0];
                 if (lane < n_unf)
-                    T.comp[T.alist[lane]] = lane; // list position of every unfinished tree
+                    T.comp[ti] = lane; // list position of every unfinished tree
                 wave_lds_fence();
+                // (the loads of the record lanes and of the tree lanes are independent: one LDS round trip for both)
+                const bool rec_on = q_id >= 0 && ru >= u0 && ru < gcount;
+                const int qi = rec_on ? q_id : 0;
+                const int pos0 = T.comp[qi];
+                int rep = T.uf[qi];
+                const int t_uf = T.uf[ti];
+                unsigned long long run = T.c_fin[ti];
+                if (rec_on && pos0 >= 0) // (an id born in this group has no list position yet: its tree is covered by the new-root bound)
                 {
-                    const bool on = ru >= u0 && ru < gcount;
-                    const int nru = on ? (int) rc_n[rsc] : 0;
-                    if (nru != 255 && rk < nru)
-                    {
-                        const int id = rc_id[rsc][rk];
-                        const int pos0 = T.comp[id];
-                        if (T.alive[id] && pos0 >= 0) // (an id born in this group has no list position yet; a dead one makes its column a cut)
-                            atomicMax(&cf[ru * 64 + T.comp[lds_find(T.uf, id)]], (unsigned long long) rc_fin[rsc][rk]);
-                    }
+                    if (rep != qi)
+                        rep = lds_find(T.uf, rep);
+                    atomicMax(&cf[ru * 64 + T.comp[rep]], q_fin);
                 }
                 wave_lds_fence();
-                const int ti = T.alist[lane < n_unf ? lane : 0];
-                const bool isrep = lane < n_unf && T.uf[ti] == ti;
-                unsigned long long run = T.c_fin[ti];
+                const bool isrep = lane < n_unf && t_uf == ti;
                 unsigned long long cfv[G];
 #pragma unroll
                 for (int u = 0; u < G; u++)

@@ -521,9 +521,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (e->assoc_waves == 3 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), dim3(192), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), dim3(cck::A3_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), dim3(192), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), dim3(cck::A3_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
     else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {

@@ -101,6 +101,24 @@ __device__ __forceinline__ double wave_min_f64(double v)
 #undef CC_LESS_F64
     return __longlong_as_double(lane63_i64(b));
 }
+// maximum of non-negative, non-NaN doubles given as their bit patterns (finished_at values): v_max_f64 per step instead of a 64-bit
+// compare and two selects
+__device__ __forceinline__ unsigned long long wave_max_f64_bits(unsigned long long bits)
+{
+    long long b = (long long) bits;
+#define CC_MAXF64(t, v) (__longlong_as_double(t) > __longlong_as_double(v))
+    {
+        long long t_;
+        t_ = dpp_mov_i64<0x111, 0xf>(0ll, b); b = __double_as_longlong(__builtin_fmax(__longlong_as_double(t_), __longlong_as_double(b)));
+        t_ = dpp_mov_i64<0x112, 0xf>(0ll, b); b = __double_as_longlong(__builtin_fmax(__longlong_as_double(t_), __longlong_as_double(b)));
+        t_ = dpp_mov_i64<0x114, 0xf>(0ll, b); b = __double_as_longlong(__builtin_fmax(__longlong_as_double(t_), __longlong_as_double(b)));
+        t_ = dpp_mov_i64<0x118, 0xf>(0ll, b); b = __double_as_longlong(__builtin_fmax(__longlong_as_double(t_), __longlong_as_double(b)));
+        t_ = dpp_mov_i64<0x142, 0xa>(0ll, b); b = __double_as_longlong(__builtin_fmax(__longlong_as_double(t_), __longlong_as_double(b)));
+        t_ = dpp_mov_i64<0x143, 0xc>(0ll, b); b = __double_as_longlong(__builtin_fmax(__longlong_as_double(t_), __longlong_as_double(b)));
+    }
+#undef CC_MAXF64
+    return (unsigned long long) lane63_i64(b);
+}
 // Single-wavefront workgroups: LDS operations of one wave execute in issue order, so ordering LDS writes before LDS reads
 // of other lanes needs neither s_barrier nor a vmcnt drain (which __syncthreads() implies and which would expose the
 // latency of every global prefetch in flight). This is a compiler barrier plus a wait for outstanding LDS operations only.
