@@ -11,7 +11,10 @@
 #pragma once
 
 constexpr int A3_REC = 8;   // records (trees receiving points) per column
-constexpr int A3_THREADS = 256; // four wavefronts: A (resolve ids), B (apply + finish), R (records + roots), L (links)
+constexpr int A3_THREADS = 256; // four wavefronts: A (resolve ids), B (apply + finish), R (records + roots), L (links). Launched with 192
+                                // threads the kernel runs without wave L and wave A looks at the links itself: one wavefront less per
+                                // stream for the throughput kernels it shares the GPU with (2 % on the 256-stream step), a slower chain
+                                // (1.78 instead of 1.54 ms per 2200 columns) where the streams are few and the chain is what one waits for
 constexpr int A3_BIRTH = 8; // new roots per column kept inline (must equal A3_REC: one lane per (column, slot))
 
 template<int RPL>
@@ -23,6 +26,8 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
+    const bool lwave = blockDim.x > 192; // wave L exists
+    const int nthreads = (int) blockDim.x;
     StreamState* st = &states[s];
     if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0 || st->batch[slot].mode != 0 ||
         st->batch[slot].acp_next >= st->batch[slot].seg_end)
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
     }
 
     // ---- load the persistent tree state (global planes indexed by root cell): id = list position ------------------------------
-    for (int i = threadIdx.x; i < TREE_SLOTS; i += A3_THREADS)
+    for (int i = threadIdx.x; i < TREE_SLOTS; i += nthreads)
     {
         T.alive[i] = 0;
         if (i < n_unf0)
@@ -108,6 +113,8 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         r_parked = 0;
         l_done = col_begin;
         l_parked = 0;
+        for (int i = 0; i < A2_INFO; i++)
+            l_foreign[i] = 0;
         T.a_done = col_begin;
         T.b_done = col_begin;
         T.restart_col = col_begin;
@@ -117,19 +124,19 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         T.tail = TREE_SLOTS - n_unf0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n_unf0; i += A3_THREADS)
+    for (int i = threadIdx.x; i < n_unf0; i += nthreads)
         atomicMax(&T.c_fin[lds_find(T.uf, i)], T.fin[i]);
     {
         // ring of tree ids for the WIN2_COLS columns before col_begin (only the last WIN_COLS can be looked at): two dependent
         // gathers per cell (root plane, then the tree planes at the root), 8 cells at a time
         constexpr int B = 8;
-        for (int i0 = threadIdx.x; i0 < WIN2_COLS * R; i0 += A3_THREADS * B)
+        for (int i0 = threadIdx.x; i0 < WIN2_COLS * R; i0 += nthreads * B)
         {
             int rr[B];
 #pragma unroll
             for (int u = 0; u < B; u++)
             {
-                const int i = i0 + u * A3_THREADS;
+                const int i = i0 + u * nthreads;
                 rr[u] = -1;
                 if (i < WIN2_COLS * R)
                 {
@@ -155,7 +162,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
 #pragma unroll
             for (int u = 0; u < B; u++)
             {
-                const int i = i0 + u * A3_THREADS;
+                const int i = i0 + u * nthreads;
                 if (i < WIN2_COLS * R)
                     s_win[i] = (short) (rr[u] < 0 ? -1 : (fin_[u] ? -2 : pos_[u]));
             }
@@ -178,6 +185,8 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         int lc = (int) (col_begin % RC);
         long long b_seen = col_begin;
         int nx_term[RPL], nx_info = 0, nx_par[RPL];
+        int nx_nl[RPL];                // (link candidates: only without wave L)
+        unsigned long long nx_link[RPL];
         double nx_fin[RPL];
         auto load_a = [&](long long gcx, int lcx)
         {
@@ -186,6 +195,8 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
             {
                 const int row = k * 64 + lane;
                 nx_term[k] = -1;
+                nx_nl[k] = 0;
+                nx_link[k] = 0;
                 nx_par[k] = -2;
                 nx_fin[k] = 0.;
                 if (row < R && gcx < col_end)
@@ -193,6 +204,11 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                     nx_par[k] = p.sc_parent[lcx * R + row];
                     nx_fin[k] = p.sc_fin[lcx * R + row];
                     nx_term[k] = p.sc_term[lcx * R + row];
+                    if (!lwave)
+                    {
+                        nx_nl[k] = p.sc_nlinks[lcx * R + row];
+                        nx_link[k] = p.sc_links[lcx * R + row]; // (stale where the point has no links: never looked at)
+                    }
                 }
             }
             if (lane == 0 && gcx < col_end)
@@ -244,11 +260,14 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
 #ifdef CC_A2_STATS
             const unsigned long long st_ta = __builtin_amdgcn_s_memtime();
 #endif
-            int term[RPL], parc[RPL];
+            int term[RPL], parc[RPL], nlk[RPL];
+            unsigned long long lk[RPL];
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
                 term[k] = nx_term[k];
+                nlk[k] = nx_nl[k];
+                lk[k] = nx_link[k];
                 parc[k] = nx_par[k];
                 const int row = k * 64 + lane;
                 if (row < R) // stage what wave B needs of this column
@@ -259,6 +278,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                 }
             }
             const int cnt_new = uniform_i32(nx_info) & 0xff;
+            const bool col_links = !lwave && ((uniform_i32(nx_info) >> 8) & 2);
             {
                 const int lc1 = lc + 1 == RC ? 0 : lc + 1;
                 load_a(gcA + 1, lc1); // prefetch
@@ -298,10 +318,38 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                 if (row < R)
                     wcol[row] = (short) ent[k];
             }
+            // Links (further accepted candidates) only matter where they lead to another tree, which is rare (two trees of one object
+            // meeting). Without wave L this wave looks the targets up and tells wave B whether the column has any.
+            int foreign = 0;
+            if (col_links && bad == 0)
+            {
+                wave_lds_fence(); // same-column targets: read what was just written
+                bool f = false;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int mine = ent[k] & A2_IDMASK;
+                    int v[LINK_SLOTS];
+#pragma unroll
+                    for (int j = 0; j < LINK_SLOTS; j++)
+                    {
+                        v[j] = -1;
+                        if (term[k] >= 0 && j < nlk[k])
+                        {
+                            const int code = (int) ((lk[k] >> (16 * j)) & 0xffff);
+                            v[j] = s_win[((wcur - (code >> 8)) & (WIN2_COLS - 1)) * R + (code & 0xff)];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < LINK_SLOTS; j++)
+                        f |= v[j] >= 0 && (v[j] & A2_IDMASK) != mine;
+                }
+                foreign = __any(f) ? 16 : 0;
+            }
             if (lane == 0)
             {
                 T.info_head[(int) (gcA & (A2_INFO - 1))] = head;
-                T.info_bad[(int) (gcA & (A2_INFO - 1))] = bad;
+                T.info_bad[(int) (gcA & (A2_INFO - 1))] = bad | foreign;
             }
             wave_lds_fence();
             if (lane == 0)
@@ -694,7 +742,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         if (lane == 0)
             lds_st(&T.cmd, (int) A2_PARK);
         int spins = 0;
-        while (uniform_i32(lds_ld(&T.a_parked)) == 0 || uniform_i32(lds_ld(&r_parked)) == 0 || uniform_i32(lds_ld(&l_parked)) == 0)
+        while (uniform_i32(lds_ld(&T.a_parked)) == 0 || uniform_i32(lds_ld(&r_parked)) == 0 || (lwave && uniform_i32(lds_ld(&l_parked)) == 0))
         {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > A2_SPIN_LIMIT)
@@ -728,6 +776,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         for (int spins = 0; a_seen < upto;)
         {
             a_seen = uniform_i64(lds_ld(&r_done)); // (records ready = resolved by wave A and summarised by wave R ...
+            if (lwave)
             {
                 const long long l_seen = uniform_i64(lds_ld(&l_done)); // ... and the links looked at by wave L)
                 a_seen = l_seen < a_seen ? l_seen : a_seen;

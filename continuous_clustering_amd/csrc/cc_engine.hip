@@ -66,7 +66,9 @@ struct cc_engine
     int scan_packed{-1};                // option "scan_packed": 1 = k_scan2 (active points packed into the lanes), 0 = k_scan (rows as lanes, lock
                                         // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch;
                                         // at 64 rows the lock-step kernel is 3 % ahead inside the pipeline although it issues 1.5 x the instructions)
-    int assoc_waves{3};                 // option "assoc_waves": 2 = k_assoc2 (front / back wavefronts), 1 = k_assoc_lds
+    int assoc_waves{3};                 // option "assoc_waves": 1 = k_assoc_lds, 2 = k_assoc2 (front / back wavefronts), 3 / 4 = k_assoc3
+                                        // without / with its links wavefront
+    bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 128 streams
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
     std::string error;
@@ -518,12 +520,16 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // ---- association + publish chain -------------------------------------------------------------------------
     CC_MARK(sa); // ev6: start of the third chain
     // k_assoc2 walks the finished-cluster checks of several columns at once and assumes one check per column
-    if (e->assoc_waves == 3 && e->cfg.cluster_point_trees_every_nth_column == 1)
+    if (e->assoc_waves >= 3 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
+        // with or without the links wave (cc_assoc3.h: A3_THREADS): by default (assoc_waves = 0) with it while the streams are few
+        // enough for the association chain to be what the step waits for
+        const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= 128);
+        const dim3 block(lwave ? cck::A3_THREADS : 192);
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), dim3(cck::A3_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), dim3(cck::A3_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
     else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
@@ -1679,7 +1685,11 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "input_on_engine_stream")
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")
-        e->assoc_waves = value == 1 ? 1 : (value == 2 ? 2 : 3);
+    {
+        // 1: k_assoc_lds, 2: k_assoc2, 3: k_assoc3 without the links wave, 4: with it, 0 (default): k_assoc3, links wave up to 128 streams
+        e->assoc_waves_auto = value <= 0 || value > 4;
+        e->assoc_waves = e->assoc_waves_auto ? 3 : (int) value;
+    }
     else if (n == "scan_packed")
     {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);

@@ -270,8 +270,10 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * continues in the global-memory association kernel, 1..256), "limit_columns" (columns one launch may emit per stream before
  * it hands back to the host), "pipeline" (0: run the kernel chains of cc_engine_add_firings_device back to back on one
  * HIP stream; 1 (default): overlap consecutive batches on three chains, with the per-point preparation of the next batch running
- * ahead; 2: window scan on a fourth chain), "assoc_waves" (2 (default): two cooperating wavefronts per stream in the association
- * kernel; 1: the one-wavefront kernel, which is also what cluster_point_trees_every_nth_column != 1 uses), "sub_batch" (firings
+ * ahead; 2: window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
+ * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 128 streams; 3 / 4: k_assoc3 without / with
+ * the links wavefront; 2: k_assoc2 (front / back wavefronts); 1: the one-wavefront kernel, which is also what
+ * cluster_point_trees_every_nth_column != 1 uses), "sub_batch" (firings
  * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never
  * use the captured-hipGraph low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in
  * production), "parallel_insert" (1 (default): the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a

@@ -100,12 +100,24 @@ def test_single_wave_association_kernel(name, oracle_lib):
     assert summary["clusters"] >= 3
 
 
-def test_two_wave_kernel_rolls_back_speculation(oracle_lib):
-    """Small calls make the front wavefront of k_assoc2 run ahead of freshly finished trees on every launch; the serially
-    replayed columns must show up (error_b doubles as their count) and nothing may change."""
+@pytest.mark.parametrize("waves", [0, 2, 3, 4])
+def test_cooperating_wave_kernels_roll_back_speculation(waves, oracle_lib):
+    """Small calls make the resolving wavefront of k_assoc2 / k_assoc3 run ahead of freshly finished trees on every launch; the serially
+    replayed columns must show up (error_b doubles as their count) and nothing may change. assoc_waves: 2 = k_assoc2, 3 / 4 = k_assoc3
+    without / with its links wavefront, 0 = the default choice."""
     stream, cfg, tf = cases.build_case("s64_forced_finish_ring")
-    summary = util.run_and_compare(stream, cfg, chunks=[37, 5, 211], robot_tf=tf)
+    summary = util.run_and_compare(stream, cfg, chunks=[37, 5, 211], robot_tf=tf, engine_setup=lambda e: e.set_option("assoc_waves", waves))
     assert summary["engine_state"]["error_b"] > 0
+
+
+@pytest.mark.parametrize("name,waves", [("s64_translate", 3), ("s64_no_early_stop", 3), ("s128_full_1700", 3), ("j_s64_jitter_wide", 3),
+                                        ("s64_translate", 2), ("s128_offsets", 2), ("s64_dropouts", 4), ("s128_full_1700", 4)])
+def test_association_kernel_selection(name, waves, oracle_lib):
+    """Every association kernel the option can select reproduces the oracle (the default — k_assoc3, links wavefront for up to 128
+    streams per launch — is what every other test runs)."""
+    stream, cfg, tf = cases.build_case(name)
+    util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns, 97]), robot_tf=tf,
+                         engine_setup=lambda e: e.set_option("assoc_waves", waves))
 
 
 @pytest.mark.parametrize("name,option,value", [
