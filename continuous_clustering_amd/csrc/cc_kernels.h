@@ -1205,7 +1205,10 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 // =====================================================================================================
 // 8 wavefronts per block: alone the kernel is faster with 16 (0.70 vs 0.8 ms), but in the pipeline it shares every CU with the
 // segmentation / scan kernels, and the step is 4 % shorter when it holds half the registers and wave slots
-constexpr int IP_WAVES = 8, IP_MAXF = 4608;
+#ifndef CC_IP_WAVES
+#define CC_IP_WAVES 8
+#endif
+constexpr int IP_WAVES = CC_IP_WAVES, IP_MAXF = 4608;
 
 template<int RPL>
 __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
