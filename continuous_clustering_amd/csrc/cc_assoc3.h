@@ -519,7 +519,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                     rc_n[sc] = (unsigned char) ((nr > A3_REC || any_orphan) ? 255 : nr);
                     bt_n[sc] = (unsigned char) (nb > A3_BIRTH ? 255 : nb);
                 }
-                // tree roots
+                // tree roots (handing them to the links wave, which then has to run behind this one, made the chain 3 % slower)
                 wave_lds_fence();
 #pragma unroll
                 for (int k = 0; k < RPL; k++)
@@ -1116,15 +1116,23 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
 #pragma unroll
                 for (int u = 0; u < G; u++)
                     cfv[u] = cf[u * 64 + lane];
+                unsigned hit = 0; // bit u: this lane's cluster is not ahead of column u's smallest azimuth
 #pragma unroll
                 for (int u = 0; u < G; u++)
                     if (u >= u0 && u < gcount)
                     {
                         run = cfv[u] > run ? cfv[u] : run;
                         const double mz = lane_f64(v_minaz, u);
-                        if (__ballot(isrep && !(__longlong_as_double((long long) run) > mz)))
-                            m_alarm |= 1ull << u;
+                        hit |= !(__longlong_as_double((long long) run) > mz) ? (1u << u) : 0u;
                     }
+                hit = isrep ? hit : 0u;
+                if (__any(hit != 0)) // (most groups finish nothing)
+                {
+#pragma unroll
+                    for (int u = 0; u < G; u++)
+                        if (__ballot((hit >> u) & 1u))
+                            m_alarm |= 1ull << u;
+                }
             }
             if (rewalk)
             {
