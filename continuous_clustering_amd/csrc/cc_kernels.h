@@ -2104,11 +2104,17 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         load_cells(c_lo, lc, cell_tag(pass));
         load_tags(c_lo + 1, lc + 1 == RC ? 0 : lc + 1);
     }
+    CazBase cb = caz_base_of_rotation(rot); // (recomputed where the rotation changes: two f64 products and two 64-bit conversions)
+    long long cb_rot = rot;
     for (long long gc = c_lo; gc < c_hi; gc++, pass += (lc + 1 == RC ? 1 : 0), lc = (lc + 1 == RC ? 0 : lc + 1), rot += (cir + 1 == NC ? 1 : 0),
                    cir = (cir + 1 == NC ? 0 : cir + 1))
     {
         const size_t base = (size_t) lc * R;
-        const CazBase cb = caz_base_of_rotation(rot);
+        if (rot != cb_rot)
+        {
+            cb = caz_base_of_rotation(rot);
+            cb_rot = rot;
+        }
         const uint16_t tag = cell_tag(pass);
         // this column's inputs (arrived during the previous column), then the loads of the next one
         uint16_t c_tg[RPL];
@@ -3384,13 +3390,19 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
     int cir = (int) ((st->batch[slot].acp_next + blockIdx.y) - rot * NC);
     const int cir_step = (int) (gridDim.y % (unsigned) NC);
     const long long rot_step = (long long) (gridDim.y / (unsigned) NC);
+    CazBase cb = caz_base_of_rotation(rot);
+    long long cb_rot = rot;
     for (long long gc = st->batch[slot].acp_next + blockIdx.y; gc < col_end;
          gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step), rot += rot_step + (cir + cir_step >= NC ? 1 : 0),
                    cir = (cir + cir_step >= NC ? cir + cir_step - NC : cir + cir_step))
     {
         // never look at columns older than the first column ever segmented (their planes are uninitialised)
         const int bound = (gc - first_column) <= (long long) cfg.max_steps_in_row + 1 ? first_lc : -1;
-        const CazBase cb = caz_base_of_rotation(rot);
+        if (rot != cb_rot)
+        {
+            cb = caz_base_of_rotation(rot);
+            cb_rot = rot;
+        }
         int parent[RPL], nlinks[RPL];
         double fin[RPL];
         unsigned long long packed[RPL];

@@ -18,6 +18,13 @@ tools/pmc_sq.sh $tag "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD 
                      "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" > $out/sq.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 3 \
   --no-cpu-baseline --no-latency --no-s128 > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
+# every kernel alone (pipeline 0), association with / without its links wavefront; stream-count sweep; per-wave cycle counters (instrumented build)
+CC_ASSOC_WAVES=4 python tools/kernel_times.py 2>&1 | grep "^pipeline" > $out/kernel_times_assoc_waves4.txt
+CC_ASSOC_WAVES=3 python tools/kernel_times.py 2>&1 | grep "^pipeline" > $out/kernel_times_assoc_waves3.txt
+for S in 32 64 128 256 384 512; do
+  python bench.py --streams $S --steps 30 --no-cpu-baseline --no-latency --no-verify --no-s128 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('streams', $S, 'Mpoints/s', round(d['value']), 'ms_per_step', round(d['ms_per_step'],3), 'dominant', d['roofline']['kernel'], 'launch_ms', round(d['roofline']['launch_ms'],3))"
+done > $out/stream_sweep.txt
+[ -f continuous_clustering_amd/libcc_hip_a2stats.so ] && python tools/prof_assoc2_stats.py > $out/assoc_wave_stats.txt 2>&1
 cp $repo/gpurun_out/prof_$tag/*kernel_stats.csv $out/kernel_stats_s64.csv 2>/dev/null
 cp $repo/gpurun_out/prof_${tag}_s128/*kernel_stats.csv $out/kernel_stats_s128.csv 2>/dev/null
 cp $repo/gpurun_out/prof_$tag/bench_line.json $out/prof_bench_line.json 2>/dev/null
