@@ -2333,9 +2333,15 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
 // One lane per column on LDS-transposed tiles of 64 columns: global traffic is coalesced (lanes = rows while loading and
 // storing), the bottom-to-top scan of each lane reads conflict-free LDS (odd row pitch).
 // grid = (tiles of 64 columns, streams), block = 64, dynamic LDS = seg_scan_lds_bytes(num_rows).
+// The look-back of the state machine (cc.cpp:513-535) walks down from a new obstacle over the ground cells right below it: rarely more
+// than a few rows. The tile keeps the azimuth-plane distance of the 16 rows [chunk, chunk + 15] per column (a ring indexed by row & 15) and
+// reads deeper rows from the staging plane — 8.7 KB per wavefront instead of 21: this kernel is one wavefront per block, so its LDS is what
+// limits how many of them share a CU with the other chains' blocks (10 KB more cost the whole step 6 %).
+constexpr int SEG_X2_RING = 16;
 __host__ __device__ inline int seg_pitch_f(int R)
 {
-    return R | 1; // odd number of words per column
+    (void) R;
+    return SEG_X2_RING + 1; // odd number of words per column
 }
 __host__ __device__ inline int seg_pitch_b(int R)
 {
@@ -2444,7 +2450,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (b + u >= 0)
-                    x2[b + u] = x8[u];
+                    x2[(b + u) & (SEG_X2_RING - 1)] = x8[u];
 #pragma unroll
             for (int u = 7; u >= 0; u--)
             {
@@ -2532,7 +2538,8 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                     const unsigned char bo = oo[below];
                     const unsigned char bg = bo & 7, bd = (bo >> 3) & 15;
                     if (bd == SG_D_YELLOW ||
-                        (bg == SG_G_GROUND && ccm::absf(cur2x - x2[below]) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
+                        (bg == SG_G_GROUND && ccm::absf(cur2x - (below < b + SEG_X2_RING ? x2[below & (SEG_X2_RING - 1)] : gx[below])) <
+                                                  cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
                     {
                         if (bg == SG_G_GROUND)
                         {
