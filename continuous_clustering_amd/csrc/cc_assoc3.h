@@ -12,9 +12,9 @@
 
 constexpr int A3_REC = 8;   // records (trees receiving points) per column
 constexpr int A3_THREADS = 256; // four wavefronts: A (resolve ids), B (apply + finish), R (records + roots), L (links). Launched with 192
-                                // threads the kernel runs without wave L and wave A looks at the links itself: one wavefront less per
-                                // stream for the throughput kernels it shares the GPU with (2 % on the 256-stream step), a slower chain
-                                // (1.78 instead of 1.54 ms per 2200 columns) where the streams are few and the chain is what one waits for
+                                // threads the kernel runs without wave L and wave A looks at the links itself (1.74 instead of 1.55 ms per
+                                // 2200 columns): one wavefront less per stream for the throughput kernels it shares the GPU with, which
+                                // only pays when a launch has more streams than CUs (cc_engine.hip: CC_LWAVE_MAX_STREAMS)
 constexpr int A3_BIRTH = 8; // new roots per column kept inline (must equal A3_REC: one lane per (column, slot))
 
 template<int RPL>

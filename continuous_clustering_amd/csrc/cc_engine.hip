@@ -68,7 +68,7 @@ struct cc_engine
                                         // at 64 rows the lock-step kernel is 3 % ahead inside the pipeline although it issues 1.5 x the instructions)
     int assoc_waves{3};                 // option "assoc_waves": 1 = k_assoc_lds, 2 = k_assoc2 (front / back wavefronts), 3 / 4 = k_assoc3
                                         // without / with its links wavefront
-    bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 128 streams
+    bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 256 streams
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
     std::string error;
@@ -524,7 +524,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     {
         // with or without the links wave (cc_assoc3.h: A3_THREADS): by default (assoc_waves = 0) with it while the streams are few
         // enough for the association chain to be what the step waits for
-        const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= 128);
+        #ifndef CC_LWAVE_MAX_STREAMS
+#define CC_LWAVE_MAX_STREAMS 256
+#endif
+        const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= CC_LWAVE_MAX_STREAMS);
         const dim3 block(lwave ? cck::A3_THREADS : 192);
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -1686,7 +1689,7 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")
     {
-        // 1: k_assoc_lds, 2: k_assoc2, 3: k_assoc3 without the links wave, 4: with it, 0 (default): k_assoc3, links wave up to 128 streams
+        // 1: k_assoc_lds, 2: k_assoc2, 3: k_assoc3 without the links wave, 4: with it, 0 (default): k_assoc3, links wave up to 256 streams
         e->assoc_waves_auto = value <= 0 || value > 4;
         e->assoc_waves = e->assoc_waves_auto ? 3 : (int) value;
     }

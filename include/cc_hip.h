@@ -271,7 +271,7 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * it hands back to the host), "pipeline" (0: run the kernel chains of cc_engine_add_firings_device back to back on one
  * HIP stream; 1 (default): overlap consecutive batches on three chains, with the per-point preparation of the next batch running
  * ahead; 2: window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
- * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 128 streams; 3 / 4: k_assoc3 without / with
+ * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 256 streams; 3 / 4: k_assoc3 without / with
  * the links wavefront; 2: k_assoc2 (front / back wavefronts); 1: the one-wavefront kernel, which is also what
  * cluster_point_trees_every_nth_column != 1 uses), "sub_batch" (firings
  * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never

@@ -113,7 +113,7 @@ def test_cooperating_wave_kernels_roll_back_speculation(waves, oracle_lib):
 @pytest.mark.parametrize("name,waves", [("s64_translate", 3), ("s64_no_early_stop", 3), ("s128_full_1700", 3), ("j_s64_jitter_wide", 3),
                                         ("s64_translate", 2), ("s128_offsets", 2), ("s64_dropouts", 4), ("s128_full_1700", 4)])
 def test_association_kernel_selection(name, waves, oracle_lib):
-    """Every association kernel the option can select reproduces the oracle (the default — k_assoc3, links wavefront for up to 128
+    """Every association kernel the option can select reproduces the oracle (the default — k_assoc3, links wavefront for up to 256
     streams per launch — is what every other test runs)."""
     stream, cfg, tf = cases.build_case(name)
     util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns, 97]), robot_tf=tf,
