@@ -99,6 +99,12 @@ def build_case(name: str):
     if name == "s64_robot_tf_tilted":
         cfg = _kitti(720)
         return synth.make_stream(720 * 2 + 50, seed=16, sensor=_s64(720), motion=Motion.turn(8.0, 0.3)), cfg, ROBOT_TF_TILTED
+    if name == "s64_deep_lookback":
+        # everything "flat" and every ground cell below a new obstacle "close": the downward fix-up of cc.cpp:513-535 relabels runs of up to
+        # 62 rows, far beyond the 16 rows k_seg_scan keeps in LDS (it reads the rest from the staging plane)
+        cfg = _kitti(360, max_slope=5.0, obstacle_because_next_certain_obstacle_max_dist_diff=1.0e6)
+        sc = SceneModel(n_objects=30, object_range=(3.0, 15.0))
+        return synth.make_stream(360 * 2 + 50, seed=31, sensor=_s64(360), scene=sc), cfg, None
     if name == "s128_offsets":
         return synth.make_stream(680 * 3, seed=17, sensor=_s128(680), start_column=20), _vls(680), None
     if name == "s128_no_offsets_translate":

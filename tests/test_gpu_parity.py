@@ -110,6 +110,17 @@ def test_cooperating_wave_kernels_roll_back_speculation(waves, oracle_lib):
     assert summary["engine_state"]["error_b"] > 0
 
 
+def test_segmentation_look_back_beyond_the_lds_ring(oracle_lib):
+    """k_seg_scan keeps the azimuth-plane distance of 16 rows per column in LDS; the downward fix-up (cc.cpp:513-535) of this case walks over
+    up to 62 ground cells, so most of its reads come from the staging plane."""
+    stream, cfg, tf = cases.build_case("s64_deep_lookback")
+    oracle, rc = util.run_oracle(stream, cfg, tf)
+    dbg = np.asarray(oracle.read_published(0, 400)["debug_ground_point_label"])
+    runs = [max(len(r) for r in "".join("x" if v == 32 else " " for v in col).split()) if (col == 32).any() else 0 for col in dbg]  # 32 = dark red
+    assert max(runs) > 40 and sum(r > 16 for r in runs) > 100
+    util.run_and_compare(stream, cfg, chunks=[360, 97], robot_tf=tf)
+
+
 @pytest.mark.parametrize("name,waves", [("s64_translate", 3), ("s64_no_early_stop", 3), ("s128_full_1700", 3), ("j_s64_jitter_wide", 3),
                                         ("s64_translate", 2), ("s128_offsets", 2), ("s64_dropouts", 4), ("s128_full_1700", 4)])
 def test_association_kernel_selection(name, waves, oracle_lib):

@@ -259,7 +259,7 @@ class Independent:
 
 
 INDEPENDENT_CASES = ["g_s64_translate", "g_s64_fog_and_ego", "g_s128_offsets", "s64_turn", "s64_counterclockwise", "s64_dropouts",
-                     "s64_no_supplement_no_incl_ignore", "s32_small_sensor", "j_s64_jitter", "j_s64_jitter_wide", "j_s128_offsets_jitter"]
+                     "s64_no_supplement_no_incl_ignore", "s32_small_sensor", "j_s64_jitter", "j_s64_jitter_wide", "j_s128_offsets_jitter", "s64_deep_lookback"]
 
 
 @pytest.mark.parametrize("name", INDEPENDENT_CASES)
