@@ -2096,13 +2096,18 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         if (gcx < c_hi)
             n_trig = p.trig[lcx];
     };
+    // (two rows per lane: the second set of cell registers costs more occupancy than the read-ahead hides — only the tags run ahead)
+    constexpr bool CELLS_AHEAD = RPL == 1;
     {
         load_tags(c_lo, lc);
+        if (CELLS_AHEAD)
+        {
 #pragma unroll
-        for (int k = 0; k < RPL; k++)
-            n_tg[k] = a_tg[k];
-        load_cells(c_lo, lc, cell_tag(pass));
-        load_tags(c_lo + 1, lc + 1 == RC ? 0 : lc + 1);
+            for (int k = 0; k < RPL; k++)
+                n_tg[k] = a_tg[k];
+            load_cells(c_lo, lc, cell_tag(pass));
+            load_tags(c_lo + 1, lc + 1 == RC ? 0 : lc + 1);
+        }
     }
     CazBase cb = caz_base_of_rotation(rot); // (recomputed where the rotation changes: two f64 products and two 64-bit conversions)
     long long cb_rot = rot;
@@ -2117,6 +2122,14 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         }
         const uint16_t tag = cell_tag(pass);
         // this column's inputs (arrived during the previous column), then the loads of the next one
+        if (!CELLS_AHEAD)
+        {
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+                n_tg[k] = a_tg[k];
+            load_cells(gc, lc, tag);
+            load_tags(gc + 1, lc + 1 == RC ? 0 : lc + 1);
+        }
         uint16_t c_tg[RPL];
         float c_dist[RPL], c_incaz[RPL];
         float4 c_rec[RPL];
@@ -2129,10 +2142,12 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             c_incaz[k] = n_incaz[k];
             c_rec[k] = n_rec[k];
             c_inten[k] = n_inten[k];
-            n_tg[k] = a_tg[k];
+            if (CELLS_AHEAD)
+                n_tg[k] = a_tg[k];
         }
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
         const int trig = uniform_i32(n_trig); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
+        if (CELLS_AHEAD)
         {
             const int lc1 = lc + 1 == RC ? 0 : lc + 1, lc2 = lc1 + 1 == RC ? 0 : lc1 + 1;
             load_cells(gc + 1, lc1, cell_tag(pass + (lc + 1 == RC ? 1 : 0)));
