@@ -2052,12 +2052,13 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     long long rot = c_lo / NC;
     int cir = (int) (c_lo - rot * NC);
     long long pass = c_lo / RC; // pass over the ring (cell_tag)
-    // The columns of a chunk are latency chains (cells -> LDS recurrence -> stores): the cells of the NEXT column are loaded before
-    // the current one is worked on, and the ring-pass tags (which say which cells hold a record at all) one column before that.
-    uint16_t a_tg[RPL];            // tags of column gc + 1 (two columns ahead when they are loaded)
+    // The ring-pass tags (which say which cells hold a record at all) are loaded one column ahead, the cells at the top of their column.
+    // (Loading the cells a column ahead as well cost a second set of cell registers — 87 instead of 69 VGPRs — and with them more
+    // occupancy than the read-ahead hid: − 2 % on the step at 64 rows, − 4 % at 128.)
+    uint16_t a_tg[RPL];            // tags of column gc + 1
     uint16_t n_tg[RPL];            // column gc's tags ...
     float n_dist[RPL], n_incaz[RPL];
-    float4 n_rec[RPL];             // ... and cells, loaded one column ahead
+    float4 n_rec[RPL];             // ... and cells
     uint8_t n_inten[RPL];
     int n_trig = 0;
     auto load_tags = [&](const long long gcx, const int lcx)
@@ -2096,19 +2097,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         if (gcx < c_hi)
             n_trig = p.trig[lcx];
     };
-    // (two rows per lane: the second set of cell registers costs more occupancy than the read-ahead hides — only the tags run ahead)
-    constexpr bool CELLS_AHEAD = RPL == 1;
-    {
-        load_tags(c_lo, lc);
-        if (CELLS_AHEAD)
-        {
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-                n_tg[k] = a_tg[k];
-            load_cells(c_lo, lc, cell_tag(pass));
-            load_tags(c_lo + 1, lc + 1 == RC ? 0 : lc + 1);
-        }
-    }
+    load_tags(c_lo, lc);
     CazBase cb = caz_base_of_rotation(rot); // (recomputed where the rotation changes: two f64 products and two 64-bit conversions)
     long long cb_rot = rot;
     for (long long gc = c_lo; gc < c_hi; gc++, pass += (lc + 1 == RC ? 1 : 0), lc = (lc + 1 == RC ? 0 : lc + 1), rot += (cir + 1 == NC ? 1 : 0),
@@ -2121,8 +2110,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             cb_rot = rot;
         }
         const uint16_t tag = cell_tag(pass);
-        // this column's inputs (arrived during the previous column), then the loads of the next one
-        if (!CELLS_AHEAD)
+        // this column's cells (its tags arrived during the previous column), then the tags of the next one
         {
 #pragma unroll
             for (int k = 0; k < RPL; k++)
@@ -2142,17 +2130,9 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             c_incaz[k] = n_incaz[k];
             c_rec[k] = n_rec[k];
             c_inten[k] = n_inten[k];
-            if (CELLS_AHEAD)
-                n_tg[k] = a_tg[k];
         }
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
         const int trig = uniform_i32(n_trig); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
-        if (CELLS_AHEAD)
-        {
-            const int lc1 = lc + 1 == RC ? 0 : lc + 1, lc2 = lc1 + 1 == RC ? 0 : lc1 + 1;
-            load_cells(gc + 1, lc1, cell_tag(pass + (lc + 1 == RC ? 1 : 0)));
-            load_tags(gc + 2, lc2);
-        }
         const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) trig) * 12;
         // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301), prepared per firing by k_ego
         const double* E = ego + ((size_t) sl * (size_t) n_batch + (size_t) trig) * 12;
