@@ -1122,7 +1122,9 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     e->g.tree_capacity = 1 << 15;
     e->g.record_events = num_streams == 1 ? 1 : 0;
     e->g.mirror_fields = e->g.record_events; // the host mirror's extra per-point fields: on where a host reads columns back (1 stream)
-    e->g.link_capacity = 8192;
+    // tree links logged per stream and call for a host mirror (8 bytes each): with the early stop of the window scan switched off a point links
+    // up to LINK_SLOTS trees, and a call may carry several rotations — roomy where a mirror is likely (few streams), small otherwise
+    e->g.link_capacity = num_streams <= 8 ? (1 << 20) : 8192;
     fill_geometry(e, num_rows);
     e->g.event_capacity = e->g.record_events ? 3 * (e->g.limit_columns + e->g.num_columns) + 4096 : 1;
     e->pending_events.resize(num_streams);
