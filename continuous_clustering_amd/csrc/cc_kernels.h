@@ -3337,7 +3337,8 @@ __device__ __forceinline__ void scan_column_epilogue(const SP& p, const int R, c
     if (MIRROR)
         reach = -wave_min_i32(-reach);
     flags = (__any(flags & 1) ? 1 : 0) | (__any(flags & 2) ? 2 : 0);
-    newfin = wave_min_f64(newfin);
+    if (cnt_new > 0) // (wave-uniform; four columns of five have no new root, and the 64-bit reduction is ~30 instructions)
+        newfin = wave_min_f64(newfin);
     if (lane == 0)
     {
         p.col_newfin[lc] = newfin;
