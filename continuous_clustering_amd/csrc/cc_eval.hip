@@ -49,6 +49,9 @@ __global__ __launch_bounds__(256) void k_eval(long long n, const uint16_t* __res
             const unsigned long long key = ((unsigned long long) gt << 32) | det;
             unsigned long long h = key * 0x9E3779B97F4A7C15ull;
             unsigned slot = (unsigned) (h >> 40) & mask;
+            if (key == EMPTY) // (the one pair that looks like a free slot is counted beside the table)
+                atomicAdd(&counts4[4], 1ull);
+            else
             while (true)
             {
                 const unsigned long long old = atomicCAS(&keys[slot], EMPTY, key);
@@ -101,8 +104,10 @@ int cc_eval_frame_device(int64_t n, const uint16_t* d_semantic, const uint32_t* 
     memset(out, 0, sizeof(*out));
     if (n == 0)
         return CC_OK;
+    if (n > (1ll << 30)) // (the table holds at least two slots per point: open addressing never meets a full table)
+        return CC_ERR_INVALID_ARGUMENT;
     unsigned table = 1024;
-    while ((int64_t) table < 2 * n && table < (1u << 26))
+    while ((int64_t) table < 2 * n)
         table <<= 1;
     unsigned long long *d_keys = nullptr, *d_counts = nullptr, *d_okeys = nullptr;
     unsigned *d_vals = nullptr, *d_ovals = nullptr, *d_on = nullptr;
@@ -112,18 +117,22 @@ int cc_eval_frame_device(int64_t n, const uint16_t* d_semantic, const uint32_t* 
             (void) hipFree(d_on);
         return CC_ERR_HIP;
     };
-    if (hipMalloc(&d_keys, (size_t) table * 8) || hipMalloc(&d_vals, (size_t) table * 4) || hipMalloc(&d_counts, 32) ||
+    if (hipMalloc(&d_keys, (size_t) table * 8) || hipMalloc(&d_vals, (size_t) table * 4) || hipMalloc(&d_counts, 40) ||
         hipMalloc(&d_okeys, (size_t) table * 8) || hipMalloc(&d_ovals, (size_t) table * 4) || hipMalloc(&d_on, 4))
         return fail();
-    if (hipMemset(d_keys, 0xFF, (size_t) table * 8) || hipMemset(d_vals, 0, (size_t) table * 4) || hipMemset(d_counts, 0, 32) ||
+    if (hipMemset(d_keys, 0xFF, (size_t) table * 8) || hipMemset(d_vals, 0, (size_t) table * 4) || hipMemset(d_counts, 0, 40) ||
         hipMemset(d_on, 0, 4))
         return fail();
     hipLaunchKernelGGL(k_eval, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, (long long) n, d_semantic, d_euclid, d_is_ground,
                        d_detection, d_counts, d_keys, d_vals, table - 1);
+    if (hipGetLastError() != hipSuccess)
+        return fail();
     hipLaunchKernelGGL(k_eval_compact, dim3((table + 255) / 256), dim3(256), 0, 0, table, d_keys, d_vals, d_okeys, d_ovals, d_on);
-    unsigned long long counts[4];
+    if (hipGetLastError() != hipSuccess)
+        return fail();
+    unsigned long long counts[5];
     unsigned npairs = 0;
-    if (hipMemcpy(counts, d_counts, 32, hipMemcpyDeviceToHost) || hipMemcpy(&npairs, d_on, 4, hipMemcpyDeviceToHost))
+    if (hipMemcpy(counts, d_counts, 40, hipMemcpyDeviceToHost) || hipMemcpy(&npairs, d_on, 4, hipMemcpyDeviceToHost))
         return fail();
     std::vector<unsigned long long> hk(npairs);
     std::vector<unsigned> hv(npairs);
@@ -140,6 +149,8 @@ int cc_eval_frame_device(int64_t n, const uint16_t* d_semantic, const uint32_t* 
     std::vector<Pair> pairs(npairs);
     for (unsigned i = 0; i < npairs; i++)
         pairs[i] = Pair{(uint32_t) (hk[i] >> 32), (uint32_t) hk[i], hv[i]};
+    if (counts[4])
+        pairs.push_back(Pair{0xffffffffu, 0xffffffffu, (unsigned) counts[4]});
     // over-segmentation entropy (kitti_evaluation.cpp:102-116): ground-truth clusters != 0 in ascending order, inside each the
     // detections (0 included) in ascending order
     std::sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.gt != b.gt ? a.gt < b.gt : a.det < b.det; });

@@ -17,6 +17,14 @@ def test_label_compare_matches_oracle_bit_exact(oracle_lib):
         f = random_frame(rng, n, n_gt, n_det)
         a, b = evaluation.eval_frame(*f), pyoracle.eval_frame(*f)
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (n, a, b)
+    # the pair (0xFFFFFFFF, 0xFFFFFFFF) has the bit pattern of a free slot of the device hash table: it is counted beside the table
+    f = [x.copy() for x in random_frame(rng, 5000, 10, 10)]
+    f[1] = f[1].astype(np.uint32)
+    f[3] = f[3].astype(np.uint32)
+    f[1][100:400] = 0xFFFFFFFF
+    f[3][100:300] = 0xFFFFFFFF
+    a, b = evaluation.eval_frame(*f), pyoracle.eval_frame(*f)
+    assert np.array_equal(a.view(np.uint64), b.view(np.uint64)), (a, b)
     z = np.zeros(0)
     assert evaluation.eval_frame(z, z, z, z).tolist() == [0.0] * 6
     # all unlabeled / all background
