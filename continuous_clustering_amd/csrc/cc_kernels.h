@@ -1619,18 +1619,58 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     int carry_cir = cir0; // its column-in-rotation
     int fore_rel = (int) (prev_fore0 - prev_rear0);
     long long done = cursor0;
+    // the inputs of the wavefront's NEXT firing (returns, intensities, pose: one lane per matrix element) are loaded before the current
+    // chunk is worked on: a chunk is a load -> ~300 instructions -> barrier chain, and two wavefronts per SIMD cannot hide the load
+    float nx_x[RPL], nx_y[RPL], nx_z[RPL];
+    uint8_t nx_i[RPL];
+    double nx_pose = 0.;
+    auto load_firing = [&](const long long f)
+    {
+        const size_t fi = fglob + (size_t) f;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            nx_x[k] = nx_y[k] = nx_z[k] = __builtin_nanf("");
+            nx_i[k] = 0;
+            if (row < R && f < n)
+            {
+                const size_t src = (fi * R + row) * 3;
+                nx_x[k] = xyz[src];
+                nx_y[k] = xyz[src + 1];
+                nx_z[k] = xyz[src + 2];
+                nx_i[k] = inten[fi * R + row];
+            }
+        }
+        if (f < n)
+            nx_pose = poses[fi * 12 + (size_t) (lane < 12 ? lane : 0)];
+    };
+    load_firing(cursor0 + wave);
     for (long long f0 = cursor0; f0 < n; f0 += IM_WAVES)
     {
         const long long f = f0 + wave;
         const bool mine = f < n;
         PreppedPoint q[RPL];
         int oc[RPL];
+        float cx[RPL], cy[RPL], cz[RPL];
+        uint8_t cint[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            cx[k] = nx_x[k];
+            cy[k] = nx_y[k];
+            cz[k] = nx_z[k];
+            cint[k] = nx_i[k];
+        }
+        double T[12]; // (wave-uniform: the matrix travels in SGPRs)
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            T[i] = lane_f64(nx_pose, i);
+        load_firing(f + IM_WAVES);
         // ---- prepare this wavefront's firing ------------------------------------------------------------------------------------
         int rear_cir = -1, span = 0;
         if (mine)
         {
-            const size_t fi = fglob + (size_t) f;
-            const double* T = poses + fi * 12;
             int c0 = -1;
 #pragma unroll
             for (int k = 0; k < RPL; k++)
@@ -1638,10 +1678,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                 const int row = k * 64 + lane;
                 q[k].cir = PP_SKIP;
                 if (row < R)
-                {
-                    const size_t src = (fi * R + row) * 3;
-                    q[k] = prep_point(xyz[src], xyz[src + 1], xyz[src + 2], T, clockwise, g.az_width);
-                }
+                    q[k] = prep_point(cx[k], cy[k], cz[k], T, clockwise, g.az_width);
                 const unsigned long long m = __ballot(q[k].cir != PP_SKIP && q[k].cir >= 0 && q[k].cir < NC);
                 if (c0 < 0 && m)
                     c0 = __builtin_amdgcn_readlane(q[k].cir, (int) __ffsll((long long) m) - 1);
@@ -1758,8 +1795,6 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
         // ---- accepted firings write their cells ------------------------------------------------------------------------------------
         if (mine && wave < stop)
         {
-            const size_t fi = fglob + (size_t) f;
-            const uint8_t* si = inten + fi * R;
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
@@ -1771,7 +1806,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                     const int lc = (int) ((unsigned) (lc0 + crel) - lcq * (unsigned) RC);
                     const size_t ci = (size_t) lc * R + row;
                     p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
-                    p.inten[ci] = si[row];
+                    p.inten[ci] = cint[k];
                     p.src[ci] = (uint32_t) (seq0 + (f - cursor0));
                     p.dist[ci] = q[k].dist;
                     p.incl[ci] = q[k].incl;
