@@ -321,7 +321,7 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
     # dominant single kernel (segment_ms is the sum of k_table + k_seg_pre + k_seg_scan, profiles/ lists them separately;
     # prep_ms covers k_insert_par — preparation fused with the block-parallel insertion — plus k_prep of what it left over;
     # insert_ms is the serial kernel k_insert2 behind it; above 64 rows the block-parallel kernel is k_insert_multi)
-    KERNEL_OF = {"prep_ms": "k_insert_par" if R <= 64 else "k_insert_multi", "insert_ms": "k_insert2", "scan_ms": "k_scan", "assoc_lds_ms": "k_assoc3",
+    KERNEL_OF = {"prep_ms": "k_insert_par" if R <= 64 else "k_insert_multi", "insert_ms": "k_insert2", "scan_ms": "k_scan" if R <= 64 else "k_scan2", "assoc_lds_ms": "k_assoc3",
                  "assoc_global_ms": "k_associate", "publish_ms": "k_publish"}
     dom = max(KERNEL_OF, key=lambda k: per_kernel.get(k, 0.0))
     cells_per_launch = float(S * F * R) / launches_per_step
