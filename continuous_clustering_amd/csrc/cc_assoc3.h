@@ -15,6 +15,7 @@ constexpr int A3_THREADS = 256; // four wavefronts: A (resolve ids), B (apply + 
                                 // threads the kernel runs without wave L and wave A looks at the links itself (1.74 instead of 1.55 ms per
                                 // 2200 columns): one wavefront less per stream for the throughput kernels it shares the GPU with, which
                                 // only pays when a launch has more streams than CUs (cc_engine.hip: CC_LWAVE_MAX_STREAMS)
+constexpr int A3_PSTAGE = 8; // columns of per-point inputs staged between wave A and wave R (power of two)
 constexpr int A3_BIRTH = 8; // new roots per column kept inline (must equal A3_REC: one lane per (column, slot))
 
 template<int RPL>
@@ -51,8 +52,11 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
     // per-point inputs of the columns between the two waves (parent code, finished_at), staged by wave A, which has the time: wave B
     // then issues no per-point global load at all, and its per-column loops are real loops over LDS (small code: the instruction
     // cache is shared and a fully unrolled group body does not fit)
-    __shared__ double st_fin[A2_STAGE * WAVE * RPL];
-    __shared__ short st_parent[A2_STAGE * WAVE * RPL];
+    // (only wave R reads them, right behind wave A: a ring of A3_PSTAGE columns, and wave A never runs further ahead of wave R than that.
+    // Staging all A2_STAGE columns cost 15 KB more LDS per block, which the other chains' blocks on the CU could not use: 32 KB more made the
+    // 256-stream step 8 % slower.)
+    __shared__ double st_fin[A3_PSTAGE * WAVE * RPL];
+    __shared__ short st_parent[A3_PSTAGE * WAVE * RPL];
     // per column between the records wave and wave B: what the column does to the tree state, as a few records instead of 64-128 points
     __shared__ short rc_id[A2_STAGE][A3_REC];                // trees that receive points of the column ...
     __shared__ unsigned short rc_cnt[A2_STAGE][A3_REC];      // ... how many ...
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         int head = 0;
         long long gcA = col_begin;
         int lc = (int) (col_begin % RC);
-        long long b_seen = col_begin;
+        long long b_seen = col_begin, r_seen = col_begin;
         int nx_term[RPL], nx_info = 0, nx_par[RPL];
         int nx_nl[RPL];                // (link candidates: only without wave L)
         unsigned long long nx_link[RPL];
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         int poll = 0;
         while (true)
         {
-            const bool idle = wait_park || gcA >= col_end || gcA - b_seen >= A2_LEAD;
+            const bool idle = wait_park || gcA >= col_end || gcA - b_seen >= A2_LEAD || gcA - r_seen >= A3_PSTAGE;
             if (idle || (++poll & 3) == 0)
             {
                 const int cmd = uniform_i32(lds_ld(&T.cmd));
@@ -238,6 +242,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                     head = uniform_i32(lds_ld(&T.head));
                     lc = (int) (gcA % RC);
                     b_seen = gcA;
+                    r_seen = gcA;
                     wait_park = false;
                     load_a(gcA, lc);
                     continue;
@@ -253,6 +258,15 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                     if (gcA - b_seen >= A2_LEAD)
                     {
                         __builtin_amdgcn_s_sleep(16); // wave B needs thousands of cycles per group: poll rarely
+                        continue;
+                    }
+                }
+                if (gcA - r_seen >= A3_PSTAGE) // the staging ring is full: wave R has to take a column first
+                {
+                    r_seen = uniform_i64(lds_ld(&r_done));
+                    if (gcA - r_seen >= A3_PSTAGE)
+                    {
+                        __builtin_amdgcn_s_sleep(1);
                         continue;
                     }
                 }
@@ -272,7 +286,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                 const int row = k * 64 + lane;
                 if (row < R) // stage what wave B needs of this column
                 {
-                    const int o = (int) (gcA & (A2_STAGE - 1)) * R + row;
+                    const int o = (int) (gcA & (A3_PSTAGE - 1)) * R + row;
                     st_parent[o] = (short) nx_par[k];
                     st_fin[o] = nx_fin[k];
                 }
@@ -441,8 +455,8 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                 {
                     const int row = k * 64 + lane;
                     const int rr = row < R ? row : 0;
-                    const int a = st_parent[sc * R + rr];
-                    const double f = st_fin[sc * R + rr];
+                    const int a = st_parent[(int) (gcR & (A3_PSTAGE - 1)) * R + rr];
+                    const double f = st_fin[(int) (gcR & (A3_PSTAGE - 1)) * R + rr];
                     const int b = s_win[(int) (gcR & (WIN2_COLS - 1)) * R + rr];
                     par[k] = row < R ? a : -2;
                     e[k] = row < R ? b : -1;
@@ -1339,7 +1353,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                     {
                         const int row = k * 64 + lane;
                         const int rr = row < R ? row : 0;
-                        const int par = row < R ? (int) st_parent[(int) (gcu & (A2_STAGE - 1)) * R + rr] : -2;
+                        const int par = row < R ? (int) p.sc_parent[lcu * R + rr] : -2; // (rare path: straight from HBM)
                         const int e = row < R ? (int) s_win[wcu * R + rr] : -1;
                         const int nlk = (par >= 0 && row < R) ? (int) p.sc_nlinks[lcu * R + row] : 0; // (rare path: straight from HBM)
                         if (nlk > 0)
