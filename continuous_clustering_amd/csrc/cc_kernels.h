@@ -2088,7 +2088,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     int cir = (int) (c_lo - rot * NC);
     long long pass = c_lo / RC; // pass over the ring (cell_tag)
     // The ring-pass tags (which say which cells hold a record at all) are loaded one column ahead, the cells at the top of their column.
-    // (Loading the cells a column ahead as well cost a second set of cell registers — 87 instead of 69 VGPRs — and with them more
+    // (Loading the cells a column ahead as well cost a second set of cell registers — 87 instead of 79 VGPRs — and with them more
     // occupancy than the read-ahead hid: − 2 % on the step at 64 rows, − 4 % at 128.)
     uint16_t a_tg[RPL];            // tags of column gc + 1
     uint16_t n_tg[RPL];            // column gc's tags ...
