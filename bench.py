@@ -51,7 +51,7 @@ MIRROR_ONLY_FIELDS = ("number_of_visited_neighbors", "finished_at_continuous_azi
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=80)  # (a timed region fills and drains a three-deep pipeline once: 40 steps read 5 % low)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=256, help="sensor streams per GPU")
     ap.add_argument("--firings", type=int, default=2200, help="firings per stream per step (2200 = one rotation)")
