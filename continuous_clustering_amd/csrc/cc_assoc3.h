@@ -19,7 +19,8 @@ constexpr int A3_PSTAGE = 8; // columns of per-point inputs staged between wave 
 constexpr int A3_BIRTH = 8; // new roots per column kept inline (must equal A3_REC: one lane per (column, slot))
 
 template<int RPL>
-__global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+                                                       int limited)
 {
     constexpr int G = RPL == 1 ? 8 : 4; // columns wave B handles per pass
     constexpr int A2_LEAD = a2_lead(RPL), A2_STAGE = a2_stage(RPL);
@@ -72,7 +73,11 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
     __shared__ int l_parked;
     __shared__ unsigned char l_foreign[A2_INFO];
 
-    const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
+    // limited: only up to where the batch-parallel kernel asked (the group it could not take); it is launched again behind this launch
+    const long long col_begin = st->batch[slot].acp_next, first_column = st->first_column;
+    const long long col_end = (limited && st->serial_until < st->batch[slot].seg_end) ? st->serial_until : st->batch[slot].seg_end;
+    if (col_begin >= col_end)
+        return;
     const int n_unf0 = st->n_unfinished;
     const int tree_limit = g.lds_tree_limit;
     if (n_unf0 > tree_limit)

@@ -92,6 +92,10 @@ struct StreamState
     uint64_t exceed_one_rotation; // how often cc.cpp:913-919 fired
     uint64_t serial_columns;      // columns that took the exact serial association path
     uint64_t stamp_alias_rounds;  // rounds whose min azimuth equalled the previous round's
+    uint64_t batch_columns;       // columns associated by the batch-parallel kernel (k_assocb)
+    uint64_t batch_bails;         // launches of k_assocb that handed the rest of their batch to the serial kernel
+    uint64_t batch_bail_reason[8]; // ... by reason (cc_assocb.h AB_BAIL_*)
+    int64_t serial_until;         // set by k_assocb when it stops in front of a group: a LIMITED launch of the serial kernel stops there
     // errors raised inside kernels
     uint64_t dbg[16];             // section cycle counters (CC_PROFILE_SECTIONS builds only): 0-7 insertion, 8-15 association
     int32_t error;

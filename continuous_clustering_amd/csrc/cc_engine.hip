@@ -68,6 +68,8 @@ struct cc_engine
                                         // at 64 rows the lock-step kernel is 3 % ahead inside the pipeline although it issues 1.5 x the instructions)
     int assoc_waves{3};                 // option "assoc_waves": 1 = k_assoc_lds, 2 = k_assoc2 (front / back wavefronts), 3 / 4 = k_assoc3
                                         // without / with its links wavefront
+    bool assoc_batch{true};             // option "assoc_batch": k_assocb in front of the serial association kernels
+    int assoc_rounds{2};                // option "assoc_rounds": (k_assocb, k_assoc3) pairs per batch; all but the last serial launch are limited
     bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 256 streams
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
@@ -519,6 +521,18 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     // ---- association + publish chain -------------------------------------------------------------------------
     CC_MARK(sa); // ev6: start of the third chain
+    // batch-parallel association in front of the serial kernels: it takes every group of columns in which nothing can differ from the
+    // reference's sequential semantics (cc_assocb.h) and stops in front of the first group that might. With k_assoc3 behind it the pair runs
+    // assoc_rounds times: a LIMITED launch of the serial kernel takes that one group, the batch-parallel kernel continues behind it; the last
+    // serial launch takes whatever is left of the batch.
+    const bool batch_assoc = e->assoc_batch && e->cfg.cluster_point_trees_every_nth_column == 1;
+    auto launch_assocb = [&]()
+    {
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_assocb<1>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else
+            hipLaunchKernelGGL(cck::k_assocb<2>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    };
     // k_assoc2 walks the finished-cluster checks of several columns at once and assumes one check per column
     if (e->assoc_waves >= 3 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
@@ -529,22 +543,36 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
 #endif
         const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= CC_LWAVE_MAX_STREAMS);
         const dim3 block(lwave ? cck::A3_THREADS : 192);
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-        else
-            hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        const int rounds = batch_assoc ? e->assoc_rounds : 1;
+        for (int r = 0; r < rounds; r++)
+        {
+            if (batch_assoc)
+                launch_assocb();
+            const int limited = r + 1 < rounds ? 1 : 0;
+            if (rpl == 1)
+                hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited);
+            else
+                hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited);
+        }
     }
     else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
+        if (batch_assoc)
+            launch_assocb();
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_assoc2<1>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else
             hipLaunchKernelGGL(cck::k_assoc2<2>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
-    else if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
-        hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    {
+        if (batch_assoc)
+            launch_assocb();
+        if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else
+            hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+    }
     CC_MARK(sa); // ev7: assoc_lds
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
     if (rpl == 1)
@@ -1695,6 +1723,10 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_waves_auto = value <= 0 || value > 4;
         e->assoc_waves = e->assoc_waves_auto ? 3 : (int) value;
     }
+    else if (n == "assoc_batch")
+        e->assoc_batch = value != 0;
+    else if (n == "assoc_rounds")
+        e->assoc_rounds = (int) (value < 1 ? 1 : (value > 8 ? 8 : value));
     else if (n == "scan_packed")
     {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);
@@ -1768,6 +1800,35 @@ int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters
         *firings_consumed = c;
     if (serial_columns)
         *serial_columns = d;
+    return CC_OK;
+}
+
+int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* batch_bails, uint64_t bail_reasons[8])
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    std::vector<StreamState> st(e->g.num_streams);
+    CC_HIP_CHECK(e, hipMemcpy(st.data(), e->d_states, st.size() * sizeof(StreamState), hipMemcpyDeviceToHost));
+    uint64_t a = 0, b = 0;
+    if (bail_reasons)
+        for (int i = 0; i < 8; i++)
+            bail_reasons[i] = 0;
+    for (auto& s : st)
+    {
+        a += s.batch_columns;
+        b += s.batch_bails;
+        if (bail_reasons)
+            for (int i = 0; i < 8; i++)
+                bail_reasons[i] += s.batch_bail_reason[i];
+    }
+    if (batch_columns)
+        *batch_columns = a;
+    if (batch_bails)
+        *batch_bails = b;
     return CC_OK;
 }
 

@@ -4731,6 +4731,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
 
 #include "cc_assoc2.h"
 #include "cc_assoc3.h"
+#include "cc_assocb.h"
 
 // =====================================================================================================
 // k_publish — cluster ids of the columns published in this pass: Point::id = id of the finished cluster of the point's

@@ -273,7 +273,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * ahead; 2: window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
  * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 256 streams; 3 / 4: k_assoc3 without / with
  * the links wavefront; 2: k_assoc2 (front / back wavefronts); 1: the one-wavefront kernel, which is also what
- * cluster_point_trees_every_nth_column != 1 uses), "sub_batch" (firings
+ * cluster_point_trees_every_nth_column != 1 uses), "assoc_batch" (1 (default): the batch-parallel association kernel runs in front of the
+ * serial one and takes every group of columns that cannot differ from the sequential semantics, see cc_engine_batch_counters; 0: serial
+ * kernels only), "sub_batch" (firings
  * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never
  * use the captured-hipGraph low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in
  * production), "parallel_insert" (1 (default): the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a
@@ -292,6 +294,14 @@ int cc_engine_kernel_times(cc_engine* e, double ms[7], uint64_t* launches);
 /* Sums over all streams (any pointer may be NULL). Implies sync. */
 int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters_finished, uint64_t* firings_consumed,
                      uint64_t* serial_columns);
+/* Sums over all streams: columns whose association + finished-cluster check (continuous_clustering.cpp:773-974) ran in the batch-parallel
+ * kernel (groups of up to 64 columns at once), and how often that kernel handed the rest of a batch to the exact serial kernel because a
+ * group could have differed from the reference's sequential semantics (attach to a finished tree, one-rotation limits, look-back past the
+ * first unpublished column, ...). Option "assoc_batch" = 0 takes the batch-parallel kernel out. Implies sync.
+ * bail_reasons[i] (may be NULL) counts them by reason: 1 more unfinished trees than the kernel's lanes, 2 link overflow, 3 a tree / cluster
+ * could reach the one-rotation limits (cc.cpp:657, 913-924), 4 a parent chain ends in a finished tree (cc.cpp:658), 5 a tree receives a point
+ * after its cluster finished, 6 a candidate from a column older than the first unpublished one (cc.cpp:762-763). */
+int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* batch_bails, uint64_t bail_reasons[8]);
 
 /* ---- label compare (src/evaluation/kitti_evaluation.cpp) ---------------------------------------------------------------- */
 /* EvaluationResultForFrame, kitti_evaluation.hpp:38-49 */

@@ -96,7 +96,7 @@ def test_single_wave_association_kernel(name, oracle_lib):
     option assoc_waves = 1 selects it for every configuration."""
     stream, cfg, tf = cases.build_case(name)
     summary = util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns]), robot_tf=tf,
-                                   engine_setup=lambda e: e.set_option("assoc_waves", 1))
+                                   engine_setup=lambda e: (e.set_option("assoc_waves", 1), e.set_option("assoc_batch", 0)))
     assert summary["clusters"] >= 3
 
 
@@ -106,7 +106,8 @@ def test_cooperating_wave_kernels_roll_back_speculation(waves, oracle_lib):
     replayed columns must show up (error_b doubles as their count) and nothing may change. assoc_waves: 2 = k_assoc2, 3 / 4 = k_assoc3
     without / with its links wavefront, 0 = the default choice."""
     stream, cfg, tf = cases.build_case("s64_forced_finish_ring")
-    summary = util.run_and_compare(stream, cfg, chunks=[37, 5, 211], robot_tf=tf, engine_setup=lambda e: e.set_option("assoc_waves", waves))
+    summary = util.run_and_compare(stream, cfg, chunks=[37, 5, 211], robot_tf=tf,
+                                   engine_setup=lambda e: (e.set_option("assoc_waves", waves), e.set_option("assoc_batch", 0)))
     assert summary["engine_state"]["error_b"] > 0
 
 
@@ -124,11 +125,54 @@ def test_segmentation_look_back_beyond_the_lds_ring(oracle_lib):
 @pytest.mark.parametrize("name,waves", [("s64_translate", 3), ("s64_no_early_stop", 3), ("s128_full_1700", 3), ("j_s64_jitter_wide", 3),
                                         ("s64_translate", 2), ("s128_offsets", 2), ("s64_dropouts", 4), ("s128_full_1700", 4)])
 def test_association_kernel_selection(name, waves, oracle_lib):
-    """Every association kernel the option can select reproduces the oracle (the default — k_assoc3, links wavefront for up to 256
-    streams per launch — is what every other test runs)."""
+    """Every serial association kernel the option can select reproduces the oracle — alone (assoc_batch = 0) and behind the batch-parallel
+    kernel, which hands them whatever it cannot take."""
     stream, cfg, tf = cases.build_case(name)
-    util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns, 97]), robot_tf=tf,
-                         engine_setup=lambda e: e.set_option("assoc_waves", waves))
+    for batch in (0, 1):
+        util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns, 97]), robot_tf=tf,
+                             engine_setup=lambda e: (e.set_option("assoc_waves", waves), e.set_option("assoc_batch", batch)))
+
+
+@pytest.mark.parametrize("name", cases.ALL_CASES)
+def test_serial_association_only(name, oracle_lib):
+    """assoc_batch = 0: the serial kernels (k_assoc3 by default) alone, as in rounds 1 and 2 — the exact fallback of the batch-parallel
+    kernel has to stay exact on everything."""
+    stream, cfg, tf = cases.build_case(name)
+    box = {}
+    summary = util.run_and_compare(stream, cfg, chunks=CHUNKS.get(name, [stream.sensor.num_columns]), robot_tf=tf,
+                                   engine_setup=lambda e: (e.set_option("assoc_batch", 0), box.setdefault("e", e)))
+    assert box["e"].batch_counters()["batch_columns"] == 0
+    assert summary["clusters"] >= 3
+
+
+@pytest.mark.parametrize("name", ["s64_static", "s64_full_2200", "s64_dropouts", "s128_full_1700", "s32_small_sensor", "j_s64_jitter_wide",
+                                  "s64_robot_tf_tilted", "s64_fog_and_ego"])
+def test_batch_parallel_association_takes_ordinary_streams(name, oracle_lib):
+    """k_assocb (groups of 64 columns at once: pointer jumping over the parent chains, one alive word per tree, a lane-parallel cluster
+    timeline) associates every column of streams without exceptions — also in mirror mode, where it re-takes the visit counts of columns
+    whose scan looked past the first unpublished column — with the oracle's events, roots, ids and per-tree values."""
+    stream, cfg, tf = cases.build_case(name)
+    box = {}
+    summary = util.run_and_compare(stream, cfg, chunks=[stream.sensor.num_columns, 97, 1, 200], robot_tf=tf,
+                                   engine_setup=lambda e: box.setdefault("e", e))
+    bc = box["e"].batch_counters()
+    assert bc["batch_bails"] == 0 and summary["engine_state"]["error_b"] == 0, bc
+    assert bc["batch_columns"] >= summary["published_columns"]
+
+
+@pytest.mark.parametrize("name,reason", [("s64_forced_finish_ring", 3), ("s64_no_early_stop", 2), ("s64_min_steps_3", 2)])
+@pytest.mark.parametrize("rounds", [1, 2, 4])
+def test_batch_parallel_association_hands_exceptions_to_the_serial_kernel(name, reason, rounds, oracle_lib):
+    """Groups that could differ from the sequential semantics (3: a tree / cluster that may reach the one-rotation limits cc.cpp:657, 913-924;
+    2: more link candidates than k_scan records) are left to k_assoc3: with assoc_rounds > 1 only that group, then the batch-parallel kernel
+    continues."""
+    stream, cfg, tf = cases.build_case(name)
+    box = {}
+    summary = util.run_and_compare(stream, cfg, chunks=[stream.sensor.num_columns, 97], robot_tf=tf,
+                                   engine_setup=lambda e: (e.set_option("assoc_rounds", rounds), box.setdefault("e", e)))
+    bc = box["e"].batch_counters()
+    assert bc["batch_bails"] > 0 and bc["bail_reasons"][reason] > 0, bc
+    assert summary["engine_state"]["error_b"] > 0
 
 
 @pytest.mark.parametrize("name,option,value", [

@@ -33,11 +33,18 @@ for i in range(n_cases):
     cfg = (cases._vls if s128 else cases._kitti)(cols, **over)
     chunks = [int(c) for c in rng.choice([1, 3, 17, 64, 97, 250, cols, 2 * cols], size=4)]
     waves = [0, 4, 3, 2, 1][i % 5]  # default (k_assoc3 + links wavefront), pinned four / three waves, k_assoc2, k_assoc_lds
+    batch = 0 if i % 7 == 6 else 1  # the batch-parallel kernel in front (default) or not
+    rounds = [2, 1, 3][i % 3]
+    box = {}
     try:
-        summ = util.run_and_compare(stream, cfg, chunks=chunks, robot_tf=None, engine_setup=lambda e: e.set_option("assoc_waves", waves))
+        summ = util.run_and_compare(stream, cfg, chunks=chunks, robot_tf=None,
+                                    engine_setup=lambda e: (e.set_option("assoc_waves", waves), e.set_option("assoc_batch", batch),
+                                                            e.set_option("assoc_rounds", rounds), box.setdefault("e", e)))
         es = summ["engine_state"]
+        bc = box["e"].batch_counters()
         print(f"case {i:3d} ok: rows {sensor.num_rows} cols {cols} firings {n} objects {scene.n_objects} chunks {chunks} waves {waves} "
-              f"clusters {summ['clusters']} serial columns {es['error_b']}", flush=True)
+              f"clusters {summ['clusters']} serial columns {es['error_b']} batch {batch} rounds {rounds} columns {bc['batch_columns']} "
+              f"bails {bc['batch_bails']} {bc['bail_reasons'][1:7]}", flush=True)
     except AssertionError as ex:
         bad += 1
         print(f"case {i:3d} FAILED (seed {seed0 + i}): {str(ex)[:300]}", flush=True)

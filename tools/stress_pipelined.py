@@ -42,7 +42,7 @@ for r in range(rounds):
                 ok = False; print("  columns:", str(ex)[:200])
         if not ok:
             bad += 1; print(f"round {r} stream {s}: MISMATCH", {k: (so[k], se[k]) for k in util.STATE_FIELDS if so[k] != se[k]})
-    print(f"round {r}: {S} streams x {NB} calls of {F} firings ok" if bad == 0 else f"round {r}: failures so far {bad}")
+    print(f"round {r}: {S} streams x {NB} calls of {F} firings ok" if bad == 0 else f"round {r}: failures so far {bad}", e.batch_counters(), e.totals())
     e.close()
 print("failures:", bad)
 sys.exit(1 if bad else 0)
