@@ -31,12 +31,15 @@
 #pragma once
 
 #ifndef CC_AB_WAVES
-#define CC_AB_WAVES 16
+#define CC_AB_WAVES 15
 #endif
-constexpr int AB_WAVES = CC_AB_WAVES;
-constexpr int AB_THREADS = 64 * AB_WAVES;
-constexpr int AB_G = 64;                   // columns per group = lanes of the timeline wave
-constexpr int AB_CPW = AB_G / AB_WAVES;    // columns per wavefront
+#ifndef CC_AB_CPW
+#define CC_AB_CPW 4
+#endif
+constexpr int AB_WAVES = CC_AB_WAVES;      // worker wavefronts (columns); one more wavefront runs the timeline
+constexpr int AB_THREADS = 64 * (AB_WAVES + 1);
+constexpr int AB_CPW = CC_AB_CPW;          // columns per worker wavefront and group
+constexpr int AB_G = AB_WAVES * AB_CPW;    // columns per group (<= 64 = lanes of the timeline wave)
 constexpr int AB_RING = 128;               // columns of the slot ring (power of two >= AB_G + WIN_COLS)
 constexpr int AB_TREES = 64;               // trees a group can see (unfinished at its start + born inside) = lanes of the timeline wave
 constexpr int AB_EVENTS = 64;              // links between different trees per group
@@ -51,7 +54,7 @@ enum
     AB_BAIL_LATE = 5,     // a tree receives a point after its cluster finished inside the group
     AB_BAIL_REACH = 6,    // a candidate from a column older than the first unpublished one
 };
-static_assert(AB_G % AB_WAVES == 0 && AB_RING >= AB_G + WIN_COLS, "group geometry");
+static_assert(AB_G <= 64 && AB_THREADS <= 1024 && AB_RING >= AB_G + WIN_COLS, "group geometry");
 
 struct AbTrees
 {
@@ -77,18 +80,42 @@ struct AbTrees
     int remap[AB_TREES];
     int cell_old[AB_TREES];
     unsigned ev[AB_EVENTS];           // column << 16 | tree a << 8 | tree b
-    int col_base[AB_G];               // new roots of the group's earlier columns
-    int col_info[AB_G];
-    double min_az[AB_G];
-    int col_ncl[AB_G];
-    int col_ebase[AB_G];
-    int col_fix[AB_G];                // >= 0: ring column of the first unpublished column while the column was associated (visit counts are re-taken)
+    int col_base[64];               // new roots of the group's earlier columns
+    int col_info[64];
+    double min_az[64];
+    int col_ncl[64];
+    int col_ebase[64];
+    int col_fix[64];                // >= 0: ring column of the first unpublished column while the column was associated (visit counts are re-taken)
     int n_ev;
     int ncols;
     int nborn;
-    int bail;
+    int bail;      // the group in work cannot be taken (nothing of it is committed)
+    int next_bail; // the kernel stops in front of the next group
     int any_finished;
+    int jflag[8];  // pointer jumping: round r left pointers unresolved
+    int next_info[64]; // column summaries of the next group (link flags for the input prefetch)
 };
+
+// inclusive prefix sum over the 64 lanes by DPP (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
+__device__ __forceinline__ int wave_incl_add_i32(int v)
+{
+    v += dpp_mov_i32<0x111, 0xf>(0, v);
+    v += dpp_mov_i32<0x112, 0xf>(0, v);
+    v += dpp_mov_i32<0x114, 0xf>(0, v);
+    v += dpp_mov_i32<0x118, 0xf>(0, v);
+    v += dpp_mov_i32<0x142, 0xa>(0, v);
+    v += dpp_mov_i32<0x143, 0xc>(0, v);
+    return v;
+}
+// the value of the lane below (wave_shr:1); lane 0 keeps its own
+__device__ __forceinline__ long long wave_shr1_i64(long long v)
+{
+    return dpp_mov_i64<0x138, 0xf>(v, v);
+}
+__device__ __forceinline__ double wave_shr1_f64(double v)
+{
+    return __longlong_as_double(wave_shr1_i64(__double_as_longlong(v)));
+}
 
 template<int RPL>
 __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
@@ -159,53 +186,86 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
     __syncthreads();
     if (wave == 0)
     {
-        // union-find parents -> cluster representative (the smallest list position of the set: unions hang the larger under the smaller)
-        int c = lane < n_unf ? T.comp[lane] : 0;
+        // union-find parents -> cluster representative = the smallest list position of the set (the serial kernels that may have left this
+        // state number their trees by ids from a free ring: the root of a set is its smallest ID, which need not be its oldest tree)
+        int rep = lane < n_unf ? T.comp[lane] : 0;
         for (int it = 0; it < 6; it++)
         {
-            const int c2 = __shfl(c, c);
-            c = c2;
+            const int r2 = __shfl(rep, rep);
+            rep = r2;
         }
+        T.remap[lane] = AB_TREES;
+        wave_lds_fence();
         if (lane < n_unf)
-            T.comp[lane] = c;
+            atomicMin(&T.remap[rep], lane);
+        wave_lds_fence();
+        if (lane < n_unf)
+            T.comp[lane] = lds_ld(&T.remap[rep]);
         if (lane == 0 && st->batch[slot].pub_begin < 0)
             st->batch[slot].pub_begin = first_unpub; // first association kernel of this pass
     }
     __syncthreads();
 
+#ifdef CC_AB_STATS
+    unsigned long long ab_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ab_mark = __builtin_amdgcn_s_memtime();
+    const unsigned long long ab_t0 = ab_mark;
+#define AB_PH(i)                                                     \
+    {                                                                \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+        ab_t[i] += n_ - ab_mark;                                     \
+        ab_mark = n_;                                                \
+    }
+#else
+#define AB_PH(i)
+#endif
     long long gc0 = col_begin;
     int lc0 = (int) (col_begin % RC);
     unsigned long long batch_cols = 0;
     bool bailed = false;
+    const double mz_inf = 1.7976931348623157e308;
+    if (threadIdx.x == 0)
+        T.bail = 0;
 
-    while (gc0 < col_end)
+    // Two roles, one barrier schedule per group: B1 (pointers written) - one barrier per pointer-jumping round - B2 (records, links) - B3
+    // (timeline done, group committed, next header in place). The timeline wavefront and the workers run separate loops (separate register
+    // allocations: the workers hold a group of prefetched inputs, the timeline wave ~60 per-tree / per-column values) that meet at these barriers.
+    if (wave == 0)
     {
-        // ================================================================================== group header (wave 0, lanes = columns)
-        if (wave == 0)
+        // =============================================================================================== timeline wavefront
+        // column summaries of the NEXT group in registers (lanes = columns), requested a whole group ahead
+        int nx_info = 0;
+        double nx_maz = mz_inf;
+        auto load_next_info = [&](const long long g0, const int l0)
         {
-            const long long gcj = gc0 + lane;
-            const bool valid = gcj < col_end;
-            int lcj = lc0 + lane;
-            lcj = lcj >= RC ? lcj - RC : lcj;
-            const int info = valid ? p.col_info[lcj] : 0;
-            const double maz = valid ? p.colminaz[lcj] : 1.7976931348623157e308;
-            const int cnt = info & 0xff;
-            int incl = cnt;
-            for (int o = 1; o < 64; o <<= 1)
+            nx_info = 0;
+            nx_maz = mz_inf;
+            if (lane < AB_G && g0 + lane < col_end)
             {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o)
-                    incl += t;
+                int lcj = l0 + lane;
+                lcj = lcj >= RC ? lcj - RC : lcj;
+                nx_info = p.col_info[lcj];
+                nx_maz = p.colminaz[lcj];
             }
-            const unsigned long long okm = __ballot(valid && n_unf + incl <= tree_limit);
+        };
+        // group header: how many columns the group takes (the trees it sees must fit the lanes), what stops the kernel in front of it;
+        // then the summaries of the group after it are requested
+        auto group_header = [&](const long long g0, const int l0, const int n_before)
+        {
+            const int info = nx_info;
+            const double maz = nx_maz;
+            const bool valid = lane < AB_G && g0 + lane < col_end;
+            const int cnt = info & 0xff;
+            const int incl = wave_incl_add_i32(cnt);
+            const unsigned long long okm = __ballot(valid && n_before + incl <= tree_limit);
             const int ncols = ~okm ? __builtin_ctzll(~okm) : 64;
             const unsigned long long cm = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
-            int bail = ncols == 0 ? AB_BAIL_TREES : 0;
+            int bail = (ncols == 0 && g0 < col_end) ? AB_BAIL_TREES : 0;
             if (__ballot(((info >> 8) & 1) != 0) & cm)
                 bail = AB_BAIL_LINKS; // a point with more link candidates than k_scan records (cc.cpp:693-694 would see them all)
             // no tree or cluster of this group can reach the one-rotation limits (cc.cpp:657, 913-924) while the oldest unfinished tree is
             // less than a rotation behind the group's last column
-            if (n_unf > 0 && ncols > 0 && (gc0 + ncols - T.gcol[0]) >= NC)
+            if (n_before > 0 && ncols > 0 && (g0 + ncols - lds_ld(&T.gcol[0])) >= NC)
                 bail = AB_BAIL_ROTATION;
             T.col_base[lane] = incl - cnt;
             T.col_info[lane] = info;
@@ -216,218 +276,66 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             T.g_pts[lane] = 0u;
             T.g_last[lane] = -1;
             T.birth[lane] = -1;
-            const int nb = __shfl(incl, ncols > 0 ? ncols - 1 : 0); // (executed by all lanes)
+            const int nb = __builtin_amdgcn_readlane(incl, ncols > 0 ? ncols - 1 : 0);
+            if (lane < 8)
+                T.jflag[lane] = 0;
             if (lane == 0)
             {
                 T.n_ev = 0;
                 T.ncols = ncols;
                 T.nborn = ncols > 0 ? nb : 0;
-                T.bail = bail;
-                T.any_finished = 0;
+                T.next_bail = bail;
             }
-        }
-        __syncthreads();
-        const int ncols = T.ncols;
-        if (T.bail)
+            int l1 = l0 + ncols;
+            l1 = l1 >= RC ? l1 - RC : l1;
+            load_next_info(g0 + ncols, l1);
+        };
+        load_next_info(gc0, lc0);
+        T.next_info[lane] = nx_info;
+        __syncthreads(); // P0a: link flags of the first group for the workers' prefetch
+        group_header(gc0, lc0, n_unf);
+        __syncthreads(); // P0b
+        if (T.next_bail)
         {
             bailed = true;
-            break;
-        }
-        const int nborn = T.nborn;
-        const double mz = T.min_az[lane]; // lanes = columns of the group
-
-        // ================================================================================== 1: inputs, initial pointers
-        int a[AB_CPW][RPL];                 // ring value of the cell: >= 0 pointer (ring index), < 0 resolved (-1 - slot, AB_NONE, AB_DEAD)
-        unsigned long long fin[AB_CPW][RPL];
-        int nl[AB_CPW][RPL];
-        unsigned long long lk[AB_CPW][RPL];
-#pragma unroll
-        for (int q = 0; q < AB_CPW; q++)
-        {
-            const int cidx = wave + q * AB_WAVES;
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                a[q][k] = AB_NONE;
-                fin[q][k] = 0ull;
-                nl[q][k] = 0;
-                lk[q][k] = 0ull;
-            }
-            if (cidx < ncols)
-            {
-                int lc = lc0 + cidx;
-                lc = lc >= RC ? lc - RC : lc;
-                const long long gc = gc0 + cidx;
-                const int info = T.col_info[cidx];
-                const bool col_links = ((info >> 8) & 2) != 0;
-                const int base = n_unf + T.col_base[cidx];
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                {
-                    const int row = k * 64 + lane;
-                    if (row < R)
-                    {
-                        const int ci = lc * R + row;
-                        const int par = p.sc_parent[ci];
-                        const int term = p.sc_term[ci];
-                        fin[q][k] = (unsigned long long) __double_as_longlong(p.sc_fin[ci]);
-                        if (col_links)
-                        {
-                            nl[q][k] = p.sc_nlinks[ci];
-                            lk[q][k] = p.sc_links[ci]; // (stale where the point has no links: never looked at)
-                        }
-                        int v = AB_NONE;
-                        if (par >= -1)
-                        {
-                            if (term >= 256)
-                                v = (int) ((gc - (term >> 8)) & (AB_RING - 1)) * R + (term & 0xff);
-                            else if (term >= 0)
-                                v = -1 - (base + term);
-                            if (par == -1)
-                            {
-                                const int sl = base + term;
-                                T.g_cell[sl] = ci;
-                                T.birth[sl] = cidx;
-                            }
-                        }
-                        else
-                            fin[q][k] = 0ull;
-                        a[q][k] = v;
-                        ring[(int) (gc & (AB_RING - 1)) * R + row] = (short) v;
-                    }
-                }
-            }
-        }
-        // what the trees that are older than the group contribute to the finished-cluster check of its columns
-        for (int t = wave; t < n_unf; t += AB_WAVES)
-        {
-            const double f = __longlong_as_double((long long) T.fin[t]);
-            const unsigned long long m = __ballot(f > mz);
             if (lane == 0)
-                T.g_alive[t] = m;
+                T.bail = T.next_bail;
         }
-        // ---------------------------------------------------------------------------------- pointer jumping
-        int pending;
-        __syncthreads();
-        do
+        while (gc0 < col_end && !bailed)
         {
-            pending = 0;
-#pragma unroll
-            for (int q = 0; q < AB_CPW; q++)
+            AB_PH(0)
+            const int ncols = T.ncols;
+            const int nborn = T.nborn;
+            const double mz = T.min_az[lane]; // lanes = columns of the group
+            // what the trees that are older than the group contribute to the finished-cluster check of its columns
+            for (int t = 0; t < n_unf; t++)
             {
-                const int cidx = wave + q * AB_WAVES;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                    if (a[q][k] >= 0)
-                    {
-                        const int b = ring[a[q][k]];
-                        a[q][k] = b;
-                        ring[(int) ((gc0 + cidx) & (AB_RING - 1)) * R + k * 64 + lane] = (short) b;
-                        pending |= b >= 0 ? 1 : 0;
-                    }
-            }
-        } while (__syncthreads_or(pending));
-
-        // ================================================================================== 2: records, alive words, links
-        int bad = 0;
-#pragma unroll
-        for (int q = 0; q < AB_CPW; q++)
-        {
-            const int cidx = wave + q * AB_WAVES;
-            if (cidx >= ncols)
-                continue;
-            int sl[RPL];
-            unsigned long long am = 0ull;
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                sl[k] = -1;
-                if (fin[q][k] != 0ull) // an active point (finished_at contributions are positive)
-                {
-                    if (a[q][k] <= AB_NONE)
-                        bad = 1; // its chain ends in a finished tree (attach refused, cc.cpp:658) or in a cell without a tree
-                    else
-                        sl[k] = -1 - a[q][k];
-                }
-            }
-            if (__any(bad))
-                break;
-            // per tree of the column: points, largest contribution; (two rows per lane: both halves of a tree are taken together)
-            unsigned long long todo[RPL];
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-                todo[k] = __ballot(sl[k] >= 0);
-            while (true)
-            {
-                int s0 = -1;
-#pragma unroll
-                for (int k = RPL - 1; k >= 0; k--)
-                    if (todo[k])
-                        s0 = __builtin_amdgcn_readlane(sl[k], __builtin_ctzll(todo[k]));
-                if (s0 < 0)
-                    break;
-                int cnt = 0;
-                unsigned long long mine = 0ull;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                {
-                    const bool in = sl[k] == s0;
-                    const unsigned long long mm = __ballot(in);
-                    cnt += __popcll(mm);
-                    todo[k] &= ~mm;
-                    if (in && fin[q][k] > mine) // (non-negative doubles order like their bit patterns)
-                        mine = fin[q][k];
-                }
-                const unsigned long long mx = wave_max_f64_bits(mine);
-                unsigned long long m = __ballot(lane >= cidx && __longlong_as_double((long long) mx) > mz);
+                const double f = __longlong_as_double((long long) lds_ld(&T.fin[t]));
+                const unsigned long long m = __ballot(f > mz);
                 if (lane == 0)
-                {
-                    if (T.birth[s0] == cidx)
-                        m |= (1ull << cidx) - 1ull; // not listed before its column: nothing to finish there
-                    atomicOr(&T.g_alive[s0], m);
-                    atomicMax(&T.g_fin[s0], mx);
-                    atomicAdd(&T.g_pts[s0], (unsigned) cnt);
-                    atomicMax(&T.g_last[s0], cidx);
-                }
+                    T.g_alive[t] = m;
             }
-            // link candidates (accepted candidates after the first, cc.cpp:693-694) that lead to another tree
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
+            __syncthreads(); // B1
+            AB_PH(1)
+            for (int r = 0; r < 8; r++)
             {
-                const int n = nl[q][k] == 255 ? 0 : nl[q][k];
-                if (sl[k] >= 0 && n > 0)
-                {
-                    const long long gc = gc0 + cidx;
-                    for (int j = 0; j < n; j++)
-                    {
-                        const int code = (int) ((lk[q][k] >> (16 * j)) & 0xffff);
-                        const int v = ring[(int) ((gc - (code >> 8)) & (AB_RING - 1)) * R + (code & 0xff)];
-                        if (v >= 0)
-                            bad = 1; // (cannot happen: every cell of the group is resolved)
-                        else if (v > AB_NONE && -1 - v != sl[k])
-                        {
-                            const int e = atomicAdd(&T.n_ev, 1);
-                            if (e < AB_EVENTS)
-                                T.ev[e] = ((unsigned) cidx << 16) | ((unsigned) sl[k] << 8) | (unsigned) (-1 - v);
-                        }
-                    }
-                }
+                __syncthreads();
+                if (!T.jflag[r])
+                    break;
             }
-        }
-        if (__any(bad) && lane == 0)
-            T.bail = AB_BAIL_DEAD;
-        __syncthreads();
-        if (T.bail || T.n_ev > AB_EVENTS)
-        {
-            if (threadIdx.x == 0 && !T.bail)
-                T.bail = AB_BAIL_LINKS;
-            bailed = true;
-            break;
-        }
-
-        // ================================================================================== 3: timeline (wave 0, lanes = trees / columns)
-        if (wave == 0)
-        {
+            AB_PH(2)
+            T.next_info[lane] = nx_info; // (requested a group ago: the workers' prefetch reads the link flags of the next group's columns)
+            __syncthreads(); // B2
+            AB_PH(4)
+            if (T.bail || T.n_ev > AB_EVENTS)
+            {
+                if (lane == 0 && !T.bail)
+                    T.bail = AB_BAIL_LINKS;
+                bailed = true;
+                break;
+            }
+            // ================================================================================== 3: timeline (lanes = trees / columns)
+            {
             const int n = n_unf + nborn;
             const bool is_t = lane < n;
             const bool old = lane < n_unf;
@@ -441,7 +349,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             T.t_gcol[lane] = tg;
             // rounds that can finish something: not the ones whose smallest azimuth equals the previous round's (the BFS of cc.cpp:854 then
             // meets its own visited stamp everywhere)
-            const double prev_az = __shfl_up(mz, 1);
+            const double prev_az = wave_shr1_f64(mz);
             const bool alias = lane < ncols && mz == (lane == 0 ? last_min_az : prev_az);
             const unsigned long long colmask = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
             const unsigned long long alias_m = __ballot(alias);
@@ -557,7 +465,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                     listed = true;
                 }
             }
-            const long long mc_prev = __shfl_up(mc, 1);
+            const long long mc_prev = wave_shr1_i64(mc);
             const long long fu = lane == 0 ? first_unpub : mc_prev; // first unpublished column while column j is associated
             const int info = T.col_info[lane];
             const int reach = (info >> 16) & 0xff;
@@ -575,13 +483,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             T.col_fix[lane] = fix; // cc.cpp:762-763: the live scan would have stopped earlier (or the bookkeeping error of :1072-1075: the serial kernel reports it)
             const int ncl = T.col_ncl[lane];
             const int per_col = lane < ncols ? 2 + ncl : 0;
-            int eincl = per_col;
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const int t = __shfl_up(eincl, o);
-                if (lane >= o)
-                    eincl += t;
-            }
+            const int eincl = wave_incl_add_i32(per_col);
             T.col_ebase[lane] = n_events + eincl - per_col;
             wave_lds_fence();
 
@@ -640,16 +542,16 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                             p.events[e2] = e;
                         }
                     }
-                    n_events += uniform_i32(__shfl(eincl, 63));
+                    n_events += __builtin_amdgcn_readlane(eincl, 63);
                 }
-                const long long new_unpub = uniform_i64(__shfl(mc, ncols - 1));
+                const long long new_unpub = lane_i64(mc, ncols - 1);
                 cells_published += (unsigned long long) (new_unpub - first_unpub) * (unsigned long long) R;
                 first_unpub = new_unpub;
                 ring_start = first_unpub - NC > 0 ? first_unpub - NC : 0;
                 cluster_counter += (unsigned long long) n_ids;
                 clusters_finished += (unsigned long long) n_ids;
                 alias_rounds += (unsigned long long) __popcll(alias_m & __ballot(listed)); // (counted like the serial kernels: only while trees are listed)
-                last_min_az = uniform_f64(__shfl(mz, ncols - 1));
+                last_min_az = lane_f64(mz, ncols - 1);
                 // finished trees leave the list: what k_publish and the host mirror read of them
                 if (fin_here)
                 {
@@ -686,22 +588,274 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 }
                 n_unf = __popcll(sm);
                 if (lane == 0)
+                {
                     T.any_finished = n_unf != n ? 1 : 0;
+                    s_nunf = n_unf;
+                }
+                wave_lds_fence();
+                // the next group's header: by the time the other wavefronts have written this group's roots it is in place
+                int l1 = lc0 + ncols;
+                l1 = l1 >= RC ? l1 - RC : l1;
+                group_header(gc0 + ncols, l1, n_unf);
+            }
             }
             wave_lds_fence();
+            __syncthreads(); // B3
+            AB_PH(5)
+            if (T.bail)
+            {
+                bailed = true;
+                break;
+            }
+#ifdef CC_AB_STATS
+            ab_t[7]++;
+#endif
+            batch_cols += (unsigned long long) ncols;
+            gc0 += ncols;
+            lc0 += ncols;
+            lc0 = lc0 >= RC ? lc0 - RC : lc0;
+            if (T.next_bail)
+            {
+                bailed = true;
+                if (lane == 0)
+                    T.bail = T.next_bail;
+            }
         }
-        __syncthreads();
-        if (T.bail)
+        if (lane == 0)
+            s_nunf = n_unf;
+    }
+    else
+    {
+        // =============================================================================================== worker wavefronts
+        const int w = wave - 1;
+        // inputs of a group, requested a group ahead (the link words only where the column has links: T.next_info)
+        int pf_par[AB_CPW][RPL], pf_term[AB_CPW][RPL], pf_nl[AB_CPW][RPL];
+        double pf_fin[AB_CPW][RPL];
+        unsigned long long pf_lk[AB_CPW][RPL];
+        auto prefetch_inputs = [&](const long long g0, const int l0)
         {
+#pragma unroll
+            for (int q = 0; q < AB_CPW; q++)
+            {
+                const int cidx = w + q * AB_WAVES;
+                const bool col_links = ((T.next_info[cidx] >> 8) & 2) != 0;
+                int lc = l0 + cidx;
+                lc = lc >= RC ? lc - RC : lc;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const int row = k * 64 + lane;
+                    pf_par[q][k] = -2;
+                    pf_term[q][k] = -1;
+                    pf_fin[q][k] = 0.;
+                    pf_nl[q][k] = 0;
+                    pf_lk[q][k] = 0ull;
+                    if (row < R && g0 + cidx < col_end)
+                    {
+                        const int ci = lc * R + row;
+                        pf_par[q][k] = p.sc_parent[ci];
+                        pf_term[q][k] = p.sc_term[ci];
+                        pf_fin[q][k] = p.sc_fin[ci];
+                        if (col_links)
+                        {
+                            pf_nl[q][k] = p.sc_nlinks[ci];
+                            pf_lk[q][k] = p.sc_links[ci]; // (stale where the point has no links: never looked at)
+                        }
+                    }
+                }
+            }
+        };
+        __syncthreads(); // P0a
+        prefetch_inputs(gc0, lc0);
+        __syncthreads(); // P0b
+        if (T.next_bail)
             bailed = true;
-            break;
+        while (gc0 < col_end && !bailed)
+        {
+            const int ncols = T.ncols;
+            const double mz = T.min_az[lane]; // lanes = columns of the group
+            // ================================================================================== 1: initial pointers
+            int a[AB_CPW][RPL]; // ring value of the cell: >= 0 pointer (ring index), < 0 resolved (-1 - slot, AB_NONE, AB_DEAD)
+#pragma unroll
+            for (int q = 0; q < AB_CPW; q++)
+            {
+                const int cidx = w + q * AB_WAVES;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                    a[q][k] = AB_NONE;
+                if (cidx < ncols)
+                {
+                    int lc = lc0 + cidx;
+                    lc = lc >= RC ? lc - RC : lc;
+                    const long long gc = gc0 + cidx;
+                    const int base = n_unf + T.col_base[cidx];
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                    {
+                        const int row = k * 64 + lane;
+                        if (row < R)
+                        {
+                            const int ci = lc * R + row;
+                            const int par = pf_par[q][k];
+                            const int term = pf_term[q][k];
+                            int v = AB_NONE;
+                            if (par >= -1)
+                            {
+                                if (term >= 256)
+                                    v = (int) ((gc - (term >> 8)) & (AB_RING - 1)) * R + (term & 0xff);
+                                else if (term >= 0)
+                                    v = -1 - (base + term);
+                                if (par == -1)
+                                {
+                                    const int sl = base + term;
+                                    T.g_cell[sl] = ci;
+                                    T.birth[sl] = cidx;
+                                }
+                            }
+                            a[q][k] = v;
+                            ring[(int) (gc & (AB_RING - 1)) * R + row] = (short) v;
+                        }
+                    }
+                }
+            }
+            __syncthreads(); // B1
+            // ---------------------------------------------------------------------------------- pointer jumping (one barrier per round)
+            for (int r = 0; r < 8; r++)
+            {
+                int pending = 0;
+#pragma unroll
+                for (int q = 0; q < AB_CPW; q++)
+                {
+                    const int cidx = w + q * AB_WAVES;
+#pragma unroll
+                    for (int k = 0; k < RPL; k++)
+                        if (a[q][k] >= 0)
+                        {
+                            const int b = ring[a[q][k]];
+                            a[q][k] = b;
+                            ring[(int) ((gc0 + cidx) & (AB_RING - 1)) * R + k * 64 + lane] = (short) b;
+                            pending |= b >= 0 ? 1 : 0;
+                        }
+                }
+                if (__any(pending) && lane == 0)
+                    T.jflag[r] = 1;
+                __syncthreads();
+                if (!T.jflag[r])
+                    break;
+            }
+            // ================================================================================== 2: records, alive words, links
+        int bad = 0;
+#pragma unroll
+        for (int q = 0; q < AB_CPW; q++)
+        {
+            const int cidx = w + q * AB_WAVES;
+            if (cidx >= ncols)
+                continue;
+            int sl[RPL];
+            unsigned long long am = 0ull;
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                sl[k] = -1;
+                if (pf_par[q][k] >= -1) // an active point
+                {
+                    if (a[q][k] <= AB_NONE)
+                        bad = 1; // its chain ends in a finished tree (attach refused, cc.cpp:658) or in a cell without a tree
+                    else
+                        sl[k] = -1 - a[q][k];
+                }
+            }
+            if (__any(bad))
+                break;
+            // per tree of the column: points, largest contribution; (two rows per lane: both halves of a tree are taken together)
+            unsigned long long todo[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+                todo[k] = __ballot(sl[k] >= 0);
+            while (true)
+            {
+                int s0 = -1;
+#pragma unroll
+                for (int k = RPL - 1; k >= 0; k--)
+                    if (todo[k])
+                        s0 = __builtin_amdgcn_readlane(sl[k], __builtin_ctzll(todo[k]));
+                if (s0 < 0)
+                    break;
+                int cnt = 0;
+                unsigned long long mine = 0ull;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const bool in = sl[k] == s0;
+                    const unsigned long long mm = __ballot(in);
+                    cnt += __popcll(mm);
+                    todo[k] &= ~mm;
+                    const unsigned long long fb = (unsigned long long) __double_as_longlong(pf_fin[q][k]);
+                    if (in && fb > mine) // (non-negative doubles order like their bit patterns)
+                        mine = fb;
+                }
+                const unsigned long long mx = wave_max_f64_bits(mine);
+                unsigned long long m = __ballot(lane >= cidx && __longlong_as_double((long long) mx) > mz);
+                if (lane == 0)
+                {
+                    if (T.birth[s0] == cidx)
+                        m |= (1ull << cidx) - 1ull; // not listed before its column: nothing to finish there
+                    atomicOr(&T.g_alive[s0], m);
+                    atomicMax(&T.g_fin[s0], mx);
+                    atomicAdd(&T.g_pts[s0], (unsigned) cnt);
+                    atomicMax(&T.g_last[s0], cidx);
+                }
+            }
+            // link candidates (accepted candidates after the first, cc.cpp:693-694) that lead to another tree
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int n = pf_nl[q][k] == 255 ? 0 : pf_nl[q][k];
+                if (sl[k] >= 0 && n > 0)
+                {
+                    const long long gc = gc0 + cidx;
+                    for (int j = 0; j < n; j++)
+                    {
+                        const int code = (int) ((pf_lk[q][k] >> (16 * j)) & 0xffff);
+                        const int v = ring[(int) ((gc - (code >> 8)) & (AB_RING - 1)) * R + (code & 0xff)];
+                        if (v >= 0)
+                            bad = 1; // (cannot happen: every cell of the group is resolved)
+                        else if (v > AB_NONE && -1 - v != sl[k])
+                        {
+                            const int e = atomicAdd(&T.n_ev, 1);
+                            if (e < AB_EVENTS)
+                                T.ev[e] = ((unsigned) cidx << 16) | ((unsigned) sl[k] << 8) | (unsigned) (-1 - v);
+                        }
+                    }
+                }
+            }
         }
-        // ================================================================================== 4b: tree roots of the group's cells, slot ring
+            if (__any(bad) && lane == 0)
+                T.bail = AB_BAIL_DEAD;
+            __syncthreads(); // B2
+            if (T.bail || T.n_ev > AB_EVENTS)
+            {
+                bailed = true;
+                break;
+            }
+            {
+                // the next group's inputs travel while the timeline wave works
+                int l1 = lc0 + ncols;
+                l1 = l1 >= RC ? l1 - RC : l1;
+                prefetch_inputs(gc0 + ncols, l1);
+            }
+            __syncthreads(); // B3
+            if (T.bail)
+            {
+                bailed = true;
+                break;
+            }
+            // ================================================================================== 4b: tree roots of the group's cells, slot ring
         const bool any_finished = T.any_finished != 0;
 #pragma unroll
         for (int q = 0; q < AB_CPW; q++)
         {
-            const int cidx = wave + q * AB_WAVES;
+            const int cidx = w + q * AB_WAVES;
             if (cidx < ncols)
             {
                 int lc = lc0 + cidx;
@@ -723,7 +877,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                     for (int k = 0; k < RPL; k++)
                     {
                         const int row = k * 64 + lane;
-                        if (row < R && fin[q][k] != 0ull)
+                        if (row < R && a[q][k] > AB_NONE)
                         {
                             const int ci = lc * R + row;
                             const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
@@ -737,14 +891,11 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 }
             }
         }
-        // every wave needs the new list length: wave 0 computed it
-        if (threadIdx.x == 0)
-            s_nunf = n_unf;
         if (any_finished)
         {
             // the look-back window of the next group: slots renumbered, finished trees marked
             const long long nb = gc0 + ncols;
-            for (int i = threadIdx.x; i < WIN_COLS * R; i += AB_THREADS)
+            for (int i = threadIdx.x - 64; i < WIN_COLS * R; i += AB_THREADS - 64)
             {
                 const int back = i / R + 1, row = i - (back - 1) * R;
                 const int ri = (int) ((nb - back) & (AB_RING - 1)) * R + row;
@@ -756,17 +907,19 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 }
             }
         }
-        __syncthreads();
-        n_unf = s_nunf;
-        batch_cols += (unsigned long long) ncols;
-        gc0 += ncols;
-        lc0 += ncols;
-        lc0 = lc0 >= RC ? lc0 - RC : lc0;
-        // (wave 0 carries the scalar state; the other waves only need n_unf, gc0, lc0)
+            // (no barrier here: the next group's first phase only writes ring columns, tree slots and words that nothing above reads)
+            n_unf = s_nunf;
+            gc0 += ncols;
+            lc0 += ncols;
+            lc0 = lc0 >= RC ? lc0 - RC : lc0;
+            if (T.next_bail)
+                bailed = true;
+        }
     }
 
     // ---- persist the tree state back to the global planes (the serial kernels and the next batch load it from there) ------------------
     __syncthreads();
+    n_unf = s_nunf;
     if ((int) threadIdx.x < n_unf)
     {
         const int i = threadIdx.x;
@@ -808,6 +961,11 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             st->n_events = n_events < g.event_capacity ? n_events : g.event_capacity;
             if (g.record_events && n_events > g.event_capacity)
                 raise_error(st, CC_ERR_CAPACITY, n_events, 0);
+#ifdef CC_AB_STATS
+            ab_t[9] = __builtin_amdgcn_s_memtime() - ab_t0;
+            for (int i = 0; i < 10; i++)
+                st->dbg[i] += ab_t[i];
+#endif
         }
     }
 }
