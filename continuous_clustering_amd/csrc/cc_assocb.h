@@ -96,6 +96,13 @@ struct AbTrees
     int next_info[64]; // column summaries of the next group (link flags for the input prefetch)
 };
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it would wait for the global loads requested a group
+// ahead and for the root-plane stores — none of which another wavefront of the block ever reads.
+__device__ __forceinline__ void ab_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // inclusive prefix sum over the 64 lanes by DPP (row_shr 1/2/4/8, row_bcast 15/31): no LDS round trips
 __device__ __forceinline__ int wave_incl_add_i32(int v)
 {
@@ -292,9 +299,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
         };
         load_next_info(gc0, lc0);
         T.next_info[lane] = nx_info;
-        __syncthreads(); // P0a: link flags of the first group for the workers' prefetch
+        ab_barrier(); // P0a: link flags of the first group for the workers' prefetch
         group_header(gc0, lc0, n_unf);
-        __syncthreads(); // P0b
+        ab_barrier(); // P0b
         if (T.next_bail)
         {
             bailed = true;
@@ -315,17 +322,17 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 if (lane == 0)
                     T.g_alive[t] = m;
             }
-            __syncthreads(); // B1
+            ab_barrier(); // B1
             AB_PH(1)
             for (int r = 0; r < 8; r++)
             {
-                __syncthreads();
+                ab_barrier();
                 if (!T.jflag[r])
                     break;
             }
             AB_PH(2)
             T.next_info[lane] = nx_info; // (requested a group ago: the workers' prefetch reads the link flags of the next group's columns)
-            __syncthreads(); // B2
+            ab_barrier(); // B2
             AB_PH(4)
             if (T.bail || T.n_ev > AB_EVENTS)
             {
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             }
             }
             wave_lds_fence();
-            __syncthreads(); // B3
+            ab_barrier(); // B3
             AB_PH(5)
             if (T.bail)
             {
@@ -665,9 +672,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 }
             }
         };
-        __syncthreads(); // P0a
+        ab_barrier(); // P0a
         prefetch_inputs(gc0, lc0);
-        __syncthreads(); // P0b
+        ab_barrier(); // P0b
         if (T.next_bail)
             bailed = true;
         while (gc0 < col_end && !bailed)
@@ -718,7 +725,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                     }
                 }
             }
-            __syncthreads(); // B1
+            ab_barrier(); // B1
             // ---------------------------------------------------------------------------------- pointer jumping (one barrier per round)
             for (int r = 0; r < 8; r++)
             {
@@ -731,7 +738,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                     for (int k = 0; k < RPL; k++)
                         if (a[q][k] >= 0)
                         {
-                            const int b = ring[a[q][k]];
+                            int b = ring[a[q][k]];
+                            if (b >= 0)
+                                b = ring[b]; // (two hops per round: a barrier costs more than an LDS round trip)
                             a[q][k] = b;
                             ring[(int) ((gc0 + cidx) & (AB_RING - 1)) * R + k * 64 + lane] = (short) b;
                             pending |= b >= 0 ? 1 : 0;
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 }
                 if (__any(pending) && lane == 0)
                     T.jflag[r] = 1;
-                __syncthreads();
+                ab_barrier();
                 if (!T.jflag[r])
                     break;
             }
@@ -832,7 +841,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
         }
             if (__any(bad) && lane == 0)
                 T.bail = AB_BAIL_DEAD;
-            __syncthreads(); // B2
+            ab_barrier(); // B2
             if (T.bail || T.n_ev > AB_EVENTS)
             {
                 bailed = true;
@@ -844,7 +853,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 l1 = l1 >= RC ? l1 - RC : l1;
                 prefetch_inputs(gc0 + ncols, l1);
             }
-            __syncthreads(); // B3
+            ab_barrier(); // B3
             if (T.bail)
             {
                 bailed = true;
