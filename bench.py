@@ -321,7 +321,7 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
     # dominant single kernel (segment_ms is the sum of k_table + k_seg_pre + k_seg_scan, profiles/ lists them separately;
     # prep_ms covers k_insert_par — preparation fused with the block-parallel insertion — plus k_prep of what it left over;
     # insert_ms is the serial kernel k_insert2 behind it; above 64 rows the block-parallel kernel is k_insert_multi)
-    KERNEL_OF = {"prep_ms": "k_insert_par" if R <= 64 else "k_insert_multi", "insert_ms": "k_insert2", "scan_ms": "k_scan" if R <= 64 else "k_scan2", "assoc_lds_ms": "k_assoc3",
+    KERNEL_OF = {"prep_ms": "k_insert_par" if R <= 64 else "k_insert_multi", "insert_ms": "k_insert2", "scan_ms": "k_scan" if R <= 64 else "k_scan2", "assoc_lds_ms": "k_assocb",
                  "assoc_global_ms": "k_associate", "publish_ms": "k_publish"}
     dom = max(KERNEL_OF, key=lambda k: per_kernel.get(k, 0.0))
     cells_per_launch = float(S * F * R) / launches_per_step
@@ -448,7 +448,10 @@ def main():
             path = tf_.name
         rt = {}
         try:
-            for key, batch, rate in (("adaptive_paced_22kHz", 0, 22000), ("adaptive_free_running", 0, 0), ("one_call_per_firing", 1, 0)):
+            # reference_api_only: nothing but the reference's calls with its default is_single_threaded = false — the class's asynchronous mode
+            # (addFiring enqueues, a worker thread runs the engine and the callbacks); latency there = due time -> ground-view callback
+            for key, batch, rate in (("reference_api_only_paced_22kHz", -1, 22000), ("reference_api_only_free_running", -1, 0),
+                                     ("adaptive_paced_22kHz", 0, 22000), ("adaptive_free_running", 0, 0), ("one_call_per_firing", 1, 0)):
                 r = subprocess.run([demo, path, "/dev/null", str(batch), str(rate)], capture_output=True, text=True, timeout=300)
                 m = re.search(r"firings_per_s=(\d+) latency_us_p50=([\d.]+) p99=([\d.]+) max=([\d.]+)", r.stdout)
                 if r.returncode == 0 and m:

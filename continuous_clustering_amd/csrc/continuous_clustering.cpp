@@ -12,8 +12,105 @@ ContinuousClustering::ContinuousClustering() = default;
 
 ContinuousClustering::~ContinuousClustering()
 {
+    try
+    {
+        stopWorker(); // drains the queue first (callbacks still run), then joins
+    }
+    catch (...)
+    {
+    }
     if (engine_)
         cc_engine_destroy(engine_);
+}
+
+// ---- asynchronous mode: is_single_threaded = false (cc.hpp:24-27, cc.cpp:49-63,92; thread_pool.hpp:58-67) -------------------------
+// The reference enqueues the firing and returns; five pools of worker threads run the stages. Here ONE worker thread takes whatever
+// has queued up behind the engine call in flight (a handful of firings at sensor rate: one captured-graph launch; everything that is
+// there when the caller runs ahead) and replays the events as callbacks, in the single-threaded order.
+void ContinuousClustering::startWorker()
+{
+    if (worker_.joinable())
+        return;
+    stop_ = false;
+    worker_ = std::thread([this] { workerLoop(); });
+}
+
+void ContinuousClustering::stopWorker()
+{
+    if (!worker_.joinable())
+        return;
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_idle_.wait(lk, [this] { return (queue_.empty() && !busy_) || worker_error_; });
+        stop_ = true;
+    }
+    cv_work_.notify_all();
+    worker_.join();
+}
+
+void ContinuousClustering::waitIdle()
+{
+    if (!worker_.joinable())
+        return;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_idle_.wait(lk, [this] { return (queue_.empty() && !busy_) || worker_error_; });
+}
+
+void ContinuousClustering::rethrowWorkerError()
+{
+    std::exception_ptr e;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        e = worker_error_;
+        worker_error_ = nullptr;
+        if (e)
+            queue_.clear(); // (the reference would have terminated; what queued up behind the failure is dropped)
+    }
+    if (e)
+        std::rethrow_exception(e);
+}
+
+void ContinuousClustering::workerLoop()
+{
+    std::vector<QueuedFiring> take;
+    while (true)
+    {
+        take.clear();
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_work_.wait(lk, [this] { return stop_ || (!queue_.empty() && !worker_error_); });
+            if (stop_)
+                return;
+            // at sensor rate a few firings queue up per engine call: at most 8 go into one captured-graph launch (~0.1 ms); a caller that
+            // runs ahead (replay from disk) gets large batches, bounded by what a call may publish (include/cc_hip.h)
+            size_t n = queue_.size();
+            const size_t big = static_cast<size_t>(std::max(64, num_columns_));
+            n = n <= 8 ? n : std::min(n, big);
+            for (size_t i = 0; i < n; i++)
+            {
+                take.push_back(std::move(queue_.front()));
+                queue_.pop_front();
+            }
+            busy_ = true;
+        }
+        try
+        {
+            for (const QueuedFiring& q : take)
+                bufferFiring(q.firing, q.tf.data());
+            process();
+        }
+        catch (...)
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            worker_error_ = std::current_exception();
+            buffered_ = 0;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            busy_ = false;
+        }
+        cv_idle_.notify_all();
+    }
 }
 
 void ContinuousClustering::toPod(const Configuration& c, cc_config& o) const
@@ -89,6 +186,12 @@ void ContinuousClustering::check(int rc)
 // ---- continuous_clustering.cpp:11-64 ----------------------------------------------------------------------------------
 void ContinuousClustering::reset(int num_rows)
 {
+    stopWorker(); // cc.cpp:20-31: the reference shuts its pools down (after their queues have drained) and starts new ones below
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        queue_.clear();
+        worker_error_ = nullptr;
+    }
     num_columns_ = config_.range_image.num_columns;
     num_rows_ = num_rows;
     ring_buffer_max_columns = num_columns_ * 10;
@@ -121,6 +224,10 @@ void ContinuousClustering::reset(int num_rows)
     tree_links_.clear();
     v_from_ = 0;
     v_to_ = -1;
+    reset_required_async_ = false;
+    async_ = !config_.general.is_single_threaded; // cc.cpp:49-63
+    if (async_)
+        startWorker();
 }
 
 // ---- continuous_clustering.cpp:66-81 ----------------------------------------------------------------------------------
@@ -132,10 +239,11 @@ void ContinuousClustering::setConfiguration(const Configuration& config)
         reset_required_ = true;
     if (config_.range_image.num_columns != config.range_image.num_columns)
         reset_required_ = true;
+    if (engine_)
+        flush(); // (asynchronous mode: the worker drains first — it reads config_)
     config_ = config;
     if (engine_ && num_rows_ > 0 && config.range_image.num_columns == num_columns_)
     {
-        flush();
         cc_config pod;
         toPod(config_, pod);
         check(cc_engine_set_config(engine_, &pod));
@@ -144,7 +252,7 @@ void ContinuousClustering::setConfiguration(const Configuration& config)
 
 bool ContinuousClustering::resetRequired() const
 {
-    return reset_required_;
+    return reset_required_ || reset_required_async_.load();
 }
 
 void ContinuousClustering::setRobotTransformImpl()
@@ -213,23 +321,21 @@ void ContinuousClustering::addFiringImpl(const RawPoints::ConstPtr& firing, cons
         throw std::runtime_error("The number of points in a firing has changed. This is probably a bug!");
     if (!engine_)
         throw std::runtime_error("continuous_clustering_amd: reset(num_rows) must be called before addFiring");
-    const size_t R = static_cast<size_t>(num_rows_);
-    buf_xyz_.resize((buffered_ + 1) * R * 3);
-    buf_int_.resize((buffered_ + 1) * R);
-    buf_pose_.resize((buffered_ + 1) * 12);
-    float* x = buf_xyz_.data() + buffered_ * R * 3;
-    uint8_t* in = buf_int_.data() + buffered_ * R;
-    for (size_t r = 0; r < R; r++)
+    if (async_)
     {
-        const RawPoint& p = firing->points[r];
-        x[r * 3 + 0] = p.x;
-        x[r * 3 + 1] = p.y;
-        x[r * 3 + 2] = p.z;
-        in[r] = p.intensity;
+        // cc.cpp:92: enqueue and return; the stages run on the worker
+        rethrowWorkerError();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            QueuedFiring q;
+            q.firing = firing;
+            std::memcpy(q.tf.data(), tf, sizeof(double) * 12);
+            queue_.push_back(std::move(q));
+        }
+        cv_work_.notify_one();
+        return;
     }
-    std::memcpy(buf_pose_.data() + buffered_ * 12, tf, 12 * sizeof(double));
-    firing_log_.push_back(firing);
-    buffered_++;
+    bufferFiring(firing, tf);
     // never pass more than 2 * num_columns firings per engine call: everything a call publishes stays readable until the
     // next call (include/cc_hip.h, cc_engine_add_firings)
     if (adaptive_)
@@ -252,8 +358,35 @@ void ContinuousClustering::addFiringImpl(const RawPoints::ConstPtr& firing, cons
         process();
 }
 
+void ContinuousClustering::bufferFiring(const RawPoints::ConstPtr& firing, const double tf[12])
+{
+    const size_t R = static_cast<size_t>(num_rows_);
+    buf_xyz_.resize((buffered_ + 1) * R * 3);
+    buf_int_.resize((buffered_ + 1) * R);
+    buf_pose_.resize((buffered_ + 1) * 12);
+    float* x = buf_xyz_.data() + buffered_ * R * 3;
+    uint8_t* in = buf_int_.data() + buffered_ * R;
+    for (size_t r = 0; r < R; r++)
+    {
+        const RawPoint& p = firing->points[r];
+        x[r * 3 + 0] = p.x;
+        x[r * 3 + 1] = p.y;
+        x[r * 3 + 2] = p.z;
+        in[r] = p.intensity;
+    }
+    std::memcpy(buf_pose_.data() + buffered_ * 12, tf, 12 * sizeof(double));
+    firing_log_.push_back(firing);
+    buffered_++;
+}
+
 void ContinuousClustering::flush()
 {
+    if (async_)
+    {
+        waitIdle();
+        rethrowWorkerError();
+        return;
+    }
     if (buffered_ > 0)
         process();
 }
@@ -480,7 +613,7 @@ void ContinuousClustering::process()
     if (cc_engine_stream_state(engine_, 0, &st) == CC_OK)
     {
         if (st.reset_required)
-            reset_required_ = true; // cc.cpp:252-261
+            reset_required_async_ = true; // cc.cpp:252-261 (set on the worker thread in the asynchronous mode)
         ring_buffer_end_global_column_index = st.ring_buffer_end_global_column_index;
     }
     check(rc);
@@ -506,6 +639,10 @@ void ContinuousClustering::process()
             const RangeImageIndex b(static_cast<uint16_t>(link_buf_[4 * k + 3]), link_buf_[4 * k + 2] % ring_buffer_max_columns);
             tree_links_[a].insert(b);
             tree_links_[b].insert(a);
+            // Point::associated_trees of both roots (cc.cpp:693-694)
+            const size_t Rr = static_cast<size_t>(num_rows_);
+            range_image_[static_cast<size_t>(a.column_index) * Rr + a.row_index].associated_trees.insert(b);
+            range_image_[static_cast<size_t>(b.column_index) * Rr + b.row_index].associated_trees.insert(a);
         }
     }
 

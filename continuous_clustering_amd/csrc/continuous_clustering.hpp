@@ -16,13 +16,22 @@
 //  * with setBatchSize(n > 1) callbacks are delivered when n firings have accumulated (or flush() is called), not
 //    inside the addFiring call that caused them; order and content are unchanged. The default n = 1 keeps the
 //    reference's synchronous behaviour.
-//  * Point::child_points / associated_trees are kept for source compatibility but stay empty (the device keeps trees
-//    as union-find slots); Point::number_of_visited_neighbors and visited_at_continuous_azimuth_angle are not tracked.
-//  * is_single_threaded is accepted but the call order is always the single-threaded one.
+//  * Point::child_points, associated_trees (of root points), number_of_visited_neighbors and the per-tree values are filled from
+//    what the engine exports (cc_column_view, tree-link log); visited_at_continuous_azimuth_angle (BFS scratch of cc.cpp:854-894)
+//    is not tracked.
+//  * is_single_threaded = false (the reference's default, cc.hpp:24-27) is the ASYNCHRONOUS mode: addFiring only enqueues
+//    (cc.cpp:92) and a worker thread inside the class hands what has queued up to the engine and runs the callbacks — in the
+//    single-threaded order, which is one of the orders the reference's thread pipeline can produce (SURVEY 8b "Threading").
+//    reset / setConfiguration / setTransformRobotFrameFromSensorFrame / flush / the destructor wait for the worker to drain.
+//    An exception on the worker (the reference: uncaught on a pool thread -> std::terminate) is kept and rethrown by the next
+//    call on the caller's thread.
 #pragma once
 
+#include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <deque>
 #include <functional>
@@ -30,10 +39,17 @@
 #include <list>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <set>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
+
+#if __has_include(<Eigen/Geometry>)
+#include <Eigen/Geometry>
+#define CC_AMD_HAVE_EIGEN 1
+#endif
 
 #include "../../include/cc_hip.h"
 
@@ -240,6 +256,25 @@ class ContinuousClustering
     }
     bool hasTransformRobotFrameFromSensorFrame();
 
+#ifdef CC_AMD_HAVE_EIGEN
+    // the reference's exact signatures (continuous_clustering.hpp:210,213): preferred over the templates for Eigen::Isometry3d arguments
+    void addFiring(const RawPoints::ConstPtr& firing, const Eigen::Isometry3d& odom_from_sensor)
+    {
+        double tf[12];
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++)
+                tf[r * 4 + c] = odom_from_sensor(r, c);
+        addFiringImpl(firing, tf);
+    }
+    void setTransformRobotFrameFromSensorFrame(const Eigen::Isometry3d& tf)
+    {
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 4; c++)
+                robot_from_sensor_[r * 4 + c] = tf(r, c);
+        setRobotTransformImpl();
+    }
+#endif
+
     // continuous clustering (continuous_clustering.hpp:217-218)
     void setFinishedColumnCallback(std::function<void(int64_t, int64_t, bool)> cb);
     void setFinishedClusterCallback(std::function<void(const std::vector<Point>&, uint64_t)> cb);
@@ -266,8 +301,15 @@ class ContinuousClustering
 
   private:
     void addFiringImpl(const RawPoints::ConstPtr& firing, const double tf[12]);
+    void bufferFiring(const RawPoints::ConstPtr& firing, const double tf[12]);
     void setRobotTransformImpl();
     void process();
+    // asynchronous mode (is_single_threaded = false)
+    void workerLoop();
+    void startWorker();
+    void stopWorker();
+    void waitIdle();
+    void rethrowWorkerError();
     void check(int rc);
     // mirror of range_image_: the columns a call touched are fetched once (fetchColumns) and applied in callback order, stage by stage
     enum MirrorStage
@@ -326,6 +368,21 @@ class ContinuousClustering
     std::vector<int64_t> link_buf_;
     std::vector<int64_t> col_min_src_; // per ring column: oldest firing that still has a point in it (-1 unknown)
     std::list<size_t> num_pending_jobs_;
+    // asynchronous mode: firings queue here (cc.cpp:92) and the worker thread takes what has queued up
+    struct QueuedFiring
+    {
+        RawPoints::ConstPtr firing;
+        std::array<double, 12> tf;
+    };
+    bool async_{false};
+    std::thread worker_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_idle_;
+    std::deque<QueuedFiring> queue_;
+    bool stop_{false};
+    bool busy_{false};
+    std::exception_ptr worker_error_;
+    std::atomic<bool> reset_required_async_{false};
 };
 
 } // namespace continuous_clustering

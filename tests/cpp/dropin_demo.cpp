@@ -36,14 +36,16 @@ int main(int argc, char** argv)
         fread(poses.data(), 8, poses.size(), f) != poses.size())
         return 2;
     fclose(f);
-    const int batch = argc > 3 ? atoi(argv[3]) : 1;      // 0 = adaptive batching (setAdaptiveBatching)
+    const int batch = argc > 3 ? atoi(argv[3]) : 1;      // 0 = adaptive batching (setAdaptiveBatching); -1 = the reference's API only, with the
+                                                         // reference's default is_single_threaded = false (the asynchronous mode)
     const double rate_hz = argc > 4 ? atof(argv[4]) : 0.;  // > 0: feed the firings paced like a live sensor (firings per second)
 
     ContinuousClustering clustering;
     Configuration config; // kitti_demo.cpp:279-294
+    const bool reference_api_only = batch < 0;
     if (kitti == 1)
     {
-        config.general.is_single_threaded = true;
+        config.general.is_single_threaded = !reference_api_only;
         config.clustering.ignore_points_in_chessboard_pattern = false;
         config.clustering.max_distance = 0.5;
         config.ground_segmentation.height_ref_to_maximum_ = 0.5;
@@ -55,7 +57,7 @@ int main(int argc, char** argv)
     }
     else if (kitti == 2) // library defaults + an ego box (tests/cases.py `_vls`)
     {
-        config.general.is_single_threaded = true;
+        config.general.is_single_threaded = !reference_api_only;
         config.ground_segmentation.height_ref_to_maximum_ = 0.5;
         config.ground_segmentation.height_ref_to_ground_ = -1.7;
         config.ground_segmentation.length_ref_to_front_end_ = 3;
@@ -67,11 +69,16 @@ int main(int argc, char** argv)
     clustering.setConfiguration(config);
     clustering.reset(rows);
     clustering.setTransformRobotFrameFromSensorFrame(Pose3d::Identity());
-    if (batch <= 0)
+    if (batch == 0)
         clustering.setAdaptiveBatching();
-    else
+    else if (batch > 0)
         clustering.setBatchSize(batch);
+    // (batch < 0: nothing but the reference's own calls)
 
+    using clk = std::chrono::steady_clock;
+    std::vector<double> due_us((size_t) n, 0.), seen_us((size_t) n, -1.);
+    const auto t0 = clk::now();
+    auto now_us = [&]() { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
     const bool dump = std::string(argv[2]) != "/dev/null"; // timing runs: callbacks installed, nothing written
     FILE* out = fopen(argv[2], "wb");
     long long n_ground_cb = 0, n_cluster_cb = 0, n_ground_view_violations = 0, n_published = 0;
@@ -80,6 +87,10 @@ int main(int argc, char** argv)
         {
             if (ground_points_only)
             {
+                // asynchronous mode: the callbacks run on the class's worker thread. The j-th ground-view callback is caused by firing j + 1
+                // (one column per firing for the streams this harness feeds): that firing has been delivered now
+                if (reference_api_only && n_ground_cb + 1 < n && seen_us[(size_t) n_ground_cb + 1] < 0)
+                    seen_us[(size_t) n_ground_cb + 1] = now_us();
                 n_ground_cb++;
                 // the ground view runs before the column is associated (cc.cpp:618-623): clustering fields still as clearColumns left them
                 int lc = static_cast<int>(from % clustering.ring_buffer_max_columns);
@@ -152,11 +163,7 @@ int main(int argc, char** argv)
 
     // real-time feed: firing k is due at t0 + k / rate; its latency is measured from that instant to the moment its ground-view callback
     // has run (the column it finishes has been segmented and handed on) — 0 pacing = as fast as the class takes them
-    using clk = std::chrono::steady_clock;
-    std::vector<double> due_us((size_t) n, 0.), seen_us((size_t) n, -1.);
     long long delivered_upto = 0; // firings [0, delivered_upto) have been through the engine
-    const auto t0 = clk::now();
-    auto now_us = [&]() { return std::chrono::duration<double, std::micro>(clk::now() - t0).count(); };
     for (int k = 0; k < n; k++)
     {
         if (rate_hz > 0)
@@ -187,7 +194,7 @@ int main(int argc, char** argv)
             pose.m[i] = poses[(size_t) k * 12 + i];
         const long long before = n_ground_cb;
         clustering.addFiring(firing, pose);
-        if (n_ground_cb != before || batch == 1)
+        if (!reference_api_only && (n_ground_cb != before || batch == 1))
         {
             // the call went through the engine: every firing fed so far has been delivered
             const double t = now_us();
@@ -200,7 +207,8 @@ int main(int argc, char** argv)
     {
         const double t = now_us();
         for (long long j = delivered_upto; j < n; j++)
-            seen_us[(size_t) j] = t;
+            if (seen_us[(size_t) j] < 0)
+                seen_us[(size_t) j] = t;
         std::vector<double> lat;
         for (int k = n / 10; k < n; k++) // skip the start-up (ring not started, graph capture)
             lat.push_back(seen_us[(size_t) k] - due_us[(size_t) k]);

@@ -52,8 +52,10 @@ def parse(path, rows):
     return ranges, cells, clusters, counts
 
 
+# batch -1: nothing but the reference's API with the reference's default configuration is_single_threaded = false — the asynchronous mode
+# (addFiring enqueues, a worker thread inside the class runs the engine and the callbacks, in the single-threaded order)
 @pytest.mark.parametrize("case,batch", [("g_s64_translate", 1), ("g_s64_translate", 97), ("g_s64_translate", 0), ("s64_dropouts", 1), ("s64_dropouts", 61),
-                                        ("s128_offsets", 170)])
+                                        ("s128_offsets", 170), ("g_s64_translate", -1), ("s64_dropouts", -1), ("s128_offsets", -1)])
 def test_dropin_class_matches_oracle(tmp_path, case, batch, oracle_lib):
     build_demo()
     stream, cfg, tf = cases.build_case(case)
@@ -146,7 +148,7 @@ def test_adaptive_batching_follows_a_live_sensor(tmp_path):
         f.write(stream.intensity.astype(np.uint8).tobytes())
         f.write(stream.poses.astype(np.float64).tobytes())
     out = {}
-    for batch, rate in ((0, 22000), (0, 0), (1, 0)):
+    for batch, rate in ((0, 22000), (0, 0), (1, 0), (-1, 22000), (-1, 0)):
         r = subprocess.run([DEMO, inp, "/dev/null", str(batch), str(rate)], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         m = re.search(r"firings_per_s=(\d+) latency_us_p50=([\d.]+) p99=([\d.]+) max=([\d.]+)", r.stdout)
@@ -156,3 +158,7 @@ def test_adaptive_batching_follows_a_live_sensor(tmp_path):
     # (p99 is 1.1 - 2.8 ms from run to run on one box: host-side jitter of the callbacks and the mirror; the bound only catches a stall)
     assert out[(0, 22000)][2] < 20000, "p99 delivery latency above 20 ms"
     assert out[(0, 0)][0] > 22000, "free-running adaptive feed slower than the sensor"
+    # the reference's API alone (default is_single_threaded = false = asynchronous mode): an unchanged front-end follows the sensor
+    assert out[(-1, 22000)][0] >= 21800, "the asynchronous mode did not keep up with 22 000 firings per second"
+    assert out[(-1, 22000)][2] < 20000, "p99 delivery latency of the asynchronous mode above 20 ms"
+    assert out[(-1, 0)][0] > 22000
