@@ -354,6 +354,70 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
     return res, eng, (xyz, inten, poses)
 
 
+def live_multi_stream(torch, cfg, sensor, xyz, inten, poses, local_rank, sizes=(8, 32, 128, 550, 2200)):
+    """The metric's second half for configs[2]: S live streams, n firings per stream per engine call. For every n:
+    throughput with the calls pipelined (three chains in flight, like the headline) and the latency of ONE call alone — submit ->
+    everything of the call associated and published, measured with a sync per call — p50 / p99 over the calls. A column of a live 10 Hz
+    sensor (22 000 firings/s) is finishable when the next firing arrives; it then waits for its call to fill (up to n / 22 000 s) and
+    for the call to be processed (call latency). `keeps_up` says whether S such sensors can be followed with calls of n firings."""
+    from continuous_clustering_amd import Engine
+    S, F, R = int(xyz.shape[1]), int(xyz.shape[2]), sensor.num_rows
+    rot = min(int(xyz.shape[0]), 4)
+    out = {}
+    for n in sizes:
+        if n > F:
+            continue
+        per_rot = F // n
+        # contiguous [S][n][...] chunks of the first `rot` rotations
+        eng = Engine(cfg, R, S, device=local_rank)
+        eng.record_events(False)
+        calls = []
+        max_calls = 400 if n < 550 else rot * per_rot
+        for b in range(rot):
+            for k in range(per_rot):
+                if len(calls) >= max_calls:
+                    break
+                calls.append((xyz[b][:, k * n:(k + 1) * n].contiguous(), inten[b][:, k * n:(k + 1) * n].contiguous(),
+                              poses[b][:, k * n:(k + 1) * n].contiguous()))
+        torch.cuda.synchronize()
+        half = len(calls) // 2
+        # first half: one call at a time (latency), second half: pipelined (throughput)
+        lat = []
+        warm = min(10, half // 4)
+        for i, (cx, ci, cp) in enumerate(calls[:half]):
+            t1 = time.perf_counter()
+            eng.add_firings_device(n, cx, ci, cp)
+            rc = eng.sync()
+            if rc != 0:
+                raise SystemExit(f"engine error {rc}: {eng.last_error()}")
+            if i >= warm:
+                lat.append(time.perf_counter() - t1)
+        t0 = time.perf_counter()
+        for cx, ci, cp in calls[half:]:
+            eng.add_firings_device(n, cx, ci, cp)
+        rc = eng.sync()
+        el = time.perf_counter() - t0
+        if rc != 0:
+            raise SystemExit(f"engine error {rc}: {eng.last_error()}")
+        ncalls = len(calls) - half
+        lat = np.array(lat) * 1e6
+        period_us = el / ncalls * 1e6
+        out[str(n)] = {"firings_per_call": n, "calls_timed": ncalls, "Mpoints_per_s": S * n * R * ncalls / el / 1e6, "call_period_us": period_us,
+                       "call_latency_us_p50": float(np.percentile(lat, 50)), "call_latency_us_p99": float(np.percentile(lat, 99)),
+                       "fill_wait_us_max": n / 22000.0 * 1e6,
+                       "column_latency_us_p99_live": float(n / 22000.0 * 1e6 + np.percentile(lat, 99)),
+                       "keeps_up_with_10Hz_sensors": bool(period_us <= n / 22000.0 * 1e6)}
+        eng.close()
+        del calls
+        torch.cuda.empty_cache()
+    out["note"] = (f"{S} streams x n firings per cc_engine_add_firings_device call, inputs resident in HBM. call_latency = submit -> sync of one call alone "
+                   "(all kernels of the path for the call's columns); call_period = pipelined calls back to back. column_latency_us_p99_live = "
+                   "time a call of a live 22 kHz sensor takes to fill + p99 call latency: the bound for 'column finishable -> column associated' "
+                   "(SURVEY 8d) when S live sensors are served with calls of n firings; keeps_up = the pipelined call period is shorter than the "
+                   "time the sensors need to deliver n firings")
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -463,6 +527,10 @@ def main():
                       "installed and the range_image_ mirror maintained; latency = firing due time -> return of the call that delivered it; "
                       "a sensor needs 22 000 firings/s")
         out["realtime_single_stream"] = rt
+
+    # ---- configs[2], second half of the metric: live streams served with small calls (throughput and latency vs firings per call) ----
+    if rank == 0 and not args.no_latency:
+        out["live_multi_stream"] = live_multi_stream(torch, cfg, sensor, xyz, inten, poses, local_rank)
 
     # ---- CPU baseline on this box's host cores (inputs: the bench's own streams, copied back from HBM) ------------
     if rank == 0 and not args.no_cpu_baseline:
