@@ -1,7 +1,10 @@
 #!/bin/bash
-# build_ref.sh — TEST INFRASTRUCTURE. Compiles the REFERENCE's own clustering core from the sources where they lie
-# (/root/reference/src/clustering/continuous_clustering.cpp + its headers) together with oracle/ref_driver.cpp into
-# oracle/_ref/libcc_ref.so, so that tests/test_reference_build.py can diff oracle/cc_oracle.cpp against the reference itself.
+# build_ref.sh — TEST INFRASTRUCTURE. Compiles the REFERENCE's own sources where they lie, each with a thin extern "C" driver of ours that
+# only uses the reference's public API, so that tests/test_reference_build.py can diff the oracle's restatements against the reference itself:
+#   oracle/_ref/libcc_ref.so      src/clustering/continuous_clustering.cpp + oracle/ref_driver.cpp         (needs Eigen3)   <-> oracle/cc_oracle.cpp
+#   oracle/_ref/libloader_ref.so  src/evaluation/kitti_loader.cpp + oracle/ref_loader_driver.cpp           (needs Eigen3)   <-> oracle/kitti_oracle.cpp
+#   oracle/_ref/libeval_ref.so    src/evaluation/kitti_evaluation.cpp + kitti_loader.cpp + oracle/ref_eval_driver.cpp (needs Eigen3 AND PCL)
+#                                                                                                          <-> oracle/eval_oracle.cpp, gt_oracle.cpp
 #
 # The reference core includes <Eigen/Geometry>. This recipe ONLY runs against a real Eigen3 installation (pkg-config eigen3,
 # $EIGEN3_INCLUDE_DIR, or one of the usual system locations). It never writes, fetches or substitutes headers: when Eigen3 is not
@@ -30,3 +33,32 @@ mkdir -p "$here/_ref"
 ${CXX:-g++} -O2 -std=c++17 -fPIC -shared -pthread -I"$ref/include" -I"$eigen" \
   -o "$here/_ref/libcc_ref.so" "$ref/src/clustering/continuous_clustering.cpp" "$here/ref_driver.cpp" || exit 1
 echo "build_ref: built $here/_ref/libcc_ref.so"
+# ---- the KITTI loader (Eigen3 only) -----------------------------------------------------------------------------------------------
+${CXX:-g++} -O2 -std=c++17 -fPIC -shared -pthread -I"$ref/include" -I"$eigen" \
+  -o "$here/_ref/libloader_ref.so" "$ref/src/evaluation/kitti_loader.cpp" "$here/ref_loader_driver.cpp" || exit 1
+echo "build_ref: built $here/_ref/libloader_ref.so"
+# ---- the evaluation library (Eigen3 + a real PCL: headers and the libraries kitti_evaluation.cpp links, CMakeLists.txt of the reference) ----
+pcl_cflags=""; pcl_libs=""
+if command -v pkg-config >/dev/null 2>&1; then
+  for v in 1.14 1.13 1.12 1.11 1.10 1.9 1.8; do
+    if pkg-config --exists "pcl_segmentation-$v" 2>/dev/null; then
+      pcl_cflags="$(pkg-config --cflags pcl_segmentation-$v pcl_search-$v pcl_kdtree-$v pcl_common-$v)"
+      pcl_libs="$(pkg-config --libs pcl_segmentation-$v pcl_search-$v pcl_kdtree-$v pcl_common-$v)"
+      break
+    fi
+  done
+fi
+if [ -z "$pcl_cflags" ]; then
+  for cand in "${PCL_INCLUDE_DIR:-}" /usr/include/pcl-1.14 /usr/include/pcl-1.13 /usr/include/pcl-1.12 /usr/include/pcl-1.10 /usr/include/pcl-1.8 /usr/local/include/pcl-1.14; do
+    if [ -n "$cand" ] && [ -f "$cand/pcl/point_types.h" ] && [ -f "$cand/pcl/segmentation/conditional_euclidean_clustering.h" ]; then
+      pcl_cflags="-I$cand"; pcl_libs="-lpcl_segmentation -lpcl_search -lpcl_kdtree -lpcl_common"; break
+    fi
+  done
+fi
+if [ -z "$pcl_cflags" ]; then
+  echo "build_ref: no PCL installation found (pkg-config pcl_segmentation-1.x, \$PCL_INCLUDE_DIR, /usr/include/pcl-1.x): libeval_ref.so is not built; oracle/eval_oracle.cpp and gt_oracle.cpp stay parity unpinned"
+  exit 0
+fi
+${CXX:-g++} -O2 -std=c++17 -fPIC -shared -pthread -I"$ref/include" -I"$eigen" $pcl_cflags \
+  -o "$here/_ref/libeval_ref.so" "$ref/src/evaluation/kitti_evaluation.cpp" "$ref/src/evaluation/kitti_loader.cpp" "$here/ref_eval_driver.cpp" $pcl_libs || exit 1
+echo "build_ref: built $here/_ref/libeval_ref.so"

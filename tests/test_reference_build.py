@@ -97,3 +97,92 @@ def test_oracle_equals_the_reference_build(name, oracle_lib):
                     assert bad.size == 0, f"{f}: first difference at column {c0 + bad[0][0]} row {bad[0][1]}"
     finally:
         L.ref_destroy(h)
+
+
+# ---- the other three restatements: oracle/kitti_oracle.cpp <-> the reference's KittiLoader (real Eigen3 only), oracle/eval_oracle.cpp and
+# ---- oracle/gt_oracle.cpp <-> the reference's KittiEvaluation (real Eigen3 AND real PCL only). Both skip in this image.
+def _aux_reference_lib(name):
+    build_reference()  # skips without the reference tree / Eigen3; builds every library its prerequisites allow
+    path = os.path.join(ROOT, "oracle", "_ref", name)
+    if not os.path.exists(path):
+        pytest.skip(f"oracle/_ref/{name} cannot be built here (PCL missing): the restatement stays parity unpinned")
+    return C.CDLL(path)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_kitti_oracle_equals_the_reference_loader(seed, oracle_lib):
+    from continuous_clustering_amd import kitti
+    from oracle import pyoracle as orc
+    L = _aux_reference_lib("libloader_ref.so")
+    i64, u64, vp = C.c_int64, C.c_uint64, C.c_void_p
+    L.kref_recover_laser_indices.argtypes = [i64, vp, vp]
+    L.kref_undo_ego_motion.argtypes = [i64, vp, u64, u64, vp, i64, vp, vp]
+    L.kref_undo_ego_motion.restype = None
+    L.kref_generate_range_image.argtypes = [i64, vp, vp, C.c_int, vp]
+    L.kref_generate_range_image.restype = None
+    L.kref_interpolate.argtypes = [i64, vp, vp, u64, vp]
+    L.kref_interpolate.restype = None
+    L.kref_start_end_stamps.argtypes = [i64, vp, vp, vp]
+    L.kref_start_end_stamps.restype = None
+    pts, rows = kitti.synthetic_frame(seed=seed, duplicate=0.15)
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    n = pts.shape[0]
+    # recoverLaserIndices (kitti_loader.cpp:48-99)
+    laser_o, _, _, threw_o = orc.kitti_recover_laser_indices(pts)
+    laser_r = np.zeros(n, dtype=np.uint8)
+    threw_r = L.kref_recover_laser_indices(n, pts.ctypes.data, laser_r.ctypes.data)
+    assert bool(threw_r) == threw_o and np.array_equal(laser_r, laser_o)
+    # poses: interpolate (kitti_loader.cpp:297-328) and getStartEndTimestampsVelodyne (:525-540)
+    rows_p, times = kitti.synthetic_poses(6, (8.0, 0.5, 0.02, 0.3))
+    poses = np.ascontiguousarray(np.stack([orc.kitti_pose_from_line(r, kitti.CALIB_TR) for r in rows_p]), dtype=np.float64)
+    stamps = np.ascontiguousarray((times * 1e9).astype(np.uint64) + np.uint64(1_700_000_000_000_000_000))
+    start_o, end_o = orc.kitti_start_end_stamps(stamps)
+    start_r, end_r = np.zeros_like(stamps), np.zeros_like(stamps)
+    L.kref_start_end_stamps(len(stamps), stamps.ctypes.data, start_r.ctypes.data, end_r.ctypes.data)
+    assert np.array_equal(start_r, start_o) and np.array_equal(end_r, end_o)
+    for frac in (0.0, 0.13, 0.5, 0.77, 1.0):
+        t = int(stamps[1]) + int(frac * (int(stamps[4]) - int(stamps[1])))
+        out_r = np.zeros(12)
+        L.kref_interpolate(len(stamps), stamps.ctypes.data, poses.ctypes.data, t, out_r.ctypes.data)
+        util.assert_float_equal("interpolated pose", out_r, orc.kitti_interpolate(stamps, poses, t))
+    # undoEgoMotionCorrection (:177-210), then generateRangeImage (:101-175) on its output
+    mid = orc.kitti_interpolate(stamps, poses, int(stamps[2]))
+    un_o = orc.kitti_undo_ego_motion(pts, int(start_o[2]), int(end_o[2]), mid, stamps, poses)
+    un_r = pts.copy()
+    L.kref_undo_ego_motion(n, un_r.ctypes.data, int(start_o[2]), int(end_o[2]), mid.ctypes.data, len(stamps), stamps.ctypes.data, poses.ctypes.data)
+    util.assert_float_equal("un-corrected points", un_r, un_o)
+    for shift in (True, False):
+        cells_o, _ = orc.kitti_generate_range_image(un_o, laser_o, shift=shift)
+        cells_r = np.zeros_like(cells_o)
+        L.kref_generate_range_image(n, un_o.ctypes.data, laser_o.ctypes.data, 1 if shift else 0, cells_r.ctypes.data)
+        assert np.array_equal(cells_r, cells_o)
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_eval_and_gt_oracles_equal_the_reference_evaluation(seed, oracle_lib):
+    from oracle import pyoracle as orc
+    L = _aux_reference_lib("libeval_ref.so")
+    i64, vp = C.c_int64, C.c_void_p
+    L.ref_eval_frame.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.ref_generate_euclidean_labels.argtypes = [i64, vp, vp, vp, vp]
+    L.ref_generate_euclidean_labels.restype = None
+    rng = np.random.default_rng(seed)
+    # generateEuclideanClusteringLabels (kitti_evaluation.cpp:224-275): PCL's ConditionalEuclideanClustering itself
+    n = 4000
+    centers = rng.uniform(-15, 15, (60, 3)).astype(np.float32)
+    which = rng.integers(0, 60, n)
+    pts = np.concatenate([centers[which] + rng.normal(0, 0.4, (n, 3)).astype(np.float32), rng.random((n, 1)).astype(np.float32)], axis=1)
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    sem = np.ascontiguousarray(rng.choice(np.array([10, 30, 40, 50, 70, 0, 72, 80], dtype=np.uint16), 60)[which])
+    inst = np.ascontiguousarray((which % 3).astype(np.uint16))
+    lab_o, _ = orc.generate_euclidean_labels(pts, sem, inst)
+    lab_r = np.zeros(n, dtype=np.uint16)
+    L.ref_generate_euclidean_labels(n, pts.ctypes.data, sem.ctypes.data, inst.ctypes.data, lab_r.ctypes.data)
+    assert np.array_equal(lab_r, lab_o)
+    # evaluateGroundPoints + evaluateClusters (kitti_evaluation.cpp:44-146)
+    euclid = np.ascontiguousarray(lab_o.astype(np.uint32))
+    det = np.ascontiguousarray(np.where(rng.random(n) < 0.8, (which // 2 + 1), 0).astype(np.uint32))
+    ground = np.ascontiguousarray((rng.random(n) < 0.4).astype(np.uint8))
+    out_r = np.zeros(6)
+    assert L.ref_eval_frame(n, sem.ctypes.data, euclid.ctypes.data, ground.ctypes.data, det.ctypes.data, out_r.ctypes.data) == 0
+    util.assert_float_equal("evaluation record", out_r, orc.eval_frame(sem, euclid, ground, det))
