@@ -418,6 +418,52 @@ def live_multi_stream(torch, cfg, sensor, xyz, inten, poses, local_rank, sizes=(
     return out
 
 
+def replay_report(local_rank, frames_scale=0.004, verify_sequences=2):
+    """BASELINE.json configs[4] shape on this GPU: the 11 SemanticKITTI train sequences as synthetic KITTI-format data on disk (frame counts of
+    kitti_loader.cpp:552-562 scaled down so that the run takes seconds), replayed CONCURRENTLY as the streams of one engine through
+    continuous_clustering_amd.replay: .bin -> rows / un-correction / range image / pseudo-firings on the GPU -> hot path -> device frame scatter
+    -> label compare on the GPU -> records. frames/s is end to end (file reads and pose interpolation on the host included); device_frames_per_s
+    leaves the host's file I/O out. A few sequences are checked against the single-sequence oracle walk (bit-equal records)."""
+    import shutil
+    import tempfile
+    from continuous_clustering_amd import kitti, replay
+    counts = {0: 4541, 1: 1101, 2: 4661, 3: 801, 4: 271, 5: 2761, 6: 1101, 7: 1101, 8: 4071, 9: 1591, 10: 1201}
+    lengths = {s: max(2, int(round(n * frames_scale))) for s, n in counts.items()}
+    root = tempfile.mkdtemp(prefix="cc_replay_")
+    try:
+        for s, nf in lengths.items():
+            kitti.write_synthetic_sequence(root, s, nf, seed=500 + s, motion=(6.0 + 0.5 * s, 0.05 * s, 0.0, 0.1))
+        timing = {}
+        t0 = time.perf_counter()
+        records, totals = replay.replay(root, list(lengths), device=local_rank, timing=timing)
+        el = time.perf_counter() - t0
+        out = {"sequences": len(lengths), "frames": totals["frames"], "frames_per_sequence": lengths, "seconds": el,
+               "frames_per_s": totals["frames"] / el, "device_frames_per_s": totals["frames"] / max(timing.get("device_s", el), 1e-9),
+               "host_io_s": timing.get("host_io_s"), "device_s": timing.get("device_s"), "records": len(records),
+               "cells_published": totals["cells_published"],
+               "note": "11 synthetic KITTI-format sequences (SemanticKITTI train frame counts x %.3g) replayed concurrently on one GPU; frame scatter "
+                       "and label compare on the device; at N GPUs sequence i runs on rank i mod N and the records meet in one all_gather" % frames_scale}
+        # oracle walk of a few sequences (loader -> clustering -> scatter -> label compare, all CPU) must give the same records, bit for bit
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        try:
+            import test_gpu_kitti_replay as tk
+            ok = 0
+            for s in sorted(lengths, key=lambda k: lengths[k])[:verify_sequences]:
+                sc, _, _ = tk.expected_records(os.path.join(root, "sequences", f"{s:02d}"), s, lengths[s])
+                sc.finish()
+                want = np.array(sc.records)
+                got = np.array(sorted([r for r in records if int(r[0]) == s], key=lambda r: r[1]))
+                if got.shape != want.shape or not np.array_equal(got.view(np.uint64), want.view(np.uint64)):
+                    raise SystemExit(f"replay: records of sequence {s} differ from the oracle walk")
+                ok += 1
+            out["verified_sequences"] = ok
+        except ImportError:
+            out["verified_sequences"] = 0
+        return out
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def main():
     args = parse()
     import torch
@@ -558,6 +604,10 @@ def main():
                            "kernel_ms_per_step": r2["kernel_ms_per_step"], "roofline": r2["roofline"],
                            "verified_streams": len(r2["verified"]["streams"]) if r2["verified"] else 0,
                            "serial_columns": r2["serial_columns"]}
+
+    # ---- BASELINE.json configs[4] shape: concurrent replay of KITTI-format sequences, end to end ----
+    if rank == 0 and not args.no_latency:
+        out["replay"] = replay_report(local_rank)
 
     if rank == 0:
         print(json.dumps(out))

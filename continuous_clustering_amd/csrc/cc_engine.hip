@@ -1803,6 +1803,71 @@ int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters
     return CC_OK;
 }
 
+// ---- frame scatter of a replayed sequence (kitti_demo.cpp:173-224), include/cc_kitti.h ------------------------------------------------
+int cc_engine_scatter_info(cc_engine* e, int n, const int32_t* streams, const int64_t* from, const int64_t* to, const int32_t* d_original_index,
+                           int slots, int32_t* h_min_frame, int32_t* h_max_frame)
+{
+    if (!e || n < 0 || slots < 1 || (n > 0 && (!streams || !from || !to || !d_original_index || !h_min_frame || !h_max_frame)))
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    size_t total = 0;
+    for (int i = 0; i < n; i++)
+    {
+        if (streams[i] < 0 || streams[i] >= e->g.num_streams || to[i] - from[i] >= e->g.ring_cols)
+            return CC_ERR_INVALID_ARGUMENT;
+        if (to[i] >= from[i])
+            total += (size_t) (to[i] - from[i] + 1);
+    }
+    if (total == 0)
+        return CC_OK;
+    const size_t need = total * 8 + 64;
+    if (e->gather_bytes < need)
+    {
+        void* p = nullptr;
+        CC_HIP_CHECK(e, hipMalloc(&p, need * 2));
+        e->allocations.push_back(p);
+        e->d_gather = (char*) p;
+        e->gather_bytes = need * 2;
+    }
+    int* d_min = (int*) e->d_gather;
+    int* d_max = d_min + total;
+    size_t o = 0;
+    for (int i = 0; i < n; i++)
+        if (to[i] >= from[i])
+        {
+            const unsigned cols = (unsigned) (to[i] - from[i] + 1);
+            hipLaunchKernelGGL(cck::k_scatter_info, dim3(cols), dim3(64), 0, e->stream, e->g, e->P, streams[i], (long long) from[i], d_original_index,
+                               slots, d_min + o, d_max + o);
+            o += cols;
+        }
+    CC_HIP_CHECK(e, hipGetLastError());
+    CC_HIP_CHECK(e, hipMemcpyAsync(h_min_frame, d_min, total * 4, hipMemcpyDeviceToHost, e->stream));
+    CC_HIP_CHECK(e, hipMemcpyAsync(h_max_frame, d_max, total * 4, hipMemcpyDeviceToHost, e->stream));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    return CC_OK;
+}
+
+int cc_engine_scatter_apply(cc_engine* e, int stream, int64_t from, int64_t to, const int32_t* d_original_index, int slots, uint8_t* d_is_ground,
+                            uint32_t* d_detection, int64_t max_points)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || slots < 1 || !d_original_index || !d_is_ground || !d_detection || max_points < 1 ||
+        to - from >= e->g.ring_cols)
+        return CC_ERR_INVALID_ARGUMENT;
+    if (to < from)
+        return CC_OK;
+    (void) hipSetDevice(e->device);
+    int rc = finish_batch(e);
+    if (rc)
+        return rc;
+    hipLaunchKernelGGL(cck::k_scatter_apply, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, stream, (long long) from,
+                       d_original_index, slots, d_is_ground, d_detection, (long long) max_points);
+    CC_HIP_CHECK(e, hipGetLastError());
+    return CC_OK; // (asynchronous on cc_engine_hip_stream(e): cc_eval_frame_device on the same stream, or cc_engine_sync, orders behind it)
+}
+
 int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* batch_bails, uint64_t bail_reasons[8])
 {
     if (!e)

@@ -7,6 +7,8 @@
 // then inner) with the host's std::log, so the result is bit-identical to the reference's on the same host — no floating-point
 // reduction happens on the device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the library is resolved at run time (cc_eval_gather_records)
 
 #include <algorithm>
 #include <cmath>
@@ -256,6 +258,81 @@ void cc_eval_summarize(const cc_eval_frame_result* frames, int64_t n, double out
         }
         cc_eval_mean_std(data.data(), n, &out[metric * 2], &out[metric * 2 + 1]);
     }
+}
+
+
+// ---- the one exchange step of the whole system: per-frame evaluation records of every rank to every rank -----------------
+// RCCL is not a link-time dependency of this library: the collective is looked up in the librccl the process already has (the harness that
+// made the communicator linked it), so nothing changes for callers that never gather.
+static void* rccl_symbol(const char* name)
+{
+    static void* lib = nullptr;
+    if (!lib)
+    {
+        for (const char* n : {"librccl.so.1", "librccl.so"})
+        {
+            lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); // the instance the communicator came from
+            if (lib)
+                break;
+        }
+        if (!lib)
+            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            {
+                lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (lib)
+                    break;
+            }
+    }
+    return lib ? dlsym(lib, name) : nullptr;
+}
+
+int cc_eval_gather_records(void* nccl_comm, int world, int device, const double* records, int64_t n, int64_t capacity, double* out,
+                           int64_t* counts)
+{
+    if (!nccl_comm || world < 1 || n < 0 || capacity < 1 || n > capacity || (n > 0 && !records) || !out || !counts)
+        return CC_ERR_INVALID_ARGUMENT;
+    typedef ncclResult_t (*allgather_fn)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
+    static allgather_fn all_gather = nullptr;
+    if (!all_gather)
+        all_gather = (allgather_fn) rccl_symbol("ncclAllGather");
+    if (!all_gather)
+        return CC_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess)
+        return CC_ERR_NO_DEVICE;
+    // fixed-size padded block per rank: row 0 = {number of records}, rows 1 .. capacity = records of 8 doubles (sequence, frame, tp, fn, fp,
+    // tn, OSE, USE: EvaluationResultForFrame, kitti_evaluation.hpp:38-49, tagged) — ONE ncclAllGather
+    const size_t row = 8, block = (size_t) (capacity + 1) * row;
+    std::vector<double> h_send(block, 0.0), h_recv(block * (size_t) world);
+    h_send[0] = (double) n;
+    if (n > 0)
+        std::memcpy(h_send.data() + row, records, (size_t) n * row * sizeof(double));
+    double *d_send = nullptr, *d_recv = nullptr;
+    hipStream_t st = nullptr;
+    int rc = CC_OK;
+    if (hipMalloc(&d_send, block * sizeof(double)) != hipSuccess || hipMalloc(&d_recv, block * world * sizeof(double)) != hipSuccess ||
+        hipStreamCreate(&st) != hipSuccess)
+        rc = CC_ERR_HIP;
+    if (rc == CC_OK && hipMemcpyAsync(d_send, h_send.data(), block * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = CC_ERR_HIP;
+    if (rc == CC_OK && all_gather(d_send, d_recv, block, ncclDouble, (ncclComm_t) nccl_comm, st) != ncclSuccess)
+        rc = CC_ERR_HIP;
+    if (rc == CC_OK && (hipMemcpyAsync(h_recv.data(), d_recv, block * world * sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                        hipStreamSynchronize(st) != hipSuccess))
+        rc = CC_ERR_HIP;
+    if (rc == CC_OK)
+        for (int r = 0; r < world; r++)
+        {
+            const double* b = h_recv.data() + (size_t) r * block;
+            counts[r] = (int64_t) b[0];
+            std::memcpy(out + (size_t) r * (size_t) capacity * row, b + row, (size_t) capacity * row * sizeof(double));
+        }
+    if (st)
+        (void) hipStreamDestroy(st);
+    if (d_send)
+        (void) hipFree(d_send);
+    if (d_recv)
+        (void) hipFree(d_recv);
+    return rc;
 }
 
 } // extern "C"

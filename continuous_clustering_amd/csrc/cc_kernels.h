@@ -4762,6 +4762,76 @@ __global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const Stre
 }
 
 // =====================================================================================================
+// k_scatter_info / k_scatter_apply — the frame scatter of the reference's harness (addColumnAndEvaluateFrameIfCompleted,
+// kitti_demo.cpp:173-224) for a replayed KITTI sequence, on the device. A stream that is fed exactly num_columns pseudo-firings per frame
+// (kitti_demo.cpp:386-403) carries, per cell, the sequence number of the firing that filled it: frame = sequence / num_columns, range-image
+// column of the frame = sequence % num_columns, and the KITTI point of the cell is original_index[frame % slots][column][row]
+// (cc_kitti_frame::d_original_index of the frame's conversion). k_scatter_info gives the smallest / largest frame among the points of every
+// published column (what the harness needs to find where frame N + 1 starts, :205-209, and its two error conditions); k_scatter_apply
+// writes is_ground_point = (ground_point_label == GP_GROUND) and detection_label = id (:214-215) of the columns' points into the frames'
+// arrays in HBM, which cc_eval_frame_device then reads. grid = columns, block = 64 (lanes = rows).
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_scatter_info(Geometry g, Planes P, int s, long long from, const int* __restrict__ original_index, int slots,
+                                                     int* __restrict__ out_min, int* __restrict__ out_max)
+{
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols, NC = g.num_columns;
+    const long long gc = from + blockIdx.x;
+    const int lc = (int) (gc % RC);
+    const int* org = original_index + (size_t) s * (size_t) slots * (size_t) NC * (size_t) R;
+    int mn = 0x7fffffff, mx = -1;
+    for (int row = lane_id(); row < R; row += 64)
+    {
+        const int ci = lc * R + row;
+        if (p.dist[ci] == p.dist[ci]) // the cell holds a return
+        {
+            const unsigned seq = p.src[ci];
+            const int frame = (int) (seq / (unsigned) NC), col = (int) (seq % (unsigned) NC);
+            if (org[((size_t) (frame % slots) * NC + col) * R + row] >= 0)
+            {
+                mn = frame < mn ? frame : mn;
+                mx = frame > mx ? frame : mx;
+            }
+        }
+    }
+    mn = wave_min_i32(mn);
+    mx = -wave_min_i32(-mx);
+    if (lane_id() == 0)
+    {
+        out_min[blockIdx.x] = mn;
+        out_max[blockIdx.x] = mx;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_scatter_apply(Geometry g, Planes P, int s, long long from, const int* __restrict__ original_index, int slots,
+                                                      unsigned char* __restrict__ is_ground, unsigned* __restrict__ detection, long long max_points)
+{
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols, NC = g.num_columns;
+    const long long gc = from + blockIdx.x;
+    const int lc = (int) (gc % RC);
+    const int* org = original_index + (size_t) s * (size_t) slots * (size_t) NC * (size_t) R;
+    unsigned char* gr = is_ground + (size_t) s * (size_t) slots * (size_t) max_points;
+    unsigned* det = detection + (size_t) s * (size_t) slots * (size_t) max_points;
+    for (int row = lane_id(); row < R; row += 64)
+    {
+        const int ci = lc * R + row;
+        if (p.dist[ci] == p.dist[ci])
+        {
+            const unsigned seq = p.src[ci];
+            const int frame = (int) (seq / (unsigned) NC), col = (int) (seq % (unsigned) NC);
+            const int pt = org[((size_t) (frame % slots) * NC + col) * R + row];
+            if (pt >= 0 && pt < max_points)
+            {
+                const size_t o = (size_t) (frame % slots) * (size_t) max_points + (size_t) pt;
+                gr[o] = p.ground[ci] == CC_GP_GROUND ? 1 : 0;
+                det[o] = p.id[ci];
+            }
+        }
+    }
+}
+
+// =====================================================================================================
 // k_gather_clusters — member points of finished clusters, compacted on the device (the point gathering of
 // collectPointsForCusterAndPublish, cc.cpp:985-1033): cluster i owns out[offset[i] .. offset[i] + n_points[i]) and receives its
 // points in (global column, row) order. grid = clusters, block = 64 (lanes = rows), one pass over the cluster's column range.

@@ -134,7 +134,125 @@ class FrameScatter:
         self._evaluate_previous()
 
 
-def gather_records(records, group=None) -> np.ndarray:
+class DeviceFrameScatter:
+    """addColumnAndEvaluateFrameIfCompleted (kitti_demo.cpp:173-224) for all streams of a replay engine with the per-cell work on the GPU:
+    cc_engine_scatter_info tells, per newly published column, which frames its points belong to (where frame N + 1 starts, the two error
+    cases), cc_engine_scatter_apply writes is_ground / detection of the columns' points into per-frame arrays in HBM, cc_eval_frame_device
+    evaluates a completed frame from them. Nothing per cell returns to the host; per step and stream the host sees two int32 per published
+    column. The converter must write cc_kitti_frame::d_original_index of frame f of stream s to ``original_index_ptr(s, f)``."""
+
+    SLOTS = 4  # frames kept per stream: a column is published within a rotation of its insertion
+
+    def __init__(self, engine, sequence_ids, max_points: int, device: int = 0, rows: int = 64, cols: int = 2200):
+        import torch
+        from . import load_library
+        self.e = engine
+        self.L = load_library()
+        i32, i64, vp = C.c_int, C.c_int64, C.c_void_p
+        self.L.cc_engine_scatter_info.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp, vp]
+        self.L.cc_engine_scatter_apply.argtypes = [vp, i32, i64, i64, vp, i32, vp, vp, i64]
+        self.seq = list(sequence_ids)
+        S = len(self.seq)
+        self.S, self.max_points, self.rows, self.cols = S, int(max_points), rows, cols
+        dev = torch.device("cuda", device)
+        self.d_org = torch.full((S, self.SLOTS, cols, rows), -1, dtype=torch.int32, device=dev)
+        self.d_ground = torch.zeros((S, self.SLOTS, self.max_points), dtype=torch.uint8, device=dev)
+        self.d_det = torch.zeros((S, self.SLOTS, self.max_points), dtype=torch.int32, device=dev)
+        self.d_sem = torch.zeros((S, self.SLOTS, self.max_points), dtype=torch.int16, device=dev)
+        self.d_eu = torch.zeros((S, self.SLOTS, self.max_points), dtype=torch.int32, device=dev)
+        self.n_points = [[0] * self.SLOTS for _ in range(S)]
+        self.previous_frame = [0] * S
+        self.published_to = [-1] * S
+        self.active = [True] * S
+        self.records = [[] for _ in range(S)]
+
+    def original_index_ptr(self, s: int, frame: int) -> int:
+        return self.d_org[s, frame % self.SLOTS].data_ptr()
+
+    def add_frame(self, s: int, frame: int, semantic, euclid):
+        """Ground truth of frame `frame` of stream s (what kitti_demo.cpp:352-376 loads before the frame is fed)."""
+        import torch
+        n = int(len(semantic))
+        if n > self.max_points:
+            raise RuntimeError(f"frame with {n} points, capacity {self.max_points}")
+        k = frame % self.SLOTS
+        self.n_points[s][k] = n
+        self.d_sem[s, k, :n] = torch.from_numpy(np.ascontiguousarray(semantic, dtype=np.uint16).view(np.int16)).to(self.d_sem.device)
+        self.d_eu[s, k, :n] = torch.from_numpy(np.ascontiguousarray(euclid, dtype=np.uint32).view(np.int32)).to(self.d_eu.device)
+        self.d_ground[s, k].zero_()
+        self.d_det[s, k].zero_()
+        torch.cuda.synchronize(self.d_sem.device)
+
+    def _apply(self, s, lo, hi):
+        if hi >= lo:
+            rc = self.L.cc_engine_scatter_apply(self.e.h, s, lo, hi, self.d_org.data_ptr(), self.SLOTS, self.d_ground.data_ptr(),
+                                                self.d_det.data_ptr(), self.max_points)
+            if rc != 0:
+                raise RuntimeError(f"cc_engine_scatter_apply failed with {rc}")
+
+    def evaluate_previous(self, s):
+        """evaluatePreviousFrame (kitti_demo.cpp:161-171)"""
+        f = self.previous_frame[s]
+        k = f % self.SLOTS
+        n = self.n_points[s][k]
+        if self.e.sync() != 0:
+            raise RuntimeError(self.e.last_error())
+        r = eval_frame_device(n, self.d_sem[s, k].data_ptr(), self.d_eu[s, k].data_ptr(), self.d_ground[s, k].data_ptr(), self.d_det[s, k].data_ptr())
+        self.records[s].append((self.seq[s], f, *[float(v) for v in r]))
+        self.previous_frame[s] += 1
+
+    def publish(self):
+        """Scatter everything the engine has published since the last call (all active streams, one info launch sequence + one D2H)."""
+        streams, lo, hi = [], [], []
+        for s in range(self.S):
+            if not self.active[s]:
+                continue
+            h = self.e.state(s)["first_unpublished_global_column_index"] - 1
+            l = max(self.published_to[s] + 1, 0)
+            if h >= l:
+                streams.append(s), lo.append(l), hi.append(h)
+        if not streams:
+            return
+        a_s, a_lo, a_hi = np.array(streams, np.int32), np.array(lo, np.int64), np.array(hi, np.int64)
+        total = int((a_hi - a_lo + 1).sum())
+        mn, mx = np.zeros(total, np.int32), np.zeros(total, np.int32)
+        rc = self.L.cc_engine_scatter_info(self.e.h, len(streams), a_s.ctypes.data, a_lo.ctypes.data, a_hi.ctypes.data, self.d_org.data_ptr(),
+                                           self.SLOTS, mn.ctypes.data, mx.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"cc_engine_scatter_info failed with {rc}")
+        o = 0
+        for s, l, h in zip(streams, lo, hi):
+            cnt = h - l + 1
+            cmn, cmx = mn[o:o + cnt], mx[o:o + cnt]
+            o += cnt
+            start = 0
+            while True:
+                prev = self.previous_frame[s]
+                seg_mn, seg_mx = cmn[start:], cmx[start:]
+                has = seg_mx >= 0
+                nxt = np.nonzero(has & (seg_mx == prev + 1))[0]
+                end = int(nxt[0]) if len(nxt) else len(seg_mx) - 1   # the column in which frame prev + 1 starts closes the segment
+                part = slice(0, end + 1)
+                if (has[part] & (seg_mn[part] < prev)).any():
+                    raise RuntimeError("Found a point belonging to a frame that was already evaluated!")   # kitti_demo.cpp:203-204
+                if (seg_mx[part] > prev + 1).any():
+                    raise RuntimeError("Found a point whose frame is too far ahead!")                      # kitti_demo.cpp:205-206
+                self._apply(s, l + start, l + start + end)
+                if not len(nxt):
+                    break
+                self.evaluate_previous(s)                                                                 # kitti_demo.cpp:221-222
+                start += end + 1
+                if start >= cnt:
+                    break
+            self.published_to[s] = h
+
+    def finish(self, s):
+        """"also evaluate final frame" (kitti_demo.cpp:417-419) with what has been published by now; the stream stops scattering."""
+        self.evaluate_previous(s)
+        self.active[s] = False
+
+
+def gather_records(records, group=None, capacity: int | None = None) -> np.ndarray:
     """All-gather the per-frame records [(sequence, frame, tp, fn, fp, tn, OSE, USE)] of every rank and return them sorted by
     (sequence, frame) — the order in which the reference's single process would have produced them. Fixed-size padded buffers,
     one collective. Works on any initialised torch.distributed backend; the tensors live on the GPU for nccl
@@ -147,16 +265,18 @@ def gather_records(records, group=None) -> np.ndarray:
         return local[order]
     world = dist.get_world_size(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    count = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(count) for _ in range(world)]
-    dist.all_gather(counts, count, group=group)
-    max_n = max(int(c.item()) for c in counts)
-    buf = torch.zeros((max(max_n, 1), 8), dtype=torch.float64, device=dev)
+    # ONE collective: every rank sends a block of `capacity` + 1 rows, row 0 carrying its record count. The capacity is a bound every rank
+    # knows without asking (the longest SemanticKITTI sequence has 4 661 frames, kitti_loader.cpp:552-562; a caller with more passes it)
+    cap = int(capacity) if capacity else 8192
+    if local.shape[0] > cap:
+        raise ValueError(f"{local.shape[0]} records exceed the gather capacity {cap}")
+    buf = torch.zeros((cap + 1, 8), dtype=torch.float64, device=dev)
+    buf[0, 0] = float(local.shape[0])
     if local.shape[0]:
-        buf[: local.shape[0]] = torch.from_numpy(local).to(dev)
+        buf[1: local.shape[0] + 1] = torch.from_numpy(local).to(dev)
     bufs = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf, group=group)
-    parts = [b[: int(c.item())].cpu().numpy() for b, c in zip(bufs, counts)]
+    parts = [b[1: int(b[0, 0].item()) + 1].cpu().numpy() for b in bufs]
     allr = np.concatenate(parts) if parts else np.zeros((0, 8))
     order = np.lexsort((allr[:, 1], allr[:, 0]))
     return allr[order]

@@ -53,9 +53,11 @@ class Sequence:
         return lab[:, 0].copy(), eu.astype(np.uint32)
 
 
-def replay(root: str, sequences, rank: int = 0, world: int = 1, device: int = 0, max_frames: int | None = None):
+def replay(root: str, sequences, rank: int = 0, world: int = 1, device: int = 0, max_frames: int | None = None, timing: dict | None = None):
     """Replay this rank's share of `sequences` concurrently. Returns this rank's records [(sequence, frame, tp, fn, fp, tn, OSE, USE)]
-    and a dict of totals."""
+    and a dict of totals. The frame scatter and the label compare run on the GPU (evaluation.DeviceFrameScatter): per step the host reads
+    files, interpolates poses and looks at two integers per published column."""
+    import time
     import torch
     mine = [Sequence(root, s) for i, s in enumerate(sequences) if i % world == rank]
     S = len(mine)
@@ -67,18 +69,20 @@ def replay(root: str, sequences, rank: int = 0, world: int = 1, device: int = 0,
     dev = torch.device("cuda", device)
     cfg = capi.Config.kitti()
     engine = Engine(cfg, kitti.ROWS, S, device=device)
-    conv = kitti.KittiConverter(max_frames=S, max_points=200000, device=device, hip_stream=engine.hip_stream())
+    max_points = 200000
+    conv = kitti.KittiConverter(max_frames=S, max_points=max_points, device=device, hip_stream=engine.hip_stream())
     engine.set_option("input_on_engine_stream", 1)   # the converter writes the engine's inputs on the engine's HIP stream
     d_xyz = torch.full((S, kitti.COLS, kitti.ROWS, 3), float("nan"), dtype=torch.float32, device=dev)
     d_int = torch.zeros((S, kitti.COLS, kitti.ROWS), dtype=torch.uint8, device=dev)
-    d_org = torch.full((S, kitti.COLS, kitti.ROWS), -1, dtype=torch.int32, device=dev)
     h_pose = np.zeros((S, kitti.COLS, 12), dtype=np.float64)
-    scatter = [evaluation.FrameScatter(q.index, [], [], []) if q.has_labels else None for q in mine]
-    origin = [[] for _ in mine]          # per stream: original index arrays [2200][64] of the frames fed so far
-    published_to = [-1] * S
+    scatter = evaluation.DeviceFrameScatter(engine, [q.index for q in mine], max_points, device=device, rows=kitti.ROWS, cols=kitti.COLS)
+    for s, q in enumerate(mine):
+        scatter.active[s] = q.has_labels
     frames_done = 0
     records = []
+    t_io = t_dev = 0.0
     for f in range(n_steps):
+        t0 = time.perf_counter()
         batch = []
         for s, q in enumerate(mine):
             if f < q.n_frames:
@@ -86,54 +90,34 @@ def replay(root: str, sequences, rank: int = 0, world: int = 1, device: int = 0,
                 _, fposes = kitti.firing_stamps_and_poses(q.stamps, q.poses, q.start[f], q.end[f])
                 h_pose[s] = fposes
                 bins = kitti.bin_transforms(q.stamps, q.poses, q.start[f], q.end[f], q.poses[f])
-                if scatter[s] is not None:
+                if scatter.active[s]:
                     sem, eu = q.labels(f, pts)
-                    sc = scatter[s]
-                    sc.semantic.append(sem)
-                    sc.euclid.append(eu)
-                    sc.is_ground.append(np.zeros(pts.shape[0], np.uint8))
-                    sc.detection.append(np.zeros(pts.shape[0], np.uint32))
+                    scatter.add_frame(s, f, sem, eu)
                 frames_done += 1
             else:  # this sequence has ended: an empty rotation keeps the stream in step with the others
                 pts, bins = np.zeros((0, 4), np.float32), None
                 h_pose[s] = np.tile(q.poses[q.n_frames - 1], (kitti.COLS, 1))
             batch.append(dict(points=pts, stages=kitti.ALL_STAGES if bins is not None and len(bins) else kitti.ALL_STAGES & ~kitti.UNDO_EGO_MOTION,
                               start=q.start[min(f, q.n_frames - 1)], end=q.end[min(f, q.n_frames - 1)], bins=bins, d_xyz=d_xyz[s].data_ptr(),
-                              d_intensity=d_int[s].data_ptr(), d_original_index=d_org[s].data_ptr()))
+                              d_intensity=d_int[s].data_ptr(), d_original_index=scatter.original_index_ptr(s, f)))
         d_pose = torch.from_numpy(h_pose).to(dev)
         torch.cuda.synchronize(dev)                                                     # the pose upload ran on torch's stream
+        t1 = time.perf_counter()
         conv.convert(batch)                                                             # same HIP stream as the engine
         engine.add_firings_device(kitti.COLS, d_xyz.data_ptr(), d_int.data_ptr(), d_pose.data_ptr())
         if engine.sync() != 0:
             raise RuntimeError(engine.last_error())
-        org = d_org.cpu().numpy()
+        scatter.publish()
         for s, q in enumerate(mine):
-            origin[s].append(org[s].copy())
-            if scatter[s] is None:
-                continue
-            st = engine.state(s)
-            hi = st["first_unpublished_global_column_index"] - 1
-            lo = max(published_to[s] + 1, 0)
-            if hi < lo:
-                continue
-            cols = engine.read_columns(lo, hi, stream=s, fields=("source_firing", "ground_point_label", "id"))
-            src = cols["source_firing"]
-            has = src >= 0
-            frame = np.where(has, src // kitti.COLS, 0)
-            col = np.where(has, src % kitti.COLS, 0)
-            allorg = np.stack(origin[s])                                                # [frame][2200][64]
-            rows = np.broadcast_to(np.arange(kitti.ROWS), src.shape)
-            o = allorg[frame, col, rows].astype(np.int64)
-            u = np.where(has & (o >= 0), (np.uint64(q.index) << np.uint64(48)) | (frame.astype(np.uint64) << np.uint64(32)) | o.astype(np.uint64),
-                         NO_POINT)
-            scatter[s].add_columns(u, cols["ground_point_label"], cols["id"])
-            published_to[s] = hi
-        for s, q in enumerate(mine):
-            if scatter[s] is not None and f == min(q.n_frames, n_steps) - 1:
-                scatter[s].finish()      # "also evaluate final frame" (kitti_demo.cpp:417-419) with what has been published by now
-                records.extend(scatter[s].records)
-                scatter[s] = None        # columns the padding rotations flush later belong to no evaluation
+            if scatter.active[s] and f == min(q.n_frames, n_steps) - 1:
+                scatter.finish(s)        # "also evaluate final frame" (kitti_demo.cpp:417-419) with what has been published by now
+                records.extend(scatter.records[s])   # columns the padding rotations flush later belong to no evaluation
+        t2 = time.perf_counter()
+        t_io += t1 - t0
+        t_dev += t2 - t1
     tot = engine.totals()
+    if timing is not None:
+        timing.update(host_io_s=t_io, device_s=t_dev)
     return records, dict(streams=S, frames=frames_done, cells_published=int(tot["cells_published"]))
 
 

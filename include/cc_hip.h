@@ -326,6 +326,15 @@ void cc_eval_mean_std(const double* data, int64_t n, double* mean, double* std_d
  * accuracy (as fractions), USE, OSE */
 void cc_eval_summarize(const cc_eval_frame_result* frames, int64_t n, double out[12]);
 
+/* The one collective of the system: every rank's per-frame records — 8 doubles each: sequence, frame, then the six values of
+ * EvaluationResultForFrame (kitti_evaluation.hpp:38-49) — to every rank, as ONE ncclAllGather of fixed-size padded blocks over RCCL / xGMI.
+ * nccl_comm: the caller's ncclComm_t (all ranks call with the same `capacity`, the largest number of records any rank holds); records: host,
+ * n x 8; out: host, world x capacity x 8 (rank r's records first in its block); counts[r] = number of records of rank r. RCCL is looked up in
+ * the process at run time (no link-time dependency of this library). The reference has no multi-process mode: a single process evaluates all
+ * sequences one after the other (kitti_demo.cpp:230-420); with the streams sharded over GPUs this gather restores its view of all records. */
+int cc_eval_gather_records(void* nccl_comm, int world, int device, const double* records, int64_t n, int64_t capacity, double* out,
+                           int64_t* counts);
+
 /* KittiEvaluation::generateEuclideanClusteringLabels (kitti_evaluation.cpp:224-275, what gt_label_generator_tool.cpp:50-70 writes to
  * labels_euclidean_clustering/): connected components of {squared distance < 1 m^2, same semantic and instance label} over one frame
  * (PCL ConditionalEuclideanClustering, tolerance 1.0, 10..300000 points), numbered 1, 2, ... in the order their first point appears; 0 for

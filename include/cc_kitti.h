@@ -87,6 +87,25 @@ void* cc_kitti_hip_stream(cc_kitti* k);
 int cc_kitti_frame_result(cc_kitti* k, int slot, cc_kitti_frame_info* info, float* h_points, uint8_t* h_laser_index,
                           int32_t* h_cell_source);
 
+/* ---- the frame scatter of the harness, addColumnAndEvaluateFrameIfCompleted (kitti_demo.cpp:173-224), on the device --------------------
+ * For an engine whose streams are each fed exactly num_columns pseudo-firings per frame (kitti_demo.cpp:386-403; cc_kitti_convert_frames
+ * writes them straight into the engine's input arrays). A published cell then names its KITTI point through the sequence number of the
+ * firing that filled it: frame = sequence / num_columns, column of the frame = sequence % num_columns, point =
+ * d_original_index[stream][frame % slots][column][row] (cc_kitti_frame::d_original_index of that frame's conversion; `slots` frames are
+ * kept per stream, 4 are enough: a column is published within a rotation of its insertion).
+ *   cc_engine_scatter_info   per published column of the ranges [from[i], to[i]] of streams[i] (concatenated in the outputs): the smallest
+ *                            and largest frame index among the column's points (INT32_MAX / -1 for a column without points) — what the
+ *                            harness needs to find the column in which frame N + 1 starts (:205-209) and its two error cases (:203-206).
+ *   cc_engine_scatter_apply  is_ground_point = (ground_point_label == GP_GROUND) and detection_label = id (:214-215) of the points of the
+ *                            columns [from, to] into d_is_ground / d_detection, laid out [stream][frame % slots][max_points]; asynchronous
+ *                            on cc_engine_hip_stream(e). cc_eval_frame_device (cc_hip.h) evaluates a frame from those arrays.
+ * Both are declared here because they belong to the replay harness; they live in the engine (include cc_hip.h first). */
+struct cc_engine;
+int cc_engine_scatter_info(struct cc_engine* e, int n, const int32_t* streams, const int64_t* from, const int64_t* to,
+                           const int32_t* d_original_index, int slots, int32_t* h_min_frame, int32_t* h_max_frame);
+int cc_engine_scatter_apply(struct cc_engine* e, int stream, int64_t from, int64_t to, const int32_t* d_original_index, int slots,
+                            uint8_t* d_is_ground, uint32_t* d_detection, int64_t max_points);
+
 /* ---- host-side pose arithmetic of the same call sites (plain C, no device work) ------------------------------------------ */
 
 /* KittiLoader::interpolate (kitti_loader.cpp:297-328): pose at `stamp` from stamp-sorted poses (slerp + lerp, clamped at the ends). */

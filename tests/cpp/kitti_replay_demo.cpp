@@ -9,6 +9,9 @@
 //
 // Output, one line per evaluated frame:  FRAME <seq> <frame> <tp> <fn> <fp> <tn> <ose> <use> <points seen>
 // then                                  SUMMARY <frames> <columns> <clusters> <cluster points>
+// with --rccl-gather: the records once more after cc_eval_gather_records (one ncclAllGather): GATHERED <seq> <frame> <tp> ... <use>
+#include <dlfcn.h>
+
 #include <cinttypes>
 #include <cstdio>
 #include <cstring>
@@ -64,13 +67,16 @@ int main(int argc, char** argv)
     }
     const Path root{argv[1]};
     const int sequence_index = std::stoi(argv[2]);
-    bool one_pass = false, write_gt_labels = false;
+    bool one_pass = false, write_gt_labels = false, rccl_gather = false;
+    std::vector<double> records; // (sequence, frame, tp, fn, fp, tn, OSE, USE) of every evaluated frame
     uint64_t fixed_start = 0;
     bool have_fixed = false;
     for (int a = 3; a < argc; a++)
     {
         if (!std::strcmp(argv[a], "--one-pass"))
             one_pass = true;
+        else if (!std::strcmp(argv[a], "--rccl-gather"))
+            rccl_gather = true;
         else if (!std::strcmp(argv[a], "--write-gt-labels"))
             write_gt_labels = true;
         else if (!std::strcmp(argv[a], "--fixed-start-stamp") && a + 1 < argc)
@@ -144,6 +150,9 @@ int main(int argc, char** argv)
                 throw std::runtime_error("cc_eval_frame failed");
             std::printf("FRAME %d %d %.17g %.17g %.17g %.17g %.17g %.17g %" PRId64 "\n", sequence_index, previous_frame_index, r.tp, r.fn, r.fp,
                         r.tn, r.over_segmentation_entropy, r.under_segmentation_entropy, seen);
+            const double rec[8] = {(double) sequence_index, (double) previous_frame_index, r.tp, r.fn, r.fp, r.tn, r.over_segmentation_entropy,
+                                   r.under_segmentation_entropy};
+            records.insert(records.end(), rec, rec + 8);
             map_frame_to_point_cloud.erase(it);
             previous_frame_index++;
             frames_evaluated++;
@@ -252,6 +261,39 @@ int main(int argc, char** argv)
         if (evaluate && map_frame_to_point_cloud.count({sequence_index, previous_frame_index}))
             evaluatePreviousFrame(); // kitti_demo.cpp:417-419
         std::printf("SUMMARY %" PRId64 " %" PRId64 " %" PRId64 " %" PRId64 "\n", frames_evaluated, columns_seen, clusters_seen, cluster_points_seen);
+        if (rccl_gather)
+        {
+            // The one exchange step of the multi-GPU replay: every rank's per-frame records to every rank through
+            // cc_eval_gather_records (one ncclAllGather). This harness is one process, so the communicator has one rank; with one process
+            // per GPU the ncclUniqueId of rank 0 is handed to the others (file, MPI, torchrun's store ...) and the call is the same.
+            void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib)
+                lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib)
+                lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            if (!lib)
+                throw std::runtime_error("no RCCL library found");
+            struct UniqueId
+            {
+                char internal[128];
+            } id;
+            auto get_id = reinterpret_cast<int (*)(UniqueId*)>(dlsym(lib, "ncclGetUniqueId"));
+            auto init = reinterpret_cast<int (*)(void**, int, UniqueId, int)>(dlsym(lib, "ncclCommInitRank"));
+            auto destroy = reinterpret_cast<int (*)(void*)>(dlsym(lib, "ncclCommDestroy"));
+            void* comm = nullptr;
+            if (!get_id || !init || get_id(&id) != 0 || init(&comm, 1, id, 0) != 0)
+                throw std::runtime_error("RCCL communicator could not be created");
+            const int64_t n = static_cast<int64_t>(records.size() / 8), cap = 8192;
+            std::vector<double> all(static_cast<size_t>(cap) * 8);
+            int64_t count = 0;
+            if (cc_eval_gather_records(comm, 1, 0, records.data(), n, cap, all.data(), &count) != CC_OK || count != n)
+                throw std::runtime_error("cc_eval_gather_records failed");
+            for (int64_t k = 0; k < count; k++)
+                std::printf("GATHERED %d %d %.17g %.17g %.17g %.17g %.17g %.17g\n", (int) all[8 * k], (int) all[8 * k + 1], all[8 * k + 2], all[8 * k + 3],
+                            all[8 * k + 4], all[8 * k + 5], all[8 * k + 6], all[8 * k + 7]);
+            if (destroy)
+                destroy(comm);
+        }
     }
     catch (const std::exception& e)
     {

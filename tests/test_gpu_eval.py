@@ -80,3 +80,39 @@ def test_stream_to_evaluation_end_to_end(oracle_lib):
     assert np.array_equal(np.array(rec_gpu).view(np.uint64), np.array(rec_cpu).view(np.uint64))
     s = evaluation.summarize(np.array(rec_gpu)[:, 2:])
     assert 0.9 < s["recall"][0] <= 1.0 and 0.9 < s["accuracy"][0] <= 1.0  # flat synthetic ground is easy
+
+
+def test_records_gather_over_rccl_through_the_c_abi():
+    """cc_eval_gather_records: the one collective of the system reachable from C / C++ harnesses — a communicator made with RCCL's own
+    API (world size 1: a box has one GPU), one ncclAllGather of a padded block, records and counts back on the host."""
+    import ctypes as C
+    from continuous_clustering_amd import load_library
+    rccl = None
+    for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+        try:
+            rccl = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    assert rccl is not None, "no RCCL library on this box"
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    L = load_library()
+    L.cc_eval_gather_records.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    rec = np.ascontiguousarray(rng.random((37, 8)))
+    rec[:, 0], rec[:, 1] = 4, np.arange(37)
+    out = np.zeros((1, 64, 8))
+    counts = np.zeros(1, dtype=np.int64)
+    assert L.cc_eval_gather_records(comm, 1, 0, rec.ctypes.data, 37, 64, out.ctypes.data, counts.ctypes.data) == 0
+    assert counts[0] == 37 and np.array_equal(out[0, :37].view(np.uint64), rec.view(np.uint64)) and not out[0, 37:].any()
+    assert L.cc_eval_gather_records(comm, 1, 0, rec.ctypes.data, 37, 16, out.ctypes.data, counts.ctypes.data) != 0  # more records than capacity
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    rccl.ncclCommDestroy(comm)

@@ -65,10 +65,13 @@ def test_sequence_replay_matches_oracle(tmp_path, oracle_lib):
     seq_dir, sizes = kitti.write_synthetic_sequence(str(tmp_path), sequence, n_frames, seed=11, motion=(9.0, 0.3, 0.0, 0.2))
     scatter, columns, ostate = expected_records(seq_dir, sequence, n_frames)
     assert len(scatter.records) == n_frames - 1
-    for mode in ([], ["--one-pass"]):
+    for mode in ([], ["--one-pass", "--rccl-gather"]):
         out = subprocess.run([DEMO, str(tmp_path), str(sequence), "--fixed-start-stamp", str(T0)] + mode, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr
         frames = [l.split() for l in out.stdout.splitlines() if l.startswith("FRAME")]
+        if "--rccl-gather" in mode:  # the records once more, after cc_eval_gather_records (one ncclAllGather over RCCL) from the C++ harness
+            gathered = [l.split()[1:] for l in out.stdout.splitlines() if l.startswith("GATHERED")]
+            assert gathered == [f[1:9] for f in frames]
         summary = [l.split() for l in out.stdout.splitlines() if l.startswith("SUMMARY")][0]
         # the harness also evaluates the last frame that received points at the end of the sequence (kitti_demo.cpp:417-419)
         assert len(frames) == n_frames
