@@ -125,7 +125,8 @@ __device__ __forceinline__ double wave_shr1_f64(double v)
 }
 
 template<int RPL>
-__global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+                                                       int* __restrict__ bail_count)
 {
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
     if (n_unf > tree_limit || cfg.max_steps_in_row > WIN_COLS - 2)
         return; // the serial kernels decide (LDS pool / global memory)
 
+    __builtin_amdgcn_s_setprio(3); // latency-bound (barriers, LDS round trips): win issue arbitration against co-resident throughput kernels
     __shared__ AbTrees T;
     __shared__ short ring[AB_RING * WAVE * RPL];
     __shared__ int s_nunf;
@@ -966,7 +968,11 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             st->batch_columns += batch_cols;
             st->batch_bails += bailed ? 1ull : 0ull;
             if (bailed)
+            {
                 st->batch_bail_reason[T.bail & 7] += 1ull;
+                if (bail_count)
+                    atomicAdd(bail_count, 1); // (the engine launches more (batch-parallel, serial) rounds for the next batches: assoc_rounds 0)
+            }
             st->n_events = n_events < g.event_capacity ? n_events : g.event_capacity;
             if (g.record_events && n_events > g.event_capacity)
                 raise_error(st, CC_ERR_CAPACITY, n_events, 0);

@@ -24,6 +24,13 @@ struct cc_engine
     StreamState* d_states{nullptr};
     int* d_remaining{nullptr};
     int* h_remaining{nullptr}; // pinned
+    int* d_bail_count{nullptr}; // launches of k_assocb that stopped in front of a group, ever (assoc_rounds 0 = adaptive)
+    int* h_bail_count{nullptr}; // pinned; refreshed behind every batch's association chain
+    int bail_seen{0}, bail_cooldown{0};
+    bool capturing{false};      // launch_batch is being captured into a hipGraph (small calls)
+    int* d_par_left{nullptr};  // streams whose batch k_insert_par did not take completely (skip_idle_fallbacks)
+    int* h_par_left{nullptr};  // pinned
+    bool skip_idle_fallbacks{true}; // option "skip_idle_fallbacks": wait for k_insert_par and launch the other insertion kernels only if needed
     hipStream_t stream{nullptr};  // insertion chain (and everything else when not pipelined)
     hipStream_t stream2{nullptr}; // table / segmentation / window-scan chain of the pipelined throughput path
     hipStream_t stream3{nullptr}; // association / publish chain of the pipelined throughput path
@@ -69,7 +76,9 @@ struct cc_engine
     int assoc_waves{3};                 // option "assoc_waves": 1 = k_assoc_lds, 2 = k_assoc2 (front / back wavefronts), 3 / 4 = k_assoc3
                                         // without / with its links wavefront
     bool assoc_batch{true};             // option "assoc_batch": k_assocb in front of the serial association kernels
-    int assoc_rounds{2};                // option "assoc_rounds": (k_assocb, k_assoc3) pairs per batch; all but the last serial launch are limited
+    int assoc_rounds{0};                // option "assoc_rounds": (k_assocb, k_assoc3) pairs per batch; all but the last serial launch are limited.
+                                        // 0 (default) = adaptive: one pair while no launch of k_assocb has had to stop lately, three for the 16
+                                        // batches after one did (an empty launch of the serial kernel costs ~0.1 ms of chain time at 256 streams)
     bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 256 streams
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
@@ -225,6 +234,10 @@ int allocate(cc_engine* e)
     A(link_log, S * (size_t) g.link_capacity);
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
+        return rc;
+    if ((rc = alloc_plane(e, &e->d_par_left, 1)) != 0)
+        return rc;
+    if ((rc = alloc_plane(e, &e->d_bail_count, 1)) != 0)
         return rc;
     if ((rc = alloc_plane(e, &e->d_remaining, 1)) != 0)
         return rc;
@@ -400,18 +413,28 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (par)
         sp = si;
     CC_MARK(sp); // ev0
+    // skip_idle_fallbacks: in steady state k_insert_par takes whole batches and the three kernels behind it (k_insert_multi, k_prep, k_insert2)
+    // have nothing to do — but their blocks wait for free CUs next to the throughput kernels of the other chains, 0.2 - 0.4 ms of chain time per
+    // batch. The host has to wait for the insertion chain before the next batch anyway, so it waits here, for k_insert_par alone, and launches the
+    // others only if some stream's batch was not taken completely (the kernel then leaves the batch descriptor to k_insert2 as before).
+    const bool gate = par && rpl == 1 && si != sb && e->skip_idle_fallbacks && n <= cck::IP_MAXF;
+    bool fallbacks = true;
     if (par && rpl == 1) // (two rows per lane = sensors with per-laser azimuth offsets in practice: straight to k_insert_multi)
     {
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_insert_par<1>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
-                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
-        else
-            hipLaunchKernelGGL(cck::k_insert_par<2>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
-                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
+        if (gate)
+            CC_HIP_CHECK(e, hipMemsetAsync(e->d_par_left, 0, sizeof(int), si));
+        hipLaunchKernelGGL(cck::k_insert_par<1>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
+                           d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, gate ? e->d_par_left : (int*) nullptr);
+        if (gate)
+        {
+            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, sizeof(int), hipMemcpyDeviceToHost, si));
+            CC_HIP_CHECK(e, hipStreamSynchronize(si));
+            fallbacks = *e->h_par_left != 0;
+        }
     }
     // multi-column firings (per-laser azimuth offsets) and whatever single-column head k_insert_par did not take: block-parallel as well,
     // with the per-row collision rule checked instead of assumed (option "parallel_insert" = 2 restricts this to the first kernel)
-    if (par && e->parallel_insert_multi)
+    if (par && e->parallel_insert_multi && fallbacks)
     {
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_insert_multi<1>, dim3(count), dim3(64 * cck::IM_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
@@ -420,7 +443,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             hipLaunchKernelGGL(cck::k_insert_multi<2>, dim3(count), dim3(64 * cck::IM_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
                                d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
     }
-    if (first_pass && !prep_done) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
+    if (first_pass && !prep_done && fallbacks) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
     {
         int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp, e->cur_ntotal, e->cur_f0, par, first_stream);
         if (rcp)
@@ -433,6 +456,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_prep[slot], 0));
     }
     const Planes Pins = planes_with_prep(e, e->prep_buf);
+    if (fallbacks)
     {
         const size_t lds = cck::insert2_lds_bytes(g.num_rows);
         if (rpl == 1)
@@ -529,10 +553,27 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     auto launch_assocb = [&]()
     {
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_assocb<1>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_assocb<1>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot,
+                               e->d_bail_count);
         else
-            hipLaunchKernelGGL(cck::k_assocb<2>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_assocb<2>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot,
+                               e->d_bail_count);
     };
+    int adaptive_rounds = 1;
+    if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
+    {
+        const int seen = *e->h_bail_count; // (as of some earlier batch: a heuristic, not a condition of correctness)
+        if (seen != e->bail_seen)
+        {
+            e->bail_seen = seen;
+            e->bail_cooldown = 16;
+        }
+        if (e->bail_cooldown > 0)
+        {
+            e->bail_cooldown--;
+            adaptive_rounds = 3;
+        }
+    }
     // k_assoc2 walks the finished-cluster checks of several columns at once and assumes one check per column
     if (e->assoc_waves >= 3 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
@@ -543,7 +584,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
 #endif
         const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= CC_LWAVE_MAX_STREAMS);
         const dim3 block(lwave ? cck::A3_THREADS : 192);
-        const int rounds = batch_assoc ? e->assoc_rounds : 1;
+        const int rounds = batch_assoc ? (e->assoc_rounds > 0 ? e->assoc_rounds : adaptive_rounds) : 1;
         for (int r = 0; r < rounds; r++)
         {
             if (batch_assoc)
@@ -573,6 +614,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         else
             hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
+    if (batch_assoc && e->h_bail_count && !e->capturing)
+        CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
     CC_MARK(sa); // ev7: assoc_lds
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
     if (rpl == 1)
@@ -609,6 +652,7 @@ __global__ void k_begin_batch(StreamState* states, int first_stream, int count, 
     if (i < count)
     {
         states[first_stream + i].cursor = 0;
+        states[first_stream + i].pre_seg_begin = 0; // (k_insert2 clears it when it closes a batch; with skip_idle_fallbacks it may not have run)
         states[first_stream + i].n_events = 0; // every event of the previous call has been collected
         states[first_stream + i].n_links = 0;
         states[first_stream + i].clear_allowed = unlimited_clear ? 0x7fffffffffffffffll : states[first_stream + i].ring_start;
@@ -973,7 +1017,9 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
             return -1;
         bool ok = hipMemcpyAsync(e->d_small, e->h_small, b_xyz + b_int + b_pose, hipMemcpyHostToDevice, e->stream) == hipSuccess;
         hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, e->stream, e->d_states, stream, 1, e->d_remaining, 0);
+        e->capturing = true;
         ok = ok && launch_batch(e, stream, 1, n, d_xyz, d_int, d_pose, true, 0, e->stream, e->stream, e->stream) == CC_OK;
+        e->capturing = false;
         ok = ok && hipMemcpyAsync(e->h_small_state, e->d_states + stream, sizeof(StreamState), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
         if (e->g.record_events)
             ok = ok && hipMemcpyAsync(e->h_small_events, e->P.events + (size_t) stream * e->g.event_capacity, SMALL_EVENTS * sizeof(cc_event),
@@ -1163,6 +1209,12 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     rc = allocate(e);
+    if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, sizeof(int)) != hipSuccess)
+        rc = CC_ERR_HIP;
+    if (rc == CC_OK && hipHostMalloc((void**) &e->h_bail_count, sizeof(int)) != hipSuccess)
+        rc = CC_ERR_HIP;
+    if (rc == CC_OK)
+        *e->h_bail_count = 0;
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_remaining, sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
     if (rc == CC_OK)
@@ -1176,6 +1228,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         free_all(e);
         if (e->h_remaining)
             (void) hipHostFree(e->h_remaining);
+        if (e->h_par_left)
+            (void) hipHostFree(e->h_par_left);
         (void) hipStreamDestroy(e->stream);
         delete e;
         return rc;
@@ -1221,6 +1275,8 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipEventDestroy(ev);
     if (e->h_remaining)
         (void) hipHostFree(e->h_remaining);
+    if (e->h_par_left)
+        (void) hipHostFree(e->h_par_left);
     (void) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1723,10 +1779,12 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_waves_auto = value <= 0 || value > 4;
         e->assoc_waves = e->assoc_waves_auto ? 3 : (int) value;
     }
+    else if (n == "skip_idle_fallbacks")
+        e->skip_idle_fallbacks = value != 0;
     else if (n == "assoc_batch")
         e->assoc_batch = value != 0;
     else if (n == "assoc_rounds")
-        e->assoc_rounds = (int) (value < 1 ? 1 : (value > 8 ? 8 : value));
+        e->assoc_rounds = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
     else if (n == "scan_packed")
     {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);

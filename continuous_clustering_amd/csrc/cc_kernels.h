@@ -1213,7 +1213,8 @@ constexpr int IP_WAVES = CC_IP_WAVES, IP_MAXF = 4608;
 template<int RPL>
 __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
                                                             const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
-                                                            const double* __restrict__ poses, long long n, long long n_total, long long fbase)
+                                                            const double* __restrict__ poses, long long n, long long n_total, long long fbase,
+                                                            int slot, int* __restrict__ left_over)
 {
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
@@ -1273,7 +1274,11 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     if (!steady)
     {
         if (tid == 0)
+        {
             st->clear_done = clear_done;
+            if (left_over)
+                atomicAdd(left_over, 1); // the other insertion kernels have to take this stream's batch
+        }
         return;
     }
     const int half = NC / 2;
@@ -1490,6 +1495,25 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
             st->cursor = done;
             st->firings_consumed = (unsigned long long) (seq0 + done);
             st->pre_seg_begin = first_unf0;
+        }
+        // left_over (the engine's "skip_idle_fallbacks"): the host launches the other insertion kernels of this batch only if some stream
+        // needs them. A stream whose whole batch went through here closes its batch descriptor itself, exactly as k_insert2 would with
+        // nothing left to do (its columns [first_unf0, G) were emitted, cursor = n).
+        if (left_over)
+        {
+            if (done == (int) n && done > 0)
+            {
+                const long long G = prev_rear0 + s_off[done - 1];
+                st->batch[slot].seg_begin = first_unf0;
+                st->batch[slot].seg_end = G;
+                st->batch[slot].acp_next = first_unf0;
+                st->batch[slot].pub_begin = -1;
+                st->batch[slot].pub_end = -1;
+                // (pre_seg_begin stays: if another stream makes the host launch the other insertion kernels after all, k_insert2 finds
+                // nothing left for this stream and writes the same descriptor again; k_begin_batch clears it for the next batch)
+            }
+            else
+                atomicAdd(left_over, 1);
         }
     }
 }

@@ -273,7 +273,10 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * ahead; 2: window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
  * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 256 streams; 3 / 4: k_assoc3 without / with
  * the links wavefront; 2: k_assoc2 (front / back wavefronts); 1: the one-wavefront kernel, which is also what
- * cluster_point_trees_every_nth_column != 1 uses), "assoc_batch" (1 (default): the batch-parallel association kernel runs in front of the
+ * cluster_point_trees_every_nth_column != 1 uses), "skip_idle_fallbacks" (1 (default): in the pipelined mode the
+ * host waits for the block-parallel insertion kernel of a batch and launches the other insertion kernels only if some stream's batch was not
+ * taken completely; 0: always launch them), "assoc_rounds" (1..8, default 2: (batch-parallel, serial) association kernel pairs per batch; all
+ * but the last serial launch only take the group of columns the batch-parallel kernel stopped in front of), "assoc_batch" (1 (default): the batch-parallel association kernel runs in front of the
  * serial one and takes every group of columns that cannot differ from the sequential semantics, see cc_engine_batch_counters; 0: serial
  * kernels only), "sub_batch" (firings
  * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never

@@ -104,6 +104,45 @@ def test_full_size_properties_256_streams():
     assert g_ptr and id_ptr
 
 
+def test_full_size_properties_256_streams_s128():
+    """BASELINE.json configs[3] shape: 256 concurrent VLS-128-shaped streams (128 rows x 1700 columns, per-laser azimuth offsets: every
+    firing spans ~60 columns; library-default parameters), two rotations through the pipelined device path. Same properties as the S64 test:
+    totals add up, replicated inputs give identical per-stream results, sampled streams equal the oracle (state + the last published columns)."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    cfg = capi.Config.vls128()
+    sensor = synth.SensorModel.s128()
+    S, F, NB = 256, 1700, 2
+    distinct = 3
+    base = [synth.make_stream(F * NB, seed=700 + s, sensor=sensor, motion=synth.Motion.translate(), start_column=40) for s in range(distinct)]
+    streams = [base[s % distinct] for s in range(S)]
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, 128, S)
+    e.record_events(False)
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+    assert e.sync() == 0, e.last_error()
+    tot = e.totals()
+    states = [e.state(s) for s in range(S)]
+    assert tot["firings_consumed"] == S * F * NB
+    assert tot["cells_published"] == sum(st["cells_published"] for st in states)
+    assert all(st["cells_published"] > 0.8 * 128 * (F * NB - 600) for st in states)
+    for s in range(distinct, S):
+        for k in util.STATE_FIELDS:
+            assert states[s][k] == states[s % distinct][k], (s, k)
+    for s in (0, 2):
+        o = Oracle(cfg, 128)
+        assert o.add_firings(streams[s].xyz, streams[s].intensity, streams[s].poses) == 0
+        so = o.state()
+        for k in util.STATE_FIELDS:
+            assert so[k] == states[s][k], (s, k)
+        hi = states[s]["first_unpublished_global_column_index"] - 1
+        lo = hi - 1200
+        for s2 in (s, s + distinct * 11):
+            util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo, mirror=False)
+
+
 @pytest.mark.parametrize("pipeline,sub_batch", [(1, 0), (2, 0), (1, 300), (0, 0)])
 def test_pipelined_throughput_path_matches_oracle(pipeline, sub_batch, oracle_lib):
     """The bench configuration of the engine (events off: consecutive batches overlap on three or four chains of HIP streams,

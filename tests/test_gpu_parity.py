@@ -161,7 +161,7 @@ def test_batch_parallel_association_takes_ordinary_streams(name, oracle_lib):
 
 
 @pytest.mark.parametrize("name,reason", [("s64_forced_finish_ring", 3), ("s64_no_early_stop", 2), ("s64_min_steps_3", 2)])
-@pytest.mark.parametrize("rounds", [1, 2, 4])
+@pytest.mark.parametrize("rounds", [0, 1, 2, 4])
 def test_batch_parallel_association_hands_exceptions_to_the_serial_kernel(name, reason, rounds, oracle_lib):
     """Groups that could differ from the sequential semantics (3: a tree / cluster that may reach the one-rotation limits cc.cpp:657, 913-924;
     2: more link candidates than k_scan records) are left to k_assoc3: with assoc_rounds > 1 only that group, then the batch-parallel kernel

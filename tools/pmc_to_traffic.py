@@ -13,7 +13,7 @@ round_tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
 out_name = sys.argv[3] if len(sys.argv) > 3 else "traffic.json"
 src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
 ALIAS = {"k_insert_multi": "insert_multi", "k_scan2": "scan_packed", "k_ego": "ego", "k_prep": "prep", "k_insert_par": "insert_parallel", "k_insert2": "insert", "k_seg_pre": "segment_pre", "k_seg_scan": "segment", "k_scan": "scan",
-         "k_assoc_lds": "assoc_lds_1wave", "k_assoc2": "assoc_2wave", "k_assoc3": "assoc_lds", "k_associate": "assoc_global", "k_publish": "publish", "k_table": "table"}
+         "k_assoc_lds": "assoc_lds_1wave", "k_assoc2": "assoc_2wave", "k_assoc3": "assoc_serial", "k_assocb": "assoc_lds", "k_associate": "assoc_global", "k_publish": "publish", "k_table": "table"}
 vals = {}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     acc = defaultdict(list)

@@ -24,7 +24,7 @@ CC_ASSOC_WAVES=3 python tools/kernel_times.py 2>&1 | grep "^pipeline" > $out/ker
 for S in 32 64 128 256 384 512; do
   python bench.py --streams $S --steps 30 --no-cpu-baseline --no-latency --no-verify --no-s128 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('streams', $S, 'Mpoints/s', round(d['value']), 'ms_per_step', round(d['ms_per_step'],3), 'dominant', d['roofline']['kernel'], 'launch_ms', round(d['roofline']['launch_ms'],3))"
 done > $out/stream_sweep.txt
-[ -f continuous_clustering_amd/libcc_hip_a2stats.so ] && python tools/prof_assoc2_stats.py > $out/assoc_wave_stats.txt 2>&1
+[ -f continuous_clustering_amd/libcc_hip_abstats.so ] && python tools/prof_assocb.py 256 > $out/assocb_phase_clocks.txt 2>&1
 cp $repo/gpurun_out/prof_$tag/*kernel_stats.csv $out/kernel_stats_s64.csv 2>/dev/null
 cp $repo/gpurun_out/prof_${tag}_s128/*kernel_stats.csv $out/kernel_stats_s128.csv 2>/dev/null
 cp $repo/gpurun_out/prof_$tag/bench_line.json $out/prof_bench_line.json 2>/dev/null

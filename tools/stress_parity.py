@@ -34,7 +34,7 @@ for i in range(n_cases):
     chunks = [int(c) for c in rng.choice([1, 3, 17, 64, 97, 250, cols, 2 * cols], size=4)]
     waves = [0, 4, 3, 2, 1][i % 5]  # default (k_assoc3 + links wavefront), pinned four / three waves, k_assoc2, k_assoc_lds
     batch = 0 if i % 7 == 6 else 1  # the batch-parallel kernel in front (default) or not
-    rounds = [2, 1, 3][i % 3]
+    rounds = [0, 2, 1, 3][i % 4]
     box = {}
     try:
         summ = util.run_and_compare(stream, cfg, chunks=chunks, robot_tf=None,
