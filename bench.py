@@ -256,8 +256,9 @@ def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args):
 # ---------------------------------------------------------------------------------------------------------------------------
 def engine_options(eng):
     for env, opt in (("CC_SUB_BATCH", "sub_batch"), ("CC_TABLE_EARLY", "table_on_insert_chain"), ("CC_PIPELINE", "pipeline"),
-                     ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed")):
-        if os.environ.get(env):
+                     ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed"),
+                     ("CC_SKIP_FALLBACKS", "skip_idle_fallbacks"), ("CC_ASSOC_ROUNDS", "assoc_rounds"), ("CC_ASSOC_BATCH", "assoc_batch")):
+        if os.environ.get(env) not in (None, ""):
             eng.set_option(opt, int(os.environ[env]))
 
 

@@ -40,7 +40,8 @@ struct cc_engine
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
     hipEvent_t ev_input{};            // option "input_on_engine_stream": recorded on `stream` when a device call arrives
-    int pipeline_depth{1};        // 1: three chains (default: four are not faster, the GPU is throughput-bound by then), 2: four
+    int pipeline_depth{2};        // 2 (default since round 3: with the batch-parallel association the segmentation + scan chain became the longest, +10 %
+                                  // at 256 streams with the window scan on a chain of its own): four chains, 1: three
     int prep_buf{0};              // staging buffer (of two) the open batch was prepared into
     std::vector<hipEvent_t> pev_pool; // pairs of events around every k_prep that ran ahead (outside the per-pass event groups)
     size_t pev_used{0};

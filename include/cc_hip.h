@@ -269,8 +269,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
 /* Engine tuning / test hooks. Names: "lds_tree_limit" (unfinished point trees per stream kept in LDS before the stream
  * continues in the global-memory association kernel, 1..256), "limit_columns" (columns one launch may emit per stream before
  * it hands back to the host), "pipeline" (0: run the kernel chains of cc_engine_add_firings_device back to back on one
- * HIP stream; 1 (default): overlap consecutive batches on three chains, with the per-point preparation of the next batch running
- * ahead; 2: window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
+ * HIP stream; 1: overlap consecutive batches on three chains (insertion | table, segmentation, window scan | association); 2 (default):
+ * the window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
  * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 256 streams; 3 / 4: k_assoc3 without / with
  * the links wavefront; 2: k_assoc2 (front / back wavefronts); 1: the one-wavefront kernel, which is also what
  * cluster_point_trees_every_nth_column != 1 uses), "skip_idle_fallbacks" (1 (default): in the pipelined mode the

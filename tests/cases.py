@@ -140,6 +140,83 @@ def build_case(name: str):
     if name == "w_s32_256x12":
         sen = SensorModel(num_rows=32, num_columns=256, incl_top_deg=10.0, incl_bottom_deg=-30.0)
         return synth.make_stream(256 * 12 + 40, seed=45, sensor=sen, motion=Motion.translate()), _vls(256, max_distance=0.5), None
+    # ---- gaps in slanted surfaces: a tree that has gone quiet for about as many columns as its points' max angle difference reaches is met
+    # again by a later, nearer point (large cylinders seen off-centre: the range changes quickly with the azimuth; every few dozen columns the
+    # obstacle returns of 4 - 15 consecutive firings are dropped). The reference then refuses attaches to trees whose cluster finished meanwhile
+    # (cc.cpp:658) or keeps a cluster alive through a link: the exceptions the batch-parallel association kernel has to detect
+    if name in ("x_s64_slanted_gaps", "x_s64_slanted_gaps_far"):
+        far = name.endswith("far")
+        sc = SceneModel(n_objects=14, object_range=(14.0, 40.0) if far else (7.0, 24.0), object_radius=(3.0, 11.0), object_top_z=2.5,
+                        wall_radius=30.0 if far else 0.0, wall_gaps_deg=((10.0, 50.0), (200.0, 260.0)), dropout=0.05)
+        st = synth.make_stream(720 * 3, seed=61 if far else 62, sensor=_s64(720), scene=sc, motion=Motion.translate(6.0))
+        xyz = st.xyz.copy()
+        rng = np.random.default_rng(161)
+        k = 0
+        while k < st.n_firings:
+            k += int(rng.integers(9, 40))
+            g = int(rng.integers(3, 16))
+            sel = st.hit[k:k + g] > 1  # obstacle returns only: the ground keeps the columns (and the insertion) regular
+            xyz[k:k + g][sel] = np.nan
+            k += g
+        return synth.Stream(xyz=xyz, intensity=st.intensity, poses=st.poses, sensor=st.sensor, hit=st.hit), _kitti(720), None
+    if name == "x_s64_refused_attach":
+        # Hand-made: the attach the reference REFUSES because the candidate's tree belongs to a finished cluster (cc.cpp:658). A tree lives until a
+        # column's smallest AZIMUTH passes its largest (azimuth + max angle difference); a later point accepts a candidate when their 3-D distance is
+        # below max_distance. For steep lasers the 3-D angle is smaller than the azimuth difference (cos(inclination) < 1), so a post seen by the rows
+        # at -21..-23 degrees at 3 m is still within 0.5 m of an equal post 20 columns later although its tree was finished a column earlier — provided
+        # the first post sits at the very start of its column and the second one too. 720 columns, static sensor, unbroken wall (every row returns).
+        sen = _s64(720)
+        sc = SceneModel(n_objects=0, wall_radius=40.0, wall_gaps_deg=(), range_noise=0.0, dropout=0.0)
+        st = synth.make_stream(720 * 2 + 100, seed=81, sensor=sen, scene=sc)
+        xyz = st.xyz.astype(np.float64)
+        w = 2 * np.pi / 720
+        incl = np.deg2rad(np.linspace(sen.incl_top_deg, sen.incl_bottom_deg, 64))
+        frac = np.full(st.n_firings, 0.5)
+        posts = []
+        k = 60
+        gaps = [20, 20, 19, 20, 18, 20, 20, 17, 20, 20, 20, 16, 20, 20]
+        i = 0
+        while k + 25 < st.n_firings:
+            gap = gaps[i % len(gaps)]
+            posts.append((k, k + gap))
+            frac[k] = 0.02
+            frac[k + 1:k + gap] = 0.5
+            frac[k + gap] = 0.01
+            k += gap + 31 + (i % 5)
+            i += 1
+        # rotate every firing about z so that it sits at (k + frac) * w instead of (k + 0.5) * w (clockwise sensor: azimuth = pi - that)
+        rot = -(frac - 0.5) * w
+        ca, sa = np.cos(rot)[:, None], np.sin(rot)[:, None]
+        x, y = xyz[..., 0].copy(), xyz[..., 1].copy()
+        xyz[..., 0] = ca * x - sa * y
+        xyz[..., 1] = sa * x + ca * y
+        rows = np.arange(54, 59)
+        for a, b in posts:
+            for kk in (a, b):
+                az = np.pi - (kk + frac[kk]) * w
+                rng_ = 3.0
+                xyz[kk, rows, 0] = rng_ * np.cos(incl[rows]) * np.cos(az)
+                xyz[kk, rows, 1] = rng_ * np.cos(incl[rows]) * np.sin(az)
+                xyz[kk, rows, 2] = rng_ * np.sin(incl[rows])
+        return synth.Stream(xyz=xyz.astype(np.float32), intensity=st.intensity, poses=st.poses, sensor=sen, hit=st.hit), _kitti(720), None
+    if name.startswith("x_s64_near_jitter_gaps"):
+        # The same close to the sensor with jittered firing azimuths: a point reaches back ceil(max angle difference / column width) columns, a
+        # tree lives until a column's smallest azimuth passes its largest azimuth + max angle difference — with every firing at its own fraction
+        # of a column and a nearer point looking back at a farther one the two can disagree by a column (only below ~6 m at 720 columns).
+        seed = int(name.rsplit("_", 1)[1]) if name[-1].isdigit() else 0
+        sc = SceneModel(n_objects=26, object_range=(2.2, 6.5), object_radius=(0.4, 3.0), object_top_z=1.5, wall_radius=0.0, dropout=0.04)
+        st = synth.make_stream(720 * 3, seed=70 + seed, sensor=_s64(720), scene=sc, motion=Motion.translate(4.0))
+        xyz = st.xyz.copy()
+        rng = np.random.default_rng(170 + seed)
+        k = 0
+        while k < st.n_firings:
+            k += int(rng.integers(6, 30))
+            g = int(rng.integers(2, 19))
+            sel = st.hit[k:k + g] > 1
+            xyz[k:k + g][sel] = np.nan
+            k += g
+        st = synth.Stream(xyz=xyz, intensity=st.intensity, poses=st.poses, sensor=st.sensor, hit=st.hit)
+        return jitter_azimuth(st, 270 + seed, 0.9), _kitti(720), None
     # ---- small variants kept as committed golden fixtures -------------------------------------------------------
     if name == "g_s64_translate":
         return synth.make_stream(800, seed=31, sensor=_s64(360), motion=Motion.translate()), _kitti(360), None
@@ -160,6 +237,8 @@ ALL_CASES = ["s64_static", "s64_translate", "s64_turn", "s64_full_2200", "s64_fo
              "s64_fog_and_ego", "s64_counterclockwise", "s64_every_2nd_column", "s64_no_early_stop", "s64_min_steps_3",
              "s64_wide_window_global_kernel", "s64_dropouts", "s64_no_supplement_no_incl_ignore", "s64_robot_tf_tilted", "s128_offsets",
              "s128_no_offsets_translate", "s128_full_1700", "s32_small_sensor", "j_s64_jitter", "j_s64_jitter_wide", "j_s128_offsets_jitter"]
+
+EXCEPTION_CASES = ["x_s64_slanted_gaps", "x_s64_slanted_gaps_far", "x_s64_near_jitter_gaps_3", "x_s64_refused_attach"]
 
 RING_WRAP_CASES = ["w_s64_240x13", "w_s64_360x12_turn", "w_s64_ring_wall_240x12", "w_s128_offsets_340x12", "w_s32_256x12"]
 

@@ -160,6 +160,24 @@ def test_batch_parallel_association_takes_ordinary_streams(name, oracle_lib):
     assert bc["batch_columns"] >= summary["published_columns"]
 
 
+@pytest.mark.parametrize("name", cases.EXCEPTION_CASES)
+@pytest.mark.parametrize("batch", [1, 0])
+def test_streams_made_to_provoke_refused_attaches(name, batch, oracle_lib):
+    """Gaps in slanted / near surfaces, jittered firing azimuths, and a hand-made case in which the reference refuses attaches because the
+    candidate's tree was finished a column earlier (cc.cpp:658; possible for steep lasers, where the 3-D angle between two returns is smaller
+    than their azimuth difference): equal to the oracle with the batch-parallel kernel in front and without it."""
+    stream, cfg, tf = cases.build_case(name)
+    box = {}
+    for chunks in ([stream.sensor.num_columns], [61, 97, 1, 200]):
+        summary = util.run_and_compare(stream, cfg, chunks=chunks, robot_tf=tf,
+                                       engine_setup=lambda e: (e.set_option("assoc_batch", batch), box.__setitem__("e", e)))
+        if name == "x_s64_refused_attach":
+            assert summary["engine_state"]["error_b"] > 0, "the exact serial replay of the refused attaches was expected"
+            if batch:
+                why = box["e"].batch_counters()["bail_reasons"]
+                assert why[4] + why[5] > 0 and why[6] > 0, why  # a tree met after its cluster finished; a candidate behind the first unpublished column
+
+
 @pytest.mark.parametrize("name,reason", [("s64_forced_finish_ring", 3), ("s64_no_early_stop", 2), ("s64_min_steps_3", 2)])
 @pytest.mark.parametrize("rounds", [0, 1, 2, 4])
 def test_batch_parallel_association_hands_exceptions_to_the_serial_kernel(name, reason, rounds, oracle_lib):
