@@ -30,6 +30,7 @@ struct cc_engine
     bool capturing{false};      // launch_batch is being captured into a hipGraph (small calls)
     int* d_par_left{nullptr};  // streams whose batch k_insert_par did not take completely (skip_idle_fallbacks)
     int* h_par_left{nullptr};  // pinned
+    int insert_wide_max_streams{96}; // option "insert_wide_max_streams": launches of at most this many streams run k_insert_par with 16 wavefronts
     bool skip_idle_fallbacks{true}; // option "skip_idle_fallbacks": wait for k_insert_par and launch the other insertion kernels only if needed
     hipStream_t stream{nullptr};  // insertion chain (and everything else when not pipelined)
     hipStream_t stream2{nullptr}; // table / segmentation / window-scan chain of the pipelined throughput path
@@ -424,8 +425,15 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     {
         if (gate)
             CC_HIP_CHECK(e, hipMemsetAsync(e->d_par_left, 0, sizeof(int), si));
-        hipLaunchKernelGGL(cck::k_insert_par<1>, dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
-                           d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, gate ? e->d_par_left : (int*) nullptr);
+        // few streams: the GPU is not full, the insertion chain is what a step waits for -> twice the wavefronts per stream
+        if (count <= e->insert_wide_max_streams)
+            hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states,
+                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot,
+                               gate ? e->d_par_left : (int*) nullptr);
+        else
+            hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states,
+                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot,
+                               gate ? e->d_par_left : (int*) nullptr);
         if (gate)
         {
             CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, sizeof(int), hipMemcpyDeviceToHost, si));
@@ -1780,6 +1788,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_waves_auto = value <= 0 || value > 4;
         e->assoc_waves = e->assoc_waves_auto ? 3 : (int) value;
     }
+    else if (n == "insert_wide_max_streams")
+        e->insert_wide_max_streams = (int) value;
     else if (n == "skip_idle_fallbacks")
         e->skip_idle_fallbacks = value != 0;
     else if (n == "assoc_batch")

@@ -1210,8 +1210,9 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 #endif
 constexpr int IP_WAVES = CC_IP_WAVES, IP_MAXF = 4608;
 
-template<int RPL>
-__global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+// (W wavefronts per block: IP_WAVES next to the other chains' kernels; twice as many when a launch has few streams and the GPU is otherwise empty)
+template<int RPL, int W = IP_WAVES>
+__global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
                                                             const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
                                                             const double* __restrict__ poses, long long n, long long n_total, long long fbase,
                                                             int slot, int* __restrict__ left_over)
@@ -1226,7 +1227,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
     __shared__ int s_c[IP_MAXF];   // column-in-rotation of every firing (its first valid return), -1 = empty firing
     __shared__ int s_off[IP_MAXF]; // G_f - prev_rearmost at entry
-    __shared__ int s_wsum[IP_WAVES];
+    __shared__ int s_wsum[W];
     __shared__ int s_upto, s_bad, s_carry;
 
     const long long prev_rear0 = st->prev_rearmost, prev_fore0 = st->prev_foremost, first_unf0 = st->first_unfinished;
@@ -1243,7 +1244,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     if (clear_done >= 0)
     {
         const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
-        for (long long c = clear_done + wave; c < clear_to; c += IP_WAVES)
+        for (long long c = clear_done + wave; c < clear_to; c += W)
         {
             const int clc = (int) (c % RC);
 #pragma unroll
@@ -1291,7 +1292,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     const long long pass0 = prev_rear0 / RC; // pass over the ring of the previous rearmost laser (cell_tag)
 
     // ---- 0: the column of every firing from its first valid return (prep_point's column arithmetic, nothing else of it)
-    for (int f = tid; f < nn; f += 64 * IP_WAVES)
+    for (int f = tid; f < nn; f += 64 * W)
     {
         const size_t base = (fglob + (size_t) f) * R * 3;
         int c = -1;
@@ -1311,7 +1312,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     }
     __syncthreads();
     // ---- B: column advance of every firing, its prefix sum over the batch, first firing that ends the run
-    for (int base = 0; base < nn; base += 64 * IP_WAVES)
+    for (int base = 0; base < nn; base += 64 * W)
     {
         const int f = base + tid;
         const int c = f < nn ? s_c[f] : -1;
@@ -1346,7 +1347,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
                 atomicMin(&s_upto, f);
         }
         __syncthreads();
-        if (tid == 64 * IP_WAVES - 1)
+        if (tid == 64 * W - 1)
             s_carry = incl;
         __syncthreads();
     }
@@ -1384,7 +1385,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     };
     if (wave < upto)
         load_firing(wave);
-    for (int f = wave; f < upto; f += IP_WAVES)
+    for (int f = wave; f < upto; f += W)
     {
         float cx[RPL], cy[RPL], cz[RPL];
         uint8_t cint[RPL];
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
 #pragma unroll
         for (int i = 0; i < 12; i++)
             T[i] = lane_f64(nx_pose, i);
-        load_firing(f + IP_WAVES);
+        load_firing(f + W);
         if (f > lds_ld(&s_bad)) // some earlier firing left the shape: nothing behind it is wanted (wave-uniform)
             break;
         const size_t fi = fglob + (size_t) f;
@@ -1455,7 +1456,7 @@ __global__ __launch_bounds__(64 * IP_WAVES) void k_insert_par(Geometry g, cc_con
     {
         // take back what firings behind the offending one have written: their cells return to the cleared state (clearColumns'
         // three planes); cells they never wrote are in that state already
-        for (int f = done + 1 + wave; f < upto; f += IP_WAVES)
+        for (int f = done + 1 + wave; f < upto; f += W)
         {
             const size_t fi = fglob + (size_t) f;
             const int lc = (int) ((unsigned) (lc0 + s_off[f]) % (unsigned) RC);
