@@ -322,11 +322,25 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
     # dominant single kernel (segment_ms is the sum of k_table + k_seg_pre + k_seg_scan, profiles/ lists them separately;
     # prep_ms covers k_insert_par — preparation fused with the block-parallel insertion — plus k_prep of what it left over;
     # insert_ms is the serial kernel k_insert2 behind it; above 64 rows the block-parallel kernel is k_insert_multi)
+    # assoc_lds_ms is k_assocb alone (the batch-parallel association); assoc_global_ms the serial kernels launched behind it (k_assoc3, k_associate:
+    # in steady state they find nothing to do)
     KERNEL_OF = {"prep_ms": "k_insert_par" if R <= 64 else "k_insert_multi", "insert_ms": "k_insert2", "scan_ms": "k_scan" if R <= 64 else "k_scan2", "assoc_lds_ms": "k_assocb",
-                 "assoc_global_ms": "k_associate", "publish_ms": "k_publish"}
+                 "assoc_global_ms": "k_assoc3", "publish_ms": "k_publish"}
     dom = max(KERNEL_OF, key=lambda k: per_kernel.get(k, 0.0))
     cells_per_launch = float(S * F * R) / launches_per_step
     achieved = cells_per_launch * alg_bytes_per_cell / (per_kernel[dom] / launches_per_step * 1e-3) / 1e9
+    # what rocprofv3 --kernel-trace --stats says about the same kernel in the committed profile of this round (profiles/): the HIP-event figure of
+    # this run must agree with it within the box-to-box spread
+    rocprof_ms = None
+    spath = os.path.join(ROOT, "profiles", "r03_final_kernel_stats.csv" if R == 64 else "r03_final_kernel_stats_s128.csv")
+    if os.path.exists(spath):
+        try:
+            import csv
+            for row in csv.reader(open(spath)):
+                if ("cck::" + KERNEL_OF[dom] + "<") in row[0] or ("cck::" + KERNEL_OF[dom] + "(") in row[0]:
+                    rocprof_ms = float(row[3]) / 1e6
+        except Exception:  # noqa: BLE001
+            rocprof_ms = None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json" if R == 64 else "traffic_s128.json")
     if os.path.exists(tpath):
@@ -346,6 +360,8 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": cells_per_launch * alg_bytes_per_cell, "launches_per_step": launches_per_step,
             "launch_ms": per_kernel[dom] / launches_per_step,
+            "launch_ms_rocprof_committed": rocprof_ms, "rocprof_source": os.path.relpath(spath, ROOT) if rocprof_ms is not None else None,
+            "traffic_source": (os.path.relpath(tpath, ROOT) + " (PMC passes of tools/pmc.sh on this round's build, not measured in this run)") if traffic is not None else None,
             "step_frac": cells * alg_bytes_per_cell / world / elapsed / 1e9 / HBM_PEAK_GBS,
             "note": "path is latency/dependency-bound (serial per-stream column recurrence), not bandwidth-bound; step_frac = "
                     "algorithmic bytes of the whole step / step time / peak",

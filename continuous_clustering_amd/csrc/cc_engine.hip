@@ -568,6 +568,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             hipLaunchKernelGGL(cck::k_assocb<2>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot,
                                e->d_bail_count);
     };
+    bool marked7 = false;
     int adaptive_rounds = 1;
     if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
     {
@@ -597,7 +598,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         for (int r = 0; r < rounds; r++)
         {
             if (batch_assoc)
+            {
                 launch_assocb();
+                if (r == 0)
+                {
+                    CC_MARK(sa); // ev7: the batch-parallel kernel alone ("assoc_lds_ms"); the serial kernels behind it count as "assoc_global_ms"
+                    marked7 = true;
+                }
+            }
             const int limited = r + 1 < rounds ? 1 : 0;
             if (rpl == 1)
                 hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited);
@@ -608,7 +616,11 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
         if (batch_assoc)
+        {
             launch_assocb();
+            CC_MARK(sa);
+            marked7 = true;
+        }
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_assoc2<1>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else
@@ -617,7 +629,11 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     else
     {
         if (batch_assoc)
+        {
             launch_assocb();
+            CC_MARK(sa);
+            marked7 = true;
+        }
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else
@@ -625,7 +641,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     if (batch_assoc && e->h_bail_count && !e->capturing)
         CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
-    CC_MARK(sa); // ev7: assoc_lds
+    if (!marked7)
+        CC_MARK(sa); // ev7: assoc_lds (without the batch-parallel kernel: the serial LDS kernel)
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
