@@ -435,6 +435,7 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
         };
         load_a(gcA, lc);
         bool wait_park = false; // a column could not be resolved: wave B will park us when it gets there
+        long long fake_begin = 0, fake_end = 0, fake_group = 0; // columns behind such a column, in wave B's group (see below)
         int poll = 0;
         while (true)
         {
@@ -460,11 +461,32 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
                     lc = (int) (gcA % RC);
                     b_seen = gcA;
                     wait_park = false;
+                    fake_end = 0;
                     load_a(gcA, lc);
                     continue;
                 }
                 if (wait_park || gcA >= col_end)
                 {
+                    if (wait_park && fake_begin < fake_end && uniform_i64(lds_ld(&T.b_done)) >= fake_group)
+                    {
+                        // wave B works on the group of the column that stopped this wave: nothing older than the group is looked at any more,
+                        // the ring entries of the group's remaining columns can be written
+                        for (long long x = fake_begin; x < fake_end; x++)
+                        {
+                            for (int k = 0; k < RPL; k++)
+                                if (k * 64 + lane < R)
+                                    s_win[(int) (x & (WIN2_COLS - 1)) * R + k * 64 + lane] = -1; // (wave B looks at the ids of the whole group)
+                            if (lane == 0)
+                            {
+                                T.info_head[(int) (x & (A2_INFO - 1))] = head;
+                                T.info_bad[(int) (x & (A2_INFO - 1))] = 1;
+                            }
+                        }
+                        wave_lds_fence();
+                        if (lane == 0)
+                            lds_st(&T.a_done, fake_end);
+                        fake_end = 0;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
@@ -593,7 +615,18 @@ __global__ __launch_bounds__(128) void k_assoc2(Geometry g, cc_config cfg, Plane
             if (lane == 0)
                 lds_st(&T.a_done, gcA + 1);
             if (bad)
+            {
+                // This wave stops until wave B has replayed the column. Wave B waits for WHOLE groups of columns (wait_a(gc + gcount)): the
+                // rest of the column's group is handed over as "not resolved" as well, once wave B has reached the group (see the idle
+                // branch above) — waiting for those columns would never end (round 3: streams that attach to trees finished before the
+                // launch, or run out of tree ids, in the middle of a group; the spin limit reported error -772).
                 wait_park = true;
+                const long long group_begin = col_begin + (gcA - col_begin) / G * G;
+                const long long group_end = group_begin + G < col_end ? group_begin + G : col_end;
+                fake_begin = gcA + 1;
+                fake_end = group_end;
+                fake_group = group_begin;
+            }
             else
                 head += cnt_new;
             gcA++;

@@ -18,14 +18,17 @@ constexpr int A3_THREADS = 256; // four wavefronts: A (resolve ids), B (apply + 
 constexpr int A3_PSTAGE = 8; // columns of per-point inputs staged between wave A and wave R (power of two)
 constexpr int A3_BIRTH = 8; // new roots per column kept inline (must equal A3_REC: one lane per (column, slot))
 
+// One stream's batch (or what k_assocb left of it). The kernel below calls it for the streams of its block: one block per stream when the serial
+// kernel is what associates (assoc_batch off, or k_assocb had to stop lately), a handful of blocks that sweep over all streams — and find nothing to do
+// — when it is only the safety net behind k_assocb: 256 blocks of 256 threads and 45 KB of LDS each took 0.2 - 0.5 ms of chain time to be PLACED next
+// to the other chains' kernels, just to return.
 template<int RPL>
-__global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                       int limited)
+__device__ __forceinline__ void assoc3_stream(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, const int s, const int slot,
+                                              const int limited)
 {
     constexpr int G = RPL == 1 ? 8 : 4; // columns wave B handles per pass
     constexpr int A2_LEAD = a2_lead(RPL), A2_STAGE = a2_stage(RPL);
     static_assert(WIN_COLS + A2_LEAD + 1 <= WIN2_COLS && A2_LEAD + G <= A2_STAGE && A2_LEAD < A2_INFO, "ring sizes");
-    const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const bool lwave = blockDim.x > 192; // wave L exists
@@ -225,6 +228,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         };
         load_a(gcA, lc);
         bool wait_park = false; // a column could not be resolved: wave B will park us when it gets there
+        long long fake_begin = 0, fake_end = 0, fake_group = 0; // columns behind such a column, in wave B's group (see below)
         int poll = 0;
         while (true)
         {
@@ -249,11 +253,29 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
                     b_seen = gcA;
                     r_seen = gcA;
                     wait_park = false;
+                    fake_end = 0;
                     load_a(gcA, lc);
                     continue;
                 }
                 if (wait_park || gcA >= col_end)
                 {
+                    if (wait_park && fake_begin < fake_end && uniform_i64(lds_ld(&T.b_done)) >= fake_group)
+                    {
+                        // wave B works on the group of the column that stopped this wave: nothing older than the group is looked at any more,
+                        // the ring entries of the group's remaining columns can be written
+                        for (long long x = fake_begin; x < fake_end; x++)
+                        {
+                            if (lane == 0)
+                            {
+                                T.info_head[(int) (x & (A2_INFO - 1))] = head;
+                                T.info_bad[(int) (x & (A2_INFO - 1))] = 1;
+                            }
+                        }
+                        wave_lds_fence();
+                        if (lane == 0)
+                            lds_st(&T.a_done, fake_end);
+                        fake_end = 0;
+                    }
                     __builtin_amdgcn_s_sleep(2);
                     continue;
                 }
@@ -374,7 +396,18 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
             if (lane == 0)
                 lds_st(&T.a_done, gcA + 1);
             if (bad)
+            {
+                // This wave stops until wave B has replayed the column. Wave B waits for WHOLE groups of columns (wait_a(gc + gcount)): the
+                // rest of the column's group is handed over as "not resolved" as well, once wave B has reached the group (see the idle
+                // branch above) — waiting for those columns would never end (round 3: streams that attach to trees finished before the
+                // launch, or run out of tree ids, in the middle of a group; the spin limit reported error -772).
                 wait_park = true;
+                const long long group_begin = col_begin + (gcA - col_begin) / G * G;
+                const long long group_end = group_begin + G < col_end ? group_begin + G : col_end;
+                fake_begin = gcA + 1;
+                fake_end = group_end;
+                fake_group = group_begin;
+            }
             else
                 head += cnt_new;
             gcA++;
@@ -1525,5 +1558,16 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
             st->assoc_mode = 1;
         if (err)
             raise_error(st, err, err_a, err_b);
+    }
+}
+
+template<int RPL>
+__global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+                                                       int limited, int count)
+{
+    for (int i = blockIdx.x; i < count; i += gridDim.x)
+    {
+        assoc3_stream<RPL>(g, cfg, P, states, first_stream + i, slot, limited);
+        __syncthreads(); // (the wavefronts leave a stream at different points; the LDS state is rebuilt from the planes for the next one)
     }
 }

@@ -95,6 +95,10 @@ struct StreamState
     uint64_t batch_columns;       // columns associated by the batch-parallel kernel (k_assocb)
     uint64_t batch_bails;         // launches of k_assocb that handed the rest of their batch to the serial kernel
     uint64_t batch_bail_reason[8]; // ... by reason (cc_assocb.h AB_BAIL_*)
+    int64_t par_clear_done;       // k_insert_par over several blocks: what block 0 cleared up to (becomes clear_done in k_insert_par_fin: the other
+                                  // blocks must not see it change),
+    int32_t par_bad;              // ... the first firing whose returns left its column (INT_MAX: none; k_begin_batch resets it),
+    int32_t par_upto;             // ... and the firing the run ends at by the batch-wide conditions (the same in every block)
     int64_t serial_until;         // set by k_assocb when it stops in front of a group: a LIMITED launch of the serial kernel stops there
     // errors raised inside kernels
     uint64_t dbg[16];             // section cycle counters (CC_PROFILE_SECTIONS builds only): 0-7 insertion, 8-15 association
@@ -178,6 +182,7 @@ struct Planes
     uint16_t* sc_visits; // Point::number_of_visited_neighbors (cc.cpp:725), only with Geometry::mirror_fields
     int2* link_log;      // [stream][link_capacity] (root cell, root cell) of every tree link made in the current call (cc.cpp:693-694), only
                          // with Geometry::mirror_fields: the host rebuilds Point::associated_trees from it
+    int32_t* par_off; // [stream][IP_MAXF] column offset of every firing of the batch (k_insert_par over several blocks -> k_insert_par_fin)
     float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
     // what k_table leaves for k_seg_pre (one set per batch-descriptor slot; the engine passes the slot's pointers):
     float* tabc;      // [stream][SEGPRE_BLOCKS][num_rows] last valid inclination step before each chunk of columns (NaN: none in its range)

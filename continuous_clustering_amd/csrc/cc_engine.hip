@@ -30,6 +30,7 @@ struct cc_engine
     bool capturing{false};      // launch_batch is being captured into a hipGraph (small calls)
     int* d_par_left{nullptr};  // streams whose batch k_insert_par did not take completely (skip_idle_fallbacks)
     int* h_par_left{nullptr};  // pinned
+    int insert_split_blocks{0};      // option "insert_split_blocks": blocks per stream of k_insert_par in such launches (0 = 4 up to 40 streams, else 2; 1 = one)
     int insert_wide_max_streams{96}; // option "insert_wide_max_streams": launches of at most this many streams run k_insert_par with 16 wavefronts
     bool skip_idle_fallbacks{true}; // option "skip_idle_fallbacks": wait for k_insert_par and launch the other insertion kernels only if needed
     hipStream_t stream{nullptr};  // insertion chain (and everything else when not pipelined)
@@ -231,6 +232,7 @@ int allocate(cc_engine* e)
     A(sc_term, C) A(col_newfin, L) A(col_info, L);
     A(sg_x2, C) A(sg_uz, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
+    A(par_off, S * (size_t) cck::IP_MAXF);
     A(tabc, (size_t) BATCH_SLOTS * S * SEGPRE_BLOCKS * (size_t) g.num_rows) A(tabw, (size_t) BATCH_SLOTS * S * TABLE_WAVES * (size_t) g.num_rows);
     A(sc_visits, C);
     A(link_log, S * (size_t) g.link_capacity);
@@ -425,18 +427,27 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     {
         if (gate)
             CC_HIP_CHECK(e, hipMemsetAsync(e->d_par_left, 0, sizeof(int), si));
-        // few streams: the GPU is not full, the insertion chain is what a step waits for -> twice the wavefronts per stream
+        // few streams: the GPU is not full and the insertion chain is what a step waits for -> twice the wavefronts per block, and the firings of a
+        // stream dealt to several blocks (k_insert_par_fin then finishes the stream's state)
+        int* left = gate ? e->d_par_left : (int*) nullptr;
         if (count <= e->insert_wide_max_streams)
-            hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states,
-                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot,
-                               gate ? e->d_par_left : (int*) nullptr);
+        {
+            const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : 2);
+            hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states,
+                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left);
+            if (nb > 1)
+                hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, e->P, e->d_states, first_stream, d_xyz, (long long) n,
+                                   (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left);
+        }
         else
             hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states,
-                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot,
-                               gate ? e->d_par_left : (int*) nullptr);
+                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left);
         if (gate)
         {
             CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, sizeof(int), hipMemcpyDeviceToHost, si));
+            // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic)
+            if (e->h_bail_count)
+                CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, si));
             CC_HIP_CHECK(e, hipStreamSynchronize(si));
             fallbacks = *e->h_par_left != 0;
         }
@@ -607,10 +618,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 }
             }
             const int limited = r + 1 < rounds ? 1 : 0;
+            // behind k_assocb the serial kernel is a safety net that finds nothing to do: a few blocks sweep over all streams instead of one block
+            // per stream waiting for 45 KB of LDS on a busy CU. One block per stream when it is what associates, or while k_assocb has had to stop
+            // lately (adaptive_rounds > 1), or when the caller pinned the number of rounds
+            const int blocks = (batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1 && !e->capturing) ? (count < 16 ? count : 16) : count;
             if (rpl == 1)
-                hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited);
+                hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count);
             else
-                hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(count), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited);
+                hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count);
         }
     }
     else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
@@ -639,8 +654,6 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         else
             hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
-    if (batch_assoc && e->h_bail_count && !e->capturing)
-        CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
     if (!marked7)
         CC_MARK(sa); // ev7: assoc_lds (without the batch-parallel kernel: the serial LDS kernel)
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
@@ -649,6 +662,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     else
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     CC_MARK(sa); // ev8: assoc_global
+    // (without the host synchronisation behind k_insert_par nobody else reads the counter of k_assocb's stops: four bytes ride along here)
+    if (batch_assoc && !gate && e->h_bail_count && !e->capturing)
+        CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
     // The ids of the published columns only read what the association of THIS batch left behind (tree root of every cell, cluster id
     // at the root cell; neither is touched again before the ring wraps), so in the pipelined mode they are written on a stream of their
     // own and the next batch's association starts without waiting for them.
@@ -678,6 +694,9 @@ __global__ void k_begin_batch(StreamState* states, int first_stream, int count, 
     if (i < count)
     {
         states[first_stream + i].cursor = 0;
+        states[first_stream + i].par_bad = 0x7fffffff;
+        states[first_stream + i].par_upto = -1;
+        states[first_stream + i].par_clear_done = -1;
         states[first_stream + i].pre_seg_begin = 0; // (k_insert2 clears it when it closes a batch; with skip_idle_fallbacks it may not have run)
         states[first_stream + i].n_events = 0; // every event of the previous call has been collected
         states[first_stream + i].n_links = 0;
@@ -1805,6 +1824,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_waves_auto = value <= 0 || value > 4;
         e->assoc_waves = e->assoc_waves_auto ? 3 : (int) value;
     }
+    else if (n == "insert_split_blocks")
+        e->insert_split_blocks = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
     else if (n == "insert_wide_max_streams")
         e->insert_wide_max_streams = (int) value;
     else if (n == "skip_idle_fallbacks")

@@ -291,6 +291,7 @@ struct SP
     int32_t* agg_first;
     uint8_t* agg_flag;
     float* curtab;
+    int32_t* par_off;
     cc_event* events;
     int16_t* sc_parent;
     int16_t* sc_term;
@@ -343,6 +344,7 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.agg_first = P.agg_first + to;
     p.agg_flag = P.agg_flag + to;
     p.curtab = P.curtab + (size_t) s * g.num_rows;
+    p.par_off = P.par_off + (size_t) s * 4608;
     p.tabc = P.tabc + (size_t) s * SEGPRE_BLOCKS * g.num_rows;
     p.tabw = P.tabw + (size_t) s * TABLE_WAVES * g.num_rows;
     p.events = P.events + (size_t) s * g.event_capacity;
@@ -1240,8 +1242,12 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     __syncthreads();
     const long long ring_start = s_ring_start;
     // deferred clearColumns (cc.cpp:1094-1145) exactly as k_insert2 would do it first, spread over the wavefronts
+    // gridDim.y > 1: the firings of the stream are dealt to several blocks (few streams on a big GPU). Every block repeats phases 0 and B (cheap), block
+    // 0 clears, nobody writes the stream state: k_insert_par_fin does that once all blocks are through.
+    const int by = (int) blockIdx.y, nby = (int) gridDim.y;
     long long clear_done = st->clear_done;
-    if (clear_done >= 0)
+    const long long clear_done_entry = clear_done;
+    if (clear_done >= 0 && by == 0)
     {
         const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
         for (long long c = clear_done + wave; c < clear_to; c += W)
@@ -1274,14 +1280,18 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     __syncthreads(); // the cleared cells are ordered before everything this block writes from here on
     if (!steady)
     {
-        if (tid == 0)
+        if (tid == 0 && by == 0)
         {
             st->clear_done = clear_done;
             if (left_over)
                 atomicAdd(left_over, 1); // the other insertion kernels have to take this stream's batch
+            st->par_upto = -1;
         }
         return;
     }
+    // (split over blocks: every block has to end the run at the same firing, so the "previous tenant of the ring slot is cleared" test uses what
+    // was cleared BEFORE this launch — block 0 clears columns >= that, accepted firings only touch slots whose previous tenant lies below it)
+    const long long clear_known = nby > 1 ? clear_done_entry : clear_done;
     const int half = NC / 2;
     const bool clockwise = cfg.sensor_is_clockwise != 0;
     const size_t fglob = (size_t) sl * (size_t) n_total + (size_t) fbase; // first firing of this batch in the caller's buffers
@@ -1343,7 +1353,7 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
             const long long rear_before = G - delta;
             // a firing is only taken while the batch has emitted fewer than limit_columns columns before it (k_insert2's loop head), and
             // while the previous tenant of its ring slot is known to be cleared
-            if (!ok || rear_before - first_unf0 >= g.limit_columns || G - RC >= clear_done)
+            if (!ok || rear_before - first_unf0 >= g.limit_columns || G - RC >= clear_known)
                 atomicMin(&s_upto, f);
         }
         __syncthreads();
@@ -1383,9 +1393,10 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
         if (f < upto)
             nx_pose = poses[fi * 12 + (size_t) (lane < 12 ? lane : 0)];
     };
-    if (wave < upto)
-        load_firing(wave);
-    for (int f = wave; f < upto; f += W)
+    const int fstep = W * nby;
+    if (wave + W * by < upto)
+        load_firing(wave + W * by);
+    for (int f = wave + W * by; f < upto; f += fstep)
     {
         float cx[RPL], cy[RPL], cz[RPL];
         uint8_t cint[RPL];
@@ -1401,7 +1412,7 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
 #pragma unroll
         for (int i = 0; i < 12; i++)
             T[i] = lane_f64(nx_pose, i);
-        load_firing(f + W);
+        load_firing(f + fstep);
         if (f > lds_ld(&s_bad)) // some earlier firing left the shape: nothing behind it is wanted (wave-uniform)
             break;
         const size_t fi = fglob + (size_t) f;
@@ -1451,6 +1462,25 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
             p.trig[(int) ((unsigned) (lc0 + (int) rel_prev + jj) % (unsigned) RC)] = f;
     }
     __syncthreads();
+    if (nby > 1)
+    {
+        // several blocks per stream: leave the offsets and the two ends of the run for k_insert_par_fin
+        if (s_bad < upto && tid == 0)
+            atomicMin(&st->par_bad, s_bad);
+        if (by == 0)
+        {
+            for (int f = tid; f < upto; f += 64 * W)
+                p.par_off[f] = s_off[f];
+            if (tid == 0)
+            {
+                st->par_upto = upto;
+                st->par_clear_done = clear_done;
+                if (upto == 0 && left_over)
+                    atomicAdd(left_over, 1); // (nothing taken: k_insert_par_fin has nothing to do either)
+            }
+        }
+        return;
+    }
     const int done = s_bad < upto ? s_bad : upto;
     if (done < upto)
     {
@@ -1512,6 +1542,90 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
                 st->batch[slot].pub_end = -1;
                 // (pre_seg_begin stays: if another stream makes the host launch the other insertion kernels after all, k_insert2 finds
                 // nothing left for this stream and writes the same descriptor again; k_begin_batch clears it for the next batch)
+            }
+            else
+                atomicAdd(left_over, 1);
+        }
+    }
+}
+
+// k_insert_par_fin — what one block of k_insert_par does behind its phase D, for launches that dealt a stream's firings to several blocks: take back
+// what firings behind the first offending one have written, then the stream state (and, with left_over, the batch descriptor). grid = streams, block = 256.
+template<int RPL>
+__global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, StreamState* states, int first_stream, const float* __restrict__ xyz,
+                                                        long long n, long long n_total, long long fbase, int slot, int* __restrict__ left_over)
+{
+    const int sl = blockIdx.x;
+    const int s = first_stream + sl;
+    const int lane = lane_id(), wave = threadIdx.x >> 6, tid = threadIdx.x;
+    StreamState* st = &states[s];
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    const int upto = st->par_upto;
+    if (upto <= 0)
+    {
+        if (upto == 0 && tid == 0 && st->par_clear_done >= 0)
+            st->clear_done = st->par_clear_done;
+        return; // (not steady, or nothing taken: block 0 of k_insert_par has counted the stream as left over)
+    }
+    const int bad = st->par_bad;
+    const int done = bad < upto ? bad : upto;
+    const long long prev_rear0 = st->prev_rearmost, first_unf0 = st->first_unfinished, ring_end0 = st->ring_end;
+    const int lc0 = (int) (prev_rear0 % RC);
+    const size_t fglob = (size_t) sl * (size_t) n_total + (size_t) fbase;
+    const long long seq0 = (long long) st->firings_consumed;
+    if (done < upto)
+        for (int f = done + 1 + wave; f < upto; f += 4)
+        {
+            const size_t fi = fglob + (size_t) f;
+            const int lc = (int) ((unsigned) (lc0 + p.par_off[f]) % (unsigned) RC);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R)
+                {
+                    const float fx = xyz[(fi * R + row) * 3];
+                    if (fx == fx)
+                    {
+                        const size_t ci = (size_t) lc * R + row;
+                        p.dist[ci] = __builtin_nanf("");
+                        p.incl[ci] = __builtin_nanf("");
+                        p.gtag[ci] = CELL_CLEARED;
+                    }
+                }
+            }
+        }
+    __syncthreads();
+    if (tid == 0)
+    {
+        st->clear_done = st->par_clear_done;
+#ifndef CC_A2_STATS
+        st->dbg[6] += (unsigned long long) done;
+        st->dbg[7] += 1;
+#endif
+        if (done > 0)
+        {
+            const long long G = prev_rear0 + p.par_off[done - 1];
+            st->prev_rearmost = G;
+            st->prev_foremost = G;
+            st->first_unfinished = G;
+            if (G > ring_end0)
+                st->ring_end = G;
+            st->cursor = done;
+            st->firings_consumed = (unsigned long long) (seq0 + done);
+            st->pre_seg_begin = first_unf0;
+        }
+        if (left_over)
+        {
+            if (done == (int) n && done > 0)
+            {
+                const long long G = prev_rear0 + p.par_off[done - 1];
+                st->batch[slot].seg_begin = first_unf0;
+                st->batch[slot].seg_end = G;
+                st->batch[slot].acp_next = first_unf0;
+                st->batch[slot].pub_begin = -1;
+                st->batch[slot].pub_end = -1;
             }
             else
                 atomicAdd(left_over, 1);

@@ -122,6 +122,19 @@ def test_segmentation_look_back_beyond_the_lds_ring(oracle_lib):
     util.run_and_compare(stream, cfg, chunks=[360, 97], robot_tf=tf)
 
 
+@pytest.mark.parametrize("waves", [1, 2, 3, 4])
+@pytest.mark.parametrize("chunks", [[360, 97, 82, 231], [360, 97, 82, 100, 131]])
+def test_serial_kernels_column_unresolved_in_the_middle_of_a_group(waves, chunks, oracle_lib):
+    """The front wave of k_assoc2 / k_assoc3 stops at a column it cannot resolve (a point attaches to a tree that finished before the launch:
+    the long ground runs of this case do that when a launch starts at the right column); the back wave waits for whole groups of columns.
+    Rounds 1 and 2 let it wait for ever when that column was not the last of its group (spin limit -> error -772) — found in round 3 when
+    k_assocb's hand-over made the serial kernel start at such columns."""
+    stream, cfg, tf = cases.build_case("s64_deep_lookback")
+    for batch in (0, 1):
+        util.run_and_compare(stream, cfg, chunks=chunks, robot_tf=tf,
+                             engine_setup=lambda e: (e.set_option("assoc_waves", waves), e.set_option("assoc_batch", batch)))
+
+
 @pytest.mark.parametrize("name,waves", [("s64_translate", 3), ("s64_no_early_stop", 3), ("s128_full_1700", 3), ("j_s64_jitter_wide", 3),
                                         ("s64_translate", 2), ("s128_offsets", 2), ("s64_dropouts", 4), ("s128_full_1700", 4)])
 def test_association_kernel_selection(name, waves, oracle_lib):
