@@ -257,7 +257,8 @@ def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args):
 def engine_options(eng):
     for env, opt in (("CC_SUB_BATCH", "sub_batch"), ("CC_TABLE_EARLY", "table_on_insert_chain"), ("CC_PIPELINE", "pipeline"),
                      ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed"),
-                     ("CC_SKIP_FALLBACKS", "skip_idle_fallbacks"), ("CC_ASSOC_ROUNDS", "assoc_rounds"), ("CC_ASSOC_BATCH", "assoc_batch")):
+                     ("CC_SKIP_FALLBACKS", "skip_idle_fallbacks"), ("CC_ASSOC_ROUNDS", "assoc_rounds"), ("CC_ASSOC_BATCH", "assoc_batch"),
+                     ("CC_EGO_EARLY", "ego_on_insert_chain"), ("CC_INSERT_WIDE", "insert_wide_max_streams"), ("CC_INSERT_SPLIT", "insert_split_blocks"), ("CC_DEBUG_NO_ASSOC_FALLBACK", "debug_no_assoc_fallback")):
         if os.environ.get(env) not in (None, ""):
             eng.set_option(opt, int(os.environ[env]))
 
@@ -354,6 +355,8 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
         "cells_published": cells,
         "clusters_finished": clusters,
         "serial_columns": after["serial_columns"],
+        # columns the batch-parallel association kernel took itself / times it stopped at a column it hands to the serial kernel (whole run)
+        "association": dict(eng.batch_counters(), kernel_launches_per_step=launches_per_step),
         "kernel_ms_per_step": per_kernel,
         "roofline": {
             "bound": "hbm", "kernel": KERNEL_OF[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -533,6 +536,7 @@ def main():
             "cells_published": res["cells_published"],
             "clusters_finished": res["clusters_finished"],
             "serial_columns": res["serial_columns"],
+            "association": res["association"],
             "kernel_ms_per_step": res["kernel_ms_per_step"],
             "roofline": res["roofline"],
             "verified_streams": len(res["verified"]["streams"]) if res["verified"] else 0,

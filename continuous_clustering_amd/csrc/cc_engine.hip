@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -37,6 +39,7 @@ struct cc_engine
     hipStream_t stream2{nullptr}; // table / segmentation / window-scan chain of the pipelined throughput path
     hipStream_t stream3{nullptr}; // association / publish chain of the pipelined throughput path
     hipStream_t stream4{nullptr}; // window-scan stage of the four-stage pipeline (option "pipeline" = 2)
+    hipStream_t stream7{nullptr}; // k_table with table_on_insert_chain = 2
     hipStream_t stream6{nullptr}; // k_publish of a pipelined batch: off the association chain, which is the longest of the three
     hipEvent_t ev_pubrdy[4]{};
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
@@ -56,7 +59,14 @@ struct cc_engine
     bool pipelined{false};        // last submitted batch used all three streams
     bool allow_pipeline{true};    // option "pipeline"
     bool publish_off_chain{true}; // option "publish_off_chain"
-    bool table_on_insert_chain{true}; // option "table_on_insert_chain"
+    int table_on_insert_chain{1}; // option "table_on_insert_chain": k_table 0 = in front of the segmentation chain, 1 = at the end of the insertion chain,
+                                  // 2 = on a (high-priority) stream of its own between the two
+    bool ego_on_insert_chain{false};  // option "ego_on_insert_chain": k_ego (needs the caller's poses only) behind k_table instead of in front of k_seg_pre
+    // CC_HOST_PROF=1: where the host's time goes inside a pipelined call (seconds, summed; printed by cc_engine_destroy)
+    bool host_prof{false};
+    double hp_pre{0}, hp_gate{0}, hp_post{0}, hp_entry{0};
+    long long hp_calls{0};
+    bool debug_no_assoc_fallback{false}; // option "debug_no_assoc_fallback": timing experiments only (results are wrong wherever k_assocb stops)
     bool parallel_insert_multi{true}; // option "parallel_insert" = 1: k_insert_multi behind / instead of k_insert_par; 2: k_insert_par only
     bool parallel_insert{true};   // option "parallel_insert": k_insert_par takes the single-column-firing head of every batch
     // low-latency path of cc_engine_add_firings for small calls: one captured hipGraph per (stream, n), pinned staging
@@ -393,6 +403,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (!sp)
         sp = si; // preparation on the insertion chain unless it runs ahead on its own stream
     const Geometry& g = e->g;
+    const auto hp_t0 = std::chrono::steady_clock::now();
+    auto hp_t1 = hp_t0;
+    bool hp_gated = false;
     const int rpl = (g.num_rows + WAVE - 1) / WAVE;
     // an upper bound of the columns one pass can emit: the in-kernel limit plus half a rotation of one firing
     const long long max_cols = std::min<long long>((long long) g.limit_columns + g.num_columns, (long long) g.ring_cols);
@@ -448,7 +461,15 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic)
             if (e->h_bail_count)
                 CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, si));
+            const auto hp1 = std::chrono::steady_clock::now();
             CC_HIP_CHECK(e, hipStreamSynchronize(si));
+            hp_t1 = std::chrono::steady_clock::now();
+            if (e->host_prof)
+            {
+                e->hp_pre += std::chrono::duration<double>(hp1 - hp_t0).count();
+                e->hp_gate += std::chrono::duration<double>(hp_t1 - hp1).count();
+                hp_gated = true;
+            }
             fallbacks = *e->h_par_left != 0;
         }
     }
@@ -495,17 +516,30 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     Planes Pt = e->P;
     Pt.tabc += (size_t) slot * (size_t) g.num_streams * cck::SEGPRE_BLOCKS * (size_t) g.num_rows;
     Pt.tabw += (size_t) slot * (size_t) g.num_streams * cck::TABLE_WAVES * (size_t) g.num_rows;
-    const bool table_early = si != sb && e->table_on_insert_chain;
+    const bool table_early = si != sb && e->table_on_insert_chain != 0;
+    // (a stream of its own: the next batch's insertion does not queue behind it)
+    hipStream_t st_table = (table_early && e->table_on_insert_chain == 2 && !e->capturing) ? e->stream7 : si;
     if (table_early)
     {
+        if (st_table != si)
+        {
+            CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
+            CC_HIP_CHECK(e, hipStreamWaitEvent(st_table, e->ev_ins[slot], 0));
+        }
         if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, Pt, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, st_table, g, Pt, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, si, g, Pt, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, st_table, g, Pt, e->d_states, first_stream, slot);
     }
+    // per-firing ego transforms of this batch (one buffer per descriptor slot: up to three batches are in flight)
+    double* d_ego = e->d_ego[slot];
+    const bool ego_early = table_early && e->ego_on_insert_chain;
+    if (ego_early)
+        hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, st_table, (const StreamState*) e->d_states, first_stream,
+                           d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
     if (si != sb)
     {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], st_table));
         CC_HIP_CHECK(e, hipStreamWaitEvent(sb, e->ev_ins[slot], 0));
     }
     // ---- table + segmentation + window-scan chain ------------------------------------------------------------
@@ -517,9 +551,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         else
             hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
     }
-    // per-firing ego transforms of this batch (one buffer per descriptor slot: up to three batches are in flight)
-    double* d_ego = e->d_ego[slot];
-    hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
+    if (!ego_early)
+        hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
                        d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
@@ -622,6 +655,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             // per stream waiting for 45 KB of LDS on a busy CU. One block per stream when it is what associates, or while k_assocb has had to stop
             // lately (adaptive_rounds > 1), or when the caller pinned the number of rounds
             const int blocks = (batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1 && !e->capturing) ? (count < 16 ? count : 16) : count;
+            if (batch_assoc && e->debug_no_assoc_fallback)
+                continue;
             if (rpl == 1)
                 hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count);
             else
@@ -657,7 +692,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (!marked7)
         CC_MARK(sa); // ev7: assoc_lds (without the batch-parallel kernel: the serial LDS kernel)
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
-    if (rpl == 1)
+    if (batch_assoc && e->debug_no_assoc_fallback)
+        ;
+    else if (rpl == 1)
         hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     else
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -684,6 +721,11 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         e->assoc_pending[slot] = true;
     }
     CC_HIP_CHECK(e, hipGetLastError());
+    if (e->host_prof && hp_gated)
+    {
+        e->hp_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - hp_t1).count();
+        e->hp_calls++;
+    }
     return CC_OK;
 }
 
@@ -760,6 +802,7 @@ int sync_all(cc_engine* e)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream4));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream5));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream6));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream7));
     for (bool& b : e->assoc_pending)
         b = false;
     e->idle = true;
@@ -798,6 +841,7 @@ int finish_batch(cc_engine* e)
 int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose,
            bool pipeline, int64_t n_total = 0, int64_t f0 = 0)
 {
+    const auto hp_e0 = std::chrono::steady_clock::now();
     std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     if (n_total <= 0)
     {
@@ -876,6 +920,8 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
         CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], e->stream5));
         CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_prep[slot], 0));
     }
+    if (e->host_prof)
+        e->hp_entry += std::chrono::duration<double>(std::chrono::steady_clock::now() - hp_e0).count();
     rc = launch_batch(e, first_stream, count, n, d_xyz, d_int, d_pose, true, slot, si, sb, sa, sc, prepared ? si : sp, prepared);
     if (rc)
         return rc;
@@ -1219,7 +1265,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream6, hipStreamNonBlocking, prio_lo) != hipSuccess)
+        hipStreamCreateWithPriority(&e->stream6, hipStreamNonBlocking, prio_lo) != hipSuccess ||
+        hipStreamCreateWithPriority(&e->stream7, hipStreamNonBlocking, prio_hi) != hipSuccess)
     {
         delete e;
         return CC_ERR_HIP;
@@ -1256,6 +1303,10 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     rc = allocate(e);
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
+    {
+        const char* hp = std::getenv("CC_HOST_PROF");
+        e->host_prof = hp && hp[0] == '1';
+    }
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_bail_count, sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
     if (rc == CC_OK)
@@ -1288,11 +1339,15 @@ void cc_engine_destroy(cc_engine* e)
     if (!e)
         return;
     (void) hipSetDevice(e->device);
+    if (e->host_prof && e->hp_calls > 0)
+        fprintf(stderr, "[cc host_prof] gated calls %lld: entry->launch_batch %.1f us, launch_batch->gate %.1f us, gate wait %.1f us, gate->return %.1f us (per call)\n",
+                e->hp_calls, e->hp_entry / e->hp_calls * 1e6, e->hp_pre / e->hp_calls * 1e6, e->hp_gate / e->hp_calls * 1e6, e->hp_post / e->hp_calls * 1e6);
     (void) hipStreamSynchronize(e->stream);
     (void) hipStreamSynchronize(e->stream2);
     (void) hipStreamSynchronize(e->stream3);
     (void) hipStreamSynchronize(e->stream4);
     (void) hipStreamSynchronize(e->stream6);
+    (void) hipStreamSynchronize(e->stream7);
     (void) hipStreamSynchronize(e->stream5);
     destroy_small_graphs(e);
     free_all(e); // also the pinned small-call staging
@@ -1315,6 +1370,7 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamDestroy(e->stream3);
     (void) hipStreamDestroy(e->stream4);
     (void) hipStreamDestroy(e->stream6);
+    (void) hipStreamDestroy(e->stream7);
     (void) hipStreamDestroy(e->stream5);
     for (hipEvent_t ev : e->ev_pool)
         (void) hipEventDestroy(ev);
@@ -1377,6 +1433,7 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream4));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream5));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream6));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream7));
     e->batch_open = false;
     const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
     if (!same_shape)
@@ -1808,7 +1865,11 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "sub_batch")
         e->sub_batch = value < 0 ? 0 : value;
     else if (n == "table_on_insert_chain")
-        e->table_on_insert_chain = value != 0;
+        e->table_on_insert_chain = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "ego_on_insert_chain")
+        e->ego_on_insert_chain = value != 0;
+    else if (n == "debug_no_assoc_fallback")
+        e->debug_no_assoc_fallback = value != 0;
     else if (n == "publish_off_chain")
         e->publish_off_chain = value != 0;
     else if (n == "parallel_insert")

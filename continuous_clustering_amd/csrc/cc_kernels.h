@@ -2499,14 +2499,18 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
 }
 
 // ---- k_seg_scan: the row-serial part (cc.cpp:306-565 state machine + downward fix-up + ignore flags 567-616).
-// One lane per column on LDS-transposed tiles of 64 columns: global traffic is coalesced (lanes = rows while loading and
-// storing), the bottom-to-top scan of each lane reads conflict-free LDS (odd row pitch).
-// grid = (tiles of 64 columns, streams), block = 64, dynamic LDS = seg_scan_lds_bytes(num_rows).
-// The look-back of the state machine (cc.cpp:513-535) walks down from a new obstacle over the ground cells right below it: rarely more
-// than a few rows. The tile keeps the azimuth-plane distance of the 16 rows [chunk, chunk + 15] per column (a ring indexed by row & 15) and
-// reads deeper rows from the staging plane — 8.7 KB per wavefront instead of 21: this kernel is one wavefront per block, so its LDS is what
-// limits how many of them share a CU with the other chains' blocks (10 KB more cost the whole step 6 %).
+// One lane per column on tiles of 64 columns; grid = (streams, tiles of 64 columns), block = 64, dynamic LDS = seg_scan_lds_bytes(num_rows).
+// The staged inputs (k_seg_pre: azimuth-plane distance, height, flags) are column-major like every plane of the ring, so a lane that read its own
+// column touched a different 128-byte line than its neighbours with every load, 32 bytes at a time: round 2 measured 1.42 GB fetched per step for
+// 0.32 GB of input (the lines did not survive in L2 next to the other chains). Round 3: the wavefront loads 16 rows x 64 columns at a time with
+// lanes = (column, 16-byte piece) — 64 contiguous bytes per column and plane, every line fetched once —, hands them to the column lanes through LDS
+// (XOR-swizzled 16-byte pieces: conflict-free both ways) one chunk ahead of the scan, and the flags of the whole tile start out in the output tile
+// (a cell's flag byte is replaced by its result when its row is done).
+// The look-back of the state machine (cc.cpp:513-535) walks down from a new obstacle over the ground cells right below it: rarely more than a few
+// rows. The tile keeps the azimuth-plane distance of two chunks (the current one and the one below) and reads deeper rows from the staging plane.
+// Row counts that are not a multiple of 16 take the round-2 form (every lane reads its own column, 8 rows at a time; 16 rows of look-back in LDS).
 constexpr int SEG_X2_RING = 16;
+constexpr int SEG_CH = 16; // rows per chunk of the tiled form
 __host__ __device__ inline int seg_pitch_f(int R)
 {
     (void) R;
@@ -2516,9 +2520,14 @@ __host__ __device__ inline int seg_pitch_b(int R)
 {
     return ((R + 3) & ~3) + 4; // bytes per column: multiple of 4 whose word count is odd
 }
+__host__ __device__ inline bool seg_tiled(int R)
+{
+    return R >= SEG_CH && (R % SEG_CH) == 0;
+}
 __host__ inline size_t seg_scan_lds_bytes(int R)
 {
-    return (size_t) 64 * seg_pitch_f(R) * 4 + (size_t) 64 * seg_pitch_b(R);
+    const size_t f = seg_tiled(R) ? (size_t) 3 * 64 * SEG_CH * 4 : (size_t) 64 * seg_pitch_f(R) * 4;
+    return f + (size_t) 64 * seg_pitch_b(R);
 }
 
 // compact codes of the label values inside the LDS tile
@@ -2529,7 +2538,7 @@ enum
     SG_D_VIOLET = 8, SG_D_LIGHTGRAY = 9
 };
 
-__global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
     StreamState* st = &states[s];
@@ -2544,24 +2553,23 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
     const int R = g.num_rows, RC = g.ring_cols;
     const int lane = lane_id();
     const int PF = seg_pitch_f(R), PB = seg_pitch_b(R);
+    const bool tiled = seg_tiled(R);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // The tile keeps only what the state machine looks back at: the azimuth-plane distance of the rows below (cc.cpp:513-535) and
     // one output byte per cell (bits 0-2 ground label code, bits 3-6 debug label code, bit 7 "ignored if it ends up an obstacle").
-    // The inputs themselves are read by the lane that consumes them, 8 rows (one 32-byte sector per plane) at a time and one chunk
-    // ahead, so there is no staging phase and the footprint (21 KB at 64 rows) lets four blocks share a CU with the serial kernels.
     float* l_x2 = (float*) smem;
-    unsigned char* l_out = (unsigned char*) (l_x2 + 64 * PF);
+    unsigned char* l_out = (unsigned char*) (l_x2 + (tiled ? 3 * 64 * SEG_CH : 64 * PF));
 
     const int lc0 = (int) (tile0 % RC);
-    if (lane < ncols && !(g.debug_flags & 1))
+    if (!(g.debug_flags & 1))
     {
+        const bool active = lane < ncols;
         const long long gc = tile0 + lane;
         int lcl = lc0 + lane;
         lcl = lcl >= RC ? lcl - RC : lcl;
         const float* gx = p.sg_x2 + (size_t) lcl * R;
         const float* gz = p.sg_uz + (size_t) lcl * R;
         const unsigned char* gf = p.sg_flags + (size_t) lcl * R;
-        float* x2 = l_x2 + lane * PF;
         unsigned char* oo = l_out + lane * PB;
         const float height_sensor_to_ground = -(float) st->robot_from_sensor[11] + cfg.height_ref_to_ground_;
         const bool chess_odd = cfg.ignore_points_in_chessboard_pattern && (gc & 1); // column parity (cc.cpp:600-606)
@@ -2570,83 +2578,29 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
         float lg2x = 0.f, lgz = height_sensor_to_ground; // last (quite certain) ground point in the azimuth plane
         float pv2x = 0.f, pvz = 0.f;
         unsigned char previous_label = 0;
-        const bool vec = (R & 7) == 0; // rows come in whole, aligned 32-byte sectors
-        float nx[8], nz[8];
-        unsigned nf0 = 0, nf1 = 0; // flags of the 8 rows, one byte each
-        auto load_chunk = [&](int b) // rows b .. b + 7 (b may be negative in the last chunk of an odd-sized column)
+        // one row of the state machine: f = the cell's flags (k_seg_pre), (cur2x, cur2y) = the point in the azimuth plane;
+        // x2_below(row) = the azimuth-plane distance of a row below
+        auto row_step = [&](const int row, const int f, const float cur2x, const float cur2y, auto&& x2_below)
         {
-            if (vec)
-            {
-                const float4 a0 = *(const float4*) (gx + b), a1 = *(const float4*) (gx + b + 4);
-                const float4 c0 = *(const float4*) (gz + b), c1 = *(const float4*) (gz + b + 4);
-                const uint2 ff = *(const uint2*) (gf + b);
-                nx[0] = a0.x, nx[1] = a0.y, nx[2] = a0.z, nx[3] = a0.w, nx[4] = a1.x, nx[5] = a1.y, nx[6] = a1.z, nx[7] = a1.w;
-                nz[0] = c0.x, nz[1] = c0.y, nz[2] = c0.z, nz[3] = c0.w, nz[4] = c1.x, nz[5] = c1.y, nz[6] = c1.z, nz[7] = c1.w;
-                nf0 = ff.x;
-                nf1 = ff.y;
-            }
-            else
-            {
-                nf0 = nf1 = 0;
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                {
-                    const int rr = b + u;
-                    nx[u] = rr >= 0 ? gx[rr] : 0.f;
-                    nz[u] = rr >= 0 ? gz[rr] : 0.f;
-                    const unsigned f = rr >= 0 ? gf[rr] : (unsigned) SG_NAN;
-                    if (u < 4)
-                        nf0 |= f << (8 * u);
-                    else
-                        nf1 |= f << (8 * (u - 4));
-                }
-            }
-        };
-        int b = R - 8; // lowest row of the chunk being processed; chunks run from the bottom ring (row R - 1) upwards
-        load_chunk(b);
-        for (; b > -8; b -= 8)
-        {
-            float x8[8], z8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-            {
-                x8[u] = nx[u];
-                z8[u] = nz[u];
-            }
-            const unsigned f0 = nf0, f1 = nf1;
-            if (b - 8 > -8)
-                load_chunk(b - 8);
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (b + u >= 0)
-                    x2[(b + u) & (SEG_X2_RING - 1)] = x8[u];
-#pragma unroll
-            for (int u = 7; u >= 0; u--)
-            {
-            const int row = b + u;
-            if (row < 0)
-                break;
-            const int f = (int) (((u < 4 ? f0 : f1) >> (8 * (u & 3))) & 0xffu);
             unsigned char ground = SG_G_UNKNOWN, debug = SG_D_WHITE;
             if (f & SG_NAN)
             {
                 oo[row] = (unsigned char) (ground | (debug << 3));
-                continue;
+                return;
             }
             if (f & SG_FOG)
             {
                 oo[row] = (unsigned char) (SG_G_FOG | (SG_D_LIGHTGRAY << 3));
-                continue;
+                return;
             }
             if (f & SG_EGO)
             {
                 oo[row] = (unsigned char) (SG_G_EGO | (SG_D_VIOLET << 3));
-                continue;
+                return;
             }
             // cc.cpp:567-616 for a point that ends up an obstacle: too close / inclination filter / chessboard thinning
             const unsigned char ign_bit =
                 ((f & (SG_TOO_CLOSE | SG_INCL_IGNORE)) || ((row & 1) ? chess_even : chess_odd)) ? (unsigned char) 0x80 : (unsigned char) 0;
-            const float cur2x = x8[u], cur2y = z8[u];
             if (!first_point_found)
             {
                 first_point_found = true;
@@ -2669,7 +2623,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                 pvz = cur2y;
                 previous_label = debug;
                 oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
-                continue;
+                return;
             }
             const float p2cx = cur2x - pv2x, p2cy = cur2y - pvz;
             const float slope_to_prev = p2cy / p2cx;
@@ -2707,8 +2661,7 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
                     const unsigned char bo = oo[below];
                     const unsigned char bg = bo & 7, bd = (bo >> 3) & 15;
                     if (bd == SG_D_YELLOW ||
-                        (bg == SG_G_GROUND && ccm::absf(cur2x - (below < b + SEG_X2_RING ? x2[below & (SEG_X2_RING - 1)] : gx[below])) <
-                                                  cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
+                        (bg == SG_G_GROUND && ccm::absf(cur2x - x2_below(below)) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
                     {
                         if (bg == SG_G_GROUND)
                         {
@@ -2734,6 +2687,167 @@ __global__ __launch_bounds__(64) void k_seg_scan(Geometry g, cc_config cfg, Plan
             pvz = cur2y;
             previous_label = debug;
             oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
+        };
+        if (tiled)
+        {
+            // ---- tiled form: lanes = (column of a group of 16, 16-byte piece) while loading, lanes = columns while scanning
+            float* t_uz = l_x2 + 2 * 64 * SEG_CH; // l_x2: two chunks (index (row / 16) & 1), t_uz: the current one
+            const int ld_c = lane >> 2, ld_q = lane & 3;
+            int ld_off[4]; // cell index of row 0 of this lane's four load columns (-1: beyond the tile)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const int c = j * 16 + ld_c;
+                int l = lc0 + c;
+                l = l >= RC ? l - RC : l;
+                ld_off[j] = c < ncols ? l * R : -1;
+            }
+            float4 nx[4], nz[4];
+            auto load_chunk = [&](const int b)
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    nx[j] = nz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (ld_off[j] >= 0)
+                    {
+                        nx[j] = *(const float4*) (p.sg_x2 + (size_t) ld_off[j] + b + ld_q * 4);
+                        nz[j] = *(const float4*) (p.sg_uz + (size_t) ld_off[j] + b + ld_q * 4);
+                    }
+                }
+            };
+            int b = R - SEG_CH;
+            load_chunk(b);
+            // flags of the whole tile -> output tile (16 bytes per lane and pass: the pieces of a column are neighbours)
+            {
+                const int npieces = R >> 4;
+                for (int idx = lane; idx < 64 * npieces; idx += 64)
+                {
+                    const int c = idx / npieces, piece = idx - c * npieces;
+                    if (c < ncols)
+                    {
+                        int l = lc0 + c;
+                        l = l >= RC ? l - RC : l;
+                        const uint4 v = *(const uint4*) (p.sg_flags + (size_t) l * R + piece * 16);
+                        unsigned* d = (unsigned*) (l_out + c * PB + piece * 16);
+                        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+                    }
+                }
+            }
+            // 16-byte piece q of column c inside a chunk buffer (floats): XOR swizzle, conflict-free for both lane mappings
+            auto piece_at = [](const int c, const int q) { return (c * 4 + (q ^ ((c >> 2) & 3))) * 4; };
+            for (; b >= 0; b -= SEG_CH)
+            {
+                float* cx = l_x2 + ((b >> 4) & 1) * (64 * SEG_CH);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    const int c = j * 16 + ld_c;
+                    *(float4*) (cx + piece_at(c, ld_q)) = nx[j];
+                    *(float4*) (t_uz + piece_at(c, ld_q)) = nz[j];
+                }
+                if (b >= SEG_CH)
+                    load_chunk(b - SEG_CH);
+                wave_lds_fence(); // one wavefront per block: its LDS accesses execute in order
+                if (active)
+                {
+                    float x16[SEG_CH], z16[SEG_CH];
+                    unsigned fw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const float4 a = *(const float4*) (cx + piece_at(lane, q));
+                        const float4 c4 = *(const float4*) (t_uz + piece_at(lane, q));
+                        x16[q * 4 + 0] = a.x, x16[q * 4 + 1] = a.y, x16[q * 4 + 2] = a.z, x16[q * 4 + 3] = a.w;
+                        z16[q * 4 + 0] = c4.x, z16[q * 4 + 1] = c4.y, z16[q * 4 + 2] = c4.z, z16[q * 4 + 3] = c4.w;
+                        fw[q] = *(const unsigned*) (oo + b + q * 4);
+                    }
+                    auto x2_below = [&](const int below) -> float
+                    {
+                        // this chunk or the one below it: LDS; deeper: the staging plane (the LDS word is read either way: a select between
+                        // an LDS and a global address would make this a flat access)
+                        float v = l_x2[((below >> 4) & 1) * (64 * SEG_CH) + piece_at(lane, (below & 15) >> 2) + (below & 3)];
+                        if (below >= b + 2 * SEG_CH)
+                            v = gx[below];
+                        return v;
+                    };
+#pragma unroll
+                    for (int u = SEG_CH - 1; u >= 0; u--)
+                        row_step(b + u, (int) ((fw[u >> 2] >> (8 * (u & 3))) & 0xffu), x16[u], z16[u], x2_below);
+                }
+                wave_lds_fence(); // (the next chunk's pieces are stored behind this chunk's reads)
+            }
+        }
+        else if (active)
+        {
+            // ---- rows not a multiple of 16: the inputs are read by the lane that consumes them, 8 rows (one 32-byte sector per plane) at a time
+            // and one chunk ahead
+            float* x2 = l_x2 + lane * PF;
+            const bool vec = (R & 7) == 0; // rows come in whole, aligned 32-byte sectors
+            float nx[8], nz[8];
+            unsigned nf0 = 0, nf1 = 0; // flags of the 8 rows, one byte each
+            auto load_chunk = [&](int b) // rows b .. b + 7 (b may be negative in the last chunk of an odd-sized column)
+            {
+                if (vec)
+                {
+                    const float4 a0 = *(const float4*) (gx + b), a1 = *(const float4*) (gx + b + 4);
+                    const float4 c0 = *(const float4*) (gz + b), c1 = *(const float4*) (gz + b + 4);
+                    const uint2 ff = *(const uint2*) (gf + b);
+                    nx[0] = a0.x, nx[1] = a0.y, nx[2] = a0.z, nx[3] = a0.w, nx[4] = a1.x, nx[5] = a1.y, nx[6] = a1.z, nx[7] = a1.w;
+                    nz[0] = c0.x, nz[1] = c0.y, nz[2] = c0.z, nz[3] = c0.w, nz[4] = c1.x, nz[5] = c1.y, nz[6] = c1.z, nz[7] = c1.w;
+                    nf0 = ff.x;
+                    nf1 = ff.y;
+                }
+                else
+                {
+                    nf0 = nf1 = 0;
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                    {
+                        const int rr = b + u;
+                        nx[u] = rr >= 0 ? gx[rr] : 0.f;
+                        nz[u] = rr >= 0 ? gz[rr] : 0.f;
+                        const unsigned f = rr >= 0 ? gf[rr] : (unsigned) SG_NAN;
+                        if (u < 4)
+                            nf0 |= f << (8 * u);
+                        else
+                            nf1 |= f << (8 * (u - 4));
+                    }
+                }
+            };
+            int b = R - 8; // lowest row of the chunk being processed; chunks run from the bottom ring (row R - 1) upwards
+            load_chunk(b);
+            for (; b > -8; b -= 8)
+            {
+                float x8[8], z8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                {
+                    x8[u] = nx[u];
+                    z8[u] = nz[u];
+                }
+                const unsigned f0 = nf0, f1 = nf1;
+                if (b - 8 > -8)
+                    load_chunk(b - 8);
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (b + u >= 0)
+                        x2[(b + u) & (SEG_X2_RING - 1)] = x8[u];
+                auto x2_below = [&](const int below) -> float
+                {
+                    float v = x2[below & (SEG_X2_RING - 1)];
+                    if (below >= b + SEG_X2_RING)
+                        v = gx[below];
+                    return v;
+                };
+#pragma unroll
+                for (int u = 7; u >= 0; u--)
+                {
+                    const int row = b + u;
+                    if (row < 0)
+                        break;
+                    row_step(row, (int) (((u < 4 ? f0 : f1) >> (8 * (u & 3))) & 0xffu), x8[u], z8[u], x2_below);
+                }
             }
         }
     }

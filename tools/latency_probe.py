@@ -1,5 +1,8 @@
 import sys, os, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import continuous_clustering_amd as _cca
+if len(sys.argv) > 1:  # another build of the library (A/B)
+    _cca.LIB_PATH = os.path.join(os.path.dirname(_cca.LIB_PATH), sys.argv[1])
 from continuous_clustering_amd import Engine, capi, synth
 cfg = capi.Config.kitti()
 st = synth.make_stream(2200 + 800, seed=5, motion=synth.Motion.translate())

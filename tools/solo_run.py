@@ -2,6 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import continuous_clustering_amd as _cca
+if len(sys.argv) > 2:  # another build of the library (A/B)
+    _cca.LIB_PATH = os.path.join(os.path.dirname(_cca.LIB_PATH), sys.argv[2])
 from continuous_clustering_amd import Engine, capi, synth
 import bench
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
