@@ -475,14 +475,36 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     // multi-column firings (per-laser azimuth offsets) and whatever single-column head k_insert_par did not take: block-parallel as well,
     // with the per-row collision rule checked instead of assumed (option "parallel_insert" = 2 restricts this to the first kernel)
+    // (above 64 rows it is the first insertion kernel, and the gate is here: k_prep and k_insert2<2> — 96 KB of LDS per block — stood 1.3 ms per batch in
+    // the insertion chain of 256 VLS-128-shaped streams, the chain the host waits for, to find nothing to do)
+    const bool gate2 = par && rpl > 1 && e->parallel_insert_multi && si != sb && e->skip_idle_fallbacks;
     if (par && e->parallel_insert_multi && fallbacks)
     {
+        if (gate2)
+            CC_HIP_CHECK(e, hipMemsetAsync(e->d_par_left, 0, sizeof(int), si));
+        int* left2 = gate2 ? e->d_par_left : (int*) nullptr;
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_insert_multi<1>, dim3(count), dim3(64 * cck::IM_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
-                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
+                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, (int*) nullptr);
         else
             hipLaunchKernelGGL(cck::k_insert_multi<2>, dim3(count), dim3(64 * cck::IM_WAVES), 0, si, g, e->cfg, e->P, e->d_states, first_stream, d_xyz,
-                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0);
+                               d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left2);
+        if (gate2)
+        {
+            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, sizeof(int), hipMemcpyDeviceToHost, si));
+            if (e->h_bail_count)
+                CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, si));
+            const auto hp1 = std::chrono::steady_clock::now();
+            CC_HIP_CHECK(e, hipStreamSynchronize(si));
+            hp_t1 = std::chrono::steady_clock::now();
+            if (e->host_prof)
+            {
+                e->hp_pre += std::chrono::duration<double>(hp1 - hp_t0).count();
+                e->hp_gate += std::chrono::duration<double>(hp_t1 - hp1).count();
+                hp_gated = true;
+            }
+            fallbacks = *e->h_par_left != 0;
+        }
     }
     if (first_pass && !prep_done && fallbacks) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
     {
@@ -700,7 +722,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     CC_MARK(sa); // ev8: assoc_global
     // (without the host synchronisation behind k_insert_par nobody else reads the counter of k_assocb's stops: four bytes ride along here)
-    if (batch_assoc && !gate && e->h_bail_count && !e->capturing)
+    if (batch_assoc && !gate && !gate2 && e->h_bail_count && !e->capturing)
         CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
     // The ids of the published columns only read what the association of THIS batch left behind (tree root of every cell, cluster id
     // at the root cell; neither is touched again before the ring wraps), so in the pipelined mode they are written on a stream of their

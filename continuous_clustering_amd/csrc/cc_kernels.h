@@ -1659,8 +1659,11 @@ constexpr int IM_WAVES = CC_IM_WAVES;
 template<int RPL>
 __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
                                                               const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
-                                                              const double* __restrict__ poses, long long n, long long n_total, long long fbase)
+                                                              const double* __restrict__ poses, long long n, long long n_total, long long fbase,
+                                                              int slot, int* __restrict__ left_over)
 {
+    // left_over (engine option skip_idle_fallbacks, launches in which this is the first insertion kernel): a stream whose whole batch is taken here
+    // gets its batch descriptor here (as in k_insert_par); every other stream is counted, and the host launches k_prep + k_insert2 only if there is one
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
     const int lane = lane_id();
@@ -1679,7 +1682,11 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
 
     const long long cursor0 = st->cursor;
     if (cursor0 >= n)
+    {
+        if (left_over && tid == 0)
+            atomicAdd(left_over, 1); // (an empty call, or a batch another kernel closed: the serial kernel writes the descriptor)
         return;
+    }
     const long long prev_rear0 = st->prev_rearmost, prev_fore0 = st->prev_foremost, first_unf0 = st->first_unfinished;
     const long long ring_end0 = st->ring_end;
     if (tid == 0)
@@ -1716,7 +1723,11 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     if (!steady)
     {
         if (tid == 0)
+        {
             st->clear_done = clear_done;
+            if (left_over)
+                atomicAdd(left_over, 1);
+        }
         return;
     }
     // what the rows have written ahead of the rearmost laser so far: the last occupied column of every row in [prev_rear0, prev_fore0]
@@ -1994,6 +2005,20 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
             st->firings_consumed = (unsigned long long) (seq0 + (done - cursor0));
             if (st->pre_seg_begin == 0)
                 st->pre_seg_begin = first_unf0;
+        }
+        if (left_over)
+        {
+            if (done == n && cursor0 == 0 && done > 0)
+            {
+                // the whole batch was taken: the columns it finished are [first_unfinished at entry, rearmost column now)
+                st->batch[slot].seg_begin = first_unf0;
+                st->batch[slot].seg_end = prev_rear0 + carry_rel;
+                st->batch[slot].acp_next = first_unf0;
+                st->batch[slot].pub_begin = -1;
+                st->batch[slot].pub_end = -1;
+            }
+            else
+                atomicAdd(left_over, 1);
         }
     }
 }

@@ -174,3 +174,41 @@ def test_pipelined_throughput_path_matches_oracle(pipeline, sub_batch, oracle_li
         hi = se["first_unpublished_global_column_index"] - 1
         lo = max(hi - 600, se["ring_buffer_start_global_column_index"])
         util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
+
+
+@pytest.mark.parametrize("firings,rounds", [(240, 0), (97, 0), (240, 1), (720, 2)])
+def test_pipelined_path_with_streams_the_batch_parallel_association_stops_at(firings, rounds, oracle_lib):
+    """Pipelined device path (events off: four chains of HIP streams, batches overlap) over streams made to make k_assocb stop (tests/cases.py
+    EXCEPTION_CASES) next to ordinary ones: the hand-over to the serial kernel (adaptive number of rounds, or pinned) happens while the next batch is
+    inserted, segmented and scanned. Every stream must end in the oracle's state with the oracle's published columns, and the exception path must
+    have been taken."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    names = ["x_s64_slanted_gaps", "s64_translate", "x_s64_slanted_gaps_far", "s64_turn", "x_s64_near_jitter_gaps_3", "s64_static", "x_s64_refused_attach"]
+    built = [cases.build_case(n) for n in names]
+    cfg = built[0][1]
+    keep = [i for i, b in enumerate(built) if bytes(b[1]) == bytes(cfg) and b[2] is None]
+    assert len(keep) >= 4, [names[i] for i in keep]
+    streams = [built[i][0] for i in keep]
+    S = len(streams)
+    F = firings
+    NB = min(st.n_firings for st in streams) // F
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    e.set_option("assoc_rounds", rounds)
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+    assert e.sync() == 0, e.last_error()
+    bc = e.batch_counters()
+    assert bc["batch_bails"] > 0, bc
+    for s in range(S):
+        o = Oracle(cfg, 64)
+        assert o.add_firings(streams[s].xyz[:NB * F], streams[s].intensity[:NB * F], streams[s].poses[:NB * F]) == 0
+        so, se = o.state(), e.state(s)
+        for k in util.STATE_FIELDS:
+            assert so[k] == se[k], (names[keep[s]], k, so[k], se[k])
+        hi = se["first_unpublished_global_column_index"] - 1
+        lo = max(hi - 600, se["ring_buffer_start_global_column_index"])
+        util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)

@@ -8,8 +8,8 @@ out=$repo/gpurun_out/round_$tag
 mkdir -p $out
 cd $repo
 python bench.py > $out/bench_line.json 2> $out/bench.err
-tools/prof.sh $tag --steps 40 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof.log 2>&1
-tools/prof.sh ${tag}_s128 --sensor s128 --firings 1700 --steps 10 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof_s128.log 2>&1
+CC_ASSOC_ROUNDS=1 tools/prof.sh $tag --steps 40 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof.log 2>&1
+CC_ASSOC_ROUNDS=1 tools/prof.sh ${tag}_s128 --sensor s128 --firings 1700 --steps 10 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof_s128.log 2>&1
 tools/pmc.sh $tag > $out/pmc.log 2>&1
 tools/pmc.sh ${tag}_s128 --sensor s128 --firings 1700 > $out/pmc_s128.log 2>&1
 tools/pmc_sq.sh $tag "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
