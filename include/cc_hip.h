@@ -275,7 +275,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * the links wavefront; 2: k_assoc2 (front / back wavefronts); 1: the one-wavefront kernel, which is also what
  * cluster_point_trees_every_nth_column != 1 uses), "skip_idle_fallbacks" (1 (default): in the pipelined mode the
  * host waits for the block-parallel insertion kernel of a batch and launches the other insertion kernels only if some stream's batch was not
- * taken completely; 0: always launch them), "assoc_rounds" (1..8, default 2: (batch-parallel, serial) association kernel pairs per batch; all
+ * taken completely (k_insert_par up to 64 rows, k_insert_multi above); 0: always launch them), "assoc_rounds" (1..8; 0 (default): adaptive — one
+ * (batch-parallel, serial) association kernel pair per batch, three for the 16 batches after the batch-parallel kernel had to stop; all
  * but the last serial launch only take the group of columns the batch-parallel kernel stopped in front of), "assoc_batch" (1 (default): the batch-parallel association kernel runs in front of the
  * serial one and takes every group of columns that cannot differ from the sequential semantics, see cc_engine_batch_counters; 0: serial
  * kernels only), "sub_batch" (firings
@@ -284,7 +285,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * production), "parallel_insert" (1 (default): the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a
  * block-parallel kernel, the serial insertion kernel continues behind it; 0: serial kernel only), "publish_off_chain" (1 (default): in the pipelined mode k_publish runs on a stream of its own instead of at the end of
  * the association chain), "table_on_insert_chain" (1 (default): in the pipelined mode k_table runs at the end of the insertion chain instead of
- * at the head of the segmentation chain), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
+ * at the head of the segmentation chain (0); 2: on a stream of its own between the two), "ego_on_insert_chain" (1: k_ego next to k_table instead of in
+ * front of k_seg_pre; default 0), "insert_wide_max_streams" / "insert_split_blocks" (launches of at most that many streams, default 96, run k_insert_par with 16
+ * wavefronts per block and deal a stream's firings to that many blocks: 0 (default) = 4 up to 40 streams, else 2), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
  * number_of_visited_neighbors, per-tree values of finished trees, the tree-link log; 0 in throughput mode), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
  * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
