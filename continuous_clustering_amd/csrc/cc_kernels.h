@@ -2743,20 +2743,36 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
             };
             int b = R - SEG_CH;
             load_chunk(b);
-            // flags of the whole tile -> output tile (16 bytes per lane and pass: the pieces of a column are neighbours)
+            // flags of the whole tile -> output tile (16 bytes per lane and pass: the pieces of a column are neighbours). Four passes' loads are in
+            // flight together (a one-column call is a chain of dependent round trips otherwise: 2 us each)
             {
                 const int npieces = R >> 4;
-                for (int idx = lane; idx < 64 * npieces; idx += 64)
+                for (int idx0 = lane; idx0 < 64 * npieces; idx0 += 4 * 64)
                 {
-                    const int c = idx / npieces, piece = idx - c * npieces;
-                    if (c < ncols)
+                    uint4 v[4];
+                    int dst[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
                     {
-                        int l = lc0 + c;
-                        l = l >= RC ? l - RC : l;
-                        const uint4 v = *(const uint4*) (p.sg_flags + (size_t) l * R + piece * 16);
-                        unsigned* d = (unsigned*) (l_out + c * PB + piece * 16);
-                        d[0] = v.x, d[1] = v.y, d[2] = v.z, d[3] = v.w;
+                        const int idx = idx0 + u * 64;
+                        const int c = idx / npieces, piece = idx - c * npieces;
+                        dst[u] = -1;
+                        v[u] = make_uint4(0, 0, 0, 0);
+                        if (idx < 64 * npieces && c < ncols)
+                        {
+                            int l = lc0 + c;
+                            l = l >= RC ? l - RC : l;
+                            v[u] = *(const uint4*) (p.sg_flags + (size_t) l * R + piece * 16);
+                            dst[u] = c * PB + piece * 16;
+                        }
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (dst[u] >= 0)
+                        {
+                            unsigned* d = (unsigned*) (l_out + dst[u]);
+                            d[0] = v[u].x, d[1] = v[u].y, d[2] = v[u].z, d[3] = v[u].w;
+                        }
                 }
             }
             // 16-byte piece q of column c inside a chunk buffer (floats): XOR swizzle, conflict-free for both lane mappings
