@@ -212,3 +212,43 @@ def test_pipelined_path_with_streams_the_batch_parallel_association_stops_at(fir
         hi = se["first_unpublished_global_column_index"] - 1
         lo = max(hi - 600, se["ring_buffer_start_global_column_index"])
         util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
+
+
+@pytest.mark.parametrize("S,split", [(48, 0), (48, 1), (24, 3), (100, 0)])
+def test_insertion_dealt_to_several_blocks_per_stream(S, split, oracle_lib):
+    """Launches of at most 96 streams run k_insert_par with 16 wavefronts per block and deal a stream's firings to several blocks (4 up to 40 streams,
+    else 2; option insert_split_blocks pins the number), k_insert_par_fin closes the stream's state; above 96 streams one block of 8 wavefronts takes a
+    stream. Streams with firings out of shape (duplicated / empty / backwards: the run ends there and later blocks' cells are taken back) next to regular
+    ones, pipelined device path: every stream ends in the oracle's state with the oracle's published columns."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    from test_gpu_parallel_insert import perturbed_stream
+    cfg = capi.Config.kitti()
+    distinct = 6
+    base = [perturbed_stream(4000 + s) if s % 2 else synth.make_stream(2200 * 2 + 200, seed=900 + s, motion=synth.Motion.translate()) for s in range(distinct)]
+    F = 1100
+    NB = min(st.n_firings for st in base) // F
+    streams = [base[s % distinct] for s in range(S)]
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    if split:
+        e.set_option("insert_split_blocks", split)
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+    assert e.sync() == 0, e.last_error()
+    states = [e.state(s) for s in range(S)]
+    for s in range(distinct, S):
+        for k in util.STATE_FIELDS:
+            assert states[s][k] == states[s % distinct][k], (s, k)
+    for s in range(distinct):
+        o = Oracle(cfg, 64)
+        assert o.add_firings(base[s].xyz[:NB * F], base[s].intensity[:NB * F], base[s].poses[:NB * F]) == 0
+        so = o.state()
+        for k in util.STATE_FIELDS:
+            assert so[k] == states[s][k], (s, k, so[k], states[s][k])
+        hi = states[s]["first_unpublished_global_column_index"] - 1
+        lo = max(hi - 1000, states[s]["ring_buffer_start_global_column_index"])
+        for s2 in (s, s + distinct * ((S - 1 - s) // distinct)):
+            util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo, mirror=False)
