@@ -1565,9 +1565,38 @@ template<int RPL>
 __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
                                                        int limited, int count)
 {
-    for (int i = blockIdx.x; i < count; i += gridDim.x)
+    if (gridDim.x >= (unsigned) count) // one block per stream
     {
-        assoc3_stream<RPL>(g, cfg, P, states, first_stream + i, slot, limited);
-        __syncthreads(); // (the wavefronts leave a stream at different points; the LDS state is rebuilt from the planes for the next one)
+        if ((int) blockIdx.x < count)
+            assoc3_stream<RPL>(g, cfg, P, states, first_stream + (int) blockIdx.x, slot, limited);
+        return;
+    }
+    // a few blocks behind k_assocb: which streams have columns left is found out by all threads at once (one stream each: a block that walked over its
+    // streams one after the other spent two dependent global round trips on each — 0.13 ms of the association chain per step at 64 streams, 20 % of the step),
+    // then the block takes those streams one after the other — almost always none
+    __shared__ int s_work[A3_THREADS];
+    __shared__ int s_nwork;
+    if (threadIdx.x == 0)
+        s_nwork = 0;
+    __syncthreads();
+    for (int base = 0; base < count; base += (int) (gridDim.x * blockDim.x))
+    {
+        const int i = base + (int) threadIdx.x * (int) gridDim.x + (int) blockIdx.x;
+        if (i < count)
+        {
+            const StreamState* st = &states[first_stream + i];
+            if (st->error == 0 && st->batch[slot].seg_begin >= 0 && st->batch[slot].acp_next < st->batch[slot].seg_end)
+                s_work[atomicAdd(&s_nwork, 1)] = i; // (at most blockDim.x entries per pass of `base`, and the list is drained before the next pass)
+        }
+        __syncthreads();
+        const int nw = s_nwork;
+        for (int k = 0; k < nw; k++)
+        {
+            assoc3_stream<RPL>(g, cfg, P, states, first_stream + s_work[k], slot, limited);
+            __syncthreads(); // (the wavefronts leave a stream at different points; the LDS state is rebuilt from the planes for the next one)
+        }
+        if (threadIdx.x == 0)
+            s_nwork = 0;
+        __syncthreads();
     }
 }
