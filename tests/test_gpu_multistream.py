@@ -252,3 +252,32 @@ def test_insertion_dealt_to_several_blocks_per_stream(S, split, oracle_lib):
         lo = max(hi - 1000, states[s]["ring_buffer_start_global_column_index"])
         for s2 in (s, s + distinct * ((S - 1 - s) // distinct)):
             util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo, mirror=False)
+
+
+@pytest.mark.parametrize("rows", [16, 48, 100])
+def test_pipelined_path_at_other_row_counts(rows, oracle_lib):
+    """The throughput path (events off, chains overlapped, block-parallel insertion, batch-parallel association) at row counts between the usual ones."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    sen = synth.SensorModel(num_rows=rows, num_columns=720, incl_top_deg=6.0, incl_bottom_deg=-26.0)
+    cfg = capi.Config.kitti()
+    cfg.num_columns = 720
+    S, F, NB = 5, 720, 4
+    motions = [synth.Motion.static(), synth.Motion.translate(), synth.Motion.turn()]
+    streams = [synth.make_stream(F * NB, seed=3100 + rows + s, sensor=sen, motion=motions[s % 3]) for s in range(S)]
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, rows, S)
+    e.record_events(False)
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+    assert e.sync() == 0, e.last_error()
+    for s in range(S):
+        o = Oracle(cfg, rows)
+        assert o.add_firings(streams[s].xyz, streams[s].intensity, streams[s].poses) == 0
+        so, se = o.state(), e.state(s)
+        for k in util.STATE_FIELDS:
+            assert so[k] == se[k], (s, k)
+        hi = se["first_unpublished_global_column_index"] - 1
+        lo = max(hi - 600, se["ring_buffer_start_global_column_index"])
+        util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)

@@ -6,7 +6,7 @@ import pytest
 
 import cases
 import util
-from continuous_clustering_amd import capi
+from continuous_clustering_amd import capi, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -236,3 +236,14 @@ def test_multi_column_insertion_takes_the_steady_part(oracle_lib):
     out = np.zeros(16, dtype=np.uint64)
     L.cc_engine_debug_counters(e.h, 0, out.ctypes.data)
     assert out[6] >= 1700, out[6]  # the whole second call (the first one starts the ring in the serial kernel)
+
+
+@pytest.mark.parametrize("rows", [8, 16, 24, 40, 48, 50, 80, 96, 100, 112])
+def test_row_counts_between_the_usual_ones(rows, oracle_lib):
+    """Sensors with row counts other than 32 / 64 / 128: k_seg_scan loads 16 rows x 64 columns at a time when the row count is a multiple of 16 and
+    falls back to every lane reading its own rows otherwise (8 at a time, or one by one when the count is not a multiple of 8); above 64 rows every
+    kernel works on two rows per lane with the upper lanes partly idle. Events and published columns equal the oracle's, chunked calls."""
+    sen = synth.SensorModel(num_rows=rows, num_columns=360, incl_top_deg=6.0, incl_bottom_deg=-26.0)
+    stream = synth.make_stream(360 * 2 + 90, seed=3000 + rows, sensor=sen, motion=synth.Motion.translate(8.0))
+    cfg = cases._kitti(360)
+    util.run_and_compare(stream, cfg, chunks=[360, 97, 23], robot_tf=None)
