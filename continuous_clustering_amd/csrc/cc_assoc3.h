@@ -1563,12 +1563,24 @@ __device__ __forceinline__ void assoc3_stream(const Geometry& g, const cc_config
 
 template<int RPL>
 __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                       int limited, int count)
+                                                       int limited, int count, int with_global)
 {
+    // with_global: streams whose unfinished trees do not fit the LDS pool (or that assoc3_stream just handed over) continue in global memory right here,
+    // on wavefront 0 (associate_stream, cc_kernels.h), instead of in a launch of k_associate behind this kernel: one kernel boundary less on the
+    // association chain (and one graph node less in a captured small call)
     if (gridDim.x >= (unsigned) count) // one block per stream
     {
         if ((int) blockIdx.x < count)
+        {
             assoc3_stream<RPL>(g, cfg, P, states, first_stream + (int) blockIdx.x, slot, limited);
+            if (with_global && !limited)
+            {
+                __threadfence_block();
+                __syncthreads(); // every wavefront has left the stream (its state is in the planes again)
+                if (threadIdx.x < 64)
+                    associate_stream<RPL>(g, cfg, P, states, first_stream + (int) blockIdx.x, slot);
+            }
+        }
         return;
     }
     // a few blocks behind k_assocb: which streams have columns left is found out by all threads at once (one stream each: a block that walked over its
@@ -1593,7 +1605,14 @@ __global__ __launch_bounds__(A3_THREADS) void k_assoc3(Geometry g, cc_config cfg
         for (int k = 0; k < nw; k++)
         {
             assoc3_stream<RPL>(g, cfg, P, states, first_stream + s_work[k], slot, limited);
+            __threadfence_block();
             __syncthreads(); // (the wavefronts leave a stream at different points; the LDS state is rebuilt from the planes for the next one)
+            if (with_global && !limited)
+            {
+                if (threadIdx.x < 64)
+                    associate_stream<RPL>(g, cfg, P, states, first_stream + s_work[k], slot);
+                __syncthreads();
+            }
         }
         if (threadIdx.x == 0)
             s_nwork = 0;

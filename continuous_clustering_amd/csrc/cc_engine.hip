@@ -29,6 +29,9 @@ struct cc_engine
     int* d_bail_count{nullptr}; // launches of k_assocb that stopped in front of a group, ever (assoc_rounds 0 = adaptive)
     int* h_bail_count{nullptr}; // pinned; refreshed behind every batch's association chain
     int bail_seen{0}, bail_cooldown{0};
+    int bail_cooldown_batches{4};  // option "assoc_cooldown": batches that run three (batch-parallel, serial) rounds after k_assocb had to stop (assoc_rounds 0).
+                                   // 16 in the first version: with the few stops of ordinary streams (5 in 47 M columns) nearly every batch of a 256-stream run
+                                   // then ran three rounds — two more placements of k_assocb's 1024-thread blocks per step, 2 - 3 % of the step
     bool capturing{false};      // launch_batch is being captured into a hipGraph (small calls)
     int* d_par_left{nullptr};  // streams whose batch k_insert_par did not take completely (skip_idle_fallbacks)
     int* h_par_left{nullptr};  // pinned
@@ -636,13 +639,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     };
     bool marked7 = false;
     int adaptive_rounds = 1;
+    bool global_done = false; // k_associate's work was done inside the last k_assoc3 launch
     if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
     {
         const int seen = *e->h_bail_count; // (as of some earlier batch: a heuristic, not a condition of correctness)
         if (seen != e->bail_seen)
         {
             e->bail_seen = seen;
-            e->bail_cooldown = 16;
+            e->bail_cooldown = e->bail_cooldown_batches;
         }
         if (e->bail_cooldown > 0)
         {
@@ -680,9 +684,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             if (batch_assoc && e->debug_no_assoc_fallback)
                 continue;
             if (rpl == 1)
-                hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count);
+                hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
             else
-                hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count);
+                hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
+            global_done = limited == 0; // (the last launch of k_assoc3 takes the streams that continue in global memory with it)
         }
     }
     else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
@@ -714,7 +719,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     if (!marked7)
         CC_MARK(sa); // ev7: assoc_lds (without the batch-parallel kernel: the serial LDS kernel)
     // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
-    if (batch_assoc && e->debug_no_assoc_fallback)
+    if ((batch_assoc && e->debug_no_assoc_fallback) || global_done)
         ;
     else if (rpl == 1)
         hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -1888,6 +1893,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->sub_batch = value < 0 ? 0 : value;
     else if (n == "table_on_insert_chain")
         e->table_on_insert_chain = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "assoc_cooldown")
+        e->bail_cooldown_batches = value < 0 ? 0 : (value > 1000 ? 1000 : (int) value);
     else if (n == "ego_on_insert_chain")
         e->ego_on_insert_chain = value != 0;
     else if (n == "debug_no_assoc_fallback")

@@ -3101,10 +3101,20 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
     }
 }
 
-template<int RPL>
-__global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+// what __syncthreads() is for a block of one wavefront, without the barrier instruction: every earlier global / LDS access of the wavefront has completed
+// before a later one is issued (lanes hand values to each other through memory between the phases of k_associate)
+__device__ __forceinline__ void assoc_wave_sync()
 {
-    const int s = first_stream + blockIdx.x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// One stream's batch in global memory, one wavefront (lanes = rows). Called by k_associate (a block = one wavefront = one stream) and, behind the serial
+// LDS kernel, by wavefront 0 of k_assoc3's block (cc_assoc3.h): no block barrier in here — assoc_wave_sync() orders the wavefront's own global and LDS
+// accesses the way __syncthreads() does for a one-wavefront block.
+template<int RPL>
+__device__ __forceinline__ void associate_stream(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, const int s, const int slot)
+{
     const int lane = lane_id();
     StreamState* st = &states[s];
     if (st->error != 0 || st->batch[slot].seg_begin < 0 || (st->assoc_mode == 0 && st->batch[slot].mode == 0) ||
@@ -3219,7 +3229,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 }
             }
         }
-        __syncthreads();
+        assoc_wave_sync();
         // resolve tree roots through same-column parents, then verify that no attach would have been refused
         int rootc[RPL];
         bool refused = overflow;
@@ -3295,7 +3305,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 n_unf += cnt;
             }
             L = wave_min_f64(L);
-            __syncthreads();
+            assoc_wave_sync();
             // (b) attach: root bookkeeping of associatePointToPointTree (cc.cpp:661-671)
 #pragma unroll
             for (int k = 0; k < RPL; k++)
@@ -3310,7 +3320,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                     atomicAdd(&p.t_pts[r], 1u);
                 }
             }
-            __syncthreads();
+            assoc_wave_sync();
             // (c) links between trees (cc.cpp:675-696) as lock-free unions
 #pragma unroll
             for (int k = 0; k < RPL; k++)
@@ -3330,7 +3340,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                     }
                 }
             }
-            __syncthreads();
+            assoc_wave_sync();
         }
         else
         {
@@ -3385,7 +3395,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 s_bd[0] = LL;
                 s_bl[0] = MM;
             }
-            __syncthreads();
+            assoc_wave_sync();
             n_unf = s_bcast[0];
             if (s_bcast[1])
             {
@@ -3394,7 +3404,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
             }
             L = s_bd[0];
             M = s_bl[0];
-            __syncthreads();
+            assoc_wave_sync();
         }
         if (err)
             break;
@@ -3428,7 +3438,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 p.agg_cid[i] = 0;
                 p.agg_flag[i] = 0;
             }
-            __syncthreads();
+            assoc_wave_sync();
             for (int i = lane; i < n_unf; i += 64)
             {
                 const int t = p.ulist[i];
@@ -3442,7 +3452,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 atomicAdd(&p.agg_pts[j], ld_agent(&p.t_pts[t]));
                 atomicMin(&p.agg_first[j], i);
             }
-            __syncthreads();
+            assoc_wave_sync();
             int exceed_local = 0;
             for (int i = lane; i < n_unf; i += 64)
             {
@@ -3459,7 +3469,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
             for (int o = 32; o > 0; o >>= 1)
                 exceed_local += __shfl_xor(exceed_local, o);
             exceed += exceed_local;
-            __syncthreads();
+            assoc_wave_sync();
             // ids in the order the reference's BFS would discover the clusters: by earliest tree in the list
             int last_first = -1;
             while (true)
@@ -3485,7 +3495,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
                 clusters_finished++;
                 last_first = best;
             }
-            __syncthreads();
+            assoc_wave_sync();
             // mark trees, minimum required column, stable compaction of the list
             long long min_all = 0x7fffffffffffffffll, min_surv = 0x7fffffffffffffffll;
             double L_new = 1.7976931348623157e308;
@@ -3532,7 +3542,7 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
             M_c = min_all;
             M = min_surv;
             n_unf = out;
-            __syncthreads();
+            assoc_wave_sync();
         }
         last_min_az = min_az;
 
@@ -3583,6 +3593,12 @@ __global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Pla
         if (err)
             raise_error(st, err, err_a, err_b);
     }
+}
+
+template<int RPL>
+__global__ __launch_bounds__(64) void k_associate(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+{
+    associate_stream<RPL>(g, cfg, P, states, first_stream + (int) blockIdx.x, slot);
 }
 
 
