@@ -2986,11 +2986,17 @@ __device__ __forceinline__ void tree_init(const SP& p, int cell, double fin)
 //  LIVE = false: record the first passing candidate as `parent` and later passing candidates as link candidates;
 //                no tree state is read (valid when no attach is refused, checked by the caller).
 //  LIVE = true : exact reference semantics with immediate attach / link (single lane, rows in order).
-template<bool LIVE, bool CODE = false, bool REC = false>
+struct NoLinkVisitor
+{
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// (ON_LINK, static scan only: called with every accepted candidate behind the first, in the reference's order, whether or not it still fits `links`:
+// k_assocb walks the complete list of a point whose recorded list overflowed with it)
+template<bool LIVE, bool CODE = false, bool REC = false, class ON_LINK = NoLinkVisitor>
 __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, const long long gc, const int row, const int first_local,
                                            const float mad, const double pcaz, int& p_root, int& parent, int* links, int& nlinks,
                                            bool& overflow, const int max_links = LINK_SLOTS_V1, int* visits = nullptr, StreamState* st = nullptr,
-                                           const Geometry* geo = nullptr, int* reach = nullptr)
+                                           const Geometry* geo = nullptr, int* reach = nullptr, const ON_LINK& on_link = ON_LINK())
 {
     const SP& p = c.p;
     const int R = c.R;
@@ -3075,10 +3081,14 @@ __device__ __forceinline__ void scan_point(const AssocCtx& c, const int lc, cons
                                     parent = cand;
                                     rooted = true;
                                 }
-                                else if (nlinks < max_links)
-                                    links[nlinks++] = cand;
                                 else
-                                    overflow = true;
+                                {
+                                    on_link(cand);
+                                    if (nlinks < max_links)
+                                        links[nlinks++] = cand;
+                                    else
+                                        overflow = true;
+                                }
                             }
                         }
                     }
