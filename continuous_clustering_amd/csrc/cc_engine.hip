@@ -29,6 +29,8 @@ struct cc_engine
     int* d_bail_count{nullptr}; // launches of k_assocb that stopped in front of a group, ever (assoc_rounds 0 = adaptive)
     int* h_bail_count{nullptr}; // pinned; refreshed behind every batch's association chain
     int bail_seen{0}, bail_cooldown{0};
+    int assoc_sweep_blocks{2};     // option "assoc_sweep_blocks": blocks of the serial kernel's launch while it is only the safety net behind k_assocb (16 at first: the fewer
+                                   // 256-thread / 50 KB blocks have to be placed next to the other chains, the sooner the next batch's k_assocb starts: 0.2 -> 0.1 ms at 256 streams)
     int bail_cooldown_batches{4};  // option "assoc_cooldown": batches that run three (batch-parallel, serial) rounds after k_assocb had to stop (assoc_rounds 0).
                                    // 16 in the first version: with the few stops of ordinary streams (5 in 47 M columns) nearly every batch of a 256-stream run
                                    // then ran three rounds — two more placements of k_assocb's 1024-thread blocks per step, 2 - 3 % of the step
@@ -680,7 +682,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             // behind k_assocb the serial kernel is a safety net that finds nothing to do: a few blocks sweep over all streams instead of one block
             // per stream waiting for 45 KB of LDS on a busy CU. One block per stream when it is what associates, or while k_assocb has had to stop
             // lately (adaptive_rounds > 1), or when the caller pinned the number of rounds
-            const int blocks = (batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1 && !e->capturing) ? (count < 16 ? count : 16) : count;
+            const int blocks = (batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1 && !e->capturing) ? (count < e->assoc_sweep_blocks ? count : e->assoc_sweep_blocks) : count;
             if (batch_assoc && e->debug_no_assoc_fallback)
                 continue;
             if (rpl == 1)
@@ -1893,6 +1895,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->sub_batch = value < 0 ? 0 : value;
     else if (n == "table_on_insert_chain")
         e->table_on_insert_chain = value < 0 ? 0 : (value > 2 ? 2 : value);
+    else if (n == "assoc_sweep_blocks")
+        e->assoc_sweep_blocks = value < 1 ? 1 : (value > 1024 ? 1024 : (int) value);
     else if (n == "assoc_cooldown")
         e->bail_cooldown_batches = value < 0 ? 0 : (value > 1000 ? 1000 : (int) value);
     else if (n == "ego_on_insert_chain")
