@@ -276,7 +276,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * cluster_point_trees_every_nth_column != 1 uses), "skip_idle_fallbacks" (1 (default): in the pipelined mode the
  * host waits for the block-parallel insertion kernel of a batch and launches the other insertion kernels only if some stream's batch was not
  * taken completely (k_insert_par up to 64 rows, k_insert_multi above); 0: always launch them), "assoc_rounds" (1..8; 0 (default): adaptive — one
- * (batch-parallel, serial) association kernel pair per batch, three for the 4 batches ("assoc_cooldown") after the batch-parallel kernel had to stop; all
+ * (batch-parallel, serial) association kernel pair per batch, three for the 4 batches ("assoc_cooldown") after the batch-parallel kernel had to stop, the serial kernel as "assoc_sweep_blocks" (default 2) blocks that look for streams
+ * with columns left while it is only the safety net; all
  * but the last serial launch only take the group of columns the batch-parallel kernel stopped in front of), "assoc_batch" (1 (default): the batch-parallel association kernel runs in front of the
  * serial one and takes every group of columns that cannot differ from the sequential semantics, see cc_engine_batch_counters; 0: serial
  * kernels only), "sub_batch" (firings
