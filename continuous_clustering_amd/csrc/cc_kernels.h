@@ -1227,8 +1227,9 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
-    __shared__ int s_c[IP_MAXF];   // column-in-rotation of every firing (its first valid return), -1 = empty firing
-    __shared__ int s_off[IP_MAXF]; // G_f - prev_rearmost at entry
+    __shared__ short s_c[IP_MAXF]; // column-in-rotation of every firing (its first valid return), -1 = empty firing (or a column index above 32767: the
+                                   // run ends there and the serial kernel takes over — 9 KB less LDS for a block that has to find room next to the other chains)
+    __shared__ unsigned short s_off[IP_MAXF]; // G_f - prev_rearmost at entry (a firing more than 65535 columns ahead of it ends the run)
     __shared__ int s_wsum[W];
     __shared__ int s_upto, s_bad, s_carry;
 
@@ -1318,7 +1319,7 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
                 break;
             }
         }
-        s_c[f] = (c >= 0 && c < NC) ? c : -1;
+        s_c[f] = (short) ((c >= 0 && c < NC && c < 32768) ? c : -1);
     }
     __syncthreads();
     // ---- B: column advance of every firing, its prefix sum over the batch, first firing that ends the run
@@ -1348,12 +1349,12 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
         const int incl = before + v;
         if (f < nn)
         {
-            s_off[f] = incl;
+            s_off[f] = (unsigned short) incl;
             const long long G = prev_rear0 + incl;
             const long long rear_before = G - delta;
             // a firing is only taken while the batch has emitted fewer than limit_columns columns before it (k_insert2's loop head), and
             // while the previous tenant of its ring slot is known to be cleared
-            if (!ok || rear_before - first_unf0 >= g.limit_columns || G - RC >= clear_known)
+            if (!ok || incl > 65535 || rear_before - first_unf0 >= g.limit_columns || G - RC >= clear_known)
                 atomicMin(&s_upto, f);
         }
         __syncthreads();
