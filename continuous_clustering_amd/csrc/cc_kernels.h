@@ -2537,6 +2537,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
 // Row counts that are not a multiple of 16 take the round-2 form (every lane reads its own column, 8 rows at a time; 16 rows of look-back in LDS).
 constexpr int SEG_X2_RING = 16;
 constexpr int SEG_CH = 16; // rows per chunk of the tiled form
+constexpr int SEG_FEW = 4; // tiles of at most this many columns are loaded whole (2 * SEG_FEW * rows floats fit the chunk buffers up to 384 rows)
 __host__ __device__ inline int seg_pitch_f(int R)
 {
     (void) R;
@@ -2714,7 +2715,51 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
             previous_label = debug;
             oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
         };
-        if (tiled)
+        if (tiled && ncols <= SEG_FEW)
+        {
+            // ---- a tile of a few columns (calls of a few firings: the per-column latency path, and the last tile of a batch): the whole columns are
+            // loaded with lanes = rows in ONE round trip (the chunked form below spends four dependent ones, 2 us each, on a tile whose scan takes 3 us),
+            // then lane c scans column c out of LDS
+            float* cx2 = l_x2;
+            float* cuz = l_x2 + SEG_FEW * R;
+            for (int c = 0; c < ncols; c++)
+            {
+                int l = lc0 + c;
+                l = l >= RC ? l - RC : l;
+                for (int row = lane; row < R; row += 64)
+                {
+                    cx2[c * R + row] = p.sg_x2[(size_t) l * R + row];
+                    cuz[c * R + row] = p.sg_uz[(size_t) l * R + row];
+                    l_out[c * PB + row] = p.sg_flags[(size_t) l * R + row];
+                }
+            }
+            wave_lds_fence();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (lane c reads what all lanes wrote)
+            if (active)
+            {
+                const float* mx = cx2 + lane * R;
+                const float* mz = cuz + lane * R;
+                auto x2_below = [&](const int below) -> float { return mx[below]; };
+                for (int b = R - SEG_CH; b >= 0; b -= SEG_CH)
+                {
+                    float x16[SEG_CH], z16[SEG_CH];
+                    unsigned fw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                    {
+                        const float4 a = *(const float4*) (mx + b + q * 4);
+                        const float4 c4 = *(const float4*) (mz + b + q * 4);
+                        x16[q * 4 + 0] = a.x, x16[q * 4 + 1] = a.y, x16[q * 4 + 2] = a.z, x16[q * 4 + 3] = a.w;
+                        z16[q * 4 + 0] = c4.x, z16[q * 4 + 1] = c4.y, z16[q * 4 + 2] = c4.z, z16[q * 4 + 3] = c4.w;
+                        fw[q] = *(const unsigned*) (oo + b + q * 4);
+                    }
+#pragma unroll
+                    for (int u = SEG_CH - 1; u >= 0; u--)
+                        row_step(b + u, (int) ((fw[u >> 2] >> (8 * (u & 3))) & 0xffu), x16[u], z16[u], x2_below);
+                }
+            }
+        }
+        else if (tiled)
         {
             // ---- tiled form: lanes = (column of a group of 16, 16-byte piece) while loading, lanes = columns while scanning
             float* t_uz = l_x2 + 2 * 64 * SEG_CH; // l_x2: two chunks (index (row / 16) & 1), t_uz: the current one
