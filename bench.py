@@ -63,18 +63,48 @@ def parse():
     ap.add_argument("--verify-streams", type=int, default=3)
     ap.add_argument("--cpu-procs", type=int, default=0, help="largest instance count of the CPU sweep (0 = all physical cores)")
     ap.add_argument("--cpu-rotations", type=int, default=20)
+    ap.add_argument("--total-streams", type=int, default=256,
+                    help="strong-split leg (north_star: '256 concurrent streams' over the node): this many streams in total, dealt stream s -> rank s mod N")
+    ap.add_argument("--no-strong-split", action="store_true")
+    ap.add_argument("--no-few-streams", action="store_true")
+    ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--kitti-root", default=os.environ.get("SEMANTIC_KITTI_ROOT", ""),
+                    help="SemanticKITTI dataset root (the directory that holds sequences/): adds the real-data acceptance leg (README.md:213-245)")
+    ap.add_argument("--kitti-sequences", default="0,1,2,3,4,5,6,7,8,9,10")
+    ap.add_argument("--kitti-max-frames", type=int, default=0, help="0 = whole sequences")
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launcher.py): tests/bench_stub.py instead of the HIP engine, gloo on CPU; exercises the launcher and the "
+                         "aggregation over ranks, the line says data = 'stub' and is not a measurement")
     return ap.parse_args()
 
 
-def gen_inputs(torch, dev, sensor, n_streams, n_firings, n_batches, seed0):
-    """[batch][stream][firing][row][3] etc., generated in HBM. Every stream has its own seeded scene."""
+def maybe_spawn(args):
+    """`python bench.py --gpus N` without a launcher around it starts the N ranks itself: re-exec under torch.distributed.run (one process per
+    GPU, rendezvous on 127.0.0.1). Under a launcher (RANK set) the world is what the launcher says."""
+    if args.gpus <= 1 or "RANK" in os.environ:
+        return
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def gen_inputs(torch, dev, sensor, seeds, n_firings, n_batches):
+    """[batch][stream][firing][row][3] etc., generated in HBM. Stream k of the engine is the seeded scene seeds[k]."""
     from continuous_clustering_amd import synth
     R = sensor.num_rows
+    n_streams = len(seeds)
     xyz = torch.empty((n_batches, n_streams, n_firings, R, 3), dtype=torch.float32, device=dev)
     inten = torch.empty((n_batches, n_streams, n_firings, R), dtype=torch.uint8, device=dev)
     poses = torch.empty((n_batches, n_streams, n_firings, 12), dtype=torch.float64, device=dev)
-    for s in range(n_streams):
-        st = synth.make_stream(n_firings * n_batches, seed=seed0 + s, sensor=sensor, motion=synth.Motion.translate(10.0),
+    for s, seed in enumerate(seeds):
+        st = synth.make_stream(n_firings * n_batches, seed=seed, sensor=sensor, motion=synth.Motion.translate(10.0),
                                start_column=40 if sensor.azimuth_offsets_deg else 0, xp=torch, device=dev, chunk=n_firings)
         xyz[:, s] = st.xyz.view(n_batches, n_firings, R, 3)
         inten[:, s] = st.intensity.view(n_batches, n_firings, R)
@@ -214,7 +244,7 @@ def cpu_mode_c(cfg, R, hx, hi, hp, cores):
             "fastest_s": min(r[2] for r in res), "latency_ns": res[0][3], "membw_GBs": sum(r[4] for r in res)}
 
 
-def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args):
+def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args, sweep_sizes=(1, 16, 64)):
     R = sensor.num_rows
     cores = physical_cores()
     nmax = min(args.cpu_procs or len(cores), len(cores))
@@ -224,7 +254,7 @@ def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args):
     hi = [inten[:nb, k].reshape(nb * F, R).cpu().numpy() for k in range(n_inputs)]
     hp = [poses[:nb, k].reshape(nb * F, 12).cpu().numpy() for k in range(n_inputs)]
     sweep, best, best_n, single, lat = {}, None, 1, None, None
-    for n in sorted({1, 16, 64, nmax}):
+    for n in sorted({*sweep_sizes, nmax}):
         if n > nmax:
             continue
         r = cpu_mode_c(cfg, R, hx, hi, hp, cores[:n])
@@ -263,13 +293,39 @@ def engine_options(eng):
             eng.set_option(opt, int(os.environ[env]))
 
 
-def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, cfg, S, F, steps, warmup, seed0, n_verify):
-    from continuous_clustering_amd import Engine
-    R = sensor.num_rows
+class Ctx:
+    """What every leg needs to know about the process: torch, the process group (RCCL; gloo with --stub-engine), rank / world, the device."""
+
+    def __init__(self, torch, dist, use_dist, world, rank, dev, local_rank, stub):
+        self.torch, self.dist, self.use_dist, self.world, self.rank, self.dev, self.local_rank, self.stub = \
+            torch, dist, use_dist, world, rank, dev, local_rank, stub
+
+    def device_sync(self):
+        if self.dev.type == "cuda":
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.use_dist:
+            self.dist.barrier()
+
+    def engine(self, cfg, R, S):
+        if self.stub:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import bench_stub
+            return bench_stub.StubEngine(cfg, R, S, rank=self.rank)
+        from continuous_clustering_amd import Engine
+        return Engine(cfg, R, S, device=self.local_rank)
+
+
+def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=None):
+    """One throughput leg: this rank's engine holds len(seeds) streams; `steps` timed passes of the hot path over one batch (F firings of
+    every stream) each, bracketed by barrier + device sync on both sides. Returns the whole-job figures (cells of all ranks / slowest rank)."""
+    torch, dist = ctx.torch, ctx.dist
+    R, S = sensor.num_rows, len(seeds)
     n_batches = warmup + steps
-    xyz, inten, poses = gen_inputs(torch, dev, sensor, S, F, n_batches, seed0=seed0)
-    torch.cuda.synchronize()
-    eng = Engine(cfg, R, S, device=local_rank)
+    xyz, inten, poses = inputs if inputs is not None else gen_inputs(torch, ctx.dev, sensor, seeds, F, n_batches)
+    ctx.device_sync()
+    eng = ctx.engine(cfg, R, S)
     eng.record_events(False)
     engine_options(eng)
 
@@ -281,16 +337,15 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
     before = eng.totals()
     eng.enable_timing(True)
 
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    ctx.device_sync()
+    ctx.barrier()
     t0 = time.perf_counter()
     for b in range(warmup, n_batches):
         eng.add_firings_device(F, xyz[b], inten[b], poses[b])
     rc = eng.sync()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
+    ctx.device_sync()
+    own_elapsed = time.perf_counter() - t0
+    ctx.barrier()
     elapsed = time.perf_counter() - t0
     if rc != 0:
         raise SystemExit(f"engine error {rc}: {eng.last_error()}")
@@ -300,16 +355,19 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
 
     cells = after["cells_published"] - before["cells_published"]
     clusters = after["clusters_finished"] - before["clusters_finished"]
+    per_rank = [{"rank": 0, "streams": S, "cells": int(cells), "seconds": own_elapsed, "value": cells / own_elapsed / 1e6}]
     # the one exchange step of the path: gather per-rank result counts (RCCL over xGMI), max of the elapsed times
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if ctx.use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        cnt = torch.tensor([cells, clusters, after["serial_columns"]], dtype=torch.int64, device=dev)
-        gathered = [torch.zeros_like(cnt) for _ in range(world)]
+        cnt = torch.tensor([cells, clusters, after["serial_columns"], S, int(own_elapsed * 1e9)], dtype=torch.int64, device=ctx.dev)
+        gathered = [torch.zeros_like(cnt) for _ in range(ctx.world)]
         dist.all_gather(gathered, cnt)
         cells = int(sum(int(g[0]) for g in gathered))
         clusters = int(sum(int(g[1]) for g in gathered))
+        per_rank = [{"rank": r, "streams": int(g[3]), "cells": int(g[0]), "seconds": int(g[4]) / 1e9,
+                     "value": int(g[0]) / max(int(g[4]) / 1e9, 1e-12) / 1e6} for r, g in enumerate(gathered)]
 
     verified = None
     if n_verify > 0:
@@ -377,13 +435,15 @@ def run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, 
             "launch_ms": per_kernel[dom] / launches_per_step,
             "launch_ms_rocprof_committed": rocprof_ms, "rocprof_source": os.path.relpath(spath, ROOT) if rocprof_ms is not None else None,
             "traffic_source": (os.path.relpath(tpath, ROOT) + " (PMC passes of tools/pmc.sh on this round's build, not measured in this run)") if traffic is not None else None,
-            "step_frac": cells * alg_bytes_per_cell / world / elapsed / 1e9 / HBM_PEAK_GBS,
+            "step_frac": cells * alg_bytes_per_cell / ctx.world / elapsed / 1e9 / HBM_PEAK_GBS,
             "dominant_by": "longest average launch in the committed rocprofv3 summary (rocprof_source)" if committed else "longest HIP-event duration of this run",
             "note": "no kernel of the path is bandwidth-bound: each is latency / issue-bound by itself and they share the GPU on four chains of HIP "
                     "streams (a kernel's launch_ms inside the pipeline is 1.5 - 2.5 x its duration alone, profiles/ROOFLINE.md); step_frac = "
                     "algorithmic bytes of the whole step / step time / peak",
         },
         "verified": verified,
+        "per_rank": per_rank,
+        "streams_total": int(sum(r["streams"] for r in per_rank)),
     }
     return res, eng, (xyz, inten, poses)
 
@@ -498,68 +558,14 @@ def replay_report(local_rank, frames_scale=0.004, verify_sequences=2):
         shutil.rmtree(root, ignore_errors=True)
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    from continuous_clustering_amd import Engine, capi, synth
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even at world size 1
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    sensor = synth.SensorModel.s64() if args.sensor == "s64" else synth.SensorModel.s128()
-    cfg = capi.Config.kitti() if args.sensor == "s64" else capi.Config.vls128()
-    S, F, R = args.streams, args.firings, sensor.num_rows
-    n_verify = 0 if args.no_verify else (args.verify_streams if rank == 0 else 0)
-    res, eng, (xyz, inten, poses) = run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor, cfg, S, F, args.steps,
-                                                   args.warmup, 1234 + rank * S, n_verify)
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "Mpoints/s clustered (64-beam streams)" if R == 64 else f"Mpoints/s clustered ({R}-beam streams)",
-            "value": res["value"],
-            "unit": "Mpoints/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"{S} concurrent synthetic S{R} sensor streams per GPU ({R} rows x {cfg.num_columns} columns/rotation, "
-                            f"{'KITTI' if R == 64 else 'library-default'} parameters), {F} firings per stream per step, "
-                            f"inputs resident in HBM; BASELINE.json configs[2] shape",
-                "streams_per_gpu": S, "firings_per_step": F, "num_rows": R, "num_columns": cfg.num_columns,
-                "sharding": f"stream-per-wavefront, {world} rank(s) x {S} streams, no data-path collective",
-            },
-            "cells_published": res["cells_published"],
-            "clusters_finished": res["clusters_finished"],
-            "serial_columns": res["serial_columns"],
-            "association": res["association"],
-            "kernel_ms_per_step": res["kernel_ms_per_step"],
-            "roofline": res["roofline"],
-            "verified_streams": len(res["verified"]["streams"]) if res["verified"] else 0,
-            "verify": res["verified"],
-            "rccl_world": world if use_dist else 0,
-        }
-
+def single_stream_report(ctx, sensor, cfg, F, xyz, inten, poses):
+    """BASELINE.json configs[1]: ONE 64-beam stream on one GPU. Per-column latency of the reference's calling pattern (one firing per call), the
+    C++ drop-in class fed like a live sensor, and the single-stream throughput with device-resident inputs."""
+    from continuous_clustering_amd import Engine
+    local_rank, R = ctx.local_rank, sensor.num_rows
+    out = {}
     # ---- single-stream latency (BASELINE.json configs[1] shape): one firing per call through the host API --------
-    if rank == 0 and not args.no_latency:
+    if True:
         e1 = Engine(cfg, R, 1, device=local_rank)
         hx = xyz[0, 0].cpu().numpy()
         hi = inten[0, 0].cpu().numpy()
@@ -578,7 +584,7 @@ def main():
     # ---- the same single stream through the C++ drop-in class, fed like a live HDL-64E (22 000 firings per second): a call per firing
     #      (the reference's calling pattern) falls behind, setAdaptiveBatching() hands over what queued up behind the running call ----
     demo = os.path.join(ROOT, "tests", "cpp", "dropin_demo")
-    if rank == 0 and not args.no_latency and R == 64 and os.path.exists(demo):
+    if R == 64 and os.path.exists(demo):
         import re
         import struct
         import subprocess
@@ -609,28 +615,206 @@ def main():
                       "a sensor needs 22 000 firings/s")
         out["realtime_single_stream"] = rt
 
-    # ---- configs[2], second half of the metric: live streams served with small calls (throughput and latency vs firings per call) ----
-    if rank == 0 and not args.no_latency:
-        out["live_multi_stream"] = live_multi_stream(torch, cfg, sensor, xyz, inten, poses, local_rank)
+    # ---- configs[1] throughput: the ONE stream with device-resident inputs, one rotation per call (the headline harness at 1 stream) ----
+    nb = int(xyz.shape[0])
+    k = max(4, min(nb - 3, 40))
+    sub = (xyz[:3 + k, :1].contiguous(), inten[:3 + k, :1].contiguous(), poses[:3 + k, :1].contiguous())
+    r1, e1, _ = run_throughput(ctx, sensor, cfg, [0], F, k, 3, 0, inputs=sub)
+    e1.close()
+    out["single_stream"] = {"metric": "Mpoints/s clustered, ONE 64-beam stream on one GPU (BASELINE.json configs[1])", "value": r1["value"],
+                            "unit": "Mpoints/s", "ms_per_step": r1["ms_per_step"], "steps": k, "firings_per_call": F,
+                            "kernel_ms_per_step": r1["kernel_ms_per_step"],
+                            "note": "inputs resident in HBM, one rotation per cc_engine_add_firings_device call, three calls in flight"}
+    return out
 
-    # ---- CPU baseline on this box's host cores (inputs: the bench's own streams, copied back from HBM) ------------
-    if rank == 0 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args)
-    elif rank == 0:
-        out["cpu_baseline"] = None
 
+def few_streams_report(ctx, sensor, cfg, F, xyz, inten, poses, steps, counts=(32, 64, 128)):
+    """What ONE GPU can say about north_star's '256 concurrent streams over the 8 GPUs of a node' (32 streams per GPU): the headline leg
+    again with only the first n streams of this GPU's inputs. Same harness, same timing brackets."""
+    out = {}
+    S = int(xyz.shape[1])
+    nb = int(xyz.shape[0])
+    warm = 3
+    k = max(4, min(steps, nb - warm, 40))
+    for n in counts:
+        if n >= S:
+            continue
+        sub = (xyz[:warm + k, :n].contiguous(), inten[:warm + k, :n].contiguous(), poses[:warm + k, :n].contiguous())
+        r, e, _ = run_throughput(Ctx(ctx.torch, ctx.dist, False, 1, 0, ctx.dev, ctx.local_rank, ctx.stub), sensor, cfg, list(range(n)), F, k, warm, 0, inputs=sub)
+        e.close()
+        out[str(n)] = {"streams": n, "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k}
+        del sub
+    out["note"] = ("the headline workload with only the first n streams on this one GPU (Mpoints/s); 32 streams per GPU is the per-GPU share when "
+                   "256 streams are dealt over 8 GPUs (strong_split at --gpus 8)")
+    return out
+
+
+def host_fed_report(ctx, sensor, cfg, F, xyz, inten, poses, steps=6):
+    """The same step with the firings starting in (pinned) HOST memory, as a front-end that receives sensor packets would hold them: H2D of every
+    batch's [S][F][...] arrays on a copy stream, cc_engine_add_firings_device once a batch has arrived. Never `value`: the timed region of the
+    headline starts with inputs resident in HBM (the contract); this key is the PCIe-inclusive rate."""
+    torch = ctx.torch
+    nb = min(int(xyz.shape[0]), steps + 2)
+    S, R = int(xyz.shape[1]), sensor.num_rows
+    host = [(xyz[b].cpu().pin_memory(), inten[b].cpu().pin_memory(), poses[b].cpu().pin_memory()) for b in range(nb)]
+    devb = [(torch.empty_like(xyz[0]), torch.empty_like(inten[0]), torch.empty_like(poses[0])) for _ in range(nb)]
+    bytes_per_batch = sum(int(t.numel() * t.element_size()) for t in host[0])
+    eng = ctx.engine(cfg, R, S)
+    eng.record_events(False)
+    copy_stream = torch.cuda.Stream(device=ctx.dev)
+    evs = [torch.cuda.Event() for _ in range(nb)]
+
+    def start_copy(b):
+        with torch.cuda.stream(copy_stream):
+            for d, h in zip(devb[b], host[b]):
+                d.copy_(h, non_blocking=True)
+            evs[b].record(copy_stream)
+
+    warm = 2
+    for b in range(warm):
+        start_copy(b)
+        evs[b].synchronize()
+        eng.add_firings_device(F, *devb[b])
+    eng.sync()
+    before = eng.totals()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    start_copy(warm)
+    for b in range(warm, nb):
+        evs[b].synchronize()
+        if b + 1 < nb:
+            start_copy(b + 1)
+        eng.add_firings_device(F, *devb[b])
+    rc = eng.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if rc != 0:
+        raise SystemExit(f"engine error {rc}: {eng.last_error()}")
+    cells = eng.totals()["cells_published"] - before["cells_published"]
     eng.close()
-    del xyz, inten, poses
-    torch.cuda.empty_cache()
+    k = nb - warm
+    return {"value": cells / el / 1e6, "unit": "Mpoints/s", "steps": k, "ms_per_step": el / k * 1e3, "h2d_bytes_per_step": bytes_per_batch,
+            "pcie_GBs": bytes_per_batch * k / el / 1e9,
+            "note": f"{S} streams x {F} firings per step copied from pinned host memory (one copy stream, the next batch's copy overlapping the "
+                    "current batch's kernels) and handed to cc_engine_add_firings_device: the PCIe-inclusive rate of the headline workload"}
+
+
+def main():
+    args = parse()
+    maybe_spawn(args)
+    import torch
+    import torch.distributed as dist
+    from continuous_clustering_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stub = args.stub_engine
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} wants GPU {local_rank} but only {torch.cuda.device_count()} are visible (--gpus {args.gpus})")
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even at world size 1
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    ctx = Ctx(torch, dist, use_dist, world, rank, dev, local_rank, stub)
+    solo = Ctx(torch, dist, False, 1, 0, dev, local_rank, stub)  # legs that only rank 0 runs
+
+    sensor = synth.SensorModel.s64() if args.sensor == "s64" else synth.SensorModel.s128()
+    cfg = capi.Config.kitti() if args.sensor == "s64" else capi.Config.vls128()
+    S, F, R = args.streams, args.firings, sensor.num_rows
+    n_verify = 0 if (args.no_verify or stub) else (args.verify_streams if rank == 0 else 0)
+
+    # ================= legs every rank takes part in =================
+    # ---- headline: weak scaling, S streams per GPU (BASELINE.json configs[2] per GPU) ----
+    res, eng, (xyz, inten, poses) = run_throughput(ctx, sensor, cfg, [1234 + rank * S + k for k in range(S)], F, args.steps, args.warmup, n_verify)
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Mpoints/s clustered (64-beam streams)" if R == 64 else f"Mpoints/s clustered ({R}-beam streams)",
+            "value": res["value"],
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "stub (launcher test, not a measurement)" if stub else "synthetic",
+            "config": {
+                "workload": f"{S} concurrent synthetic S{R} sensor streams per GPU ({R} rows x {cfg.num_columns} columns/rotation, "
+                            f"{'KITTI' if R == 64 else 'library-default'} parameters), {F} firings per stream per step, "
+                            f"inputs resident in HBM; BASELINE.json configs[2] shape",
+                "streams_per_gpu": S, "firings_per_step": F, "num_rows": R, "num_columns": cfg.num_columns,
+                "sharding": f"stream-per-wavefront, {world} rank(s) x {S} streams, no data-path collective",
+            },
+            "cells_published": res["cells_published"],
+            "clusters_finished": res["clusters_finished"],
+            "serial_columns": res["serial_columns"],
+            "association": res["association"],
+            "kernel_ms_per_step": res["kernel_ms_per_step"],
+            "roofline": res["roofline"],
+            "verified_streams": len(res["verified"]["streams"]) if res["verified"] else 0,
+            "verify": res["verified"],
+            "rccl_world": world if use_dist else 0,
+            "per_rank_value": [r["value"] for r in res["per_rank"]],
+            "per_rank": res["per_rank"],
+        }
+    eng.close()
+
+    # ---- strong split (north_star: "256 concurrent streams" sharded across the GPUs of one node): --total-streams streams in all,
+    #      stream s on rank s mod N; the same step, fewer streams per GPU as N grows ----
+    T = args.total_streams
+    if not args.no_strong_split and T > 0:
+        mine = [s for s in range(T) if s % world == rank]
+        if world == 1 and T == S:
+            if rank == 0:
+                out["strong_split"] = {"total_streams": T, "streams_per_gpu": [T], "value": res["value"], "ms_per_step": res["ms_per_step"],
+                                       "scaling": "strong", "note": "one GPU holds all the streams: this IS the headline leg (not run twice)"}
+        else:
+            # rank r's engine stream k is global stream mine[k]; its inputs are the scene of seed 1234 + s like the headline's stream s of rank 0
+            sub = None
+            if world == 1 and T <= S:
+                nbk = args.warmup + args.steps
+                sub = (xyz[:nbk, :T].contiguous(), inten[:nbk, :T].contiguous(), poses[:nbk, :T].contiguous())
+            else:
+                del xyz, inten, poses
+                if dev.type == "cuda":
+                    torch.cuda.empty_cache()
+                xyz = inten = poses = None
+            r3, e3, b3 = run_throughput(ctx, sensor, cfg, [1234 + s for s in mine], F, args.steps, args.warmup, 0, inputs=sub)
+            e3.close()
+            if rank == 0:
+                out["strong_split"] = {"total_streams": r3["streams_total"], "streams_per_gpu": [r["streams"] for r in r3["per_rank"]],
+                                       "value": r3["value"], "ms_per_step": r3["ms_per_step"], "scaling": "strong",
+                                       "per_rank_value": [r["value"] for r in r3["per_rank"]],
+                                       "kernel_ms_per_step": r3["kernel_ms_per_step"],
+                                       "note": "stream s lives on rank s mod N; no data-path collective; value = cells of all ranks / slowest rank"}
+            if xyz is None:
+                xyz, inten, poses = b3  # (rank 0's solo legs below use whatever inputs are resident)
+            del sub
 
     # ---- BASELINE.json configs[3]: 128-row VLS-128-shaped streams (same harness, fewer steps; the headline stays S64) ----
+    s128_inputs = None
     if args.sensor == "s64" and not args.no_s128:
         sensor2, cfg2 = synth.SensorModel.s128(), capi.Config.vls128()
         steps2, warm2 = max(4, min(args.steps, 10)), 3
-        r2, eng2, bufs2 = run_throughput(torch, dist, use_dist, world, rank, dev, local_rank, sensor2, cfg2, S, 1700, steps2, warm2,
-                                         5678 + rank * S, min(n_verify, 2))
+        r2, eng2, s128_inputs = run_throughput(ctx, sensor2, cfg2, [5678 + rank * S + k for k in range(S)], 1700, steps2, warm2, min(n_verify, 2))
         eng2.close()
-        del bufs2
         if rank == 0:
             out["s128"] = {"metric": "Mpoints/s clustered (128-beam streams)", "value": r2["value"], "unit": "Mpoints/s",
                            "ms_per_step": r2["ms_per_step"], "steps": steps2, "warmup": warm2,
@@ -638,16 +822,63 @@ def main():
                                        f"offsets: every firing spans ~60 columns; library-default parameters), 1700 firings per stream per step",
                            "kernel_ms_per_step": r2["kernel_ms_per_step"], "roofline": r2["roofline"],
                            "verified_streams": len(r2["verified"]["streams"]) if r2["verified"] else 0,
-                           "serial_columns": r2["serial_columns"]}
+                           "serial_columns": r2["serial_columns"], "per_rank_value": [r["value"] for r in r2["per_rank"]]}
+        if rank != 0 or args.no_cpu_baseline:
+            s128_inputs = None
 
-    # ---- BASELINE.json configs[4] shape: concurrent replay of KITTI-format sequences, end to end ----
-    if rank == 0 and not args.no_latency:
-        out["replay"] = replay_report(local_rank)
+    # ---- real-data acceptance (BASELINE.json configs[0] / [4]): only where SemanticKITTI is mounted; sequence i on rank i mod N,
+    #      per-frame records gathered with one all_gather (RCCL) ----
+    sk = None
+    if args.kitti_root and not stub:
+        from continuous_clustering_amd import acceptance
+        seqs = [int(v) for v in args.kitti_sequences.split(",") if v.strip()]
+        sk = acceptance.run(args.kitti_root, seqs, rank=rank, world=world, device=local_rank, max_frames=args.kitti_max_frames or None)
 
-    if rank == 0:
-        print(json.dumps(out))
+    # ================= the other ranks are done: everything below is rank 0 alone (the job's timed legs are over) =================
+    ctx.barrier()
     if use_dist:
         dist.destroy_process_group()
+    if rank != 0:
+        return
+    Sx = int(xyz.shape[1])  # streams of the inputs that are resident now (S, or this rank's share of the strong split)
+
+    # ---- what one GPU says about fewer streams per GPU (the strong-split regime) ----
+    if not args.no_few_streams and not stub and world == 1:
+        out["few_streams"] = few_streams_report(solo, sensor, cfg, F, xyz, inten, poses, args.steps)
+
+    # ---- single-stream latency (BASELINE.json configs[1] shape): one firing per call through the host API --------
+    if not args.no_latency and not stub:
+        out.update(single_stream_report(solo, sensor, cfg, F, xyz, inten, poses))
+
+    # ---- configs[2], second half of the metric: live streams served with small calls (throughput and latency vs firings per call) ----
+    if not args.no_latency and not stub:
+        out["live_multi_stream"] = live_multi_stream(torch, cfg, sensor, xyz, inten, poses, local_rank)
+
+    # ---- the headline workload fed from pinned host memory (PCIe-inclusive; never `value`) ----
+    if not args.no_host_fed and not stub:
+        out["host_fed"] = host_fed_report(solo, sensor, cfg, F, xyz, inten, poses)
+
+    # ---- CPU baseline on this box's host cores (inputs: the bench's own streams, copied back from HBM) ------------
+    if not args.no_cpu_baseline and not stub:
+        out["cpu_baseline"] = cpu_baseline_report(cfg, sensor, xyz, inten, poses, Sx, F, args)
+        if s128_inputs is not None and "s128" in out:
+            a2 = argparse.Namespace(**vars(args))
+            a2.cpu_rotations = min(args.cpu_rotations, 10)
+            out["s128"]["cpu_baseline"] = cpu_baseline_report(capi.Config.vls128(), synth.SensorModel.s128(), *s128_inputs, Sx, 1700, a2, sweep_sizes=(1, 64))
+    else:
+        out["cpu_baseline"] = None
+    del xyz, inten, poses, s128_inputs
+    if dev.type == "cuda":
+        torch.cuda.empty_cache()
+
+    # ---- BASELINE.json configs[4] shape: concurrent replay of KITTI-format sequences, end to end ----
+    if not args.no_latency and not stub:
+        out["replay"] = replay_report(local_rank)
+
+    # ---- real-data acceptance (BASELINE.json configs[0] / [4]): only where SemanticKITTI is mounted ----
+    out["semantic_kitti"] = sk if sk is not None else {"skipped": "no --kitti-root / $SEMANTIC_KITTI_ROOT: the dataset is not in this image"}
+
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

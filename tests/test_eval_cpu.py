@@ -150,3 +150,29 @@ def test_gather_records_world_size_2_gloo():
     for _, _, _, out in res:  # every rank ends up with the same, ordered, complete table
         assert out.shape == (len(all_recs), 8)
         assert np.array_equal(out, np.array(all_recs))
+
+
+def test_acceptance_table_compare_at_two_decimals(oracle_lib):
+    """The real-data hook's comparison (continuous_clustering_amd/acceptance.py): rows are formatted like generateEvaluationResults and compared
+    with the reference's published README tables as printed; a differing last digit must show up; a frame cap asserts nothing."""
+    from continuous_clustering_amd import acceptance, build, evaluation
+    from oracle import pyoracle
+    build.build()
+    tables = acceptance.load_tables()
+    assert sorted(tables) == sorted(["all"] + [str(i) for i in range(11)]) and tables["6"]["use"] == ["36.90", "5.35"] and tables["all"]["recall"] == ["95.95", "3.60"]
+    rng = np.random.default_rng(5)
+    recs = []
+    for s in (3, 4):
+        for f in range(25):
+            recs.append((s, f, *pyoracle.eval_frame(*random_frame(rng, 2000))))
+    recs = np.array(recs)
+    mine = {str(s): acceptance.printed(evaluation.summarize(recs[recs[:, 0] == s][:, 2:8])) for s in (3, 4)}
+    ok = acceptance.compare(recs[::-1], [3, 4], tables=mine)  # (record order must not matter: sorted by frame inside)
+    assert ok["all_ok"] is True and ok["cells_checked"] == 12 and "all" not in ok["rows"]
+    wrong = {k: {m: list(v) for m, v in r.items()} for k, r in mine.items()}
+    wrong["4"]["ose"][1] = "%.2f" % (float(wrong["4"]["ose"][1]) + 0.01)
+    bad = acceptance.compare(recs, [3, 4], tables=wrong)
+    assert bad["all_ok"] is False and bad["cells_equal"] == 11 and bad["rows"]["4"]["ose"]["ok"] is False
+    capped = acceptance.compare(recs, [3, 4], tables=mine, complete=False)
+    assert capped["all_ok"] is None and capped["cells_checked"] == 0
+    assert evaluation.format_row("3", evaluation.summarize(recs[recs[:, 0] == 3][:, 2:8])).count(mine["3"]["f1"][0]) >= 1
