@@ -25,7 +25,7 @@ constexpr int PP_SKIP = 0x7fffffff;
 #define CC_INS_WIN 64
 #endif
 constexpr int INS_WIN = CC_INS_WIN;          // columns of `distance` kept in LDS by the insertion kernel
-constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLOSE = 16;
+constexpr int SG_NAN = 1, SG_FOG = 2, SG_EGO = 4, SG_INCL_IGNORE = 8, SG_TOO_CLOSE = 16, SG_PENDING = 32; // (k_seg_pre / k_insert_par -> k_seg_scan)
 #ifndef CC_TREE_SLOTS
 #define CC_TREE_SLOTS 256
 #endif
@@ -80,6 +80,8 @@ struct StreamState
         int64_t mode;      // assoc_mode as of the start of the batch's segmentation chain (k_table): decides whether k_scan stages the
                            // batch for the LDS association kernels; the global-memory kernel takes the batch if either this or the
                            // current assoc_mode is non-zero
+        int64_t fused;     // 1: k_insert_par took the whole batch AND did the per-cell part of its segmentation (staging planes, table carries):
+                           // k_table / k_seg_pre have nothing to do for this stream
     } batch[4];
     int32_t assoc_mode; // 0: tree state in LDS (k_assoc2 / k_assoc_lds), 1: tree state in global memory (k_associate); the global kernel
                         // hands a stream back once its unfinished trees fit the LDS pool comfortably again
@@ -166,6 +168,7 @@ struct Planes
     float* sg_x2;       // ||xy|| of the point relative to the sensor (to2dInAzimuthPlane(...).x, cc.hpp:229-232)
     float* sg_uz;       // z of the point relative to the sensor
     uint8_t* sg_flags;  // SG_* bits
+    float* sg_w;        // the column's own inclination step / the distance / the inclination below (cc_kernels.h: seg_pre_cells)
     // one 16-byte record per cell: {x, y, z, inclination} of the return in the odom frame, written by the insertion kernels (the only
     // copy of x, y, z); cells without a return get {NaN, NaN, NaN, supplemented inclination} from k_seg_pre. What the window scan
     // reads per visited cell.
@@ -185,8 +188,8 @@ struct Planes
     int32_t* par_off; // [stream][IP_MAXF] column offset of every firing of the batch (k_insert_par over several blocks -> k_insert_par_fin)
     float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
     // what k_table leaves for k_seg_pre (one set per batch-descriptor slot; the engine passes the slot's pointers):
-    float* tabc;      // [stream][SEGPRE_BLOCKS][num_rows] last valid inclination step before each chunk of columns (NaN: none in its range)
-    float* tabw;      // [stream][TABLE_WAVES][num_rows] the table at the start of each range of chunks
+    float* tabc;      // [stream][Geometry::tab_tiles][num_rows] sc_inclination_angles_between_lasers_ as of the column in front of each tile of 64
+                      // columns of the batch (k_table, or k_insert_par for batches it segmented itself)
 };
 
 struct Geometry
@@ -207,6 +210,7 @@ struct Geometry
     int32_t mirror_fields;   // also produce the per-point fields only the host mirror of range_image_ shows (visited-neighbour counts, the
                              // parent of live-replayed points, per-tree values of finished trees, the tree-link log)
     int32_t link_capacity;
+    int32_t tab_tiles;       // tiles of 64 columns a batch can have: entries of Planes::tabc per stream and batch-descriptor slot
 };
 
 } // namespace ccd

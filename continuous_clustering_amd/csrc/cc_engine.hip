@@ -192,6 +192,7 @@ void fill_geometry(cc_engine* e, int num_rows)
     g.cells = (int64_t) g.ring_cols * num_rows;
     g.max_distance_squared = e->cfg.max_distance * e->cfg.max_distance; // cc.cpp:80
     g.limit_columns = 2 * g.num_columns;
+    g.tab_tiles = g.ring_cols / 64 + 2; // (a pass never emits more than a ring of columns)
     if (g.lds_tree_limit <= 0 || g.lds_tree_limit > TREE_SLOTS)
         g.lds_tree_limit = TREE_SLOTS;
 }
@@ -245,10 +246,10 @@ int allocate(cc_engine* e)
     A(events, S * (size_t) g.event_capacity);
     A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
     A(sc_term, C) A(col_newfin, L) A(col_info, L);
-    A(sg_x2, C) A(sg_uz, C) A(sg_flags, C) A(sc_rec, C);
+    A(sg_x2, C) A(sg_uz, C) A(sg_w, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
     A(par_off, S * (size_t) cck::IP_MAXF);
-    A(tabc, (size_t) BATCH_SLOTS * S * SEGPRE_BLOCKS * (size_t) g.num_rows) A(tabw, (size_t) BATCH_SLOTS * S * TABLE_WAVES * (size_t) g.num_rows);
+    A(tabc, (size_t) BATCH_SLOTS * S * (size_t) g.tab_tiles * (size_t) g.num_rows);
     A(sc_visits, C);
     A(link_log, S * (size_t) g.link_capacity);
 #undef A
@@ -302,7 +303,7 @@ int reset_state(cc_engine* e, bool keep_table)
         st.overrun_col = std::numeric_limits<int64_t>::max();
         st.n_links = 0;
         for (auto& d : st.batch)
-            d.seg_begin = d.seg_end = d.acp_next = d.pub_begin = d.pub_end = -1, d.mode = 0;
+            d.seg_begin = d.seg_end = d.acp_next = d.pub_begin = d.pub_end = -1, d.mode = 0, d.fused = 0;
         st.assoc_mode = e->cfg.max_steps_in_row > WIN_COLS - 2 ? 1 : 0;
     }
     CC_HIP_CHECK(e, hipMemcpyAsync(e->d_states, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice, e->stream));
@@ -395,7 +396,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             const size_t cap = need < 4096 ? 4096 : need;
             for (int i = 0; i < 4; i++)
             {
-                int rce = alloc_plane(e, &e->d_ego[i], cap * 12);
+                int rce = alloc_plane(e, &e->d_ego[i], cap * cck::EGO_STRIDE);
                 if (rce)
                     return rce;
             }
@@ -541,8 +542,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
     // k_table -> k_seg_pre scratch of this batch-descriptor slot (up to BATCH_SLOTS batches are in flight)
     Planes Pt = e->P;
-    Pt.tabc += (size_t) slot * (size_t) g.num_streams * cck::SEGPRE_BLOCKS * (size_t) g.num_rows;
-    Pt.tabw += (size_t) slot * (size_t) g.num_streams * cck::TABLE_WAVES * (size_t) g.num_rows;
+    Pt.tabc += (size_t) slot * (size_t) g.num_streams * (size_t) g.tab_tiles * (size_t) g.num_rows;
     const bool table_early = si != sb && e->table_on_insert_chain != 0;
     // (a stream of its own: the next batch's insertion does not queue behind it)
     hipStream_t st_table = (table_early && e->table_on_insert_chain == 2 && !e->capturing) ? e->stream7 : si;
@@ -563,7 +563,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     const bool ego_early = table_early && e->ego_on_insert_chain;
     if (ego_early)
         hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, st_table, (const StreamState*) e->d_states, first_stream,
-                           d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
+                           e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
     if (si != sb)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], st_table));
@@ -580,7 +580,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     if (!ego_early)
         hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
-                       d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
+                       e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
     if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
@@ -589,7 +589,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
-        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, Pt, e->d_states, first_stream, slot); // (Pt: this slot's table carries)
     }
     if (sc != sb)
     {
@@ -1112,7 +1112,7 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     if (e->ego_capacity < 4096)
     {
         for (int i = 0; i < 4; i++)
-            if (alloc_plane(e, &e->d_ego[i], (size_t) 4096 * 12) != CC_OK)
+            if (alloc_plane(e, &e->d_ego[i], (size_t) 4096 * cck::EGO_STRIDE) != CC_OK)
                 return -1;
         e->ego_capacity = 4096;
         e->small_graphs_stale = true;

@@ -267,10 +267,12 @@ __device__ __forceinline__ uint16_t cell_tag(const long long pass)
     return (uint16_t) (0x8000u | ((unsigned) pass & 0x7fffu));
 }
 
+constexpr int IP_MAXF = 4608; // firings of a batch k_insert_par can take (LDS tables of its block scan)
+
 // Pointers of one stream (planes offset to the stream's first cell / column / pool slot).
 struct SP
 {
-    float *dist, *incl, *tabc, *tabw;
+    float *dist, *incl, *tabc;
     float* incaz;
     uint16_t* gtag;
     uint32_t* src;
@@ -300,7 +302,7 @@ struct SP
     uint8_t* sc_nlinks;
     unsigned long long* sc_links;
     double* sc_fin;
-    float *sg_x2, *sg_uz;
+    float *sg_x2, *sg_uz, *sg_w;
     uint8_t* sg_flags;
     float4* sc_rec;
     uint16_t* sc_visits;
@@ -344,9 +346,8 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.agg_first = P.agg_first + to;
     p.agg_flag = P.agg_flag + to;
     p.curtab = P.curtab + (size_t) s * g.num_rows;
-    p.par_off = P.par_off + (size_t) s * 4608;
-    p.tabc = P.tabc + (size_t) s * SEGPRE_BLOCKS * g.num_rows;
-    p.tabw = P.tabw + (size_t) s * TABLE_WAVES * g.num_rows;
+    p.par_off = P.par_off + (size_t) s * IP_MAXF;
+    p.tabc = P.tabc + (size_t) s * (size_t) g.tab_tiles * g.num_rows;
     p.events = P.events + (size_t) s * g.event_capacity;
     p.sc_parent = P.sc_parent + co;
     p.sc_term = P.sc_term + co;
@@ -357,6 +358,7 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.sc_fin = P.sc_fin + co;
     p.sg_x2 = P.sg_x2 + co;
     p.sg_uz = P.sg_uz + co;
+    p.sg_w = P.sg_w + co;
     p.sg_flags = P.sg_flags + co;
     p.sc_rec = P.sc_rec + co;
     p.sc_visits = P.sc_visits + co;
@@ -1172,6 +1174,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         st->batch[slot].acp_next = seg_begin;
         st->batch[slot].pub_begin = -1;
         st->batch[slot].pub_end = -1;
+        st->batch[slot].fused = 0;
         st->cursor = f;
         st->pre_seg_begin = 0;
         st->firings_consumed = (unsigned long long) (seq0 + (f - cursor0));
@@ -1210,7 +1213,7 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
 #ifndef CC_IP_WAVES
 #define CC_IP_WAVES 8
 #endif
-constexpr int IP_WAVES = CC_IP_WAVES, IP_MAXF = 4608;
+constexpr int IP_WAVES = CC_IP_WAVES;
 
 // (W wavefronts per block: IP_WAVES next to the other chains' kernels; twice as many when a launch has few streams and the GPU is otherwise empty)
 template<int RPL, int W = IP_WAVES>
@@ -1541,6 +1544,7 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
                 st->batch[slot].acp_next = first_unf0;
                 st->batch[slot].pub_begin = -1;
                 st->batch[slot].pub_end = -1;
+                st->batch[slot].fused = 0;
                 // (pre_seg_begin stays: if another stream makes the host launch the other insertion kernels after all, k_insert2 finds
                 // nothing left for this stream and writes the same descriptor again; k_begin_batch clears it for the next batch)
             }
@@ -1627,6 +1631,7 @@ __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, St
                 st->batch[slot].acp_next = first_unf0;
                 st->batch[slot].pub_begin = -1;
                 st->batch[slot].pub_end = -1;
+                st->batch[slot].fused = 0;
             }
             else
                 atomicAdd(left_over, 1);
@@ -2017,6 +2022,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                 st->batch[slot].acp_next = first_unf0;
                 st->batch[slot].pub_begin = -1;
                 st->batch[slot].pub_end = -1;
+                st->batch[slot].fused = 0;
             }
             else
                 atomicAdd(left_over, 1);
@@ -2026,28 +2032,62 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
 
 // =====================================================================================================
 // k_table — sc_inclination_angles_between_lasers_ (cc.cpp:353-357): per row the last non-NaN inclination step over the
-// emitted columns, in column order = a per-row "last valid value" scan along the columns. k_seg_pre needs the table as of every column.
-// The batch's columns are cut into TABLE_WAVES contiguous ranges (one wavefront each, lanes = rows) of SEGPRE_BLOCKS / TABLE_WAVES
-// chunks; k_seg_pre handles one chunk per wavefront, in column order, and carries the table through its chunk in registers. This
-// kernel reads every column once and leaves what a chunk needs to start:
-//   tabc[chunk][row]  the last valid step between the start of the wavefront's range and the start of the chunk (NaN: none), and
-//   tabw[wave][row]   the table at the start of the wavefront's range (earlier ranges' last valid step, else the stream's table),
-// and the table after the last column of the batch (Planes::curtab). grid = streams, block = 64 * TABLE_WAVES.
+// emitted columns, in column order = a per-row "last valid value" scan along the columns. The segmentation needs the table as of every
+// column. Round 4: the scan inside a TILE of 64 columns is done where the tile is segmented (k_seg_scan: lanes = columns, one ballot and
+// one lane permute per row), so all this kernel leaves is the table as of the column in front of every tile:
+//   1  wavefront w walks tiles w, w + TABLE_WAVES, ... (lanes = rows, every column read once): the last valid step INSIDE the tile
+//      (NaN: none) -> tabc[tile][row]
+//   2  one wavefront, lanes = rows: running "last valid" over the tiles in order, starting from the stream's table; tabc[tile][row]
+//      becomes the table in front of the tile, Planes::curtab the table after the batch's last column.
+// Streams whose batch went through the fused insertion (BatchDesc::fused, k_insert_par) have their tabc from there.
+// grid = streams, block = 64 * TABLE_WAVES.
 // =====================================================================================================
 
-// the columns [lo, hi) of chunk `chunk` (0 .. SEGPRE_BLOCKS - 1) of a batch that segments [seg_begin, seg_end); wave = chunk / CPW
-struct TableChunks
+// phase 2 (shared with k_insert_par / k_insert_par_fin): tl[t][row] holds the last valid step inside tile t or NaN
+template<int RPL>
+__device__ __forceinline__ void table_scan_tiles(const SP& p, const int R, const int ntiles, const int lane)
 {
-    long long per_wave, chunk_len;
-    __device__ __forceinline__ TableChunks(const long long seg_begin, const long long seg_end)
+    float carry[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
     {
-        const long long total = seg_end - seg_begin;
-        per_wave = (total + TABLE_WAVES - 1) / TABLE_WAVES;
-        constexpr int CPW = SEGPRE_BLOCKS / TABLE_WAVES;
-        chunk_len = (per_wave + CPW - 1) / CPW;
-        chunk_len = chunk_len < 1 ? 1 : chunk_len;
+        const int row = k * 64 + lane;
+        carry[k] = row < R ? p.curtab[row] : 0.f;
     }
-};
+    constexpr int U = 8;
+    for (int t0 = 0; t0 < ntiles; t0 += U)
+    {
+        float v[U][RPL];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                v[u][k] = (row < R && t0 + u < ntiles) ? p.tabc[(size_t) (t0 + u) * R + row] : __builtin_nanf("");
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R && t0 + u < ntiles)
+                {
+                    p.tabc[(size_t) (t0 + u) * R + row] = carry[k];
+                    if (!(v[u][k] != v[u][k]))
+                        carry[k] = v[u][k];
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        if (row < R)
+            p.curtab[row] = carry[k];
+    }
+}
 
 template<int RPL>
 __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
@@ -2064,114 +2104,78 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
     const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || seg_begin >= seg_end)
         return;
+    if (st->batch[slot].fused)
+        return; // (k_insert_par segmented the batch's per-cell part and left the table carries)
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    __shared__ float s_last[TABLE_WAVES][WAVE * RPL];
-    __shared__ int s_has[TABLE_WAVES][WAVE * RPL];
-    constexpr int CPW = SEGPRE_BLOCKS / TABLE_WAVES;
-    const TableChunks tc(seg_begin, seg_end);
-    const long long c_lo = seg_begin + tc.per_wave * wave, c_hi = (c_lo + tc.per_wave < seg_end ? c_lo + tc.per_wave : seg_end);
-    float* tabc = p.tabc + (size_t) wave * CPW * R; // this wavefront's chunks
+    const int ntiles = (int) ((seg_end - seg_begin + 63) >> 6);
     constexpr int U = 16;
-    float last[RPL]; // NaN = no valid step in this range so far
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-        last[k] = __builtin_nanf("");
-    int lc = c_lo < c_hi ? (int) (c_lo % RC) : 0;
-    long long in_chunk = 0; // columns of the current chunk already walked
-    int chunk = 0;
-    for (long long c0 = c_lo; c0 < c_hi; c0 += U)
+    for (int t = wave; t < ntiles; t += TABLE_WAVES)
     {
-        float cur[U][RPL], below[U][RPL];
+        const long long c_lo = seg_begin + 64ll * t, c_hi = (c_lo + 64 < seg_end ? c_lo + 64 : seg_end);
+        float last[RPL]; // NaN = no valid step in this tile so far
 #pragma unroll
-        for (int u = 0; u < U; u++)
+        for (int k = 0; k < RPL; k++)
+            last[k] = __builtin_nanf("");
+        int lc = (int) (c_lo % RC);
+        for (long long c0 = c_lo; c0 < c_hi; c0 += U)
         {
+            float cur[U][RPL], below[U][RPL];
 #pragma unroll
-            for (int k = 0; k < RPL; k++)
+            for (int u = 0; u < U; u++)
             {
-                const int row = k * 64 + lane;
-                cur[u][k] = below[u][k] = 0.f;
-                if (row < R && c0 + u < c_hi)
-                {
-                    const size_t ci = (size_t) lc * R + row;
-                    cur[u][k] = p.incl[ci];
-                    below[u][k] = row + 1 < R ? p.incl[ci + 1] : 0.f;
-                }
-            }
-            lc = lc + 1 == RC ? 0 : lc + 1;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-        {
-            if (c0 + u >= c_hi)
-                break;
-            if (in_chunk == 0)
-            {
-                // the table state a chunk starts from
 #pragma unroll
                 for (int k = 0; k < RPL; k++)
                 {
                     const int row = k * 64 + lane;
-                    if (row < R)
-                        tabc[(size_t) chunk * R + row] = last[k];
+                    cur[u][k] = below[u][k] = 0.f;
+                    if (row < R && c0 + u < c_hi)
+                    {
+                        const size_t ci = (size_t) lc * R + row;
+                        cur[u][k] = p.incl[ci];
+                        below[u][k] = row + 1 < R ? p.incl[ci + 1] : 0.f;
+                    }
                 }
-                chunk++;
+                lc = lc + 1 == RC ? 0 : lc + 1;
             }
-            in_chunk = in_chunk + 1 == tc.chunk_len ? 0 : in_chunk + 1;
 #pragma unroll
-            for (int k = 0; k < RPL; k++)
+            for (int u = 0; u < U; u++)
             {
-                const float diff = cur[u][k] - below[u][k];
-                if (!(diff != diff))
-                    last[k] = diff;
+                if (c0 + u >= c_hi)
+                    break;
+#pragma unroll
+                for (int k = 0; k < RPL; k++)
+                {
+                    const float diff = cur[u][k] - below[u][k];
+                    if (!(diff != diff))
+                        last[k] = diff;
+                }
             }
         }
-    }
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        const int row = k * 64 + lane;
-        if (row < R)
-        {
-            s_last[wave][row] = last[k];
-            s_has[wave][row] = (last[k] != last[k]) ? 0 : 1;
-        }
-    }
-    __syncthreads();
-    // the table at the start of this range: the last valid step of the nearest earlier range that has one, else the stream's table
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        const int row = k * 64 + lane;
-        if (row < R)
-        {
-            float carry = p.curtab[row];
-            for (int w = 0; w < wave; w++)
-                if (s_has[w][row])
-                    carry = s_last[w][row];
-            p.tabw[(size_t) wave * R + row] = carry;
-            last[k] = (last[k] != last[k]) ? carry : last[k];
-        }
-    }
-    __syncthreads(); // every wavefront has read the stream's table before it is replaced
-    if (wave == TABLE_WAVES - 1)
-    {
-        // table after the last emitted column (ranges may be empty: then it is the carry-in)
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
             const int row = k * 64 + lane;
             if (row < R)
-                p.curtab[row] = last[k];
+                p.tabc[(size_t) t * R + row] = last[k];
         }
     }
+    __syncthreads(); // (workgroup-scope release / acquire: the tiles' entries are visible to wavefront 0)
+    if (wave == 0)
+        table_scan_tiles<RPL>(p, R, ntiles, lane);
 }
 
 // ---- k_ego: ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1 (cc.cpp:300-301) once per FIRING of the batch (one
-// thread each) instead of once per column and wavefront in k_seg_pre, where all 64 lanes evaluated the same ~80 double-precision
-// operations. Same expressions, same order. out[(stream in launch * n + firing) * 12] = {R (3x3, row major), t}. grid = (n / 256, streams).
-__global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ states, int first_stream, const double* __restrict__ poses, long long n,
-                                             long long n_total, long long fbase, double* __restrict__ out)
+// thread each) instead of once per column and wavefront, where all 64 lanes evaluated the same ~80 double-precision operations. Same expressions,
+// same order. out[(stream in launch * n + firing) * EGO_STRIDE] = {R (3x3, row major), t, skip_r2}. grid = (n / 256, streams).
+// skip_r2 (round 4): the ego-box test of cc.cpp:390-403 transforms every return with this matrix in double precision — 18 f64 operations per
+// cell to find that a return 20 m away is not on the ego vehicle. With e = M (p - t_T) + A_t (M = A_R R_T^T) a box hit needs |e| < B, B = the
+// box's farthest corner, hence sigma_min(M) |p - t_T| - |A_t| < B. skip_r2 is a rigorous upper bound of the squared f32 distance (as the
+// segmentation computes it: x2 * x2 + uz * uz, relative to this firing's sensor position) up to which a hit is possible; +inf when the rotation
+// blocks are too far from orthonormal to say. Cells beyond it skip the transform; the others evaluate it exactly as before.
+constexpr int EGO_STRIDE = 16;
+__global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ states, int first_stream, cc_config cfg, const double* __restrict__ poses,
+                                             long long n, long long n_total, long long fbase, double* __restrict__ out)
 {
     const int sl = blockIdx.y;
     const long long f = (long long) blockIdx.x * 256 + threadIdx.x;
@@ -2185,18 +2189,171 @@ __global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ sta
             ir[i * 3 + j] = T[j * 4 + i];
     for (int i = 0; i < 3; i++)
         it[i] = ((-ir[i * 3 + 0]) * T[3] + (-ir[i * 3 + 1]) * T[7]) + (-ir[i * 3 + 2]) * T[11];
-    double* o = out + ((size_t) sl * (size_t) n + (size_t) f) * 12;
+    double* o = out + ((size_t) sl * (size_t) n + (size_t) f) * EGO_STRIDE;
     for (int i = 0; i < 3; i++)
     {
         for (int j = 0; j < 3; j++)
             o[i * 3 + j] = (A[i * 4 + 0] * ir[0 * 3 + j] + A[i * 4 + 1] * ir[1 * 3 + j]) + A[i * 4 + 2] * ir[2 * 3 + j];
         o[9 + i] = ((A[i * 4 + 0] * it[0] + A[i * 4 + 1] * it[1]) + A[i * 4 + 2] * it[2]) + A[i * 4 + 3];
     }
+    // how far the Gram matrix of a 3x3 block is from the identity (Frobenius): sigma_min^2 >= 1 - dev
+    auto gram_dev = [](const double* m, const int stride) -> double
+    {
+        double dev = 0.;
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++)
+            {
+                double d = 0.;
+                for (int k = 0; k < 3; k++)
+                    d += m[k * stride + a] * m[k * stride + b];
+                d -= a == b ? 1. : 0.;
+                dev += d * d;
+            }
+        return __builtin_sqrt(dev);
+    };
+    const double dev_t = gram_dev(T, 4), dev_a = gram_dev(A, 4);
+    auto mx2 = [](const float a, const float b) -> double
+    {
+        const double x = a, y = b;
+        return x * x > y * y ? x * x : y * y;
+    };
+    const double box = __builtin_sqrt(mx2(cfg.length_ref_to_front_end_, cfg.length_ref_to_rear_end_) + mx2(cfg.width_ref_to_left_mirror_, cfg.width_ref_to_right_mirror_) +
+                                      mx2(cfg.height_ref_to_maximum_, cfg.height_ref_to_ground_));
+    const double at = __builtin_sqrt((A[3] * A[3] + A[7] * A[7]) + A[11] * A[11]);
+    double skip = __builtin_inf();
+    if (dev_t < 0.5 && dev_a < 0.5 && box == box && at == at) // (NaN anywhere: no skipping)
+    {
+        const double sigma = __builtin_sqrt((1. - dev_t) * (1. - dev_a));
+        const double delta = 2.4e-7 * ((__builtin_fabs(T[3]) + __builtin_fabs(T[7])) + __builtin_fabs(T[11])) + 1e-6;
+        const double r = ((box + at) / sigma + delta) * 1.00001;
+        const double r2 = r * r * 1.00001;
+        float r2f = (float) r2;
+        if ((double) r2f < r2)
+            r2f = __builtin_bit_cast(float, __builtin_bit_cast(int, r2f) + 1); // round up
+        skip = r2f == r2f ? (double) r2f : __builtin_inf();
+    }
+    o[12] = skip;
 }
 
-// ---- k_seg_pre: everything of the segmentation that does not depend on the rows below. Lanes = rows (coalesced); one wavefront per
-// chunk of consecutive columns (TableChunks), which it walks in column order carrying sc_inclination_angles_between_lasers_ in
-// registers. grid = (streams, SEGPRE_BLOCKS), block = 64.
+// ---- the per-cell part of the segmentation of ONE column (everything of cc.cpp:306-403, 567-603 that does not depend on other columns or on
+// the rows below), lanes = rows, cells in registers. Shared by k_seg_pre (cells from the ring) and k_insert_par (cells it has just computed).
+//   x, y, z, dist, incl : the cell (odom frame; dist = incl = NaN without a return), inten its intensity
+//   sp*                 : sgps_sensor_position of the column's job (the finishing firing's pose, cc.cpp:111-113, 291)
+//   E                   : that firing's k_ego record (wave-uniform pointer: scalar loads)
+// Staging for k_seg_scan: x2, uz (the point in the azimuth plane of the job's sensor position), flags (SG_*), and ONE more float w:
+//   cell with a return, inclination step to the row below valid  w = that step (the column's own entry of the table, cc.cpp:353-357: k_seg_scan
+//                                                                  takes the last valid one along the columns), cc.cpp:597-603 decided here
+//   cell with a return, step not valid (SG_PENDING)              w = distance (k_seg_scan evaluates cc.cpp:597-603 once it knows the table)
+//   cell without a return (SG_NAN)                               w = raw inclination of the row below (where the supplement chain of
+//                                                                  cc.cpp:364-369 starts when that row has a return)
+template<int RPL>
+__device__ __forceinline__ void seg_pre_cells(const cc_config& cfg, const int R, const int lane, const float (&cx)[RPL], const float (&cy)[RPL],
+                                              const float (&cz)[RPL], const float (&dist)[RPL], const float (&incl)[RPL], const uint8_t (&inten)[RPL],
+                                              const float spx, const float spy, const float spz, const double* __restrict__ E, float (&x2)[RPL],
+                                              float (&uz)[RPL], float (&w)[RPL], int (&flags)[RPL])
+{
+    // raw inclination of the row below (0 below the last row, cc.cpp:312)
+    float below[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const float nxt0 = (k + 1 < RPL) ? __shfl(incl[(k + 1 < RPL) ? k + 1 : k], 0, 64) : 0.f;
+        const float dn = __shfl_down(incl[k], 1, 64);
+        below[k] = lane == 63 ? nxt0 : dn;
+        if (k * 64 + lane + 1 >= R)
+            below[k] = 0.f;
+    }
+    const float skip_r2 = (float) E[12];
+    bool close = false, need_exact = false;
+    bool incl_ignore[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        flags[k] = SG_NAN;
+        x2[k] = uz[k] = 0.f;
+        w[k] = below[k];
+        incl_ignore[k] = false;
+        if (row >= R)
+            continue;
+        const bool isnan_ = dist[k] != dist[k];
+        if (isnan_)
+            continue;
+        int f = 0;
+        if (cfg.fog_filtering_enabled && inten[k] < (uint8_t) cfg.fog_filtering_intensity_below && dist[k] < cfg.fog_filtering_distance_below &&
+            incl[k] > cfg.fog_filtering_inclination_above)
+            f |= SG_FOG;
+        const float ux = cx[k] - spx, uy = cy[k] - spy;
+        uz[k] = cz[k] - spz;
+        x2[k] = len2(ux, uy);
+        const float r2 = x2[k] * x2[k] + uz[k] * uz[k];
+        if (!(r2 > skip_r2))
+        {
+            f |= SG_EGO; // provisional: "needs the transform"
+            close = true;
+        }
+        if ((double) dist[k] < 1. * (double) cfg.max_distance)
+            f |= SG_TOO_CLOSE;
+        const float diff = incl[k] - below[k];
+        if (diff != diff)
+        {
+            f |= SG_PENDING;
+            w[k] = dist[k];
+        }
+        else
+        {
+            w[k] = diff;
+            // cc.cpp:597-603: atan2f(max_distance, distance) < inclination step to the next laser. The exact (glibc-identical) atan2f
+            // costs ~100 instructions per wave, and the test can only hold beyond ~100 m: a rigorous filter first. With
+            // x = max_distance / distance >= 1.01 t (0 <= t < 0.05): atan(x) >= x - x^3/3 >= 1.006 t for x <= 0.1, atan(x) > 0.099 > t
+            // otherwise, and atan2f is within an ulp of atan — so the test is false without evaluating it.
+            if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1))
+            {
+                const bool surely_false = cfg.max_distance > 0.f && diff >= 0.f && diff < 0.05f && cfg.max_distance >= 1.01f * dist[k] * diff;
+                incl_ignore[k] = !surely_false; // provisional: "needs the exact evaluation"
+                need_exact |= !surely_false;
+            }
+        }
+        flags[k] = f;
+    }
+    if (__any(need_exact))
+    {
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+            if (incl_ignore[k])
+                incl_ignore[k] = ccm::atan2f_exact(cfg.max_distance, dist[k]) < w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+        if (incl_ignore[k])
+            flags[k] |= SG_INCL_IGNORE;
+    if (__any(close))
+    {
+        // ego_robot_frame_from_odom_frame * point (cc.cpp:390-403), Eigen's evaluation order
+        double er[9], et[3];
+        for (int i = 0; i < 9; i++)
+            er[i] = E[i];
+        for (int i = 0; i < 3; i++)
+            et[i] = E[9 + i];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            if (!(flags[k] & SG_EGO) || (flags[k] & SG_NAN))
+                continue;
+            const double dx = cx[k], dy = cy[k], dz = cz[k];
+            const double ex = ((er[0] * dx + er[1] * dy) + er[2] * dz) + et[0];
+            const double ey = ((er[3] * dx + er[4] * dy) + er[5] * dz) + et[1];
+            const double ez = ((er[6] * dx + er[7] * dy) + er[8] * dz) + et[2];
+            const bool in_box = ex < cfg.length_ref_to_front_end_ && ex > cfg.length_ref_to_rear_end_ && ey < cfg.width_ref_to_left_mirror_ &&
+                                ey > cfg.width_ref_to_right_mirror_ && ez < cfg.height_ref_to_maximum_ && ez > cfg.height_ref_to_ground_;
+            if (!in_box)
+                flags[k] &= ~SG_EGO;
+        }
+    }
+}
+
+// ---- k_seg_pre: the per-cell part for columns whose cells come from the ring (everything the fused insertion did not take). Lanes = rows
+// (coalesced); one wavefront per chunk of consecutive columns. grid = (streams, SEGPRE_BLOCKS), block = 64.
 
 template<int RPL>
 __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
@@ -2209,6 +2366,8 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
     if (seg_begin < 0 || seg_begin >= seg_end)
         return;
+    if (st->batch[slot].fused)
+        return;
     if (!st->has_robot_tf)
     {
         if (blockIdx.y == 0 && lane_id() == 0)
@@ -2218,34 +2377,13 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
     const int lane = lane_id();
-    __shared__ float s_incl[WAVE * RPL];
-    __shared__ int s_done[WAVE * RPL];
-    const double* A = st->robot_from_sensor;
-    const float height_sensor_to_ground = -(float) A[11] + cfg.height_ref_to_ground_;
-    (void) height_sensor_to_ground;
 
-    // this wavefront's chunk of the batch's columns (the partition k_table prepared the table for), in column order
-    constexpr int CPW = SEGPRE_BLOCKS / TABLE_WAVES;
-    const TableChunks tc(seg_begin, seg_end);
-    const int tw = (int) blockIdx.y / CPW, tj = (int) blockIdx.y % CPW;
-    const long long w_lo = seg_begin + tc.per_wave * tw, w_hi = (w_lo + tc.per_wave < seg_end ? w_lo + tc.per_wave : seg_end);
-    const long long c_lo = w_lo + tc.chunk_len * tj, c_hi = (c_lo + tc.chunk_len < w_hi ? c_lo + tc.chunk_len : w_hi);
+    // this wavefront's chunk of the batch's columns
+    const long long total = seg_end - seg_begin;
+    const long long chunk_len = (total + SEGPRE_BLOCKS - 1) / SEGPRE_BLOCKS;
+    const long long c_lo = seg_begin + chunk_len * (long long) blockIdx.y, c_hi = (c_lo + chunk_len < seg_end ? c_lo + chunk_len : seg_end);
     if (c_lo >= c_hi)
         return;
-    // sc_inclination_angles_between_lasers_ (cc.cpp:353-357) as of the chunk's first column: the last valid step since the start of the
-    // table wavefront's range, else the table at the start of that range (k_table); carried through the chunk in registers
-    float tabv[RPL];
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        const int row = k * 64 + lane;
-        tabv[k] = 0.f;
-        if (row < R)
-        {
-            const float t = p.tabc[(size_t) blockIdx.y * R + row];
-            tabv[k] = (t != t) ? p.tabw[(size_t) tw * R + row] : t;
-        }
-    }
     // (ring column, rotation index and ring pass advanced incrementally: a 64-bit division per column costs ~100 scalar instructions)
     const int NC = g.num_columns;
     int lc = (int) (c_lo % RC);
@@ -2318,47 +2456,27 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             load_cells(gc, lc, tag);
             load_tags(gc + 1, lc + 1 == RC ? 0 : lc + 1);
         }
-        uint16_t c_tg[RPL];
-        float c_dist[RPL], c_incaz[RPL];
-        float4 c_rec[RPL];
-        uint8_t c_inten[RPL];
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            c_tg[k] = n_tg[k];
-            c_dist[k] = n_dist[k];
-            c_incaz[k] = n_incaz[k];
-            c_rec[k] = n_rec[k];
-            c_inten[k] = n_inten[k];
-        }
         // the caller's [stream][n_total] pose buffer; this batch is its firings [fbase, ...), trig is relative to the batch
         const int trig = uniform_i32(n_trig); // (wave-uniform: the pose and the matrices below arrive by scalar loads)
         const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) trig) * 12;
         // ego_robot_frame_from_odom_frame = robot_from_sensor * odom_from_sensor^-1   (cc.cpp:300-301), prepared per firing by k_ego
-        const double* E = ego + ((size_t) sl * (size_t) n_batch + (size_t) trig) * 12;
-        double er[9], et[3];
-        for (int i = 0; i < 9; i++)
-            er[i] = E[i];
-        for (int i = 0; i < 3; i++)
-            et[i] = E[9 + i];
+        const double* E = ego + ((size_t) sl * (size_t) n_batch + (size_t) trig) * EGO_STRIDE;
         const float spx = (float) T[3], spy = (float) T[7], spz = (float) T[11]; // sgps_sensor_position (cc.cpp:111-113)
 
-        float dist[RPL], incl[RPL];
-        float4 rec[RPL];
-        bool isnan_[RPL], empty_cell[RPL], overrun = false;
+        float cx[RPL], cy[RPL], cz[RPL], dist[RPL], incl[RPL];
+        bool empty_cell[RPL], overrun = false;
         int overrun_row = -1;        // the reference walks the rows bottom-up and reports the first stale cell it meets (cc.cpp:314-345)
         long long overrun_gcol = -1;
-        double min_az = 1.7976931348623157e308;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
             const int row = k * 64 + lane;
-            dist[k] = incl[k] = 0.f;
-            isnan_[k] = true;
+            dist[k] = incl[k] = __builtin_nanf("");
+            cx[k] = cy[k] = cz[k] = 0.f;
             empty_cell[k] = false;
             if (row < R)
             {
-                const uint16_t tg = c_tg[k];
+                const uint16_t tg = n_tg[k];
                 if (tg != tag && tg != CELL_CLEARED)
                 {
                     overrun = true; // cc.cpp:320-345
@@ -2367,12 +2485,11 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
                     overrun_gcol = gc - (long long) ((((unsigned) tag - (unsigned) tg) & 0x7fffu)) * RC;
                 }
                 empty_cell[k] = tg != tag;
-                dist[k] = c_dist[k];
-                rec[k] = c_rec[k];
-                incl[k] = rec[k].w;
-                isnan_[k] = dist[k] != dist[k];
-                s_incl[row] = incl[k];
-                s_done[row] = (!isnan_[k] || !cfg.supplement_inclination_angle_for_nan_cells || row == R - 1) ? 1 : 0;
+                dist[k] = n_dist[k];
+                cx[k] = n_rec[k].x;
+                cy[k] = n_rec[k].y;
+                cz[k] = n_rec[k].z;
+                incl[k] = n_rec[k].w;
             }
         }
         if (__any(overrun))
@@ -2387,84 +2504,10 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             }
             continue;
         }
-        wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
-        // the column's valid inclination steps enter the table before it is used (cc.cpp:353-357; the raw inclinations, NaN where empty)
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            const int row = k * 64 + lane;
-            if (row < R)
-            {
-                const float diff = incl[k] - (row + 1 < R ? s_incl[row + 1] : 0.f);
-                if (!(diff != diff))
-                    tabv[k] = diff;
-            }
-        }
-        // NaN cells: inclination of the cell below (already supplemented) + the per-row step (cc.cpp:364-369); runs of NaN
-        // cells resolve bottom-up, one row per iteration
-        while (true)
-        {
-            bool pending = false;
-            float nv[RPL];
-            bool upd[RPL];
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                upd[k] = false;
-                nv[k] = 0.f;
-                if (row < R && !s_done[row])
-                {
-                    if (s_done[row + 1])
-                    {
-                        nv[k] = s_incl[row + 1] + tabv[k];
-                        upd[k] = true;
-                    }
-                    else
-                        pending = true;
-                }
-            }
-            wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (upd[k])
-                {
-                    s_incl[row] = nv[k];
-                    s_done[row] = 1;
-                    incl[k] = nv[k];
-                }
-            }
-            wave_lds_fence(); // one wavefront per block: LDS accesses of a wave execute in order
-            if (!__any(pending))
-                break;
-        }
-        // cc.cpp:597-603: atan2f(max_distance, distance) < inclination step to the next laser. The exact (glibc-identical) atan2f
-        // costs ~100 instructions per wave, and the test can only hold beyond ~100 m: a rigorous filter first. With
-        // x = max_distance / distance >= 1.01 t (0 <= t < 0.05): atan(x) >= x - x^3/3 >= 1.006 t for x <= 0.1, atan(x) > 0.099 > t
-        // otherwise, and atan2f is within an ulp of atan — so the test is false without evaluating it.
-        bool incl_ignore[RPL], need_exact = false;
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            const int row = k * 64 + lane;
-            incl_ignore[k] = false;
-            if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1) && !isnan_[k])
-            {
-                const float t = tabv[k];
-                const bool surely_false = cfg.max_distance > 0.f && t >= 0.f && t < 0.05f && cfg.max_distance >= 1.01f * dist[k] * t;
-                incl_ignore[k] = !surely_false; // provisional: "needs the exact evaluation"
-                need_exact |= !surely_false;
-            }
-        }
-        if (__any(need_exact))
-        {
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-                if (incl_ignore[k])
-                    incl_ignore[k] = ccm::atan2f_exact(cfg.max_distance, dist[k]) < tabv[k];
-        }
+        float x2[RPL], uz[RPL], w[RPL];
+        int flags[RPL];
+        seg_pre_cells<RPL>(cfg, R, lane, cx, cy, cz, dist, incl, n_inten, spx, spy, spz, E, x2, uz, w, flags);
+        double min_az = 1.7976931348623157e308;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -2474,46 +2517,14 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             const size_t ci = base + row;
             if (empty_cell[k])
                 p.gtag[ci] = tag; // cells that received a return already carry it (insertion kernels)
-            int flags = 0;
-            float x2 = 0.f, uz = 0.f;
-            if (isnan_[k])
-            {
-                flags = SG_NAN;
-                if (cfg.supplement_inclination_angle_for_nan_cells && row < R - 1)
-                    p.incl[ci] = incl[k];
-                // (the window scan leaves its inclination window by this value, and never accepts the cell: x = NaN)
-                p.sc_rec[ci] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), incl[k]);
-                const double caz = empty_cell_caz(gc, g.az_width); // cc.cpp:371-372 (not stored: every reader knows the cell's column)
-                if (caz < min_az)
-                    min_az = caz;
-            }
-            else
-            {
-                const double caz = cell_caz(cb, c_incaz[k]);
-                if (caz < min_az)
-                    min_az = caz;
-                const float cx = rec[k].x, cy = rec[k].y, cz = rec[k].z;
-                if (cfg.fog_filtering_enabled && c_inten[k] < (uint8_t) cfg.fog_filtering_intensity_below &&
-                    dist[k] < cfg.fog_filtering_distance_below && incl[k] > cfg.fog_filtering_inclination_above)
-                    flags |= SG_FOG;
-                const double dx = cx, dy = cy, dz = cz;
-                const double ex = ((er[0] * dx + er[1] * dy) + er[2] * dz) + et[0];
-                const double ey = ((er[3] * dx + er[4] * dy) + er[5] * dz) + et[1];
-                const double ez = ((er[6] * dx + er[7] * dy) + er[8] * dz) + et[2];
-                if (ex < cfg.length_ref_to_front_end_ && ex > cfg.length_ref_to_rear_end_ && ey < cfg.width_ref_to_left_mirror_ &&
-                    ey > cfg.width_ref_to_right_mirror_ && ez < cfg.height_ref_to_maximum_ && ez > cfg.height_ref_to_ground_)
-                    flags |= SG_EGO;
-                const float ux = cx - spx, uy = cy - spy;
-                uz = cz - spz;
-                x2 = len2(ux, uy);
-                if ((double) dist[k] < 1. * (double) cfg.max_distance)
-                    flags |= SG_TOO_CLOSE;
-                if (incl_ignore[k])
-                    flags |= SG_INCL_IGNORE;
-            }
-            p.sg_x2[ci] = x2;
-            p.sg_uz[ci] = uz;
-            p.sg_flags[ci] = (uint8_t) flags;
+            // (continuous azimuth of a cell without a return: cc.cpp:371-372 — not stored: every reader knows the cell's column)
+            const double caz = (flags[k] & SG_NAN) ? empty_cell_caz(gc, g.az_width) : cell_caz(cb, n_incaz[k]);
+            if (caz < min_az)
+                min_az = caz;
+            p.sg_x2[ci] = x2[k];
+            p.sg_uz[ci] = uz[k];
+            p.sg_w[ci] = w[k];
+            p.sg_flags[ci] = (uint8_t) flags[k];
         }
         min_az = wave_min_f64(min_az);
         if (lane == 0)
@@ -2524,9 +2535,15 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
     }
 }
 
-// ---- k_seg_scan: the row-serial part (cc.cpp:306-565 state machine + downward fix-up + ignore flags 567-616).
+// ---- k_seg_scan: the part of the segmentation that runs along the rows of a column (cc.cpp:306-565 state machine + downward fix-up +
+// ignore flags 567-616) and, since round 4, everything that needs sc_inclination_angles_between_lasers_ (cc.cpp:353-357): the table as of
+// every column, the supplemented inclination of cells without a return (:364-369) and the inclination-step filter (:597-603) of the cells
+// whose own column has no valid step.
 // One lane per column on tiles of 64 columns; grid = (streams, tiles of 64 columns), block = 64, dynamic LDS = seg_scan_lds_bytes(num_rows).
-// The staged inputs (k_seg_pre: azimuth-plane distance, height, flags) are column-major like every plane of the ring, so a lane that read its own
+// The table along the columns of a tile: a lane whose cell has a valid step to the row below holds it (staging plane sg_w); the table entry of
+// row r as of column c is the step of the nearest such lane at or before c — one ballot, one count-leading-zeros and one lane permute per row —
+// or, when the tile has none before c, the table in front of the tile (Planes::tabc: k_table / k_insert_par).
+// The staged inputs are column-major like every plane of the ring, so a lane that read its own
 // column touched a different 128-byte line than its neighbours with every load, 32 bytes at a time: round 2 measured 1.42 GB fetched per step for
 // 0.32 GB of input (the lines did not survive in L2 next to the other chains). Round 3: the wavefront loads 16 rows x 64 columns at a time with
 // lanes = (column, 16-byte piece) — 64 contiguous bytes per column and plane, every line fetched once —, hands them to the column lanes through LDS
@@ -2537,7 +2554,7 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
 // Row counts that are not a multiple of 16 take the round-2 form (every lane reads its own column, 8 rows at a time; 16 rows of look-back in LDS).
 constexpr int SEG_X2_RING = 16;
 constexpr int SEG_CH = 16; // rows per chunk of the tiled form
-constexpr int SEG_FEW = 4; // tiles of at most this many columns are loaded whole (2 * SEG_FEW * rows floats fit the chunk buffers up to 384 rows)
+constexpr int SEG_FEW = 4; // tiles of at most this many columns are loaded whole (3 * SEG_FEW * rows floats fit the chunk buffers up to 341 rows)
 __host__ __device__ inline int seg_pitch_f(int R)
 {
     (void) R;
@@ -2553,7 +2570,7 @@ __host__ __device__ inline bool seg_tiled(int R)
 }
 __host__ inline size_t seg_scan_lds_bytes(int R)
 {
-    const size_t f = seg_tiled(R) ? (size_t) 3 * 64 * SEG_CH * 4 : (size_t) 64 * seg_pitch_f(R) * 4;
+    const size_t f = seg_tiled(R) ? (size_t) 4 * 64 * SEG_CH * 4 : (size_t) 64 * seg_pitch_f(R) * 4;
     return f + (size_t) 64 * seg_pitch_b(R);
 }
 
@@ -2565,7 +2582,8 @@ enum
     SG_D_VIOLET = 8, SG_D_LIGHTGRAY = 9
 };
 
-__global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+// (20 KB of LDS per wavefront: two of them per SIMD at most — the register budget that goes with that, not 128)
+__global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
     StreamState* st = &states[s];
@@ -2585,7 +2603,7 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
     // The tile keeps only what the state machine looks back at: the azimuth-plane distance of the rows below (cc.cpp:513-535) and
     // one output byte per cell (bits 0-2 ground label code, bits 3-6 debug label code, bit 7 "ignored if it ends up an obstacle").
     float* l_x2 = (float*) smem;
-    unsigned char* l_out = (unsigned char*) (l_x2 + (tiled ? 3 * 64 * SEG_CH : 64 * PF));
+    unsigned char* l_out = (unsigned char*) (l_x2 + (tiled ? 4 * 64 * SEG_CH : 64 * PF));
 
     const int lc0 = (int) (tile0 % RC);
     if (!(g.debug_flags & 1))
@@ -2596,7 +2614,11 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
         lcl = lcl >= RC ? lcl - RC : lcl;
         const float* gx = p.sg_x2 + (size_t) lcl * R;
         const float* gz = p.sg_uz + (size_t) lcl * R;
+        const float* gw = p.sg_w + (size_t) lcl * R;
         const unsigned char* gf = p.sg_flags + (size_t) lcl * R;
+        float4* g_rec = p.sc_rec + (size_t) lcl * R; // (cells without a return: {NaN, NaN, NaN, supplemented inclination}, what the window scan reads)
+        float* g_incl = p.incl + (size_t) lcl * R;
+        const float* tab_in = p.tabc + (size_t) blockIdx.y * R; // the table in front of this tile (wave-uniform: scalar loads)
         unsigned char* oo = l_out + lane * PB;
         const float height_sensor_to_ground = -(float) st->robot_from_sensor[11] + cfg.height_ref_to_ground_;
         const bool chess_odd = cfg.ignore_points_in_chessboard_pattern && (gc & 1); // column parity (cc.cpp:600-606)
@@ -2715,6 +2737,62 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
             previous_label = debug;
             oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
         };
+        // ---- the table along the columns, the supplemented inclination and the pending inclination-step tests of one row, then its state machine
+        // step. EVERY lane comes here for every row (lanes beyond the tile as columns without returns): the ballot and the permute are wave-wide.
+        const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull); // lanes at or before this one
+        const bool supplement = cfg.supplement_inclination_angle_for_nan_cells != 0;
+        const bool step_filter = cfg.ignore_points_with_too_big_inclination_angle_diff != 0;
+        float supp_below = __builtin_nanf(""); // inclination the row below ended up with, if it had no return
+        bool below_nan = false;
+        // `stash(tab)` is called (predicated, no branch around it) by lanes whose test survives both bounds: the exact evaluation — ~100 instructions,
+        // ~1 % of the far cells — is done behind the chunk's rows (the row loops are unrolled: one copy of it per loop, not sixteen); returns "pending"
+        auto row_all = [&](const int row, const int f, const float cur2x, const float cur2y, const float wv, const float carry, auto&& x2_below,
+                           auto&& stash) -> bool
+        {
+            const bool own = !(f & (SG_NAN | SG_PENDING)); // this cell's step to the row below is valid: it IS the table entry as of this column
+            const unsigned long long m = __ballot(own) & le_mask;
+            const int src = m ? 63 - __clzll((long long) m) : lane;
+            const float got = __shfl(wv, src, 64);
+            const float tab = m ? got : carry; // sc_inclination_angles_between_lasers_[row] after this column (cc.cpp:353-357)
+            int fx = f;
+            bool need = false;
+            if (f & SG_NAN)
+            {
+                // cc.cpp:364-369: the inclination of the cell below (after ITS supplement) + the table entry
+                float supp = __builtin_nanf("");
+                if (supplement && row < R - 1)
+                    supp = (below_nan ? supp_below : wv) + tab;
+                if (active)
+                {
+                    g_rec[row] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), supp);
+                    if (supplement && row < R - 1)
+                        g_incl[row] = supp;
+                }
+                supp_below = supp;
+                below_nan = true;
+            }
+            else
+            {
+                below_nan = false;
+                if ((f & SG_PENDING) && step_filter && row < R - 1 && !(tab != tab))
+                {
+                    // cc.cpp:597-603 with the table entry of an earlier column: atan2f(max_distance, distance) < tab. Two rigorous bounds first
+                    // (seg_pre_cells has the first; the second: atan2f(y, x) <= (y / x) (1 + 3 * 2^-23) for positive arguments)
+                    const float dist = wv, a = dist * tab;
+                    const bool in_range = cfg.max_distance > 0.f && tab >= 0.f && tab < 0.05f && dist > 0.f && dist < 3.0e38f;
+                    if (in_range && cfg.max_distance >= 1.01f * a)
+                        ;
+                    else if (in_range && cfg.max_distance * 1.000002f < a)
+                        fx |= SG_INCL_IGNORE;
+                    else
+                        need = true;
+                }
+            }
+            if (need)
+                stash(tab);
+            row_step(row, fx, cur2x, cur2y, x2_below);
+            return need;
+        };
         if (tiled && ncols <= SEG_FEW)
         {
             // ---- a tile of a few columns (calls of a few firings: the per-column latency path, and the last tile of a batch): the whole columns are
@@ -2722,6 +2800,7 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
             // then lane c scans column c out of LDS
             float* cx2 = l_x2;
             float* cuz = l_x2 + SEG_FEW * R;
+            float* cw = l_x2 + 2 * SEG_FEW * R;
             for (int c = 0; c < ncols; c++)
             {
                 int l = lc0 + c;
@@ -2730,39 +2809,43 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
                 {
                     cx2[c * R + row] = p.sg_x2[(size_t) l * R + row];
                     cuz[c * R + row] = p.sg_uz[(size_t) l * R + row];
+                    cw[c * R + row] = p.sg_w[(size_t) l * R + row];
                     l_out[c * PB + row] = p.sg_flags[(size_t) l * R + row];
                 }
             }
             wave_lds_fence();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // (lane c reads what all lanes wrote)
-            if (active)
             {
-                const float* mx = cx2 + lane * R;
-                const float* mz = cuz + lane * R;
+                const int lc_ = active ? lane : 0; // (lanes beyond the tile read column 0's floats and take them for a column without returns)
+                const float* mx = cx2 + lc_ * R;
+                const float* mz = cuz + lc_ * R;
+                const float* mw = cw + lc_ * R;
                 auto x2_below = [&](const int below) -> float { return mx[below]; };
-                for (int b = R - SEG_CH; b >= 0; b -= SEG_CH)
+                for (int b = R - 4; b >= 0; b -= 4)
                 {
-                    float x16[SEG_CH], z16[SEG_CH];
-                    unsigned fw[4];
+                    const float4 a = *(const float4*) (mx + b);
+                    const float4 c4 = *(const float4*) (mz + b);
+                    const float4 w4 = *(const float4*) (mw + b);
+                    const float x4[4] = {a.x, a.y, a.z, a.w}, z4[4] = {c4.x, c4.y, c4.z, c4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                    const unsigned fw = active ? *(const unsigned*) (oo + b) : 0x01010101u * (unsigned) SG_NAN;
+                    unsigned pend = 0;
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                    {
-                        const float4 a = *(const float4*) (mx + b + q * 4);
-                        const float4 c4 = *(const float4*) (mz + b + q * 4);
-                        x16[q * 4 + 0] = a.x, x16[q * 4 + 1] = a.y, x16[q * 4 + 2] = a.z, x16[q * 4 + 3] = a.w;
-                        z16[q * 4 + 0] = c4.x, z16[q * 4 + 1] = c4.y, z16[q * 4 + 2] = c4.z, z16[q * 4 + 3] = c4.w;
-                        fw[q] = *(const unsigned*) (oo + b + q * 4);
-                    }
-#pragma unroll
-                    for (int u = SEG_CH - 1; u >= 0; u--)
-                        row_step(b + u, (int) ((fw[u >> 2] >> (8 * (u & 3))) & 0xffu), x16[u], z16[u], x2_below);
+                    for (int u = 3; u >= 0; u--)
+                        if (row_all(b + u, (int) ((fw >> (8 * u)) & 0xffu), x4[u], z4[u], ww[u], tab_in[b + u], x2_below,
+                                    [&](const float tab) { cuz[lc_ * R + b + u] = tab; })) // (the row's height has been consumed: its slot takes the table entry)
+                            pend |= 1u << u;
+                    if (__any(pend != 0))
+                        for (int u = 0; u < 4; u++)
+                            if (((pend >> u) & 1) && ccm::atan2f_exact(cfg.max_distance, mw[b + u]) < mz[b + u])
+                                oo[b + u] |= 0x80; // (bit 7 only matters for a cell that ends up an obstacle, and nothing in the state machine reads it)
                 }
             }
         }
         else if (tiled)
         {
             // ---- tiled form: lanes = (column of a group of 16, 16-byte piece) while loading, lanes = columns while scanning
-            float* t_uz = l_x2 + 2 * 64 * SEG_CH; // l_x2: two chunks (index (row / 16) & 1), t_uz: the current one
+            float* t_uz = l_x2 + 2 * 64 * SEG_CH; // l_x2: two chunks (index (row / 16) & 1), t_uz / t_w: the current one
+            float* t_w = l_x2 + 3 * 64 * SEG_CH;
             const int ld_c = lane >> 2, ld_q = lane & 3;
             int ld_off[4]; // cell index of row 0 of this lane's four load columns (-1: beyond the tile)
 #pragma unroll
@@ -2773,17 +2856,18 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
                 l = l >= RC ? l - RC : l;
                 ld_off[j] = c < ncols ? l * R : -1;
             }
-            float4 nx[4], nz[4];
+            float4 nx[4], nz[4], nw[4];
             auto load_chunk = [&](const int b)
             {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                 {
-                    nx[j] = nz[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    nx[j] = nz[j] = nw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (ld_off[j] >= 0)
                     {
                         nx[j] = *(const float4*) (p.sg_x2 + (size_t) ld_off[j] + b + ld_q * 4);
                         nz[j] = *(const float4*) (p.sg_uz + (size_t) ld_off[j] + b + ld_q * 4);
+                        nw[j] = *(const float4*) (p.sg_w + (size_t) ld_off[j] + b + ld_q * 4);
                     }
                 }
             };
@@ -2832,23 +2916,12 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
                     const int c = j * 16 + ld_c;
                     *(float4*) (cx + piece_at(c, ld_q)) = nx[j];
                     *(float4*) (t_uz + piece_at(c, ld_q)) = nz[j];
+                    *(float4*) (t_w + piece_at(c, ld_q)) = nw[j];
                 }
                 if (b >= SEG_CH)
                     load_chunk(b - SEG_CH);
                 wave_lds_fence(); // one wavefront per block: its LDS accesses execute in order
-                if (active)
                 {
-                    float x16[SEG_CH], z16[SEG_CH];
-                    unsigned fw[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++)
-                    {
-                        const float4 a = *(const float4*) (cx + piece_at(lane, q));
-                        const float4 c4 = *(const float4*) (t_uz + piece_at(lane, q));
-                        x16[q * 4 + 0] = a.x, x16[q * 4 + 1] = a.y, x16[q * 4 + 2] = a.z, x16[q * 4 + 3] = a.w;
-                        z16[q * 4 + 0] = c4.x, z16[q * 4 + 1] = c4.y, z16[q * 4 + 2] = c4.z, z16[q * 4 + 3] = c4.w;
-                        fw[q] = *(const unsigned*) (oo + b + q * 4);
-                    }
                     auto x2_below = [&](const int below) -> float
                     {
                         // this chunk or the one below it: LDS; deeper: the staging plane (the LDS word is read either way: a select between
@@ -2858,30 +2931,61 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
                             v = gx[below];
                         return v;
                     };
+                    // four rows (one 16-byte piece per plane) per iteration of a ROLLED loop: the state machine's code stays small
+                    // (sixteen unrolled copies of it, for three forms of this kernel, were 25 k instructions)
+                    unsigned pend = 0;
+#pragma unroll 1
+                    for (int q = 3; q >= 0; q--)
+                    {
+                        const int at = piece_at(lane, q);
+                        const float4 a = *(const float4*) (cx + at);
+                        const float4 c4 = *(const float4*) (t_uz + at);
+                        const float4 w4 = *(const float4*) (t_w + at);
+                        const float x4[4] = {a.x, a.y, a.z, a.w}, z4[4] = {c4.x, c4.y, c4.z, c4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                        const unsigned fw = active ? *(const unsigned*) (oo + b + q * 4) : 0x01010101u * (unsigned) SG_NAN;
 #pragma unroll
-                    for (int u = SEG_CH - 1; u >= 0; u--)
-                        row_step(b + u, (int) ((fw[u >> 2] >> (8 * (u & 3))) & 0xffu), x16[u], z16[u], x2_below);
+                        for (int u = 3; u >= 0; u--)
+                            if (row_all(b + q * 4 + u, (int) ((fw >> (8 * u)) & 0xffu), x4[u], z4[u], ww[u], tab_in[b + q * 4 + u], x2_below,
+                                        [&](const float tab) { t_uz[at + u] = tab; })) // (the row's height is in registers: its slot takes the table entry)
+                                pend |= 1u << (q * 4 + u);
+                    }
+                    if (__any(pend != 0))
+                        for (int u = 0; u < SEG_CH; u++)
+                        {
+                            const int at = piece_at(lane, u >> 2) + (u & 3);
+                            if (((pend >> u) & 1) && ccm::atan2f_exact(cfg.max_distance, t_w[at]) < t_uz[at])
+                                oo[b + u] |= 0x80; // (bit 7 only matters for a cell that ends up an obstacle, and nothing in the state machine reads it)
+                        }
                 }
                 wave_lds_fence(); // (the next chunk's pieces are stored behind this chunk's reads)
             }
         }
-        else if (active)
+        else
         {
             // ---- rows not a multiple of 16: the inputs are read by the lane that consumes them, 8 rows (one 32-byte sector per plane) at a time
             // and one chunk ahead
             float* x2 = l_x2 + lane * PF;
             const bool vec = (R & 7) == 0; // rows come in whole, aligned 32-byte sectors
-            float nx[8], nz[8];
+            float nx[8], nz[8], nw[8];
             unsigned nf0 = 0, nf1 = 0; // flags of the 8 rows, one byte each
             auto load_chunk = [&](int b) // rows b .. b + 7 (b may be negative in the last chunk of an odd-sized column)
             {
-                if (vec)
+                if (!active)
+                {
+                    nf0 = nf1 = 0x01010101u * (unsigned) SG_NAN;
+#pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        nx[u] = nz[u] = nw[u] = 0.f;
+                }
+                else if (vec)
                 {
                     const float4 a0 = *(const float4*) (gx + b), a1 = *(const float4*) (gx + b + 4);
                     const float4 c0 = *(const float4*) (gz + b), c1 = *(const float4*) (gz + b + 4);
+                    const float4 w0 = *(const float4*) (gw + b), w1 = *(const float4*) (gw + b + 4);
                     const uint2 ff = *(const uint2*) (gf + b);
                     nx[0] = a0.x, nx[1] = a0.y, nx[2] = a0.z, nx[3] = a0.w, nx[4] = a1.x, nx[5] = a1.y, nx[6] = a1.z, nx[7] = a1.w;
                     nz[0] = c0.x, nz[1] = c0.y, nz[2] = c0.z, nz[3] = c0.w, nz[4] = c1.x, nz[5] = c1.y, nz[6] = c1.z, nz[7] = c1.w;
+                    nw[0] = w0.x, nw[1] = w0.y, nw[2] = w0.z, nw[3] = w0.w, nw[4] = w1.x, nw[5] = w1.y, nw[6] = w1.z, nw[7] = w1.w;
                     nf0 = ff.x;
                     nf1 = ff.y;
                 }
@@ -2894,6 +2998,7 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
                         const int rr = b + u;
                         nx[u] = rr >= 0 ? gx[rr] : 0.f;
                         nz[u] = rr >= 0 ? gz[rr] : 0.f;
+                        nw[u] = rr >= 0 ? gw[rr] : 0.f;
                         const unsigned f = rr >= 0 ? gf[rr] : (unsigned) SG_NAN;
                         if (u < 4)
                             nf0 |= f << (8 * u);
@@ -2906,12 +3011,13 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
             load_chunk(b);
             for (; b > -8; b -= 8)
             {
-                float x8[8], z8[8];
+                float x8[8], z8[8], w8[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++)
                 {
                     x8[u] = nx[u];
                     z8[u] = nz[u];
+                    w8[u] = nw[u];
                 }
                 const unsigned f0 = nf0, f1 = nf1;
                 if (b - 8 > -8)
@@ -2933,7 +3039,12 @@ __global__ __launch_bounds__(64, 4) void k_seg_scan(Geometry g, cc_config cfg, P
                     const int row = b + u;
                     if (row < 0)
                         break;
-                    row_step(row, (int) (((u < 4 ? f0 : f1) >> (8 * (u & 3))) & 0xffu), x8[u], z8[u], x2_below);
+                    float tab_u = 0.f;
+                    const bool pend = row_all(row, (int) (((u < 4 ? f0 : f1) >> (8 * (u & 3))) & 0xffu), x8[u], z8[u], w8[u], tab_in[row], x2_below,
+                                              [&](const float tab) { tab_u = tab; });
+                    if (__any(pend))
+                        if (pend && ccm::atan2f_exact(cfg.max_distance, w8[u]) < tab_u)
+                            oo[row] |= 0x80;
                 }
             }
         }
