@@ -160,7 +160,19 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
     const int tree_limit = g.lds_tree_limit < AB_TREES ? g.lds_tree_limit : AB_TREES;
     int n_unf = st->n_unfinished;
     if (n_unf > tree_limit || cfg.max_steps_in_row > WIN_COLS - 2)
-        return; // the serial kernels decide (LDS pool / global memory)
+    {
+        // the serial kernels decide (LDS pool / global memory). Counted like a stop in front of the first group: the host keeps ONE serial block
+        // per stream while this counter moves (cc_engine.hip: bail_seen / bail_cooldown) — with the two sweeping blocks it launches behind an idle
+        // batch-parallel kernel, a dense scene (65 .. 256 unfinished trees on many streams) would be associated by two blocks, stream after stream
+        if (threadIdx.x == 0)
+        {
+            st->batch_bails += 1ull;
+            st->batch_bail_reason[AB_BAIL_TREES] += 1ull;
+            if (bail_count)
+                atomicAdd(bail_count, 1);
+        }
+        return;
+    }
 
     __builtin_amdgcn_s_setprio(3); // latency-bound (barriers, LDS round trips): win issue arbitration against co-resident throughput kernels
     __shared__ AbTrees T;

@@ -187,6 +187,8 @@ struct Planes
                          // with Geometry::mirror_fields: the host rebuilds Point::associated_trees from it
     int32_t* par_off; // [stream][IP_MAXF] column offset of every firing of the batch (k_insert_par over several blocks -> k_insert_par_fin)
     float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
+    unsigned long long* tab_acc; // [stream][Geometry::tab_tiles][num_rows] (column + 1) << 32 | bits of the last valid inclination step inside a tile, as the
+                      // wavefronts of the fused insertion find them (atomic max); k_insert_par / k_insert_par_fin turn them into tabc and wipe them
     // what k_table leaves for k_seg_pre (one set per batch-descriptor slot; the engine passes the slot's pointers):
     float* tabc;      // [stream][Geometry::tab_tiles][num_rows] sc_inclination_angles_between_lasers_ as of the column in front of each tile of 64
                       // columns of the batch (k_table, or k_insert_par for batches it segmented itself)

@@ -35,7 +35,9 @@ struct cc_engine
                                    // 16 in the first version: with the few stops of ordinary streams (5 in 47 M columns) nearly every batch of a 256-stream run
                                    // then ran three rounds — two more placements of k_assocb's 1024-thread blocks per step, 2 - 3 % of the step
     bool capturing{false};      // launch_batch is being captured into a hipGraph (small calls)
-    int* d_par_left{nullptr};  // streams whose batch k_insert_par did not take completely (skip_idle_fallbacks)
+    int* d_par_left{nullptr};  // [0] streams whose batch k_insert_par did not take completely (skip_idle_fallbacks), [1] streams whose batch still needs
+                               // k_table / k_seg_pre (not closed as fused)
+    bool fuse_front{true};     // option "fuse_front": k_insert_par also does the per-cell part of the segmentation of the columns it fills
     int* h_par_left{nullptr};  // pinned
     int insert_split_blocks{0};      // option "insert_split_blocks": blocks per stream of k_insert_par in such launches (0 = 4 up to 40 streams, else 2; 1 = one)
     int insert_wide_max_streams{96}; // option "insert_wide_max_streams": launches of at most this many streams run k_insert_par with 16 wavefronts
@@ -248,6 +250,7 @@ int allocate(cc_engine* e)
     A(sc_term, C) A(col_newfin, L) A(col_info, L);
     A(sg_x2, C) A(sg_uz, C) A(sg_w, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
+    A(tab_acc, S * (size_t) g.tab_tiles * (size_t) g.num_rows);
     A(par_off, S * (size_t) cck::IP_MAXF);
     A(tabc, (size_t) BATCH_SLOTS * S * (size_t) g.tab_tiles * (size_t) g.num_rows);
     A(sc_visits, C);
@@ -255,7 +258,7 @@ int allocate(cc_engine* e)
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
         return rc;
-    if ((rc = alloc_plane(e, &e->d_par_left, 1)) != 0)
+    if ((rc = alloc_plane(e, &e->d_par_left, 2)) != 0)
         return rc;
     if ((rc = alloc_plane(e, &e->d_bail_count, 1)) != 0)
         return rc;
@@ -282,6 +285,7 @@ int reset_state(cc_engine* e, bool keep_table)
     CC_HIP_CHECK(e, hipMemsetAsync(P.debug, CC_DBG_WHITE, C, e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.ignored, 0, C, e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.root, 0xFF, C * sizeof(int32_t), e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.tab_acc, 0, S * (size_t) g.tab_tiles * (size_t) g.num_rows * sizeof(unsigned long long), e->stream));
     if (!keep_table)
         CC_HIP_CHECK(e, hipMemsetAsync(P.curtab, 0xFF, S * (size_t) g.num_rows * sizeof(float), e->stream));
     std::vector<StreamState> init(S);
@@ -440,30 +444,47 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // have nothing to do — but their blocks wait for free CUs next to the throughput kernels of the other chains, 0.2 - 0.4 ms of chain time per
     // batch. The host has to wait for the insertion chain before the next batch anyway, so it waits here, for k_insert_par alone, and launches the
     // others only if some stream's batch was not taken completely (the kernel then leaves the batch descriptor to k_insert2 as before).
-    const bool gate = par && rpl == 1 && si != sb && e->skip_idle_fallbacks && n <= cck::IP_MAXF;
+    // (with the fused segmentation also outside the pipelined mode: the fused path needs the counters the gate reads)
+    const bool gate = par && rpl == 1 && (si != sb || e->fuse_front) && e->skip_idle_fallbacks && n <= cck::IP_MAXF && !e->capturing;
     bool fallbacks = true;
+    bool need_segpre = true; // some stream's batch is not closed as fused: k_table / k_seg_pre have work
+    bool ego_done = false;
+    // k_table -> k_seg_scan scratch of this batch-descriptor slot (up to BATCH_SLOTS batches are in flight)
+    Planes Pt = e->P;
+    Pt.tabc += (size_t) slot * (size_t) g.num_streams * (size_t) g.tab_tiles * (size_t) g.num_rows;
+    // per-firing ego transforms of this batch (one buffer per descriptor slot: up to three batches are in flight)
+    double* d_ego = e->d_ego[slot];
     if (par && rpl == 1) // (two rows per lane = sensors with per-laser azimuth offsets in practice: straight to k_insert_multi)
     {
+        const bool fuse = gate && e->fuse_front;
+        if (fuse)
+        {
+            // the fused insertion needs the per-firing ego records: they only depend on the caller's poses
+            hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, si, (const StreamState*) e->d_states, first_stream,
+                               e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
+            ego_done = true;
+        }
+        const double* ego_in = fuse ? (const double*) d_ego : (const double*) nullptr;
         if (gate)
-            CC_HIP_CHECK(e, hipMemsetAsync(e->d_par_left, 0, sizeof(int), si));
+            CC_HIP_CHECK(e, hipMemsetAsync(e->d_par_left, 0, 2 * sizeof(int), si));
         // few streams: the GPU is not full and the insertion chain is what a step waits for -> twice the wavefronts per block, and the firings of a
         // stream dealt to several blocks (k_insert_par_fin then finishes the stream's state)
         int* left = gate ? e->d_par_left : (int*) nullptr;
         if (count <= e->insert_wide_max_streams)
         {
             const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : 2);
-            hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states,
-                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left);
+            hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
+                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, ego_in);
             if (nb > 1)
-                hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, e->P, e->d_states, first_stream, d_xyz, (long long) n,
-                                   (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left);
+                hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
+                                   (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, fuse ? 1 : 0);
         }
         else
-            hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, e->P, e->d_states,
-                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left);
+            hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
+                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, ego_in);
         if (gate)
         {
-            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, sizeof(int), hipMemcpyDeviceToHost, si));
+            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, 2 * sizeof(int), hipMemcpyDeviceToHost, si));
             // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic)
             if (e->h_bail_count)
                 CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, si));
@@ -476,7 +497,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 e->hp_gate += std::chrono::duration<double>(hp_t1 - hp1).count();
                 hp_gated = true;
             }
-            fallbacks = *e->h_par_left != 0;
+            fallbacks = e->h_par_left[0] != 0;
+            need_segpre = e->h_par_left[1] != 0;
         }
     }
     // multi-column firings (per-laser azimuth offsets) and whatever single-column head k_insert_par did not take: block-parallel as well,
@@ -540,13 +562,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // k_table only needs what the insertion of this batch wrote. It is a latency-bound kernel (8 wavefronts per stream) that takes 0.8 ms
     // when it shares the GPU with the throughput kernels — on the segmentation chain, which is the longest of the three, that is a
     // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
-    // k_table -> k_seg_pre scratch of this batch-descriptor slot (up to BATCH_SLOTS batches are in flight)
-    Planes Pt = e->P;
-    Pt.tabc += (size_t) slot * (size_t) g.num_streams * (size_t) g.tab_tiles * (size_t) g.num_rows;
     const bool table_early = si != sb && e->table_on_insert_chain != 0;
     // (a stream of its own: the next batch's insertion does not queue behind it)
     hipStream_t st_table = (table_early && e->table_on_insert_chain == 2 && !e->capturing) ? e->stream7 : si;
-    if (table_early)
+    if (table_early && need_segpre)
     {
         if (st_table != si)
         {
@@ -558,10 +577,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         else
             hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, st_table, g, Pt, e->d_states, first_stream, slot);
     }
-    // per-firing ego transforms of this batch (one buffer per descriptor slot: up to three batches are in flight)
-    double* d_ego = e->d_ego[slot];
     const bool ego_early = table_early && e->ego_on_insert_chain;
-    if (ego_early)
+    if (ego_early && !ego_done && need_segpre)
         hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, st_table, (const StreamState*) e->d_states, first_stream,
                            e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
     if (si != sb)
@@ -571,17 +588,19 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     // ---- table + segmentation + window-scan chain ------------------------------------------------------------
     CC_MARK(sb); // ev3: start of the second chain
-    if (!table_early)
+    if (!table_early && need_segpre)
     {
         if (rpl == 1)
             hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
         else
             hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
     }
-    if (!ego_early)
+    if (!ego_early && !ego_done && need_segpre)
         hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
                        e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
-    if (rpl == 1)
+    if (!need_segpre)
+        ;
+    else if (rpl == 1)
         hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
     else
@@ -1330,7 +1349,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     rc = allocate(e);
-    if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, sizeof(int)) != hipSuccess)
+    if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, 2 * sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
     {
         const char* hp = std::getenv("CC_HOST_PROF");
@@ -1355,6 +1374,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
             (void) hipHostFree(e->h_remaining);
         if (e->h_par_left)
             (void) hipHostFree(e->h_par_left);
+        if (e->h_bail_count)
+            (void) hipHostFree(e->h_bail_count);
         (void) hipStreamDestroy(e->stream);
         delete e;
         return rc;
@@ -1407,6 +1428,8 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipHostFree(e->h_remaining);
     if (e->h_par_left)
         (void) hipHostFree(e->h_par_left);
+    if (e->h_bail_count)
+        (void) hipHostFree(e->h_bail_count);
     (void) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1924,6 +1947,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->insert_wide_max_streams = (int) value;
     else if (n == "skip_idle_fallbacks")
         e->skip_idle_fallbacks = value != 0;
+    else if (n == "fuse_front")
+        e->fuse_front = value != 0;
     else if (n == "assoc_batch")
         e->assoc_batch = value != 0;
     else if (n == "assoc_rounds")
@@ -2017,8 +2042,8 @@ int cc_engine_scatter_info(cc_engine* e, int n, const int32_t* streams, const in
     size_t total = 0;
     for (int i = 0; i < n; i++)
     {
-        if (streams[i] < 0 || streams[i] >= e->g.num_streams || to[i] - from[i] >= e->g.ring_cols)
-            return CC_ERR_INVALID_ARGUMENT;
+        if (streams[i] < 0 || streams[i] >= e->g.num_streams || from[i] < 0 || to[i] - from[i] >= e->g.ring_cols)
+            return CC_ERR_INVALID_ARGUMENT; // (columns outside the stream's published ring window read as empty: the kernels check)
         if (to[i] >= from[i])
             total += (size_t) (to[i] - from[i] + 1);
     }
@@ -2040,7 +2065,7 @@ int cc_engine_scatter_info(cc_engine* e, int n, const int32_t* streams, const in
         if (to[i] >= from[i])
         {
             const unsigned cols = (unsigned) (to[i] - from[i] + 1);
-            hipLaunchKernelGGL(cck::k_scatter_info, dim3(cols), dim3(64), 0, e->stream, e->g, e->P, streams[i], (long long) from[i], d_original_index,
+            hipLaunchKernelGGL(cck::k_scatter_info, dim3(cols), dim3(64), 0, e->stream, e->g, e->P, (const StreamState*) e->d_states, streams[i], (long long) from[i], d_original_index,
                                slots, d_min + o, d_max + o);
             o += cols;
         }
@@ -2055,7 +2080,7 @@ int cc_engine_scatter_apply(cc_engine* e, int stream, int64_t from, int64_t to, 
                             uint32_t* d_detection, int64_t max_points)
 {
     if (!e || stream < 0 || stream >= e->g.num_streams || slots < 1 || !d_original_index || !d_is_ground || !d_detection || max_points < 1 ||
-        to - from >= e->g.ring_cols)
+        from < 0 || to - from >= e->g.ring_cols)
         return CC_ERR_INVALID_ARGUMENT;
     if (to < from)
         return CC_OK;
@@ -2063,7 +2088,7 @@ int cc_engine_scatter_apply(cc_engine* e, int stream, int64_t from, int64_t to, 
     int rc = finish_batch(e);
     if (rc)
         return rc;
-    hipLaunchKernelGGL(cck::k_scatter_apply, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, stream, (long long) from,
+    hipLaunchKernelGGL(cck::k_scatter_apply, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, (const StreamState*) e->d_states, stream, (long long) from,
                        d_original_index, slots, d_is_ground, d_detection, (long long) max_points);
     CC_HIP_CHECK(e, hipGetLastError());
     return CC_OK; // (asynchronous on cc_engine_hip_stream(e): cc_eval_frame_device on the same stream, or cc_engine_sync, orders behind it)

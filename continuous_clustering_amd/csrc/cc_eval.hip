@@ -8,7 +8,12 @@
 // reduction happens on the device.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h> // types only: the library is resolved at run time (cc_eval_gather_records)
+// RCCL is not a build-time dependency: the three types cc_eval_gather_records names are declared here as rccl.h declares them (ncclComm_t is an
+// opaque pointer, ncclDouble = 8 and ncclSuccess = 0 in every NCCL / RCCL release), the library itself is resolved in the process at run time
+typedef struct ncclComm* ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+#include <mutex>
 
 #include <algorithm>
 #include <cmath>
@@ -267,22 +272,23 @@ void cc_eval_summarize(const cc_eval_frame_result* frames, int64_t n, double out
 static void* rccl_symbol(const char* name)
 {
     static void* lib = nullptr;
-    if (!lib)
-    {
-        for (const char* n : {"librccl.so.1", "librccl.so"})
-        {
-            lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); // the instance the communicator came from
-            if (lib)
-                break;
-        }
-        if (!lib)
-            for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
-            {
-                lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-                if (lib)
-                    break;
-            }
-    }
+    static std::once_flag once; // (callers may gather from several threads)
+    std::call_once(once,
+                   []()
+                   {
+                       for (const char* n : {"librccl.so.1", "librccl.so"})
+                       {
+                           lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD); // the instance the communicator came from
+                           if (lib)
+                               return;
+                       }
+                       for (const char* n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+                       {
+                           lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                           if (lib)
+                               return;
+                       }
+                   });
     return lib ? dlsym(lib, name) : nullptr;
 }
 
@@ -293,10 +299,10 @@ int cc_eval_gather_records(void* nccl_comm, int world, int device, const double*
         return CC_ERR_INVALID_ARGUMENT;
     typedef ncclResult_t (*allgather_fn)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t);
     static allgather_fn all_gather = nullptr;
+    static std::once_flag once;
+    std::call_once(once, []() { all_gather = (allgather_fn) rccl_symbol("ncclAllGather"); });
     if (!all_gather)
-        all_gather = (allgather_fn) rccl_symbol("ncclAllGather");
-    if (!all_gather)
-        return CC_ERR_HIP;
+        return CC_ERR_HIP; // (no RCCL in this process)
     if (hipSetDevice(device) != hipSuccess)
         return CC_ERR_NO_DEVICE;
     // fixed-size padded block per rank: row 0 = {number of records}, rows 1 .. capacity = records of 8 doubles (sequence, frame, tp, fn, fp,

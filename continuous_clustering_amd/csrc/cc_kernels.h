@@ -257,6 +257,40 @@ __device__ __forceinline__ double empty_cell_caz(const long long gc, const float
     return ((double) gc + 0.5) * (double) az_width;
 }
 
+// The smallest continuous azimuth over the cells of a column (Planes::colminaz) without a double per cell: cell_caz is monotone in the packed f32
+// inside each of its two classes (this rotation / the previous one), so the minimum over a class is cell_caz of the class's smallest f32 —
+// two 32-bit wave reductions and three f64 operations per column instead of an f64 add and compare per cell and a 64-bit reduction.
+// kpos / kneg: this lane's smallest |packed| bits per class (0x7fffffff: none); any_empty: some cell of the column has no return.
+__device__ __forceinline__ double column_min_caz(const CazBase& b, int kpos, int kneg, const bool any_empty, const long long gc, const float az_width)
+{
+    kpos = wave_min_i32(kpos);
+    kneg = wave_min_i32(kneg);
+    double m = 1.7976931348623157e308;
+    if (kneg != 0x7fffffff)
+        m = b.b1 + (double) __int_as_float(kneg);
+    if (kpos != 0x7fffffff)
+    {
+        const double c = b.b0 + (double) __int_as_float(kpos);
+        m = c < m ? c : m;
+    }
+    if (__any(any_empty))
+    {
+        const double c = empty_cell_caz(gc, az_width);
+        m = c < m ? c : m;
+    }
+    return m;
+}
+// the (class, key) of one cell for column_min_caz
+__device__ __forceinline__ void caz_key(const float packed, int& kpos, int& kneg)
+{
+    const unsigned u = __float_as_uint(packed);
+    const int k = (int) (u & 0x7fffffffu);
+    if (u >> 31)
+        kneg = k < kneg ? k : kneg;
+    else
+        kpos = k < kpos ? k : kpos;
+}
+
 // ---- which pass over the ring a cell belongs to (Planes::gtag). The reference keeps the 64-bit global column index in every cell
 // (Point::global_column_index, cleared to -1: cc.cpp:1110-1119) and compares it with the column being segmented (cc.cpp:320-345). A cell
 // of ring column lc can only ever hold a global column lc + pass * ring_cols, so the pass index says the same in two bytes:
@@ -293,6 +327,7 @@ struct SP
     int32_t* agg_first;
     uint8_t* agg_flag;
     float* curtab;
+    unsigned long long* tab_acc;
     int32_t* par_off;
     cc_event* events;
     int16_t* sc_parent;
@@ -347,6 +382,7 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.agg_flag = P.agg_flag + to;
     p.curtab = P.curtab + (size_t) s * g.num_rows;
     p.par_off = P.par_off + (size_t) s * IP_MAXF;
+    p.tab_acc = P.tab_acc + (size_t) s * (size_t) g.tab_tiles * g.num_rows;
     p.tabc = P.tabc + (size_t) s * (size_t) g.tab_tiles * g.num_rows;
     p.events = P.events + (size_t) s * g.event_capacity;
     p.sc_parent = P.sc_parent + co;
@@ -373,6 +409,126 @@ __device__ __forceinline__ float len2(float a, float b)
 {
     return ccm::sqrt_rn(a * a + b * b);
 }
+
+constexpr int EGO_STRIDE = 16; // doubles per firing in k_ego's output: {R 3x3, t, skip_r2, -}
+
+// ---- the per-cell part of the segmentation of ONE column (everything of cc.cpp:306-403, 567-603 that does not depend on other columns or on
+// the rows below), lanes = rows, cells in registers. Shared by k_seg_pre (cells from the ring) and k_insert_par (cells it has just computed).
+//   x, y, z, dist, incl : the cell (odom frame; dist = incl = NaN without a return), inten its intensity
+//   sp*                 : sgps_sensor_position of the column's job (the finishing firing's pose, cc.cpp:111-113, 291)
+//   E                   : that firing's k_ego record (wave-uniform pointer: scalar loads)
+// Staging for k_seg_scan: x2, uz (the point in the azimuth plane of the job's sensor position), flags (SG_*), and ONE more float w:
+//   cell with a return, inclination step to the row below valid  w = that step (the column's own entry of the table, cc.cpp:353-357: k_seg_scan
+//                                                                  takes the last valid one along the columns), cc.cpp:597-603 decided here
+//   cell with a return, step not valid (SG_PENDING)              w = distance (k_seg_scan evaluates cc.cpp:597-603 once it knows the table)
+//   cell without a return (SG_NAN)                               w = raw inclination of the row below (where the supplement chain of
+//                                                                  cc.cpp:364-369 starts when that row has a return)
+template<int RPL>
+__device__ __forceinline__ void seg_pre_cells(const cc_config& cfg, const int R, const int lane, const float (&cx)[RPL], const float (&cy)[RPL],
+                                              const float (&cz)[RPL], const float (&dist)[RPL], const float (&incl)[RPL], const uint8_t (&inten)[RPL],
+                                              const float spx, const float spy, const float spz, const double* __restrict__ E, float (&x2)[RPL],
+                                              float (&uz)[RPL], float (&w)[RPL], int (&flags)[RPL])
+{
+    // raw inclination of the row below (0 below the last row, cc.cpp:312)
+    float below[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const float nxt0 = (k + 1 < RPL) ? __shfl(incl[(k + 1 < RPL) ? k + 1 : k], 0, 64) : 0.f;
+        const float dn = __shfl_down(incl[k], 1, 64);
+        below[k] = lane == 63 ? nxt0 : dn;
+        if (k * 64 + lane + 1 >= R)
+            below[k] = 0.f;
+    }
+    const float skip_r2 = (float) E[12];
+    bool close = false, need_exact = false;
+    bool incl_ignore[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        flags[k] = SG_NAN;
+        x2[k] = uz[k] = 0.f;
+        w[k] = below[k];
+        incl_ignore[k] = false;
+        if (row >= R)
+            continue;
+        const bool isnan_ = dist[k] != dist[k];
+        if (isnan_)
+            continue;
+        int f = 0;
+        if (cfg.fog_filtering_enabled && inten[k] < (uint8_t) cfg.fog_filtering_intensity_below && dist[k] < cfg.fog_filtering_distance_below &&
+            incl[k] > cfg.fog_filtering_inclination_above)
+            f |= SG_FOG;
+        const float ux = cx[k] - spx, uy = cy[k] - spy;
+        uz[k] = cz[k] - spz;
+        x2[k] = len2(ux, uy);
+        const float r2 = x2[k] * x2[k] + uz[k] * uz[k];
+        if (!(r2 > skip_r2))
+        {
+            f |= SG_EGO; // provisional: "needs the transform"
+            close = true;
+        }
+        if (dist[k] < cfg.max_distance) // (cc.cpp:590: distance < 1. * max_distance in double — both convert exactly, the same comparison)
+            f |= SG_TOO_CLOSE;
+        const float diff = incl[k] - below[k];
+        if (diff != diff)
+        {
+            f |= SG_PENDING;
+            w[k] = dist[k];
+        }
+        else
+        {
+            w[k] = diff;
+            // cc.cpp:597-603: atan2f(max_distance, distance) < inclination step to the next laser. The exact (glibc-identical) atan2f
+            // costs ~100 instructions per wave, and the test can only hold beyond ~100 m: a rigorous filter first. With
+            // x = max_distance / distance >= 1.01 t (0 <= t < 0.05): atan(x) >= x - x^3/3 >= 1.006 t for x <= 0.1, atan(x) > 0.099 > t
+            // otherwise, and atan2f is within an ulp of atan — so the test is false without evaluating it.
+            if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1))
+            {
+                const bool surely_false = cfg.max_distance > 0.f && diff >= 0.f && diff < 0.05f && cfg.max_distance >= 1.01f * dist[k] * diff;
+                incl_ignore[k] = !surely_false; // provisional: "needs the exact evaluation"
+                need_exact |= !surely_false;
+            }
+        }
+        flags[k] = f;
+    }
+    if (__any(need_exact))
+    {
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+            if (incl_ignore[k])
+                incl_ignore[k] = ccm::atan2f_exact(cfg.max_distance, dist[k]) < w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+        if (incl_ignore[k])
+            flags[k] |= SG_INCL_IGNORE;
+    if (__any(close))
+    {
+        // ego_robot_frame_from_odom_frame * point (cc.cpp:390-403), Eigen's evaluation order
+        double er[9], et[3];
+        for (int i = 0; i < 9; i++)
+            er[i] = E[i];
+        for (int i = 0; i < 3; i++)
+            et[i] = E[9 + i];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            if (!(flags[k] & SG_EGO) || (flags[k] & SG_NAN))
+                continue;
+            const double dx = cx[k], dy = cy[k], dz = cz[k];
+            const double ex = ((er[0] * dx + er[1] * dy) + er[2] * dz) + et[0];
+            const double ey = ((er[3] * dx + er[4] * dy) + er[5] * dz) + et[1];
+            const double ez = ((er[6] * dx + er[7] * dy) + er[8] * dz) + et[2];
+            const bool in_box = ex < cfg.length_ref_to_front_end_ && ex > cfg.length_ref_to_rear_end_ && ey < cfg.width_ref_to_left_mirror_ &&
+                                ey > cfg.width_ref_to_right_mirror_ && ez < cfg.height_ref_to_maximum_ && ez > cfg.height_ref_to_ground_;
+            if (!in_box)
+                flags[k] &= ~SG_EGO;
+        }
+    }
+}
+
 
 // =====================================================================================================
 // k_prep — the per-point part of insertFiringIntoRangeImage (cc.cpp:127-151, 189, 224-232): rigid transform, range,
@@ -1174,7 +1330,8 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
         st->batch[slot].acp_next = seg_begin;
         st->batch[slot].pub_begin = -1;
         st->batch[slot].pub_end = -1;
-        st->batch[slot].fused = 0;
+        if (cursor0 < n)
+            st->batch[slot].fused = 0; // (nothing left for this kernel: the batch is k_insert_par's, and so is the flag)
         st->cursor = f;
         st->pre_seg_begin = 0;
         st->firings_consumed = (unsigned long long) (seq0 + (f - cursor0));
@@ -1184,6 +1341,138 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     negative_cols = (unsigned long long) wave_max_i64((long long) negative_cols);
     if (lane == 0 && negative_cols)
         st->error_b += (long long) negative_cols;
+}
+
+// ---- pieces shared by k_insert_par and k_insert_par_fin ---------------------------------------------------------------------------
+// take back what firings behind the first offending one have written: every cell of the columns (rel_from .. rel_to past prev_rear0) returns
+// to the cleared state (clearColumns' three planes: all the serial kernel looks at). Whole columns: with the fused segmentation cells without
+// a return carry the ring-pass tag as well.
+template<int RPL>
+__device__ __forceinline__ void par_take_back(const SP& p, const int R, const int RC, const int lc0, const int rel_from, const int rel_to, const int wave,
+                                              const int nwaves, const int lane)
+{
+    for (int rel = rel_from + wave; rel <= rel_to; rel += nwaves)
+    {
+        const int lc = (int) ((unsigned) (lc0 + rel) % (unsigned) RC);
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row < R)
+            {
+                const size_t ci = (size_t) lc * R + row;
+                p.dist[ci] = __builtin_nanf("");
+                p.incl[ci] = __builtin_nanf("");
+                p.gtag[ci] = CELL_CLEARED;
+            }
+        }
+    }
+}
+
+// the stream's state behind a run of `done` firings (one thread); returns whether the batch is closed as FUSED
+__device__ __forceinline__ int par_close_stream(StreamState* st, const int slot, int* left_over, const bool fuse, const bool whole, const int done,
+                                                const long long n, const long long prev_rear0, const long long first_unf0, const long long ring_end0,
+                                                const long long seq0, const long long rel_last)
+{
+    (void) n;
+    int fused = 0;
+    if (done > 0)
+    {
+        const long long G = prev_rear0 + rel_last;
+        st->prev_rearmost = G;
+        st->prev_foremost = G;
+        st->first_unfinished = G;
+        if (G > ring_end0)
+            st->ring_end = G;
+        st->cursor = done;
+        st->firings_consumed = (unsigned long long) (seq0 + done);
+        st->pre_seg_begin = first_unf0;
+    }
+    // left_over (the engine's "skip_idle_fallbacks"): the host launches the other insertion kernels of this batch only if some stream
+    // needs them. A stream whose whole batch went through here closes its batch descriptor itself, exactly as k_insert2 would with
+    // nothing left to do (its columns [first_unf0, G) were emitted, cursor = n).
+    if (left_over)
+    {
+        if (whole)
+        {
+            const long long G = prev_rear0 + rel_last;
+            fused = fuse && ld_agent(&st->error) == 0 ? 1 : 0;
+            st->batch[slot].seg_begin = first_unf0;
+            st->batch[slot].seg_end = G;
+            st->batch[slot].acp_next = first_unf0;
+            st->batch[slot].pub_begin = -1;
+            st->batch[slot].pub_end = -1;
+            st->batch[slot].fused = fused;
+            if (fused)
+                st->batch[slot].mode = st->assoc_mode; // (what k_table does first for the streams it sees)
+            // (pre_seg_begin stays: if another stream makes the host launch the other insertion kernels after all, k_insert2 finds
+            // nothing left for this stream and leaves the descriptor alone; k_begin_batch clears it for the next batch)
+            if (!fused)
+                atomicAdd(left_over + 1, 1); // streams whose batch still needs k_table / k_seg_pre
+        }
+        else
+        {
+            atomicAdd(left_over, 1);
+            atomicAdd(left_over + 1, 1);
+        }
+    }
+    return fused;
+}
+
+// k_table's phase 2 from the partials the wavefronts of the fused insertion left in Planes::tab_acc (one wavefront, lanes = rows): the tiles'
+// entries become the table in front of each tile (Planes::tabc) and the stream's table moves on — or, when the batch is not closed as fused,
+// the partials are only wiped (k_table will read the columns from the ring). `touched` tiles may hold partials, `ntiles` are the batch's.
+template<int RPL>
+__device__ __forceinline__ void table_from_partials(const SP& p, const int R, const bool fused, const int touched, const int ntiles, const int lane)
+{
+    float carry[RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        carry[k] = (fused && row < R) ? p.curtab[row] : 0.f;
+    }
+    constexpr int U = 8;
+    for (int t0 = 0; t0 < touched; t0 += U)
+    {
+        unsigned long long v[U][RPL];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                v[u][k] = (row < R && t0 + u < touched) ? p.tab_acc[(size_t) (t0 + u) * R + row] : 0ull;
+            }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R && t0 + u < touched)
+                {
+                    if (v[u][k])
+                        p.tab_acc[(size_t) (t0 + u) * R + row] = 0ull;
+                    if (fused && t0 + u < ntiles)
+                    {
+                        p.tabc[(size_t) (t0 + u) * R + row] = carry[k];
+                        if (v[u][k] >> 32)
+                            carry[k] = __uint_as_float((unsigned) v[u][k]);
+                    }
+                }
+            }
+    }
+    if (fused)
+    {
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row < R)
+                p.curtab[row] = carry[k];
+        }
+    }
 }
 
 // =====================================================================================================
@@ -1220,7 +1509,7 @@ template<int RPL, int W = IP_WAVES>
 __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
                                                             const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
                                                             const double* __restrict__ poses, long long n, long long n_total, long long fbase,
-                                                            int slot, int* __restrict__ left_over)
+                                                            int slot, int* __restrict__ left_over, const double* __restrict__ ego)
 {
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
@@ -1230,6 +1519,13 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
+    // FUSED SEGMENTATION (round 4): a firing of the run fills its column alone and the next firing finishes it, so the wavefront that has the
+    // column's cells in registers also does the per-cell part of its ground segmentation (seg_pre_cells: what k_seg_pre would read back from
+    // the ring) with the NEXT firing's pose (the job's pose, cc.cpp:291) and leaves each tile's last valid inclination step (k_table's phase 1)
+    // in Planes::tab_acc. When the whole batch is taken that way the batch descriptor says so (BatchDesc::fused) and neither k_table nor
+    // k_seg_pre has anything to do for the stream; otherwise they redo the batch's columns from the ring as before (everything written here
+    // is what they would write, or is overwritten by them). Needs the gate (left_over) and the per-firing records of k_ego.
+    const bool fuse = left_over != nullptr && ego != nullptr && st->has_robot_tf != 0;
     __shared__ short s_c[IP_MAXF]; // column-in-rotation of every firing (its first valid return), -1 = empty firing (or a column index above 32767: the
                                    // run ends there and the serial kernel takes over — 9 KB less LDS for a block that has to find room next to the other chains)
     __shared__ unsigned short s_off[IP_MAXF]; // G_f - prev_rearmost at entry (a firing more than 65535 columns ahead of it ends the run)
@@ -1288,7 +1584,10 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
         {
             st->clear_done = clear_done;
             if (left_over)
+            {
                 atomicAdd(left_over, 1); // the other insertion kernels have to take this stream's batch
+                atomicAdd(left_over + 1, 1); // ... and k_table / k_seg_pre its segmentation
+            }
             st->par_upto = -1;
         }
         return;
@@ -1375,10 +1674,12 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     // the current one is worked on.
     float nx_x[RPL], nx_y[RPL], nx_z[RPL];
     uint8_t nx_i[RPL];
-    double nx_pose = 0.;
+    double nx_pose = 0., nx_trig = 0.; // (nx_trig: translation of the NEXT firing's pose in lanes 0 - 2 = sgps_sensor_position of this column's job)
     auto load_firing = [&](const int f)
     {
         const size_t fi = fglob + (size_t) f;
+        if (fuse && f + 1 < upto)
+            nx_trig = poses[(fi + 1) * 12 + (size_t) (3 + 4 * (lane < 3 ? lane : 0))];
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -1398,6 +1699,187 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
             nx_pose = poses[fi * 12 + (size_t) (lane < 12 ? lane : 0)];
     };
     const int fstep = W * nby;
+    // ---- fused segmentation: per-wavefront partial of k_table's phase 1 (a wavefront's columns increase: the last valid step it has seen in the
+    // tile it is in; flushed into Planes::tab_acc with an atomic max on (column, step) when it moves on to another tile)
+    float tl_val[RPL];
+    int tl_col[RPL], tl_tile = -1;
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        tl_val[k] = 0.f;
+        tl_col[k] = 0;
+    }
+    auto tl_flush = [&]()
+    {
+        if (tl_tile >= 0)
+        {
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                if (row < R && tl_col[k] > 0)
+                    atomicMax(&p.tab_acc[(size_t) tl_tile * R + row], ((unsigned long long) (unsigned) tl_col[k] << 32) | (unsigned long long) __float_as_uint(tl_val[k]));
+                tl_col[k] = 0;
+            }
+        }
+    };
+    // staging of one segmented column (column `rel` columns past prev_rear0): the per-cell results, the ring-pass tag and a record for EVERY cell
+    // (cells without a return: the NaN record k_seg_scan completes with the supplemented inclination), the column's entries, its table partial
+    const float rcp_rc = 1.0f / (float) RC, rcp_nc = 1.0f / (float) NC;
+    // x / d for x < 2^17 (columns past prev_rear0 plus a ring / rotation offset): float estimate, corrected — a hardware-free 32-bit division
+    // costs ~25 instructions, and two of them per firing were 6 % of this kernel
+    auto div_small = [](const int x, const int d, const float rcp, int& rem) -> int
+    {
+        int q = (int) ((float) x * rcp);
+        int r = x - q * d;
+        if (r < 0)
+        {
+            q--;
+            r += d;
+        }
+        else if (r >= d)
+        {
+            q++;
+            r -= d;
+        }
+        rem = r;
+        return q;
+    };
+    CazBase cbw = caz_base_of_rotation(rot0);
+    int cbw_rot = 0; // rotations past rot0 the cached base belongs to
+    auto stage_column = [&](const int rel, const float (&x2)[RPL], const float (&uz)[RPL], const float (&w)[RPL], const int (&flags)[RPL],
+                            const float (&incaz)[RPL], const bool write_empty_cells)
+    {
+        int lc;
+        const int lcq = div_small(lc0 + rel, RC, rcp_rc, lc);
+        const uint16_t tag = cell_tag(pass0 + (long long) lcq);
+        const long long G = prev_rear0 + rel;
+        int cirg;
+        const int rq = div_small(cir0 + rel, NC, rcp_nc, cirg);
+        if (rq != cbw_rot) // (wave-uniform; once per rotation)
+        {
+            cbw = caz_base_of_rotation(rot0 + (long long) rq);
+            cbw_rot = rq;
+        }
+        const int tile = rel >> 6;
+        if (tile != tl_tile)
+        {
+            tl_flush();
+            tl_tile = tile;
+        }
+        int kpos = 0x7fffffff, kneg = 0x7fffffff;
+        bool any_empty = false;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row >= R)
+                continue;
+            const size_t ci = (size_t) lc * R + row;
+            p.sg_x2[ci] = x2[k];
+            p.sg_uz[ci] = uz[k];
+            p.sg_w[ci] = w[k];
+            p.sg_flags[ci] = (uint8_t) flags[k];
+            if ((flags[k] & SG_NAN) && write_empty_cells)
+            {
+                p.gtag[ci] = tag;
+                p.sc_rec[ci] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+            }
+            if (flags[k] & SG_NAN)
+                any_empty = true;
+            else
+                caz_key(incaz[k], kpos, kneg);
+            if (!(flags[k] & (SG_NAN | SG_PENDING)))
+            {
+                tl_val[k] = w[k];
+                tl_col[k] = rel + 1;
+            }
+        }
+        const double min_az = column_min_caz(cbw, kpos, kneg, any_empty, G, g.az_width);
+        if (lane == 0)
+        {
+            p.colg[lc] = G;
+            p.colminaz[lc] = min_az;
+        }
+    };
+    // the columns (from, to) past prev_rear0 that no firing fills (the sensor skipped them): segmented as columns without returns
+    auto stage_gap = [&](const int from, const int to)
+    {
+        for (int rel = from; rel < to; rel++)
+        {
+            float x2[RPL], uz[RPL], w[RPL], az[RPL];
+            int flags[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                x2[k] = uz[k] = az[k] = 0.f;
+                w[k] = __builtin_nanf("");
+                flags[k] = SG_NAN;
+            }
+            stage_column(rel, x2, uz, w, flags, az, true);
+        }
+    };
+    if (fuse && by == 0 && wave == 0 && upto > 0)
+    {
+        // the column the previous batch left open (prev_rear0 = first_unf0, cells in the ring) is finished by this batch's first firing
+        const uint16_t tag = cell_tag(pass0);
+        float cx[RPL], cy[RPL], cz[RPL], dist[RPL], incl[RPL], az[RPL];
+        uint8_t it[RPL];
+        bool overrun = false;
+        int overrun_row = -1;
+        long long overrun_gcol = -1;
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            cx[k] = cy[k] = cz[k] = az[k] = 0.f;
+            dist[k] = incl[k] = __builtin_nanf("");
+            it[k] = 0;
+            if (row < R)
+            {
+                const size_t ci = (size_t) lc0 * R + row;
+                const uint16_t tg = p.gtag[ci];
+                dist[k] = p.dist[ci];
+                if (tg == tag)
+                {
+                    const float4 r4 = p.sc_rec[ci];
+                    cx[k] = r4.x, cy[k] = r4.y, cz[k] = r4.z, incl[k] = r4.w;
+                    az[k] = p.incaz[ci];
+                    it[k] = p.inten[ci];
+                }
+                else if (tg != CELL_CLEARED)
+                {
+                    overrun = true; // cc.cpp:320-345 (as in k_seg_pre)
+                    overrun_row = row;
+                    overrun_gcol = prev_rear0 - (long long) ((((unsigned) tag - (unsigned) tg) & 0x7fffu)) * RC;
+                }
+                else
+                {
+                    p.gtag[ci] = tag; // (as the segmentation tags a cell without a return, cc.cpp:348-351 — with the record such a cell has)
+                    p.sc_rec[ci] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                }
+            }
+        }
+        if (__any(overrun))
+        {
+            const int worst = -wave_min_i32(-overrun_row);
+            if (overrun_row == worst)
+            {
+                atomicMin((unsigned long long*) &st->overrun_col, (unsigned long long) prev_rear0);
+                raise_error(st, CC_ERR_RING_OVERRUN, overrun_gcol, prev_rear0);
+            }
+        }
+        else
+        {
+            const double* T0 = poses + fglob * 12;
+            const double* E0 = ego + ((size_t) sl * (size_t) n) * EGO_STRIDE;
+            float x2[RPL], uz[RPL], w[RPL];
+            int flags[RPL];
+            seg_pre_cells<RPL>(cfg, R, lane, cx, cy, cz, dist, incl, it, (float) T0[3], (float) T0[7], (float) T0[11], E0, x2, uz, w, flags);
+            stage_column(0, x2, uz, w, flags, az, false);
+        }
+        stage_gap(1, (int) s_off[0]);
+    }
     if (wave + W * by < upto)
         load_firing(wave + W * by);
     for (int f = wave + W * by; f < upto; f += fstep)
@@ -1416,6 +1898,7 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
 #pragma unroll
         for (int i = 0; i < 12; i++)
             T[i] = lane_f64(nx_pose, i);
+        const float spx = (float) lane_f64(nx_trig, 0), spy = (float) lane_f64(nx_trig, 1), spz = (float) lane_f64(nx_trig, 2);
         load_firing(f + fstep);
         if (f > lds_ld(&s_bad)) // some earlier firing left the shape: nothing behind it is wanted (wave-uniform)
             break;
@@ -1441,30 +1924,64 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
         const long long rel = s_off[f];                    // G_f - prev_rear0
         const long long rel_prev = f > 0 ? s_off[f - 1] : 0; // G_(f-1) - prev_rear0
         const long long G = prev_rear0 + rel;
-        const unsigned lcq = (unsigned) (lc0 + (int) rel) / (unsigned) RC; // (one division: quotient = passes over the ring since lc0)
-        const int lc = (int) ((unsigned) (lc0 + (int) rel) - lcq * (unsigned) RC);
+        int lc;
+        const int lcq = div_small(lc0 + (int) rel, RC, rcp_rc, lc); // (quotient = passes over the ring since lc0)
         const uint16_t tag = cell_tag(pass0 + (long long) lcq);
+        const bool seg_here = fuse && f + 1 < upto; // (the run's last firing leaves its column open: nobody has finished it yet)
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
             const int row = k * 64 + lane;
-            if (q[k].cir != PP_SKIP)
+            const size_t ci = (size_t) lc * R + row;
+            const bool has = q[k].cir != PP_SKIP;
+            // a cell without a return of a column segmented here is tagged like the segmentation tags it (cc.cpp:348-351) and gets the record of a
+            // cell without a return (k_seg_scan completes it with the supplemented inclination): one store each for all the column's cells
+            if (has | (seg_here & (row < R)))
             {
-                const size_t ci = (size_t) lc * R + row;
-                p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
+                const float nn = __builtin_nanf("");
+                p.sc_rec[ci] = make_float4(has ? q[k].x : nn, has ? q[k].y : nn, has ? q[k].z : nn, has ? q[k].incl : nn);
+                p.gtag[ci] = tag;
+            }
+            if (has)
+            {
                 p.inten[ci] = cint[k];
                 p.src[ci] = (uint32_t) (seq0 + f);
                 p.dist[ci] = q[k].dist;
                 p.incl[ci] = q[k].incl;
                 p.incaz[ci] = q[k].incaz; // (c0 < num_columns and nothing moves on: the return's rotation is its column's)
-                p.gtag[ci] = tag;
             }
         }
         // columns [G_(f-1), G_f) are finished by this firing and carry its pose (cc.cpp:289-291)
         const int cnt = (int) (rel - rel_prev);
         for (int jj = lane; jj < cnt; jj += 64)
-            p.trig[(int) ((unsigned) (lc0 + (int) rel_prev + jj) % (unsigned) RC)] = f;
+        {
+            int tlc;
+            (void) div_small(lc0 + (int) rel_prev + jj, RC, rcp_rc, tlc);
+            p.trig[tlc] = f;
+        }
+        if (seg_here)
+        {
+            // the per-cell part of this column's ground segmentation; its job carries the NEXT firing's pose
+            float sx[RPL], sy[RPL], sz[RPL], sd[RPL], si_[RPL], saz[RPL], x2[RPL], uz[RPL], w[RPL];
+            int flags[RPL];
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const bool has = q[k].cir != PP_SKIP;
+                sx[k] = q[k].x, sy[k] = q[k].y, sz[k] = q[k].z, saz[k] = q[k].incaz;
+                sd[k] = has ? q[k].dist : __builtin_nanf("");
+                si_[k] = has ? q[k].incl : __builtin_nanf("");
+            }
+            // (f is wave-uniform, but only readfirstlane tells the compiler: the record then arrives by SCALAR loads — as vector loads its first
+            // word cost an s_waitcnt vmcnt(0) per firing, i.e. a wait for every store of the previous firing)
+            const double* E = ego + ((size_t) sl * (size_t) n + (size_t) (uniform_i32(f) + 1)) * EGO_STRIDE;
+            seg_pre_cells<RPL>(cfg, R, lane, sx, sy, sz, sd, si_, cint, spx, spy, spz, E, x2, uz, w, flags);
+            stage_column((int) rel, x2, uz, w, flags, saz, false);
+            stage_gap((int) rel + 1, (int) s_off[f + 1]);
+        }
     }
+    if (fuse)
+        tl_flush();
     __syncthreads();
     if (nby > 1)
     {
@@ -1480,38 +1997,19 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
                 st->par_upto = upto;
                 st->par_clear_done = clear_done;
                 if (upto == 0 && left_over)
+                {
                     atomicAdd(left_over, 1); // (nothing taken: k_insert_par_fin has nothing to do either)
+                    atomicAdd(left_over + 1, 1);
+                }
             }
         }
         return;
     }
     const int done = s_bad < upto ? s_bad : upto;
     if (done < upto)
-    {
-        // take back what firings behind the offending one have written: their cells return to the cleared state (clearColumns'
-        // three planes); cells they never wrote are in that state already
-        for (int f = done + 1 + wave; f < upto; f += W)
-        {
-            const size_t fi = fglob + (size_t) f;
-            const int lc = (int) ((unsigned) (lc0 + s_off[f]) % (unsigned) RC);
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (row < R)
-                {
-                    const float fx = xyz[(fi * R + row) * 3];
-                    if (fx == fx)
-                    {
-                        const size_t ci = (size_t) lc * R + row;
-                        p.dist[ci] = __builtin_nanf("");
-                        p.incl[ci] = __builtin_nanf("");
-                        p.gtag[ci] = CELL_CLEARED;
-                    }
-                }
-            }
-        }
-    }
+        par_take_back<RPL>(p, R, RC, lc0, (int) s_off[done], (int) s_off[upto - 1], wave, W, lane);
+    const bool whole = done == (int) n && done > 0;
+    __shared__ int s_fused;
     if (tid == 0)
     {
         st->clear_done = clear_done;
@@ -1519,47 +2017,23 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
         st->dbg[6] += (unsigned long long) done; // firings taken by this kernel / batches it saw (cc_engine_debug_counters)
         st->dbg[7] += 1;
 #endif
-        if (done > 0)
-        {
-            const long long G = prev_rear0 + s_off[done - 1];
-            st->prev_rearmost = G;
-            st->prev_foremost = G;
-            st->first_unfinished = G;
-            if (G > ring_end0)
-                st->ring_end = G;
-            st->cursor = done;
-            st->firings_consumed = (unsigned long long) (seq0 + done);
-            st->pre_seg_begin = first_unf0;
-        }
-        // left_over (the engine's "skip_idle_fallbacks"): the host launches the other insertion kernels of this batch only if some stream
-        // needs them. A stream whose whole batch went through here closes its batch descriptor itself, exactly as k_insert2 would with
-        // nothing left to do (its columns [first_unf0, G) were emitted, cursor = n).
-        if (left_over)
-        {
-            if (done == (int) n && done > 0)
-            {
-                const long long G = prev_rear0 + s_off[done - 1];
-                st->batch[slot].seg_begin = first_unf0;
-                st->batch[slot].seg_end = G;
-                st->batch[slot].acp_next = first_unf0;
-                st->batch[slot].pub_begin = -1;
-                st->batch[slot].pub_end = -1;
-                st->batch[slot].fused = 0;
-                // (pre_seg_begin stays: if another stream makes the host launch the other insertion kernels after all, k_insert2 finds
-                // nothing left for this stream and writes the same descriptor again; k_begin_batch clears it for the next batch)
-            }
-            else
-                atomicAdd(left_over, 1);
-        }
+        s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0,
+                                   done > 0 ? (long long) s_off[done - 1] : 0);
     }
+    __syncthreads(); // (also: every wavefront's table partials have reached Planes::tab_acc)
+    if (fuse && wave == 0 && upto > 0)
+        table_from_partials<RPL>(p, R, s_fused != 0, ((int) s_off[upto - 1] >> 6) + 1, s_fused ? (int) ((s_off[done - 1] + 63) >> 6) : 0, lane);
 }
 
 // k_insert_par_fin — what one block of k_insert_par does behind its phase D, for launches that dealt a stream's firings to several blocks: take back
-// what firings behind the first offending one have written, then the stream state (and, with left_over, the batch descriptor). grid = streams, block = 256.
+// what lies behind the first offending firing, then the stream state, the batch descriptor and (fused segmentation) the table. grid = streams, block = 256.
 template<int RPL>
 __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, StreamState* states, int first_stream, const float* __restrict__ xyz,
-                                                        long long n, long long n_total, long long fbase, int slot, int* __restrict__ left_over)
+                                                        long long n, long long n_total, long long fbase, int slot, int* __restrict__ left_over, int fuse_on)
 {
+    (void) xyz;
+    (void) n_total;
+    (void) fbase;
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
     const int lane = lane_id(), wave = threadIdx.x >> 6, tid = threadIdx.x;
@@ -1573,35 +2047,17 @@ __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, St
             st->clear_done = st->par_clear_done;
         return; // (not steady, or nothing taken: block 0 of k_insert_par has counted the stream as left over)
     }
+    const bool fuse = fuse_on != 0 && left_over != nullptr && st->has_robot_tf != 0;
     const int bad = st->par_bad;
     const int done = bad < upto ? bad : upto;
     const long long prev_rear0 = st->prev_rearmost, first_unf0 = st->first_unfinished, ring_end0 = st->ring_end;
     const int lc0 = (int) (prev_rear0 % RC);
-    const size_t fglob = (size_t) sl * (size_t) n_total + (size_t) fbase;
     const long long seq0 = (long long) st->firings_consumed;
     if (done < upto)
-        for (int f = done + 1 + wave; f < upto; f += 4)
-        {
-            const size_t fi = fglob + (size_t) f;
-            const int lc = (int) ((unsigned) (lc0 + p.par_off[f]) % (unsigned) RC);
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int row = k * 64 + lane;
-                if (row < R)
-                {
-                    const float fx = xyz[(fi * R + row) * 3];
-                    if (fx == fx)
-                    {
-                        const size_t ci = (size_t) lc * R + row;
-                        p.dist[ci] = __builtin_nanf("");
-                        p.incl[ci] = __builtin_nanf("");
-                        p.gtag[ci] = CELL_CLEARED;
-                    }
-                }
-            }
-        }
-    __syncthreads();
+        par_take_back<RPL>(p, R, RC, lc0, p.par_off[done], p.par_off[upto - 1], wave, 4, lane);
+    const bool whole = done == (int) n && done > 0;
+    __shared__ int s_fused;
+    __syncthreads(); // (everybody has read the state thread 0 is about to replace)
     if (tid == 0)
     {
         st->clear_done = st->par_clear_done;
@@ -1609,34 +2065,11 @@ __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, St
         st->dbg[6] += (unsigned long long) done;
         st->dbg[7] += 1;
 #endif
-        if (done > 0)
-        {
-            const long long G = prev_rear0 + p.par_off[done - 1];
-            st->prev_rearmost = G;
-            st->prev_foremost = G;
-            st->first_unfinished = G;
-            if (G > ring_end0)
-                st->ring_end = G;
-            st->cursor = done;
-            st->firings_consumed = (unsigned long long) (seq0 + done);
-            st->pre_seg_begin = first_unf0;
-        }
-        if (left_over)
-        {
-            if (done == (int) n && done > 0)
-            {
-                const long long G = prev_rear0 + p.par_off[done - 1];
-                st->batch[slot].seg_begin = first_unf0;
-                st->batch[slot].seg_end = G;
-                st->batch[slot].acp_next = first_unf0;
-                st->batch[slot].pub_begin = -1;
-                st->batch[slot].pub_end = -1;
-                st->batch[slot].fused = 0;
-            }
-            else
-                atomicAdd(left_over, 1);
-        }
+        s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0, done > 0 ? (long long) p.par_off[done - 1] : 0);
     }
+    __syncthreads();
+    if (fuse && wave == 0)
+        table_from_partials<RPL>(p, R, s_fused != 0, (p.par_off[upto - 1] >> 6) + 1, s_fused ? ((p.par_off[done - 1] + 63) >> 6) : 0, lane);
 }
 
 // =====================================================================================================
@@ -2173,7 +2606,6 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
 // box's farthest corner, hence sigma_min(M) |p - t_T| - |A_t| < B. skip_r2 is a rigorous upper bound of the squared f32 distance (as the
 // segmentation computes it: x2 * x2 + uz * uz, relative to this firing's sensor position) up to which a hit is possible; +inf when the rotation
 // blocks are too far from orthonormal to say. Cells beyond it skip the transform; the others evaluate it exactly as before.
-constexpr int EGO_STRIDE = 16;
 __global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ states, int first_stream, cc_config cfg, const double* __restrict__ poses,
                                              long long n, long long n_total, long long fbase, double* __restrict__ out)
 {
@@ -2233,123 +2665,6 @@ __global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ sta
         skip = r2f == r2f ? (double) r2f : __builtin_inf();
     }
     o[12] = skip;
-}
-
-// ---- the per-cell part of the segmentation of ONE column (everything of cc.cpp:306-403, 567-603 that does not depend on other columns or on
-// the rows below), lanes = rows, cells in registers. Shared by k_seg_pre (cells from the ring) and k_insert_par (cells it has just computed).
-//   x, y, z, dist, incl : the cell (odom frame; dist = incl = NaN without a return), inten its intensity
-//   sp*                 : sgps_sensor_position of the column's job (the finishing firing's pose, cc.cpp:111-113, 291)
-//   E                   : that firing's k_ego record (wave-uniform pointer: scalar loads)
-// Staging for k_seg_scan: x2, uz (the point in the azimuth plane of the job's sensor position), flags (SG_*), and ONE more float w:
-//   cell with a return, inclination step to the row below valid  w = that step (the column's own entry of the table, cc.cpp:353-357: k_seg_scan
-//                                                                  takes the last valid one along the columns), cc.cpp:597-603 decided here
-//   cell with a return, step not valid (SG_PENDING)              w = distance (k_seg_scan evaluates cc.cpp:597-603 once it knows the table)
-//   cell without a return (SG_NAN)                               w = raw inclination of the row below (where the supplement chain of
-//                                                                  cc.cpp:364-369 starts when that row has a return)
-template<int RPL>
-__device__ __forceinline__ void seg_pre_cells(const cc_config& cfg, const int R, const int lane, const float (&cx)[RPL], const float (&cy)[RPL],
-                                              const float (&cz)[RPL], const float (&dist)[RPL], const float (&incl)[RPL], const uint8_t (&inten)[RPL],
-                                              const float spx, const float spy, const float spz, const double* __restrict__ E, float (&x2)[RPL],
-                                              float (&uz)[RPL], float (&w)[RPL], int (&flags)[RPL])
-{
-    // raw inclination of the row below (0 below the last row, cc.cpp:312)
-    float below[RPL];
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        const float nxt0 = (k + 1 < RPL) ? __shfl(incl[(k + 1 < RPL) ? k + 1 : k], 0, 64) : 0.f;
-        const float dn = __shfl_down(incl[k], 1, 64);
-        below[k] = lane == 63 ? nxt0 : dn;
-        if (k * 64 + lane + 1 >= R)
-            below[k] = 0.f;
-    }
-    const float skip_r2 = (float) E[12];
-    bool close = false, need_exact = false;
-    bool incl_ignore[RPL];
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-    {
-        const int row = k * 64 + lane;
-        flags[k] = SG_NAN;
-        x2[k] = uz[k] = 0.f;
-        w[k] = below[k];
-        incl_ignore[k] = false;
-        if (row >= R)
-            continue;
-        const bool isnan_ = dist[k] != dist[k];
-        if (isnan_)
-            continue;
-        int f = 0;
-        if (cfg.fog_filtering_enabled && inten[k] < (uint8_t) cfg.fog_filtering_intensity_below && dist[k] < cfg.fog_filtering_distance_below &&
-            incl[k] > cfg.fog_filtering_inclination_above)
-            f |= SG_FOG;
-        const float ux = cx[k] - spx, uy = cy[k] - spy;
-        uz[k] = cz[k] - spz;
-        x2[k] = len2(ux, uy);
-        const float r2 = x2[k] * x2[k] + uz[k] * uz[k];
-        if (!(r2 > skip_r2))
-        {
-            f |= SG_EGO; // provisional: "needs the transform"
-            close = true;
-        }
-        if ((double) dist[k] < 1. * (double) cfg.max_distance)
-            f |= SG_TOO_CLOSE;
-        const float diff = incl[k] - below[k];
-        if (diff != diff)
-        {
-            f |= SG_PENDING;
-            w[k] = dist[k];
-        }
-        else
-        {
-            w[k] = diff;
-            // cc.cpp:597-603: atan2f(max_distance, distance) < inclination step to the next laser. The exact (glibc-identical) atan2f
-            // costs ~100 instructions per wave, and the test can only hold beyond ~100 m: a rigorous filter first. With
-            // x = max_distance / distance >= 1.01 t (0 <= t < 0.05): atan(x) >= x - x^3/3 >= 1.006 t for x <= 0.1, atan(x) > 0.099 > t
-            // otherwise, and atan2f is within an ulp of atan — so the test is false without evaluating it.
-            if (cfg.ignore_points_with_too_big_inclination_angle_diff && row < (R - 1))
-            {
-                const bool surely_false = cfg.max_distance > 0.f && diff >= 0.f && diff < 0.05f && cfg.max_distance >= 1.01f * dist[k] * diff;
-                incl_ignore[k] = !surely_false; // provisional: "needs the exact evaluation"
-                need_exact |= !surely_false;
-            }
-        }
-        flags[k] = f;
-    }
-    if (__any(need_exact))
-    {
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-            if (incl_ignore[k])
-                incl_ignore[k] = ccm::atan2f_exact(cfg.max_distance, dist[k]) < w[k];
-    }
-#pragma unroll
-    for (int k = 0; k < RPL; k++)
-        if (incl_ignore[k])
-            flags[k] |= SG_INCL_IGNORE;
-    if (__any(close))
-    {
-        // ego_robot_frame_from_odom_frame * point (cc.cpp:390-403), Eigen's evaluation order
-        double er[9], et[3];
-        for (int i = 0; i < 9; i++)
-            er[i] = E[i];
-        for (int i = 0; i < 3; i++)
-            et[i] = E[9 + i];
-#pragma unroll
-        for (int k = 0; k < RPL; k++)
-        {
-            if (!(flags[k] & SG_EGO) || (flags[k] & SG_NAN))
-                continue;
-            const double dx = cx[k], dy = cy[k], dz = cz[k];
-            const double ex = ((er[0] * dx + er[1] * dy) + er[2] * dz) + et[0];
-            const double ey = ((er[3] * dx + er[4] * dy) + er[5] * dz) + et[1];
-            const double ez = ((er[6] * dx + er[7] * dy) + er[8] * dz) + et[2];
-            const bool in_box = ex < cfg.length_ref_to_front_end_ && ex > cfg.length_ref_to_rear_end_ && ey < cfg.width_ref_to_left_mirror_ &&
-                                ey > cfg.width_ref_to_right_mirror_ && ez < cfg.height_ref_to_maximum_ && ez > cfg.height_ref_to_ground_;
-            if (!in_box)
-                flags[k] &= ~SG_EGO;
-        }
-    }
 }
 
 // ---- k_seg_pre: the per-cell part for columns whose cells come from the ring (everything the fused insertion did not take). Lanes = rows
@@ -2507,7 +2822,8 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
         float x2[RPL], uz[RPL], w[RPL];
         int flags[RPL];
         seg_pre_cells<RPL>(cfg, R, lane, cx, cy, cz, dist, incl, n_inten, spx, spy, spz, E, x2, uz, w, flags);
-        double min_az = 1.7976931348623157e308;
+        int kpos = 0x7fffffff, kneg = 0x7fffffff;
+        bool any_empty = false;
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -2518,15 +2834,16 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
             if (empty_cell[k])
                 p.gtag[ci] = tag; // cells that received a return already carry it (insertion kernels)
             // (continuous azimuth of a cell without a return: cc.cpp:371-372 — not stored: every reader knows the cell's column)
-            const double caz = (flags[k] & SG_NAN) ? empty_cell_caz(gc, g.az_width) : cell_caz(cb, n_incaz[k]);
-            if (caz < min_az)
-                min_az = caz;
+            if (flags[k] & SG_NAN)
+                any_empty = true;
+            else
+                caz_key(n_incaz[k], kpos, kneg);
             p.sg_x2[ci] = x2[k];
             p.sg_uz[ci] = uz[k];
             p.sg_w[ci] = w[k];
             p.sg_flags[ci] = (uint8_t) flags[k];
         }
-        min_az = wave_min_f64(min_az);
+        const double min_az = column_min_caz(cb, kpos, kneg, any_empty, gc, g.az_width);
         if (lane == 0)
         {
             p.colg[lc] = gc;
@@ -2628,114 +2945,79 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
         float pv2x = 0.f, pvz = 0.f;
         unsigned char previous_label = 0;
         // one row of the state machine: f = the cell's flags (k_seg_pre), (cur2x, cur2y) = the point in the azimuth plane;
-        // x2_below(row) = the azimuth-plane distance of a row below
+        // x2_below(row) = the azimuth-plane distance of a row below.
+        // Round 4: written WITHOUT divergent branches. As nested ifs the compiler turned a row into 22 s_and_saveexec / s_cbranch_execz pairs and
+        // ~90 scalar mask operations — on a lone wavefront every one of those branches costs 15 - 30 clocks (lone-wave cost model) —
+        // so every quantity is computed for every lane (garbage where the cell has no return: nothing traps) and the cases are selects. The one
+        // loop (the downward fix-up of cc.cpp:513-535) stays a loop behind a wave-uniform test.
         auto row_step = [&](const int row, const int f, const float cur2x, const float cur2y, auto&& x2_below)
         {
-            unsigned char ground = SG_G_UNKNOWN, debug = SG_D_WHITE;
-            if (f & SG_NAN)
-            {
-                oo[row] = (unsigned char) (ground | (debug << 3));
-                return;
-            }
-            if (f & SG_FOG)
-            {
-                oo[row] = (unsigned char) (SG_G_FOG | (SG_D_LIGHTGRAY << 3));
-                return;
-            }
-            if (f & SG_EGO)
-            {
-                oo[row] = (unsigned char) (SG_G_EGO | (SG_D_VIOLET << 3));
-                return;
-            }
+            const bool valid = (f & (SG_NAN | SG_FOG | SG_EGO)) == 0;
+            const bool first = valid & !first_point_found;
+            const bool normal = valid & first_point_found;
             // cc.cpp:567-616 for a point that ends up an obstacle: too close / inclination filter / chessboard thinning
-            const unsigned char ign_bit =
-                ((f & (SG_TOO_CLOSE | SG_INCL_IGNORE)) || ((row & 1) ? chess_even : chess_odd)) ? (unsigned char) 0x80 : (unsigned char) 0;
-            if (!first_point_found)
-            {
-                first_point_found = true;
-                const float h = cur2y - height_sensor_to_ground;
-                if (h > cfg.first_ring_as_ground_min_allowed_z_diff && h < cfg.first_ring_as_ground_max_allowed_z_diff)
-                {
-                    ground = SG_G_GROUND;
-                    debug = SG_D_GRAY;
-                    lg2x = cur2x;
-                    lgz = cur2y;
-                    first_obstacle_detected = false;
-                }
-                else
-                {
-                    ground = SG_G_OBSTACLE;
-                    debug = SG_D_ORANGE;
-                    first_obstacle_detected = true;
-                }
-                pv2x = cur2x;
-                pvz = cur2y;
-                previous_label = debug;
-                oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
-                return;
-            }
+            const bool ign = ((f & (SG_TOO_CLOSE | SG_INCL_IGNORE)) != 0) | ((row & 1) ? chess_even : chess_odd);
+            // the first point outside the ego box (cc.cpp:408-432)
+            const float h = cur2y - height_sensor_to_ground;
+            const bool first_ground = (h > cfg.first_ring_as_ground_min_allowed_z_diff) & (h < cfg.first_ring_as_ground_max_allowed_z_diff);
+            // slopes w.r.t. the previous point and the last certain ground point (cc.cpp:434-447)
             const float p2cx = cur2x - pv2x, p2cy = cur2y - pvz;
             const float slope_to_prev = p2cy / p2cx;
-            bool flat_prev = ccm::absf(slope_to_prev) < cfg.max_slope && p2cx > 0;
-            flat_prev = flat_prev && (!cfg.use_terrain || p2cx < 5);
+            const bool flat_prev = (ccm::absf(slope_to_prev) < cfg.max_slope) & (p2cx > 0) & ((cfg.use_terrain == 0) | (p2cx < 5));
             const float l2cx = cur2x - lg2x, l2cy = cur2y - lgz;
             const float slope_to_lg = l2cy / l2cx;
-            const bool flat_lg = ccm::absf(slope_to_lg) < cfg.max_slope && l2cx > 0;
-            if (!first_obstacle_detected && flat_prev)
+            const bool flat_lg = (ccm::absf(slope_to_lg) < cfg.max_slope) & (l2cx > 0);
+            const bool no_terrain = cfg.use_terrain == 0;
+            const bool green = !first_obstacle_detected & flat_prev;                                                     // cc.cpp:450-454
+            const bool yellowgreen = !green & no_terrain & first_obstacle_detected & flat_prev & flat_lg;                // :489-493
+            const bool yellow = !green & !yellowgreen & no_terrain &
+                                (ccm::absf(l2cx) < cfg.ground_because_close_to_last_certain_ground_max_dist_diff) &
+                                (ccm::absf(l2cy) < cfg.ground_because_close_to_last_certain_ground_max_z_diff);           // :494-500
+            const bool ground_n = green | yellowgreen | yellow;
+            const unsigned d_n = green ? (unsigned) SG_D_GREEN : (yellowgreen ? (unsigned) SG_D_YELLOWGREEN : (yellow ? (unsigned) SG_D_YELLOW : (unsigned) SG_D_RED));
+            const unsigned g_n = ground_n ? (unsigned) SG_G_GROUND : (unsigned) SG_G_OBSTACLE;
+            const unsigned d_f = first_ground ? (unsigned) SG_D_GRAY : (unsigned) SG_D_ORANGE;
+            const unsigned g_f = first_ground ? (unsigned) SG_G_GROUND : (unsigned) SG_G_OBSTACLE;
+            unsigned g = first ? g_f : g_n, d = first ? d_f : d_n;
+            g = (f & SG_EGO) ? (unsigned) SG_G_EGO : g;
+            d = (f & SG_EGO) ? (unsigned) SG_D_VIOLET : d;
+            g = (f & SG_FOG) ? (unsigned) SG_G_FOG : g;
+            d = (f & SG_FOG) ? (unsigned) SG_D_LIGHTGRAY : d;
+            g = (f & SG_NAN) ? (unsigned) SG_G_UNKNOWN : g;
+            d = (f & SG_NAN) ? (unsigned) SG_D_WHITE : d;
+            const bool red = normal & !ground_n;
+            if (__any(red))
             {
-                ground = SG_G_GROUND;
-                debug = SG_D_GREEN;
-            }
-            else if (!cfg.use_terrain)
-            {
-                if (first_obstacle_detected && flat_prev && flat_lg)
+                // cc.cpp:513-535: go down in the rows and mark very close (ground) points as obstacle too — nearly always over after one look
+                int below = row + 1;
+                bool go = red & (below < R);
+                while (__any(go))
                 {
-                    ground = SG_G_GROUND;
-                    debug = SG_D_YELLOWGREEN;
-                }
-                else if (ccm::absf(l2cx) < cfg.ground_because_close_to_last_certain_ground_max_dist_diff &&
-                         ccm::absf(l2cy) < cfg.ground_because_close_to_last_certain_ground_max_z_diff)
-                {
-                    ground = SG_G_GROUND;
-                    debug = SG_D_YELLOW;
-                }
-            }
-            if (ground != SG_G_GROUND)
-            {
-                ground = SG_G_OBSTACLE;
-                debug = SG_D_RED;
-                int below = row + 1; // cc.cpp:513-535
-                while (below < R)
-                {
-                    const unsigned char bo = oo[below];
-                    const unsigned char bg = bo & 7, bd = (bo >> 3) & 15;
-                    if (bd == SG_D_YELLOW ||
-                        (bg == SG_G_GROUND && ccm::absf(cur2x - x2_below(below)) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
-                    {
-                        if (bg == SG_G_GROUND)
-                        {
-                            oo[below] = (unsigned char) ((bo & 0x80) | SG_G_OBSTACLE | (SG_D_DARKRED << 3));
-                        }
-                        below++;
-                    }
-                    else
-                        break;
+                    const int bi = go ? below : row + 1 < R ? row + 1 : row; // (lanes that are through look at a harmless row)
+                    const unsigned bo = oo[bi];
+                    const unsigned bg = bo & 7u, bd = (bo >> 3) & 15u;
+                    const float xb = x2_below(bi, go);
+                    const bool is_ground = bg == (unsigned) SG_G_GROUND;
+                    const bool cont = go & ((bd == (unsigned) SG_D_YELLOW) |
+                                            (is_ground & (ccm::absf(cur2x - xb) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff)));
+                    if (cont & is_ground)
+                        oo[bi] = (unsigned char) ((bo & 0x80u) | SG_G_OBSTACLE | (SG_D_DARKRED << 3));
+                    below += cont ? 1 : 0;
+                    go = cont & (below < R);
                 }
             }
-            first_obstacle_detected |= ground == SG_G_OBSTACLE;
-            if (debug == SG_D_GREEN || debug == SG_D_YELLOWGREEN)
-            {
-                if (slope_to_prev > cfg.last_ground_point_slope_higher_than &&
-                    ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than && previous_label != SG_D_YELLOW)
-                {
-                    lg2x = cur2x;
-                    lgz = cur2y;
-                }
-            }
-            pv2x = cur2x;
-            pvz = cur2y;
-            previous_label = debug;
-            oo[row] = (unsigned char) (ground | (debug << 3) | ign_bit);
+            // check whether we have ever seen an obstacle; the last (certain) ground point (cc.cpp:538-560)
+            first_obstacle_detected = first ? !first_ground : (first_obstacle_detected | red);
+            const bool keep_as_ground = normal & (green | yellowgreen) & (slope_to_prev > cfg.last_ground_point_slope_higher_than) &
+                                        (ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than) & (previous_label != SG_D_YELLOW);
+            const bool new_lg = (first & first_ground) | keep_as_ground;
+            lg2x = new_lg ? cur2x : lg2x;
+            lgz = new_lg ? cur2y : lgz;
+            pv2x = valid ? cur2x : pv2x;
+            pvz = valid ? cur2y : pvz;
+            previous_label = valid ? (unsigned char) d : previous_label;
+            first_point_found |= valid;
+            oo[row] = (unsigned char) (g | (d << 3) | ((valid & ign) ? 0x80u : 0u));
         };
         // ---- the table along the columns, the supplemented inclination and the pending inclination-step tests of one row, then its state machine
         // step. EVERY lane comes here for every row (lanes beyond the tile as columns without returns): the ballot and the permute are wave-wide.
@@ -2754,46 +3036,32 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
             const int src = m ? 63 - __clzll((long long) m) : lane;
             const float got = __shfl(wv, src, 64);
             const float tab = m ? got : carry; // sc_inclination_angles_between_lasers_[row] after this column (cc.cpp:353-357)
-            int fx = f;
-            bool need = false;
-            if (f & SG_NAN)
+            // cc.cpp:364-369: the inclination of the cell below (after ITS supplement) + the table entry. (Without the option, and in the last row,
+            // the cell keeps the inclination of a cell without a return: NaN. Branch-free like row_step.)
+            const bool is_nan = (f & SG_NAN) != 0;
+            const float supp = (supplement & (row < R - 1)) ? (below_nan ? supp_below : wv) + tab : __builtin_nanf("");
+            if (is_nan & active)
             {
-                // cc.cpp:364-369: the inclination of the cell below (after ITS supplement) + the table entry
-                float supp = __builtin_nanf("");
-                if (supplement && row < R - 1)
-                    supp = (below_nan ? supp_below : wv) + tab;
-                if (active)
-                {
-                    g_rec[row] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), supp);
-                    if (supplement && row < R - 1)
-                        g_incl[row] = supp;
-                }
-                supp_below = supp;
-                below_nan = true;
+                g_rec[row] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), supp);
+                g_incl[row] = supp;
             }
-            else
-            {
-                below_nan = false;
-                if ((f & SG_PENDING) && step_filter && row < R - 1 && !(tab != tab))
-                {
-                    // cc.cpp:597-603 with the table entry of an earlier column: atan2f(max_distance, distance) < tab. Two rigorous bounds first
-                    // (seg_pre_cells has the first; the second: atan2f(y, x) <= (y / x) (1 + 3 * 2^-23) for positive arguments)
-                    const float dist = wv, a = dist * tab;
-                    const bool in_range = cfg.max_distance > 0.f && tab >= 0.f && tab < 0.05f && dist > 0.f && dist < 3.0e38f;
-                    if (in_range && cfg.max_distance >= 1.01f * a)
-                        ;
-                    else if (in_range && cfg.max_distance * 1.000002f < a)
-                        fx |= SG_INCL_IGNORE;
-                    else
-                        need = true;
-                }
-            }
+            supp_below = is_nan ? supp : supp_below;
+            below_nan = is_nan;
+            // cc.cpp:597-603 with the table entry of an earlier column: atan2f(max_distance, distance) < tab. Two rigorous bounds first
+            // (seg_pre_cells has the first; the second: atan2f(y, x) <= (y / x) (1 + 3 * 2^-23) for positive arguments)
+            const bool pend = ((f & (SG_PENDING | SG_NAN)) == SG_PENDING) & step_filter & (row < R - 1) & !(tab != tab);
+            const float a = wv * tab; // (wv: the distance of a pending cell)
+            const bool in_range = (cfg.max_distance > 0.f) & (tab >= 0.f) & (tab < 0.05f) & (wv > 0.f) & (wv < 3.0e38f);
+            const bool surely_not = in_range & (cfg.max_distance >= 1.01f * a);
+            const bool surely = in_range & !surely_not & (cfg.max_distance * 1.000002f < a);
+            const int fx = f | ((pend & surely) ? SG_INCL_IGNORE : 0);
+            const bool need = pend & !surely_not & !surely;
             if (need)
                 stash(tab);
             row_step(row, fx, cur2x, cur2y, x2_below);
             return need;
         };
-        if (tiled && ncols <= SEG_FEW)
+        if (tiled && ncols <= SEG_FEW && 3 * SEG_FEW * R <= 4 * 64 * SEG_CH) // (the whole columns of three planes fit the chunk buffers)
         {
             // ---- a tile of a few columns (calls of a few firings: the per-column latency path, and the last tile of a batch): the whole columns are
             // loaded with lanes = rows in ONE round trip (the chunked form below spends four dependent ones, 2 us each, on a tile whose scan takes 3 us),
@@ -2820,7 +3088,13 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
                 const float* mx = cx2 + lc_ * R;
                 const float* mz = cuz + lc_ * R;
                 const float* mw = cw + lc_ * R;
-                auto x2_below = [&](const int below) -> float { return mx[below]; };
+                auto x2_below = [&](const int below, const bool wanted) -> float { (void) wanted; return mx[below]; };
+                // the table in front of the tile, one row per lane (read back with v_readlane: a scalar load per row would drain the LDS counter)
+                const float carry_lo = lane < R ? tab_in[lane] : 0.f, carry_hi = 64 + lane < R ? tab_in[64 + lane] : 0.f;
+                auto carry_of = [&](const int row) -> float
+                {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row < 64 ? carry_lo : carry_hi), row & 63));
+                };
                 for (int b = R - 4; b >= 0; b -= 4)
                 {
                     const float4 a = *(const float4*) (mx + b);
@@ -2831,7 +3105,7 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
                     unsigned pend = 0;
 #pragma unroll
                     for (int u = 3; u >= 0; u--)
-                        if (row_all(b + u, (int) ((fw >> (8 * u)) & 0xffu), x4[u], z4[u], ww[u], tab_in[b + u], x2_below,
+                        if (row_all(b + u, (int) ((fw >> (8 * u)) & 0xffu), x4[u], z4[u], ww[u], carry_of(b + u), x2_below,
                                     [&](const float tab) { cuz[lc_ * R + b + u] = tab; })) // (the row's height has been consumed: its slot takes the table entry)
                             pend |= 1u << u;
                     if (__any(pend != 0))
@@ -2857,8 +3131,10 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
                 ld_off[j] = c < ncols ? l * R : -1;
             }
             float4 nx[4], nz[4], nw[4];
+            float ncarry = 0.f; // the table in front of the tile for the chunk's 16 rows, one per lane (read back with v_readlane)
             auto load_chunk = [&](const int b)
             {
+                ncarry = tab_in[b + (lane & 15)];
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                 {
@@ -2918,17 +3194,20 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
                     *(float4*) (t_uz + piece_at(c, ld_q)) = nz[j];
                     *(float4*) (t_w + piece_at(c, ld_q)) = nw[j];
                 }
+                const int carry_bits = __builtin_bit_cast(int, ncarry);
                 if (b >= SEG_CH)
                     load_chunk(b - SEG_CH);
                 wave_lds_fence(); // one wavefront per block: its LDS accesses execute in order
                 {
-                    auto x2_below = [&](const int below) -> float
+                    auto x2_below = [&](const int below, const bool wanted) -> float
                     {
                         // this chunk or the one below it: LDS; deeper: the staging plane (the LDS word is read either way: a select between
                         // an LDS and a global address would make this a flat access)
                         float v = l_x2[((below >> 4) & 1) * (64 * SEG_CH) + piece_at(lane, (below & 15) >> 2) + (below & 3)];
-                        if (below >= b + 2 * SEG_CH)
-                            v = gx[below];
+                        const bool deep = wanted & (below >= b + 2 * SEG_CH);
+                        if (__any(deep))
+                            if (deep)
+                                v = gx[below];
                         return v;
                     };
                     // four rows (one 16-byte piece per plane) per iteration of a ROLLED loop: the state machine's code stays small
@@ -2945,7 +3224,8 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
                         const unsigned fw = active ? *(const unsigned*) (oo + b + q * 4) : 0x01010101u * (unsigned) SG_NAN;
 #pragma unroll
                         for (int u = 3; u >= 0; u--)
-                            if (row_all(b + q * 4 + u, (int) ((fw >> (8 * u)) & 0xffu), x4[u], z4[u], ww[u], tab_in[b + q * 4 + u], x2_below,
+                            if (row_all(b + q * 4 + u, (int) ((fw >> (8 * u)) & 0xffu), x4[u], z4[u], ww[u],
+                                        __builtin_bit_cast(float, __builtin_amdgcn_readlane(carry_bits, q * 4 + u)), x2_below,
                                         [&](const float tab) { t_uz[at + u] = tab; })) // (the row's height is in registers: its slot takes the table entry)
                                 pend |= 1u << (q * 4 + u);
                     }
@@ -3026,11 +3306,13 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
                 for (int u = 0; u < 8; u++)
                     if (b + u >= 0)
                         x2[(b + u) & (SEG_X2_RING - 1)] = x8[u];
-                auto x2_below = [&](const int below) -> float
+                auto x2_below = [&](const int below, const bool wanted) -> float
                 {
                     float v = x2[below & (SEG_X2_RING - 1)];
-                    if (below >= b + SEG_X2_RING)
-                        v = gx[below];
+                    const bool deep = wanted & (below >= b + SEG_X2_RING);
+                    if (__any(deep))
+                        if (deep)
+                            v = gx[below];
                     return v;
                 };
 #pragma unroll
@@ -5248,8 +5530,9 @@ __global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const Stre
 // writes is_ground_point = (ground_point_label == GP_GROUND) and detection_label = id (:214-215) of the columns' points into the frames'
 // arrays in HBM, which cc_eval_frame_device then reads. grid = columns, block = 64 (lanes = rows).
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_scatter_info(Geometry g, Planes P, int s, long long from, const int* __restrict__ original_index, int slots,
-                                                     int* __restrict__ out_min, int* __restrict__ out_max)
+__global__ __launch_bounds__(64) void k_scatter_info(Geometry g, Planes P, const StreamState* __restrict__ states, int s, long long from,
+                                                     const int* __restrict__ original_index, int slots, int* __restrict__ out_min,
+                                                     int* __restrict__ out_max)
 {
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols, NC = g.num_columns;
@@ -5257,7 +5540,10 @@ __global__ __launch_bounds__(64) void k_scatter_info(Geometry g, Planes P, int s
     const int lc = (int) (gc % RC);
     const int* org = original_index + (size_t) s * (size_t) slots * (size_t) NC * (size_t) R;
     int mn = 0x7fffffff, mx = -1;
-    for (int row = lane_id(); row < R; row += 64)
+    // only published columns that are still in the ring hold what this reads (anything else: "no point", like an empty column)
+    // (clearing is deferred by one call, so what a call published stays readable behind ring_start: the lower end is what has been CLEARED)
+    const bool live = gc >= 0 && gc >= states[s].clear_done && gc < states[s].first_unpublished;
+    for (int row = lane_id(); live && row < R; row += 64)
     {
         const int ci = lc * R + row;
         if (p.dist[ci] == p.dist[ci]) // the cell holds a return
@@ -5280,12 +5566,15 @@ __global__ __launch_bounds__(64) void k_scatter_info(Geometry g, Planes P, int s
     }
 }
 
-__global__ __launch_bounds__(64) void k_scatter_apply(Geometry g, Planes P, int s, long long from, const int* __restrict__ original_index, int slots,
-                                                      unsigned char* __restrict__ is_ground, unsigned* __restrict__ detection, long long max_points)
+__global__ __launch_bounds__(64) void k_scatter_apply(Geometry g, Planes P, const StreamState* __restrict__ states, int s, long long from,
+                                                      const int* __restrict__ original_index, int slots, unsigned char* __restrict__ is_ground,
+                                                      unsigned* __restrict__ detection, long long max_points)
 {
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols, NC = g.num_columns;
     const long long gc = from + blockIdx.x;
+    if (gc < 0 || gc < states[s].clear_done || gc >= states[s].first_unpublished)
+        return; // (not a published column of the live ring)
     const int lc = (int) (gc % RC);
     const int* org = original_index + (size_t) s * (size_t) slots * (size_t) NC * (size_t) R;
     unsigned char* gr = is_ground + (size_t) s * (size_t) slots * (size_t) max_points;

@@ -39,6 +39,11 @@ void ContinuousClustering::stopWorker()
 {
     if (!worker_.joinable())
         return;
+    // a callback runs ON the worker: reset() / setConfiguration() / flush() from inside one would wait for the worker to become idle, or join the
+    // calling thread itself — a deadlock. The reference's callbacks run on pool threads that reset() shuts down too; say so instead of hanging.
+    if (std::this_thread::get_id() == worker_.get_id())
+        throw std::runtime_error("ContinuousClustering: reset / setConfiguration / setTransformRobotFrameFromSensorFrame / flush called from inside a callback "
+                                 "of the asynchronous mode (the callback runs on the worker thread it would have to wait for)");
     {
         std::unique_lock<std::mutex> lk(mu_);
         cv_idle_.wait(lk, [this] { return (queue_.empty() && !busy_) || worker_error_; });
@@ -52,6 +57,9 @@ void ContinuousClustering::waitIdle()
 {
     if (!worker_.joinable())
         return;
+    if (std::this_thread::get_id() == worker_.get_id())
+        throw std::runtime_error("ContinuousClustering: reset / setConfiguration / setTransformRobotFrameFromSensorFrame / flush called from inside a callback "
+                                 "of the asynchronous mode (the callback runs on the worker thread it would have to wait for)");
     std::unique_lock<std::mutex> lk(mu_);
     cv_idle_.wait(lk, [this] { return (queue_.empty() && !busy_) || worker_error_; });
 }
@@ -104,6 +112,9 @@ void ContinuousClustering::workerLoop()
             std::lock_guard<std::mutex> lk(mu_);
             worker_error_ = std::current_exception();
             buffered_ = 0;
+            // (the failed batch's firings are still in firing_log_, which the mirror indexes by firing number: after the error has been rethrown to
+            // the caller the only consistent way on is reset(), as after the reference's own soft error, cc.cpp:252-261)
+            reset_required_async_ = true;
         }
         {
             std::lock_guard<std::mutex> lk(mu_);

@@ -42,7 +42,7 @@ if what in ("times", "all"):
     sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
     F, NB = 2200, 5
     for S in (32, 128, 256):
-        xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, S, F, NB, 1234)
+        xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
         torch.cuda.synchronize()
         for ab in (0, 1):
             for pipe in (0, 1):

@@ -5,7 +5,7 @@ from continuous_clustering_amd import Engine, capi, synth
 import bench
 sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 S,F,NB = 256,2200,4
-xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, S, F, NB, 1234)
+xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 for pipe, par in [(0, 0), (0, 1), (1, 0), (1, 1)]:
     flags = 0

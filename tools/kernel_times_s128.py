@@ -5,7 +5,7 @@ from continuous_clustering_amd import Engine, capi, synth
 import bench
 sensor = synth.SensorModel.s128(); cfg = capi.Config.vls128()
 S,F,NB = 128,1700,4
-xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, S, F, NB, 1234)
+xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 for pipe, par in [(0, 0), (0, 1), (1, 0), (1, 1)]:
     flags = 0

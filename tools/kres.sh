@@ -6,7 +6,7 @@ grep -E "error" -A5 /tmp/cc_engine.res | head -30
 for k in "$@"; do
   grep -A7 "Function Name: _ZN3cck[0-9]*$k" /tmp/cc_engine.res | grep -E "Function Name|VGPRs:|Scratch|Occupancy|LDS" | sed 's/.*remark: *//'
   for n in $(grep -n "^_ZN3cck[0-9]*$k.*:" /tmp/cc_engine.s | cut -d: -f1); do
-    awk -v n=$n 'NR>=n{print} /s_endpgm/{if(NR>n){exit}}' /tmp/cc_engine.s > /tmp/kres_$k.s
+    awk -v n=$n 'NR>=n{print} /^\.Lfunc_end/{if(NR>n){exit}}' /tmp/cc_engine.s > /tmp/kres_$k.s
     echo "asm lines: $(wc -l < /tmp/kres_$k.s) scratch ops: $(grep -c scratch_ /tmp/kres_$k.s)"
   done
 done

@@ -11,7 +11,7 @@ import torch
 import bench
 from continuous_clustering_amd import capi, synth
 sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
-xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, 256, 2200, 4, 1234)
+xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(256)], 2200, 4)
 torch.cuda.synchronize()
 out = bench.live_multi_stream(torch, cfg, sensor, xyz, inten, poses, 0, sizes=sizes)
 for k, v in out.items():

@@ -7,7 +7,7 @@ from continuous_clustering_amd import Engine, capi, synth
 import bench
 sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 S, F, NB = 8, 2200, 5
-xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, S, F, NB, 1234)
+xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 L = cca.load_library(); L.cc_engine_debug_counters.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 e = Engine(cfg, 64, S); e.record_events(False)

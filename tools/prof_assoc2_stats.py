@@ -7,7 +7,7 @@ from continuous_clustering_amd import Engine, capi, synth
 import bench
 sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 S, F, NB = 64, 2200, 3
-xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, S, F, NB, 1234)
+xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", 0)
 for b in range(NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])

@@ -10,7 +10,7 @@ import bench
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 F, NB = 2200, 4
-xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, S, F, NB, 1234)
+xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 for pipe in (0, 1):
     e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", pipe)

@@ -7,7 +7,7 @@ from continuous_clustering_amd import Engine, capi, synth
 import bench
 sensor = synth.SensorModel.s128(); cfg = capi.Config.vls128()
 S,F,NB = 64,1700,3
-xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, S, F, NB, 1234)
+xyz,inten,poses = bench.gen_inputs(torch, torch.device("cuda",0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 e = Engine(cfg, 128, S); e.record_events(False); e.set_option("pipeline", 0)
 for b in range(NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])

@@ -10,7 +10,7 @@ import bench
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 F, NB = 2200, 3
-xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, S, F, NB, 1234)
+xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", 0)
 for b in range(NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])
