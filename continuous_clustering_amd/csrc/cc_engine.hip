@@ -37,6 +37,7 @@ struct cc_engine
     bool capturing{false};      // launch_batch is being captured into a hipGraph (small calls)
     int* d_par_left{nullptr};  // [0] streams whose batch k_insert_par did not take completely (skip_idle_fallbacks), [1] streams whose batch still needs
                                // k_table / k_seg_pre (not closed as fused)
+    int seg_small_max{63};     // option "seg_small_max": calls of at most this many firings (64-row sensors) segment their columns with k_seg_small
     bool fuse_front{true};     // option "fuse_front": k_insert_par also does the per-cell part of the segmentation of the columns it fills
     int* h_par_left{nullptr};  // pinned
     int insert_split_blocks{0};      // option "insert_split_blocks": blocks per stream of k_insert_par in such launches (0 = 4 up to 40 streams, else 2; 1 = one)
@@ -562,6 +563,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // k_table only needs what the insertion of this batch wrote. It is a latency-bound kernel (8 wavefronts per stream) that takes 0.8 ms
     // when it shares the GPU with the throughput kernels — on the segmentation chain, which is the longest of the three, that is a
     // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
+    // calls of a few firings (the per-column latency path): ONE wavefront per stream segments the call's columns, rows as lanes (k_seg_small)
+    const bool seg_small = !par && rpl == 1 && first_pass && n <= e->seg_small_max;
+    if (seg_small)
+        need_segpre = false;
     const bool table_early = si != sb && e->table_on_insert_chain != 0;
     // (a stream of its own: the next batch's insertion does not queue behind it)
     hipStream_t st_table = (table_early && e->table_on_insert_chain == 2 && !e->capturing) ? e->stream7 : si;
@@ -606,6 +611,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     else
         hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
                            first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
+    if (seg_small)
+    {
+        hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
+                           e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
+        hipLaunchKernelGGL(cck::k_seg_small, dim3((unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot, d_pose,
+                           (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
+    }
+    else
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
         hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, Pt, e->d_states, first_stream, slot); // (Pt: this slot's table carries)
@@ -1949,6 +1962,11 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->skip_idle_fallbacks = value != 0;
     else if (n == "fuse_front")
         e->fuse_front = value != 0;
+    else if (n == "seg_small_max")
+    {
+        e->seg_small_max = (int) value;
+        e->small_graphs_stale = true;
+    }
     else if (n == "assoc_batch")
         e->assoc_batch = value != 0;
     else if (n == "assoc_rounds")

@@ -3364,6 +3364,271 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
 }
 
 // =====================================================================================================
+// k_seg_small — the whole ground segmentation of a column (cc.cpp:294-624) by ONE wavefront with lanes = ROWS, for calls of a few firings
+// (the per-column latency path: BASELINE.json configs[1]). Round 4.
+//
+// k_seg_scan walks a column bottom-up on one lane — fine when 64 columns share the wavefront, 20 - 40 us when a call brings one column: 64 rows x
+// ~250 dependent instructions on a lone wavefront. Here the rows are the lanes and the row-serial state machine is solved as a FIXED POINT:
+//   * what does not depend on the labels below is computed once, for all rows at once: the previous point outside the ego box (nearest valid row
+//     below: one ballot + find-first-set + lane permute), the slope to it, "flat w.r.t. previous", the first point's test, the geometric part of
+//     the last-ground-point rule (cc.cpp:546-548);
+//   * the state a row sees — first_obstacle_detected, last_ground_position, previous_label — is a function of the LABELS of the rows below it:
+//     "some row below is RED (or the first point was an obstacle)", "the nearest row below that updates the last ground point", "the label of
+//     the previous valid row". Given a guess of all labels, every row recomputes its own label from the guess; rows only depend on rows below, so
+//     after k rounds the lowest k valid rows are final and the iteration ends at the unique sequential solution, in at most `rows` rounds — on
+//     real columns after 3 - 6 (ground, then one or two obstacle / ground changes);
+//   * the downward fix-up of cc.cpp:513-535 (ground cells right below a new obstacle become obstacles) only reaches down to the next RED row, so
+//     the walks of different RED rows are disjoint: a cell is converted iff every cell between it and the nearest RED row above passes the
+//     walk's test — one ballot and two mask operations.
+// The table of inclination steps needs no tiles here: the stream's table as of the previous column is Planes::curtab (rows = lanes).
+// One wavefront per stream, the batch's columns in order (a call of n firings finishes about n columns). Reads the cells from the ring like
+// k_seg_pre; writes labels, ignore flags, tags, the records / inclinations of cells without a return, column entries, curtab. No staging planes.
+// grid = streams, block = 64; num_rows <= 64.
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_seg_small(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+                                                  const double* __restrict__ poses, long long n_total, long long fbase, const double* __restrict__ ego,
+                                                  long long n_batch)
+{
+    const int sl = blockIdx.x;
+    const int s = first_stream + sl;
+    StreamState* st = &states[s];
+    const int lane = lane_id();
+    if (lane == 0)
+        st->batch[slot].mode = st->assoc_mode; // (what k_table does first)
+    const long long seg_begin = st->batch[slot].seg_begin, seg_end = st->batch[slot].seg_end;
+    if (seg_begin < 0 || seg_begin >= seg_end || st->error != 0)
+        return;
+    if (!st->has_robot_tf)
+    {
+        if (lane == 0)
+            raise_error(st, CC_ERR_NO_ROBOT_TRANSFORM, seg_begin, 0);
+        return;
+    }
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols, NC = g.num_columns;
+    const int row = lane;
+    const bool inrow = row < R;
+    const float height_sensor_to_ground = -(float) st->robot_from_sensor[11] + cfg.height_ref_to_ground_;
+    const bool supplement = cfg.supplement_inclination_angle_for_nan_cells != 0;
+    const bool step_filter = cfg.ignore_points_with_too_big_inclination_angle_diff != 0;
+    const bool no_terrain = cfg.use_terrain == 0;
+    // lane masks: rows strictly below this one (= larger row index, visited earlier by the bottom-up walk) / strictly above
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long below = ~le, above = le >> 1;
+    float tabrow = inrow ? p.curtab[row] : 0.f; // sc_inclination_angles_between_lasers_[row] as of the previous column
+    int lc = (int) (seg_begin % RC);
+    long long rot = seg_begin / NC;
+    int cir = (int) (seg_begin - rot * NC);
+    long long pass = seg_begin / RC;
+    CazBase cb = caz_base_of_rotation(rot);
+    for (long long gc = seg_begin; gc < seg_end; gc++)
+    {
+        const size_t ci = (size_t) lc * R + row;
+        const uint16_t tag = cell_tag(pass);
+        // ---- the column's cells (as k_seg_pre reads them)
+        float cx[1] = {0.f}, cy[1] = {0.f}, cz[1] = {0.f}, dist[1] = {__builtin_nanf("")}, incl[1] = {__builtin_nanf("")};
+        uint8_t inten[1] = {0};
+        float incaz = 0.f;
+        bool empty_cell = false, overrun = false;
+        long long overrun_gcol = -1;
+        if (inrow)
+        {
+            const uint16_t tg = p.gtag[ci];
+            dist[0] = p.dist[ci];
+            if (tg == tag)
+            {
+                const float4 r4 = p.sc_rec[ci];
+                cx[0] = r4.x, cy[0] = r4.y, cz[0] = r4.z, incl[0] = r4.w;
+                incaz = p.incaz[ci];
+                inten[0] = p.inten[ci];
+            }
+            else
+            {
+                empty_cell = true;
+                if (tg != CELL_CLEARED)
+                {
+                    overrun = true; // cc.cpp:320-345
+                    overrun_gcol = gc - (long long) ((((unsigned) tag - (unsigned) tg) & 0x7fffu)) * RC;
+                }
+            }
+        }
+        if (__any(overrun))
+        {
+            const int worst = -wave_min_i32(overrun ? -row : 1); // the highest stale row = the first one of the reference's bottom-up walk
+            if (overrun && row == worst)
+            {
+                atomicMin((unsigned long long*) &st->overrun_col, (unsigned long long) gc);
+                raise_error(st, CC_ERR_RING_OVERRUN, overrun_gcol, gc);
+            }
+            break; // (the reference throws here: nothing behind this column is segmented; the host reports the error)
+        }
+        const int trig = uniform_i32(p.trig[lc]);
+        const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) trig) * 12;
+        const double* E = ego + ((size_t) sl * (size_t) n_batch + (size_t) trig) * EGO_STRIDE;
+        float x2a[1], uza[1], wa[1];
+        int fla[1];
+        seg_pre_cells<1>(cfg, R, lane, cx, cy, cz, dist, incl, inten, (float) T[3], (float) T[7], (float) T[11], E, x2a, uza, wa, fla);
+        const int f = fla[0];
+        const float cur2x = x2a[0], cur2y = uza[0], wv = wa[0];
+        // ---- the table as of this column, supplemented inclinations (cc.cpp:353-369), pending inclination-step tests (:597-603)
+        const bool is_nan = (f & SG_NAN) != 0;
+        const bool own = !(f & (SG_NAN | SG_PENDING));
+        const float tab = own ? wv : tabrow;
+        tabrow = tab;
+        float sincl = incl[0];                                        // inclination the cell ends up with
+        bool done = !is_nan | !supplement | (row >= R - 1) | !inrow; // (a cell without a return in the last row keeps NaN)
+        while (__any(!done))
+        {
+            // runs of cells without a return resolve bottom-up, one row per round: the row below first (its value AFTER the supplement)
+            const float sb = __shfl_down(sincl, 1, 64);
+            const int db = __shfl_down(done ? 1 : 0, 1, 64);
+            if (!done && db)
+            {
+                sincl = sb + tab;
+                done = true;
+            }
+        }
+        bool ign = (f & (SG_TOO_CLOSE | SG_INCL_IGNORE)) != 0;
+        {
+            const bool pend = ((f & (SG_PENDING | SG_NAN)) == SG_PENDING) & step_filter & (row < R - 1) & !(tab != tab);
+            const float a = wv * tab; // (wv: the distance of a pending cell)
+            const bool in_range = (cfg.max_distance > 0.f) & (tab >= 0.f) & (tab < 0.05f) & (wv > 0.f) & (wv < 3.0e38f);
+            const bool surely_not = in_range & (cfg.max_distance >= 1.01f * a);
+            const bool surely = in_range & !surely_not & (cfg.max_distance * 1.000002f < a);
+            const bool need = pend & !surely_not & !surely;
+            ign |= pend & surely;
+            if (__any(need))
+                if (need && ccm::atan2f_exact(cfg.max_distance, wv) < tab)
+                    ign = true;
+        }
+        if (cfg.ignore_points_in_chessboard_pattern)
+            ign |= ((gc & 1) != 0) != ((row & 1) != 0); // cc.cpp:600-606: column parity differs from row parity
+        // ---- state machine, label-independent part
+        const bool valid = inrow & ((f & (SG_NAN | SG_FOG | SG_EGO)) == 0);
+        const unsigned long long V = __ballot(valid);
+        const unsigned long long mb = V & below;
+        const bool has_prev = mb != 0;
+        const int pb = has_prev ? __ffsll((long long) mb) - 1 : lane; // previous point outside the ego box = nearest valid row below
+        const bool first = valid & !has_prev, normal = valid & has_prev;
+        const float pv2x = __shfl(cur2x, pb, 64), pvz = __shfl(cur2y, pb, 64);
+        const float p2cx = cur2x - pv2x, p2cy = cur2y - pvz;
+        const float slope_to_prev = p2cy / p2cx;
+        const bool flat_prev = (ccm::absf(slope_to_prev) < cfg.max_slope) & (p2cx > 0) & (no_terrain | (p2cx < 5));
+        const bool keep_geo = (slope_to_prev > cfg.last_ground_point_slope_higher_than) & (ccm::absf(p2cx) < cfg.last_ground_point_distance_smaller_than);
+        const float h = cur2y - height_sensor_to_ground;
+        const bool first_ground = (h > cfg.first_ring_as_ground_min_allowed_z_diff) & (h < cfg.first_ring_as_ground_max_allowed_z_diff);
+        const bool first_obst = __any(first & !first_ground);
+        // ---- fixed point over the labels (debug codes; the ground label follows from them)
+        unsigned d = first ? (first_ground ? (unsigned) SG_D_GRAY : (unsigned) SG_D_ORANGE)
+                           : (normal ? (flat_prev ? (unsigned) SG_D_GREEN : (unsigned) SG_D_RED) : (unsigned) SG_D_WHITE);
+        for (int round = 0; round <= R; round++)
+        {
+            const unsigned long long REDm = __ballot(normal & (d == (unsigned) SG_D_RED));
+            const unsigned long long YELm = __ballot(normal & (d == (unsigned) SG_D_YELLOW));
+            const bool fod = first_obst | ((REDm & below) != 0);                      // first_obstacle_detected as this row sees it
+            const bool prev_yellow = has_prev & (((YELm >> pb) & 1ull) != 0);         // previous_label == YELLOW
+            const bool upd = (first & first_ground) | (normal & ((d == (unsigned) SG_D_GREEN) | (d == (unsigned) SG_D_YELLOWGREEN)) & keep_geo & !prev_yellow);
+            const unsigned long long ml = __ballot(upd) & below;
+            const bool has_lg = ml != 0;
+            const int lgrow = has_lg ? __ffsll((long long) ml) - 1 : lane;            // the row that set last_ground_position
+            const float lgx = __shfl(cur2x, lgrow, 64), lgy = __shfl(cur2y, lgrow, 64);
+            const float lg2x = has_lg ? lgx : 0.f, lgz = has_lg ? lgy : height_sensor_to_ground;
+            const float l2cx = cur2x - lg2x, l2cy = cur2y - lgz;
+            const float slope_to_lg = l2cy / l2cx;
+            const bool flat_lg = (ccm::absf(slope_to_lg) < cfg.max_slope) & (l2cx > 0);
+            const bool green = !fod & flat_prev;
+            const bool yellowgreen = !green & no_terrain & fod & flat_prev & flat_lg;
+            const bool yellow = !green & !yellowgreen & no_terrain & (ccm::absf(l2cx) < cfg.ground_because_close_to_last_certain_ground_max_dist_diff) &
+                                (ccm::absf(l2cy) < cfg.ground_because_close_to_last_certain_ground_max_z_diff);
+            const unsigned dn = normal ? (green ? (unsigned) SG_D_GREEN
+                                                : (yellowgreen ? (unsigned) SG_D_YELLOWGREEN : (yellow ? (unsigned) SG_D_YELLOW : (unsigned) SG_D_RED)))
+                                       : d;
+            const bool changed = dn != d;
+            d = dn;
+            if (!__any(changed))
+                break;
+        }
+        unsigned gl = (d == (unsigned) SG_D_ORANGE || d == (unsigned) SG_D_RED) ? (unsigned) SG_G_OBSTACLE : (unsigned) SG_G_GROUND;
+        gl = valid ? gl : (unsigned) SG_G_UNKNOWN;
+        if (f & SG_EGO)
+        {
+            gl = SG_G_EGO;
+            d = SG_D_VIOLET;
+        }
+        if (f & SG_FOG)
+        {
+            gl = SG_G_FOG;
+            d = SG_D_LIGHTGRAY;
+        }
+        if ((f & SG_NAN) || !inrow)
+        {
+            gl = SG_G_UNKNOWN;
+            d = SG_D_WHITE;
+        }
+        // ---- downward fix-up (cc.cpp:513-535): ground cells (and YELLOW ones) right below a RED row, as far as every cell passes the test
+        {
+            const unsigned long long REDm = __ballot(normal & (d == (unsigned) SG_D_RED));
+            const unsigned long long RA = REDm & above; // RED rows above this cell
+            const bool has_ra = RA != 0;
+            const int ra = has_ra ? 63 - __clzll((long long) RA) : lane; // the nearest one: its walk is the only one that can get here
+            const float xr = __shfl(cur2x, ra, 64);
+            const bool pass_test = has_ra & ((d == (unsigned) SG_D_YELLOW) |
+                                             ((gl == (unsigned) SG_G_GROUND) & (ccm::absf(xr - cur2x) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff)));
+            const unsigned long long NP = __ballot(!pass_test);
+            const unsigned long long le_ra = ra == 63 ? ~0ull : ((2ull << ra) - 1ull);
+            const bool reached = has_ra & ((NP & le & ~le_ra) == 0); // every cell of (ra, this row] passes
+            if (reached & (gl == (unsigned) SG_G_GROUND))
+            {
+                gl = SG_G_OBSTACLE;
+                d = SG_D_DARKRED;
+            }
+        }
+        // ---- results
+        if (inrow)
+        {
+            constexpr unsigned long long GV = (unsigned long long) CC_GP_UNKNOWN | ((unsigned long long) CC_GP_GROUND << 8) |
+                                              ((unsigned long long) CC_GP_OBSTACLE << 16) | ((unsigned long long) CC_GP_EGO_VEHICLE << 24) |
+                                              ((unsigned long long) CC_GP_FOG << 32);
+            constexpr unsigned long long DV0 = (unsigned long long) CC_DBG_WHITE | ((unsigned long long) CC_DBG_GRAY << 8) |
+                                               ((unsigned long long) CC_DBG_ORANGE << 16) | ((unsigned long long) CC_DBG_GREEN << 24) |
+                                               ((unsigned long long) CC_DBG_YELLOWGREEN << 32) | ((unsigned long long) CC_DBG_YELLOW << 40) |
+                                               ((unsigned long long) CC_DBG_RED << 48) | ((unsigned long long) CC_DBG_DARKRED << 56);
+            constexpr unsigned DV1 = (unsigned) CC_DBG_VIOLET | ((unsigned) CC_DBG_LIGHTGRAY << 8);
+            p.ground[ci] = (unsigned char) (GV >> (8 * gl));
+            p.debug[ci] = (unsigned char) (d < 8 ? (DV0 >> (8 * d)) : (unsigned long long) (DV1 >> (8 * (d - 8))));
+            p.ignored[ci] = (gl != (unsigned) SG_G_OBSTACLE || ign) ? 1 : 0; // cc.cpp:567-616
+            if (empty_cell)
+                p.gtag[ci] = tag;
+            if (is_nan)
+            {
+                p.sc_rec[ci] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), sincl);
+                p.incl[ci] = sincl;
+            }
+        }
+        int kpos = 0x7fffffff, kneg = 0x7fffffff;
+        if (inrow && !is_nan)
+            caz_key(incaz, kpos, kneg);
+        const double min_az = column_min_caz(cb, kpos, kneg, inrow && is_nan, gc, g.az_width);
+        if (lane == 0)
+        {
+            p.colg[lc] = gc;
+            p.colminaz[lc] = min_az;
+        }
+        // next column
+        lc = lc + 1 == RC ? 0 : lc + 1;
+        pass += lc == 0 ? 1 : 0;
+        cir = cir + 1 == NC ? 0 : cir + 1;
+        if (cir == 0)
+        {
+            rot++;
+            cb = caz_base_of_rotation(rot);
+        }
+    }
+    if (inrow)
+        p.curtab[row] = tabrow;
+}
+
+// =====================================================================================================
 // k_associate — continuous_clustering.cpp:638-1145. One wavefront per stream, lanes = rows.
 // =====================================================================================================
 constexpr int LINK_SLOTS_V1 = 8;
