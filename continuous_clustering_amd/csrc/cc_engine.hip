@@ -35,8 +35,10 @@ struct cc_engine
                                    // 16 in the first version: with the few stops of ordinary streams (5 in 47 M columns) nearly every batch of a 256-stream run
                                    // then ran three rounds — two more placements of k_assocb's 1024-thread blocks per step, 2 - 3 % of the step
     bool capturing{false};      // launch_batch is being captured into a hipGraph (small calls)
+    cck::HostMirror capture_mirror{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr}; // set while such a graph is captured with the results mirrored by k_publish
     int* d_par_left{nullptr};  // [0] streams whose batch k_insert_par did not take completely (skip_idle_fallbacks), [1] streams whose batch still needs
                                // k_table / k_seg_pre (not closed as fused)
+    bool small_front{true};    // option "small_front": a call of < 64 firings on one stream of a 64-row engine runs k_small_front (begin + ego + prep + insertion + segmentation in one launch)
     int seg_small_max{63};     // option "seg_small_max": calls of at most this many firings (64-row sensors) segment their columns with k_seg_small
     bool fuse_front{true};     // option "fuse_front": k_insert_par also does the per-cell part of the segmentation of the columns it fills
     int* h_par_left{nullptr};  // pinned
@@ -88,6 +90,9 @@ struct cc_engine
     std::vector<SmallGraph> small_graphs;
     unsigned char* h_small{nullptr}; // pinned: packed xyz | intensity | poses of up to SMALL_MAX firings
     unsigned char* d_small{nullptr};
+    unsigned long long* h_small_seq{nullptr}; // pinned: calls whose results k_publish has mirrored (the host spins on it)
+    unsigned long long* d_small_seq{nullptr}; // device: that number + a block counter
+    unsigned long long small_seq_expected{0};
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
@@ -216,12 +221,17 @@ int free_all(cc_engine* e)
     e->d_gather = nullptr;
     e->gather_bytes = 0;
     e->d_small = nullptr;
+    e->d_small_seq = nullptr; // (freed with the allocations above; the pinned counter below goes with it)
+    e->small_seq_expected = 0;
     // the pinned staging of the small-call path is sized for the row count it was created with
     if (e->h_small)
     {
         (void) hipHostFree(e->h_small);
         (void) hipHostFree(e->h_small_state);
         (void) hipHostFree(e->h_small_events);
+        if (e->h_small_seq)
+            (void) hipHostFree(e->h_small_seq);
+        e->h_small_seq = nullptr;
         e->h_small = nullptr;
         e->h_small_state = nullptr;
         e->h_small_events = nullptr;
@@ -386,6 +396,13 @@ int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const do
     return CC_OK;
 }
 
+// calls of a few firings on ONE stream outside the pipeline (cc_engine_add_firings: the per-column latency path) run everything in front of the window
+// scan in one kernel
+static bool use_small_front(const cc_engine* e, int count, int64_t n, bool pipeline)
+{
+    return e->small_front && !pipeline && count == 1 && n <= e->seg_small_max && n < 64 && e->g.num_rows <= WAVE;
+}
+
 // One pass over a batch: insertion on `si`, table + segmentation + window scan on `sb`, association + publish on `sa`
 // (all three equal when not pipelined).
 int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int,
@@ -535,6 +552,18 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             fallbacks = *e->h_par_left != 0;
         }
     }
+    const bool small_front = first_pass && !prep_done && !par && use_small_front(e, count, n, si != sb);
+    if (small_front)
+    {
+        int rcp = ensure_prep(e, (size_t) n * g.num_rows);
+        if (rcp)
+            return rcp;
+        const Planes Pf = planes_with_prep(e, e->prep_buf);
+        hipLaunchKernelGGL(cck::k_small_front, dim3(1), dim3(256), cck::insert2_lds_bytes(g.num_rows), si, g, e->cfg, Pf, e->d_states, first_stream, slot, d_xyz,
+                           d_int, d_pose, (long long) n, e->d_remaining, d_ego);
+        fallbacks = false;
+        need_segpre = false;
+    }
     if (first_pass && !prep_done && fallbacks) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
     {
         int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp, e->cur_ntotal, e->cur_f0, par, first_stream);
@@ -559,12 +588,13 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                                d_int, (long long) n, e->d_remaining, (long long) e->cur_ntotal, (long long) e->cur_f0);
     }
     CC_MARK(si); // ev2: insert
-    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
+    if (!e->capture_mirror.state) // (a small call's graph gets the counter through k_publish's mirror)
+        CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
     // k_table only needs what the insertion of this batch wrote. It is a latency-bound kernel (8 wavefronts per stream) that takes 0.8 ms
     // when it shares the GPU with the throughput kernels — on the segmentation chain, which is the longest of the three, that is a
     // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
     // calls of a few firings (the per-column latency path): ONE wavefront per stream segments the call's columns, rows as lanes (k_seg_small)
-    const bool seg_small = !par && rpl == 1 && first_pass && n <= e->seg_small_max;
+    const bool seg_small = !par && rpl == 1 && first_pass && n <= e->seg_small_max && !small_front;
     if (seg_small)
         need_segpre = false;
     const bool table_early = si != sb && e->table_on_insert_chain != 0;
@@ -618,7 +648,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         hipLaunchKernelGGL(cck::k_seg_small, dim3((unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot, d_pose,
                            (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
     }
-    else
+    else if (!small_front)
     {
         const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
         hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, Pt, e->d_states, first_stream, slot); // (Pt: this slot's table carries)
@@ -630,7 +660,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     CC_MARK(sc); // ev4: table + segment (start of the window scan)
     const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
-    if (e->scan_packed == 1 || (e->scan_packed < 0 && rpl > 1))
+    if (small_front)
+        ; // (k_small_front has scanned the call's columns)
+    else if (e->scan_packed == 1 || (e->scan_packed < 0 && rpl > 1))
     {
         if (rpl == 1 && !g.mirror_fields)
             hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -773,7 +805,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         CC_HIP_CHECK(e, hipStreamWaitEvent(spub, e->ev_pubrdy[slot], 0));
     }
     hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, spub, g, e->P, e->d_states, first_stream,
-                       slot);
+                       slot, e->capture_mirror);
     CC_MARK(spub); // ev9: publish
 #undef CC_MARK
     if (si != sa)
@@ -974,8 +1006,9 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
         CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_assoc[slot], 0));
         e->assoc_pending[slot] = false;
     }
-    hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining,
-                       pipeline ? 1 : 0);
+    if (!use_small_front(e, count, n, pipeline)) // (k_small_front begins the batch itself)
+        hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining,
+                           pipeline ? 1 : 0);
     if (prepared)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], e->stream5));
@@ -1131,6 +1164,7 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     if (!e->h_small)
     {
         if (hipHostMalloc((void**) &e->h_small, b_xyz + b_int + b_pose) != hipSuccess ||
+            hipHostMalloc((void**) &e->h_small_seq, 64) != hipSuccess ||
             hipHostMalloc((void**) &e->h_small_state, sizeof(StreamState)) != hipSuccess ||
             hipHostMalloc((void**) &e->h_small_events, SMALL_EVENTS * sizeof(cc_event)) != hipSuccess)
             return -1;
@@ -1154,6 +1188,30 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         destroy_small_graphs(e);
         e->small_graphs_stale = false;
     }
+    // With k_small_front the call's inputs are read once, by that kernel, straight from the pinned staging (zero copy), and the results are
+    // written to pinned memory by the last kernel (k_publish's mirror): the graph has no copy nodes and no k_begin_batch — five kernels.
+    bool lean = use_small_front(e, 1, n, false);
+    void *zx = nullptr, *zs = nullptr, *zev = nullptr, *zr = nullptr, *zq = nullptr;
+    if (lean && !e->d_small_seq)
+    {
+        if (alloc_plane(e, &e->d_small_seq, 2) != CC_OK || hipMemset(e->d_small_seq, 0, 16) != hipSuccess)
+            lean = false;
+        else
+        {
+            *e->h_small_seq = 0;
+            e->small_seq_expected = 0;
+        }
+    }
+    if (lean)
+        lean = hipHostGetDevicePointer(&zx, e->h_small, 0) == hipSuccess && hipHostGetDevicePointer(&zs, e->h_small_state, 0) == hipSuccess &&
+               hipHostGetDevicePointer(&zev, e->h_small_events, 0) == hipSuccess && hipHostGetDevicePointer(&zr, e->h_remaining, 0) == hipSuccess &&
+               hipHostGetDevicePointer(&zq, e->h_small_seq, 0) == hipSuccess;
+    if (lean)
+    {
+        d_xyz = (const float*) zx;
+        d_int = (const uint8_t*) zx + b_xyz;
+        d_pose = (const double*) ((const unsigned char*) zx + b_xyz + b_int);
+    }
     hipGraphExec_t exec = nullptr;
     for (auto& g : e->small_graphs)
         if (g.stream == stream && g.n == n && g.record == e->g.record_events)
@@ -1167,15 +1225,27 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
             return -1;
-        bool ok = hipMemcpyAsync(e->d_small, e->h_small, b_xyz + b_int + b_pose, hipMemcpyHostToDevice, e->stream) == hipSuccess;
-        hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, e->stream, e->d_states, stream, 1, e->d_remaining, 0);
+        bool ok = true;
+        if (lean)
+            e->capture_mirror = cck::HostMirror{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                                (unsigned long long*) zq, e->d_small_seq};
+        else
+        {
+            ok = hipMemcpyAsync(e->d_small, e->h_small, b_xyz + b_int + b_pose, hipMemcpyHostToDevice, e->stream) == hipSuccess;
+            hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, e->stream, e->d_states, stream, 1, e->d_remaining, 0);
+        }
         e->capturing = true;
         ok = ok && launch_batch(e, stream, 1, n, d_xyz, d_int, d_pose, true, 0, e->stream, e->stream, e->stream) == CC_OK;
         e->capturing = false;
-        ok = ok && hipMemcpyAsync(e->h_small_state, e->d_states + stream, sizeof(StreamState), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
-        if (e->g.record_events)
-            ok = ok && hipMemcpyAsync(e->h_small_events, e->P.events + (size_t) stream * e->g.event_capacity, SMALL_EVENTS * sizeof(cc_event),
-                                      hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        const bool mirrored = e->capture_mirror.state != nullptr;
+        e->capture_mirror = cck::HostMirror{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        if (!mirrored)
+        {
+            ok = ok && hipMemcpyAsync(e->h_small_state, e->d_states + stream, sizeof(StreamState), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+            if (e->g.record_events)
+                ok = ok && hipMemcpyAsync(e->h_small_events, e->P.events + (size_t) stream * e->g.event_capacity, SMALL_EVENTS * sizeof(cc_event),
+                                          hipMemcpyDeviceToHost, e->stream) == hipSuccess;
+        }
         if (hipStreamEndCapture(e->stream, &graph) != hipSuccess || !ok || !graph)
         {
             if (graph)
@@ -1200,7 +1270,35 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     const bool was_idle = e->idle;
     CC_HIP_CHECK(e, hipGraphLaunch(exec, e->stream));
-    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    if (lean)
+    {
+        // the call's last kernel writes the results into pinned memory and then this counter: spinning on it returns as soon as they are
+        // there (a stream synchronisation adds the driver's wake-up to every column); the stream itself is in order for whatever follows
+        const unsigned long long want = ++e->small_seq_expected;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = false;
+        for (unsigned spins = 0;; spins++)
+        {
+            if (__atomic_load_n(e->h_small_seq, __ATOMIC_ACQUIRE) >= want)
+            {
+                seen = true;
+                break;
+            }
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+                break; // (a first launch loading code, a stop in a debugger: let the driver wait)
+        }
+        if (!seen)
+        {
+            CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+            if (__atomic_load_n(e->h_small_seq, __ATOMIC_ACQUIRE) < want)
+            {
+                e->error = "small call: the results were not mirrored";
+                return CC_ERR_HIP;
+            }
+        }
+    }
+    else
+        CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     e->idle = was_idle; // (capturing the graph went through launch_batch; replaying it only touches `stream`, which is drained again)
     if (*e->h_remaining != 0)
     {
@@ -1360,6 +1458,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     e->state_cached.assign(num_streams, 0);
     (void) hipFuncSetAttribute((const void*) cck::k_seg_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void) hipFuncSetAttribute((const void*) cck::k_small_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     rc = allocate(e);
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, 2 * sizeof(int)) != hipSuccess)
@@ -1962,6 +2061,11 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->skip_idle_fallbacks = value != 0;
     else if (n == "fuse_front")
         e->fuse_front = value != 0;
+    else if (n == "small_front")
+    {
+        e->small_front = value != 0;
+        e->small_graphs_stale = true;
+    }
     else if (n == "seg_small_max")
     {
         e->seg_small_max = (int) value;

@@ -632,11 +632,12 @@ __host__ inline size_t insert2_lds_bytes(int R)
 
 // block = 128: wavefront 0 is the consumer (the serial algorithm), wavefront 1 the loader that streams the staged points
 // of the coming firings from HBM into an LDS ring, so that the consumer never waits for a global load.
+// (a device function: k_insert2 is its kernel; k_small_front runs it behind the preparation of a small call, in the same block)
 template<int RPL>
-__global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                 const uint8_t* __restrict__ inten, long long n, int* remaining, long long n_total, long long fbase)
+__device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, int first_stream, int slot,
+                                             const uint8_t* __restrict__ inten, long long n, int* remaining, long long n_total, long long fbase,
+                                             const int sl)
 {
-    const int sl = blockIdx.x;
     const int s = first_stream + sl;
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -1341,6 +1342,13 @@ __global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Plan
     negative_cols = (unsigned long long) wave_max_i64((long long) negative_cols);
     if (lane == 0 && negative_cols)
         st->error_b += (long long) negative_cols;
+}
+
+template<int RPL>
+__global__ __launch_bounds__(128) void k_insert2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+                                                 const uint8_t* __restrict__ inten, long long n, int* remaining, long long n_total, long long fbase)
+{
+    insert2_body<RPL>(g, cfg, P, states, first_stream, slot, inten, n, remaining, n_total, fbase, (int) blockIdx.x);
 }
 
 // ---- pieces shared by k_insert_par and k_insert_par_fin ---------------------------------------------------------------------------
@@ -2606,13 +2614,9 @@ __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P
 // box's farthest corner, hence sigma_min(M) |p - t_T| - |A_t| < B. skip_r2 is a rigorous upper bound of the squared f32 distance (as the
 // segmentation computes it: x2 * x2 + uz * uz, relative to this firing's sensor position) up to which a hit is possible; +inf when the rotation
 // blocks are too far from orthonormal to say. Cells beyond it skip the transform; the others evaluate it exactly as before.
-__global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ states, int first_stream, cc_config cfg, const double* __restrict__ poses,
-                                             long long n, long long n_total, long long fbase, double* __restrict__ out)
+__device__ __forceinline__ void ego_record(const StreamState* __restrict__ states, int first_stream, const cc_config& cfg, const double* __restrict__ poses,
+                                           long long n, long long n_total, long long fbase, double* __restrict__ out, const int sl, const long long f)
 {
-    const int sl = blockIdx.y;
-    const long long f = (long long) blockIdx.x * 256 + threadIdx.x;
-    if (f >= n)
-        return;
     const double* A = states[first_stream + sl].robot_from_sensor;
     const double* T = poses + ((size_t) sl * (size_t) n_total + (size_t) fbase + (size_t) f) * 12;
     double ir[9], it[3];
@@ -2665,6 +2669,14 @@ __global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ sta
         skip = r2f == r2f ? (double) r2f : __builtin_inf();
     }
     o[12] = skip;
+}
+
+__global__ __launch_bounds__(256) void k_ego(const StreamState* __restrict__ states, int first_stream, cc_config cfg, const double* __restrict__ poses,
+                                             long long n, long long n_total, long long fbase, double* __restrict__ out)
+{
+    const long long f = (long long) blockIdx.x * 256 + threadIdx.x;
+    if (f < n)
+        ego_record(states, first_stream, cfg, poses, n, n_total, fbase, out, (int) blockIdx.y, f);
 }
 
 // ---- k_seg_pre: the per-cell part for columns whose cells come from the ring (everything the fused insertion did not take). Lanes = rows
@@ -3385,11 +3397,10 @@ __global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, P
 // k_seg_pre; writes labels, ignore flags, tags, the records / inclinations of cells without a return, column entries, curtab. No staging planes.
 // grid = streams, block = 64; num_rows <= 64.
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_seg_small(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                  const double* __restrict__ poses, long long n_total, long long fbase, const double* __restrict__ ego,
-                                                  long long n_batch)
+__device__ __forceinline__ void seg_small_body(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, int first_stream, int slot,
+                                               const double* __restrict__ poses, long long n_total, long long fbase, const double* __restrict__ ego,
+                                               long long n_batch, const int sl)
 {
-    const int sl = blockIdx.x;
     const int s = first_stream + sl;
     StreamState* st = &states[s];
     const int lane = lane_id();
@@ -3626,6 +3637,13 @@ __global__ __launch_bounds__(64) void k_seg_small(Geometry g, cc_config cfg, Pla
     }
     if (inrow)
         p.curtab[row] = tabrow;
+}
+
+__global__ __launch_bounds__(64) void k_seg_small(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+                                                  const double* __restrict__ poses, long long n_total, long long fbase, const double* __restrict__ ego,
+                                                  long long n_batch)
+{
+    seg_small_body(g, cfg, P, states, first_stream, slot, poses, n_total, fbase, ego, n_batch, (int) blockIdx.x);
 }
 
 // =====================================================================================================
@@ -4421,10 +4439,12 @@ constexpr int SCAN_BLOCKS = CC_SCAN_BLOCKS;
 
 // MIRROR: also count Point::number_of_visited_neighbors (cc.cpp:725) and how far back the scan looked (the live scan stops at the first
 // unpublished column, cc.cpp:762-763, so a count is only right if it did not look past it: the association kernels replay such columns).
+// (a device function: k_scan is its kernel — grid (streams, SCAN_BLOCKS), one wavefront per block —; k_small_front runs it on its four wavefronts)
 template<int RPL, bool MIRROR>
-__global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+__device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, int first_stream, int slot,
+                                          const int bx, const int by, const int ny)
 {
-    const int s = first_stream + blockIdx.x;
+    const int s = first_stream + bx;
     const int lane = lane_id();
     const StreamState* st = &states[s];
     if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->batch[slot].mode != 0)
@@ -4445,17 +4465,17 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
     const long long col_end = st->batch[slot].seg_end, first_column = st->first_column;
     // (ring columns advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
     const int first_lc = (int) (first_column % RC);
-    int lc = (int) ((st->batch[slot].acp_next + blockIdx.y) % RC);
-    const int lc_step = (int) (gridDim.y % (unsigned) RC);
+    int lc = (int) ((st->batch[slot].acp_next + by) % RC);
+    const int lc_step = (int) ((unsigned) ny % (unsigned) RC);
     const int NC = g.num_columns;
-    long long rot = (st->batch[slot].acp_next + blockIdx.y) / NC; // rotation index / column within the rotation, advanced the same way
-    int cir = (int) ((st->batch[slot].acp_next + blockIdx.y) - rot * NC);
-    const int cir_step = (int) (gridDim.y % (unsigned) NC);
-    const long long rot_step = (long long) (gridDim.y / (unsigned) NC);
+    long long rot = (st->batch[slot].acp_next + by) / NC; // rotation index / column within the rotation, advanced the same way
+    int cir = (int) ((st->batch[slot].acp_next + by) - rot * NC);
+    const int cir_step = (int) ((unsigned) ny % (unsigned) NC);
+    const long long rot_step = (long long) ((unsigned) ny / (unsigned) NC);
     CazBase cb = caz_base_of_rotation(rot);
     long long cb_rot = rot;
-    for (long long gc = st->batch[slot].acp_next + blockIdx.y; gc < col_end;
-         gc += gridDim.y, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step), rot += rot_step + (cir + cir_step >= NC ? 1 : 0),
+    for (long long gc = st->batch[slot].acp_next + by; gc < col_end;
+         gc += (unsigned) ny, lc = (lc + lc_step >= RC ? lc + lc_step - RC : lc + lc_step), rot += rot_step + (cir + cir_step >= NC ? 1 : 0),
                    cir = (cir + cir_step >= NC ? cir + cir_step - NC : cir + cir_step))
     {
         // never look at columns older than the first column ever segmented (their planes are uninitialised)
@@ -4612,6 +4632,73 @@ __global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P
         }
         scan_column_epilogue<RPL, MIRROR>(p, R, lc, lane, parent, nlinks, fin, packed, reach);
     }
+}
+
+template<int RPL, bool MIRROR>
+__global__ __launch_bounds__(64) void k_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+{
+    scan_body<RPL, MIRROR>(g, cfg, P, states, first_stream, slot, (int) blockIdx.x, (int) blockIdx.y, (int) gridDim.y);
+}
+
+// =====================================================================================================
+// k_small_front — everything up to and including the window scan for a call of a few firings on ONE stream, in one launch (the per-column latency
+// path, cc_engine_add_firings with n < 64): what k_begin_batch, k_ego, k_prep, k_insert2 and k_seg_small do one after the other. A captured
+// graph spends ~4.5 us per kernel node on a call whose kernels need 1 - 10 us each; five nodes less are ~20 us of a 65 us call.
+// grid = 1, block = 256, dynamic LDS = insert2_lds_bytes(num_rows); num_rows <= 64.
+//   A  all threads: the batch begins (thread 0), per-firing ego records, per-point preparation into the staging planes
+//   B  wavefronts 0 and 1: the serial insertion (insert2_body: consumer + loader)
+//   C  wavefront 0: the segmentation of the columns the call finished (seg_small_body)
+//   D  all wavefronts: the window scan of those columns (scan_body)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_small_front(Geometry g, cc_config cfg, Planes P, StreamState* states, int stream, int slot,
+                                                     const float* __restrict__ xyz, const uint8_t* __restrict__ inten, const double* __restrict__ poses,
+                                                     long long n, int* remaining, double* __restrict__ ego)
+{
+    const int R = g.num_rows;
+    StreamState* st = &states[stream];
+    if (threadIdx.x == 0)
+    {
+        // k_begin_batch (cc_engine.hip) for this stream; a call on the host path never clears past what the host has seen
+        st->cursor = 0;
+        st->par_bad = 0x7fffffff;
+        st->par_upto = -1;
+        st->par_clear_done = -1;
+        st->pre_seg_begin = 0;
+        st->n_events = 0;
+        st->n_links = 0;
+        st->clear_allowed = st->ring_start;
+        *remaining = 0;
+    }
+    for (long long f = threadIdx.x; f < n; f += 256)
+        ego_record(states, stream, cfg, poses, n, n, 0, ego, 0, f);
+    for (long long i = threadIdx.x; i < n * R; i += 256)
+    {
+        const PreppedPoint q = prep_point(xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], poses + (i / R) * 12, cfg.sensor_is_clockwise != 0, g.az_width);
+        P.pp_cir[i] = q.cir;
+        if (q.cir == PP_SKIP)
+            continue;
+        P.pp_x[i] = q.x;
+        P.pp_y[i] = q.y;
+        P.pp_z[i] = q.z;
+        P.pp_dist[i] = q.dist;
+        P.pp_incl[i] = q.incl;
+        P.pp_incaz[i] = q.incaz;
+    }
+    __syncthreads(); // (workgroup-scope release / acquire: the staging planes, the ego records and the stream state are visible to wavefronts 0 and 1)
+    if (threadIdx.x < 128)
+        insert2_body<1>(g, cfg, P, states, stream, slot, inten, n, remaining, n, 0, 0);
+    else
+        __syncthreads(); // (insert2_body has ONE block barrier, right at its start: the wavefronts that do not run it must meet it, or every
+                         // barrier behind it pairs the wrong phases — the hardware only counts arrivals)
+    __syncthreads();
+    if (threadIdx.x < 64)
+        seg_small_body(g, cfg, P, states, stream, slot, poses, n, 0, ego, n, 0);
+    __syncthreads();
+    // D  all four wavefronts: the window scan of the call's columns (scan_body: what k_scan does with one wavefront per block)
+    if (g.mirror_fields)
+        scan_body<1, true>(g, cfg, P, states, stream, slot, 0, (int) (threadIdx.x >> 6), 4);
+    else
+        scan_body<1, false>(g, cfg, P, states, stream, slot, 0, (int) (threadIdx.x >> 6), 4);
 }
 
 // =====================================================================================================
@@ -5763,24 +5850,72 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
 // =====================================================================================================
 constexpr int PUBLISH_BLOCKS = 64;
 
-__global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot)
+// what a small call on the host path hands back (cc_engine.hip: add_firings_small), written straight into pinned host memory by the last kernel of
+// the call instead of by three copy nodes of its graph: the stream's state, its first events, the early-stop counter
+struct HostMirror
+{
+    StreamState* state;
+    cc_event* events;
+    int max_events;
+    int* remaining;
+    const int* d_remaining;
+    unsigned long long* seq;   // pinned: the number of mirrored calls so far, written LAST (the host spins on it instead of synchronising the stream)
+    unsigned long long* d_seq; // device: [0] that number, [1] blocks of the current launch that are through
+};
+
+__global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot, HostMirror hm)
 {
     const int s = first_stream + blockIdx.x;
     const StreamState* st = &states[s];
-    if (st->batch[slot].pub_begin < 0)
-        return;
-    const SP p = stream_ptrs(P, g, s);
-    const int R = g.num_rows, RC = g.ring_cols;
-    int plc = (int) ((st->batch[slot].pub_begin + blockIdx.y) % RC);
-    const int plc_step = (int) (gridDim.y % (unsigned) RC);
-    for (long long pc = st->batch[slot].pub_begin + blockIdx.y; pc < st->batch[slot].pub_end;
-         pc += gridDim.y, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
+    if (st->batch[slot].pub_begin >= 0)
     {
-        for (int row = lane_id(); row < R; row += 64)
+        const SP p = stream_ptrs(P, g, s);
+        const int R = g.num_rows, RC = g.ring_cols;
+        int plc = (int) ((st->batch[slot].pub_begin + blockIdx.y) % RC);
+        const int plc_step = (int) (gridDim.y % (unsigned) RC);
+        for (long long pc = st->batch[slot].pub_begin + blockIdx.y; pc < st->batch[slot].pub_end;
+             pc += gridDim.y, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
         {
-            const int ci = plc * R + row;
-            const int r = p.root[ci];
-            p.id[ci] = r >= 0 ? p.t_cid[r] : 0u;
+            for (int row = lane_id(); row < R; row += 64)
+            {
+                const int ci = plc * R + row;
+                const int r = p.root[ci];
+                p.id[ci] = r >= 0 ? p.t_cid[r] : 0u;
+            }
+        }
+    }
+    if (hm.state)
+    {
+        // the LAST block of the launch to get here mirrors the call's results: every cluster id of the call has been written by then, and the
+        // association chain in front of this kernel left the state final
+        const int lane = lane_id();
+        __threadfence();
+        unsigned long long through = 0;
+        if (lane == 0)
+            through = atomicAdd(&hm.d_seq[1], 1ull);
+        through = (unsigned long long) uniform_i64((long long) through);
+        if (through == (unsigned long long) gridDim.x * gridDim.y - 1ull)
+        {
+            const StreamState* s0 = &states[first_stream];
+            const unsigned* src = (const unsigned*) s0;
+            unsigned* dst = (unsigned*) hm.state;
+            for (int i = lane; i < (int) (sizeof(StreamState) / 4); i += 64)
+                dst[i] = src[i];
+            const int ne = s0->n_events < hm.max_events ? s0->n_events : hm.max_events;
+            const unsigned* es = (const unsigned*) (P.events + (size_t) first_stream * g.event_capacity);
+            unsigned* ed = (unsigned*) hm.events;
+            for (int i = lane; i < ne * (int) (sizeof(cc_event) / 4); i += 64)
+                ed[i] = es[i];
+            if (lane == 0)
+                *hm.remaining = *hm.d_remaining;
+            __threadfence_system();
+            if (lane == 0)
+            {
+                hm.d_seq[1] = 0ull;
+                const unsigned long long v = hm.d_seq[0] + 1ull;
+                hm.d_seq[0] = v;
+                __hip_atomic_store(hm.seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
