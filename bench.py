@@ -244,6 +244,40 @@ def cpu_mode_c(cfg, R, hx, hi, hp, cores):
             "fastest_s": min(r[2] for r in res), "latency_ns": res[0][3], "membw_GBs": sum(r[4] for r in res)}
 
 
+def _cpu_mode_b_worker(cores, cfg, R, hx, hi, hp, conn):
+    try:
+        os.sched_setaffinity(0, set(cores))
+        from oracle.pyoracle import Oracle
+        x, i, p = np.array(hx, copy=True), np.array(hi, copy=True), np.array(hp, copy=True)
+        o = Oracle(cfg, R, record=False)
+        sec = o.time_firings_pipeline(x, i, p)
+        conn.send((o.state()["cells_published"], sec, o.last_error() if sec < 0 else ""))
+    except Exception as ex:  # noqa: BLE001
+        conn.send((0, -1.0, repr(ex)))
+    finally:
+        conn.close()
+
+
+def cpu_mode_b(cfg, R, hx, hi, hp, cores):
+    """BASELINE.md mode B: ONE instance, its stages on threads connected by bounded queues with back-pressure (oracle/cc_oracle.cpp: Oracle::Pipe —
+    the three-thread, race-free part of the reference's five-stage pipeline, cc.cpp:49-63), pinned to three physical cores."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    a, b = ctx.Pipe(duplex=False)
+    pr = ctx.Process(target=_cpu_mode_b_worker, args=(cores[:3], cfg, R, hx, hi, hp, b))
+    pr.start()
+    b.close()
+    cells, sec, err = a.recv()
+    pr.join()
+    if sec <= 0:
+        return {"value": None, "error": err}
+    return {"value": cells / sec / 1e6, "unit": "Mpoints/s", "threads": 3, "cores": len(cores[:3]), "seconds": sec,
+            "note": "one oracle instance, stages handed from thread to thread: insertion | segmentation | association + tree combination + publishing "
+                    "(bounded queues, producer back-pressure). The reference's own pipeline has five stages on seven threads that share the range image "
+                    "and the tree lists without locks; the oracle keeps the single-threaded data structures and runs the three stages that are free "
+                    "of data races on them. Same results as single-threaded (tests/test_oracle_properties.py)"}
+
+
 def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args, sweep_sizes=(1, 16, 64)):
     R = sensor.num_rows
     cores = physical_cores()
@@ -274,6 +308,12 @@ def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args, sweep_sizes=
         "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "physical_cores": len(cores), "rotations_per_instance": nb,
         "single_core_value": single, "sweep": sweep,
     }
+    try:
+        out["mode_b"] = cpu_mode_b(cfg, R, hx[0], hi[0], hp[0], cores)
+        if out["mode_b"].get("value") and single:
+            out["mode_b"]["vs_single_thread"] = out["mode_b"]["value"] / single
+    except Exception as ex:  # noqa: BLE001
+        out["mode_b"] = {"value": None, "error": repr(ex)}
     if lat:
         out["mode_a_latency_us_per_column"] = {"p50": lat[0] / 1e3, "p99": lat[1] / 1e3, "mean": lat[2] / 1e3,
                                                 "note": "one instance, one core: steady_clock around every addFiring call (1 firing = 1 column), "

@@ -1,4 +1,4 @@
-// Three-wave association kernel (included by cc_kernels.h inside namespace cck, after cc_assoc2.h whose structures and helpers it shares).
+// Three-wave association kernel (included by cc_kernels.h inside namespace cck, after cc_assoc_shared.h whose structures and helpers it uses).
 //
 // k_assoc3 is k_assoc2 with the per-point work taken off the back wave. k_assoc2's back wave needs ~2 300 clocks per column, of which
 // ~1 000 go into looking at every point of the column twice (liveness check, run-length aggregation) although a column touches one to
@@ -7,7 +7,7 @@
 // plane. The back wave then checks and applies whole groups of columns with one lane per record (two LDS round trips per group), keeps its
 // scalar walk, the exact finished-cluster check and the publish bookkeeping. Columns whose records do not fit (more than A3_REC trees or
 // A3_BIRTH new roots in one column) take the exact serial replay like every other exception. Same results as k_assoc2, bit for bit
-// (tests: every parity case runs with it; option "assoc_waves" = 2 selects k_assoc2).
+// (tests: every parity case runs with it).
 #pragma once
 
 constexpr int A3_REC = 8;   // records (trees receiving points) per column

@@ -128,14 +128,6 @@ __device__ __forceinline__ double wave_shr1_f64(double v)
     return __longlong_as_double(wave_shr1_i64(__double_as_longlong(v)));
 }
 
-// CC_AB_RESCAN = 1: a point whose link list overflowed in k_scan (more than LINK_SLOTS accepted candidates behind the first) has its window scanned again by
-// the worker wavefront (scan_point with a visitor) instead of ending the kernel for the stream's batch. Exact (all GPU tests and the randomised sweeps pass
-// with it), but the extra code in the workers' loop costs k_assocb 5 - 7 % (0.375 -> 0.40 ms per 2200 columns at 32 streams) and ordinary streams never
-// need it: their only stops were groups with more link EVENTS than the timeline has lanes, which the per-column filter T.pair removes. Off.
-#ifndef CC_AB_RESCAN
-#define CC_AB_RESCAN 0
-#endif
-
 template<int RPL>
 __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
                                                        int* __restrict__ bail_count)
@@ -294,12 +286,8 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             const int ncols = ~okm ? __builtin_ctzll(~okm) : 64;
             const unsigned long long cm = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
             int bail = (ncols == 0 && g0 < col_end) ? AB_BAIL_TREES : 0;
-#if CC_AB_RESCAN
-            // (a point with more link candidates than k_scan records, flag bit 8 of the column summary: the workers walk its complete list themselves)
-#else
             if (__ballot(((info >> 8) & 1) != 0) & cm)
                 bail = AB_BAIL_LINKS; // a point with more link candidates than k_scan records (cc.cpp:693-694 would see them all)
-#endif
             // no tree or cluster of this group can reach the one-rotation limits (cc.cpp:657, 913-924) while the oldest unfinished tree is
             // less than a rotation behind the group's last column
             if (n_before > 0 && ncols > 0 && (g0 + ncols - lds_ld(&T.gcol[0])) >= NC)
@@ -850,45 +838,6 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             {
                 T.pair[w][lane] = 0ull;
                 wave_lds_fence();
-            }
-            {
-                // a point whose list overflowed in k_scan (more than LINK_SLOTS candidates: 1 column in 10^7 of ordinary streams, but each one used to
-                // end the kernel for the stream's batch): its window is scanned again here and every candidate behind the first is looked up
-                if (CC_AB_RESCAN && ((lds_ld(&T.col_info[cidx]) >> 8) & 1)) // (wave-uniform: the column summary says whether any list overflowed)
-                {
-                    const long long gcq = gc0 + cidx;
-                    int lcq = lc0 + cidx;
-                    lcq = lcq >= RC ? lcq - RC : lcq;
-                    const int bound = (gcq - first_column) <= (long long) cfg.max_steps_in_row + 1 ? (int) (first_column % RC) : -1;
-#pragma unroll
-                    for (int k = 0; k < RPL; k++)
-                        if (sl[k] >= 0 && pf_nl[q][k] == 255)
-                        {
-                            const int row = k * 64 + lane;
-                            const int mine = sl[k];
-                            const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[lcq * R + row]);
-                            int d_root = -1, d_parent = -1, d_n = 0;
-                            bool d_ov = false;
-                            auto on_link = [&](const int code)
-                            {
-                                const int v = ring[(int) ((gcq - (code >> 8)) & (AB_RING - 1)) * R + (code & 0xff)];
-                                if (v >= 0)
-                                    bad = 1;
-                                else if (v > AB_NONE && -1 - v != mine)
-                                {
-                                    const unsigned long long bit = 1ull << (-1 - v);
-                                    if (!(atomicOr(&T.pair[w][mine], bit) & bit))
-                                    {
-                                        const int e = atomicAdd(&T.n_ev, 1);
-                                        if (e < AB_EVENTS)
-                                            T.ev[e] = ((unsigned) cidx << 16) | ((unsigned) mine << 8) | (unsigned) (-1 - v);
-                                    }
-                                }
-                            };
-                            scan_point<false, true, true>(c, lcq, gcq, row, bound, mad, 0., d_root, d_parent, nullptr, d_n, d_ov, 0, nullptr, nullptr, nullptr,
-                                                          nullptr, on_link);
-                        }
-                }
             }
 #pragma unroll
             for (int k = 0; k < RPL; k++)

@@ -83,7 +83,7 @@ struct StreamState
         int64_t fused;     // 1: k_insert_par took the whole batch AND did the per-cell part of its segmentation (staging planes, table carries):
                            // k_table / k_seg_pre have nothing to do for this stream
     } batch[4];
-    int32_t assoc_mode; // 0: tree state in LDS (k_assoc2 / k_assoc_lds), 1: tree state in global memory (k_associate); the global kernel
+    int32_t assoc_mode; // 0: tree state in LDS (k_assocb / k_assoc3 / k_assoc_lds), 1: tree state in global memory (k_associate); the global kernel
                         // hands a stream back once its unfinished trees fit the LDS pool comfortably again
     int32_t pad1;
     int64_t cursor;     // firings of the current batch already consumed

@@ -99,7 +99,7 @@ struct cc_engine
     int scan_packed{-1};                // option "scan_packed": 1 = k_scan2 (active points packed into the lanes), 0 = k_scan (rows as lanes, lock
                                         // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch;
                                         // at 64 rows the lock-step kernel is 3 % ahead inside the pipeline although it issues 1.5 x the instructions)
-    int assoc_waves{3};                 // option "assoc_waves": 1 = k_assoc_lds, 2 = k_assoc2 (front / back wavefronts), 3 / 4 = k_assoc3
+    int assoc_waves{3};                 // option "assoc_waves": 1 = k_assoc_lds, 3 / 4 = k_assoc3 (2, the retired two-wavefront kernel, selects k_assoc3)
                                         // without / with its links wavefront
     bool assoc_batch{true};             // option "assoc_batch": k_assocb in front of the serial association kernels
     int assoc_rounds{0};                // option "assoc_rounds": (k_assocb, k_assoc3) pairs per batch; all but the last serial launch are limited.
@@ -720,8 +720,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             adaptive_rounds = 3;
         }
     }
-    // k_assoc2 walks the finished-cluster checks of several columns at once and assumes one check per column
-    if (e->assoc_waves >= 3 && e->cfg.cluster_point_trees_every_nth_column == 1)
+    // k_assoc3 walks the finished-cluster checks of several columns at once and assumes one check per column
+    if (e->assoc_waves >= 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
         // with or without the links wave (cc_assoc3.h: A3_THREADS): by default (assoc_waves = 0) with it while the streams are few
         // enough for the association chain to be what the step waits for
@@ -755,19 +755,6 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
             global_done = limited == 0; // (the last launch of k_assoc3 takes the streams that continue in global memory with it)
         }
-    }
-    else if (e->assoc_waves == 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
-    {
-        if (batch_assoc)
-        {
-            launch_assocb();
-            CC_MARK(sa);
-            marked7 = true;
-        }
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_assoc2<1>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-        else
-            hipLaunchKernelGGL(cck::k_assoc2<2>, dim3(count), dim3(128), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
     }
     else
     {
@@ -1492,6 +1479,15 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         delete e;
         return rc;
     }
+    // experiment switches for harnesses that only see the reference's class API (tests/cpp/dropin_demo): CC_OPT_<OPTION>=<value> in the environment
+    for (const char* name : {"small_front", "seg_small_max", "fuse_front", "small_graphs"})
+    {
+        std::string key = std::string("CC_OPT_") + name;
+        for (auto& ch : key)
+            ch = (char) toupper((unsigned char) ch);
+        if (const char* v = getenv(key.c_str()))
+            (void) cc_engine_set_option(e, name, atoll(v));
+    }
     *out = e;
     return CC_OK;
 }
@@ -2049,7 +2045,7 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->input_on_engine_stream = value != 0;
     else if (n == "assoc_waves")
     {
-        // 1: k_assoc_lds, 2: k_assoc2, 3: k_assoc3 without the links wave, 4: with it, 0 (default): k_assoc3, links wave up to 256 streams
+        // 1: k_assoc_lds, 3: k_assoc3 without the links wave, 4: with it, 0 (default): k_assoc3, links wave up to 256 streams (2: as 3)
         e->assoc_waves_auto = value <= 0 || value > 4;
         e->assoc_waves = e->assoc_waves_auto ? 3 : (int) value;
     }

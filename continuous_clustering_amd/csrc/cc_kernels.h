@@ -1707,6 +1707,9 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
             nx_pose = poses[fi * 12 + (size_t) (lane < 12 ? lane : 0)];
     };
     const int fstep = W * nby;
+#ifdef CC_IP_PRIO
+    __builtin_amdgcn_s_setprio(CC_IP_PRIO); // (experiment switch: issue priority of the insertion's wavefronts next to the other chains' kernels)
+#endif
     // ---- fused segmentation: per-wavefront partial of k_table's phase 1 (a wavefront's columns increase: the last valid step it has seen in the
     // tile it is in; flushed into Planes::tab_acc with an atomic max on (column, step) when it moves on to another tile)
     float tl_val[RPL];
@@ -5840,7 +5843,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     }
 }
 
-#include "cc_assoc2.h"
+#include "cc_assoc_shared.h"
 #include "cc_assoc3.h"
 #include "cc_assocb.h"
 

@@ -272,7 +272,7 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * HIP stream; 1: overlap consecutive batches on three chains (insertion | table, segmentation, window scan | association); 2 (default):
  * the window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
  * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 256 streams; 3 / 4: k_assoc3 without / with
- * the links wavefront; 2: k_assoc2 (front / back wavefronts); 1: the one-wavefront kernel, which is also what
+ * the links wavefront; 1: the one-wavefront kernel, which is also what
  * cluster_point_trees_every_nth_column != 1 uses), "skip_idle_fallbacks" (1 (default): in the pipelined mode the
  * host waits for the block-parallel insertion kernel of a batch and launches the other insertion kernels only if some stream's batch was not
  * taken completely (k_insert_par up to 64 rows, k_insert_multi above); 0: always launch them), "assoc_rounds" (1..8; 0 (default): adaptive — one

@@ -34,6 +34,9 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <thread>
+#include <mutex>
+#include <atomic>
 
 #include "../include/cc_hip.h"
 
@@ -180,6 +183,13 @@ struct Oracle
     int64_t keep_tail{0};                  // > 0: only the most recent snapshots are kept (long verification runs of bench.py)
     uint64_t firings_consumed{0}, cells_published{0}, clusters_finished{0};
     uint64_t exceed_one_rotation{0};
+    // ---- BASELINE.md mode B (orc_time_firings_pipeline below): the stages handed from thread to thread instead of called depth first
+    struct Pipe;
+    Pipe* pipe{nullptr};
+    float seg_pos[3]{0, 0, 0}; // sgps_sensor_position of the column being segmented (pipeline: owned by the segmentation thread)
+    bool ring_inited{false};   // (what `ring_start == -1` tells insert_firing, without reading a field the publishing thread writes)
+    void pipe_push_segment(int64_t gcol, const Iso& pose);
+    void pipe_push_associate(int64_t gcol);
     uint64_t max_unfinished{0};
     std::string error;
 
@@ -240,6 +250,7 @@ struct Oracle
         clear_columns(0, ring_cols - 1);
         ring_start = -1;
         ring_end = -1;
+        ring_inited = false;
         prev_rearmost = 0;
         prev_foremost = -1;
         first_unfinished = -1;
@@ -271,10 +282,14 @@ struct Oracle
         max_distance_squared = cfg.max_distance * cfg.max_distance;
     }
 
+    std::mutex emit_mutex; // (pipeline mode with recording on: two stage threads append events)
     void emit(int type, int64_t a, int64_t b, uint32_t c, uint32_t d, int64_t column)
     {
         if (!record)
             return;
+        std::unique_lock<std::mutex> lk(emit_mutex, std::defer_lock);
+        if (pipe)
+            lk.lock();
         cc_event e{};
         e.type = type;
         e.stream = 0;
@@ -392,8 +407,9 @@ struct Oracle
         }
         if (prev_foremost < 0)
             return;
-        if (ring_start == -1)
+        if (!ring_inited)
         {
+            ring_inited = true;
             ring_start = prev_rearmost;
             first_unpublished = prev_rearmost;
         }
@@ -402,7 +418,16 @@ struct Oracle
         if (first_unfinished == -1)
             first_unfinished = prev_rearmost;
         while (first_unfinished < prev_rearmost)
-            segment_column(first_unfinished++, odom_from_sensor);
+        {
+            if (pipe)
+                pipe_push_segment(first_unfinished++, odom_from_sensor); // (the segmentation thread takes it from here)
+            else
+            {
+                for (int i = 0; i < 3; i++)
+                    seg_pos[i] = sensor_pos_f[i];
+                segment_column(first_unfinished++, odom_from_sensor);
+            }
+        }
     }
 
     static inline float len2(float a, float b)
@@ -470,7 +495,7 @@ struct Oracle
                 continue;
             }
 
-            float cur[3] = {c.x - sensor_pos_f[0], c.y - sensor_pos_f[1], c.z - sensor_pos_f[2]};
+            float cur[3] = {c.x - seg_pos[0], c.y - seg_pos[1], c.z - seg_pos[2]};
 
             if (!first_point_found)
             {
@@ -539,7 +564,7 @@ struct Oracle
                 while (below < num_rows)
                 {
                     Cell& b = at(lc, below);
-                    float bx = len2(b.x - sensor_pos_f[0], b.y - sensor_pos_f[1]);
+                    float bx = len2(b.x - seg_pos[0], b.y - seg_pos[1]);
                     if (b.debug == CC_DBG_YELLOW ||
                         (b.ground == CC_GP_GROUND &&
                          std::abs(cur2x - bx) < cfg.obstacle_because_next_certain_obstacle_max_dist_diff))
@@ -613,7 +638,10 @@ struct Oracle
         }
 
         emit(CC_EV_GROUND_COLUMN, gcol, gcol, 0, 0, gcol);
-        associate_column(gcol);
+        if (pipe)
+            pipe_push_associate(gcol); // (the association thread takes it from here)
+        else
+            associate_column(gcol);
     }
 
     // ---- cc.cpp:638-641 -------------------------------------------------------------------------------
@@ -939,6 +967,145 @@ struct Oracle
     }
 };
 
+// ---- BASELINE.md 3, mode B: "reference pipeline" ---------------------------------------------------------------------------------------
+// The reference's multi-threaded mode (cc.cpp:49-63) hands every column from stage to stage through thread pools: insertion (1 thread),
+// segmentation (1), association (1), tree combination (1), publishing (3). Its stages share the range image, the tree lists and
+// sc_first_unpublished without further synchronisation (the association of column c + 1 may run while column c's trees are combined). This
+// restatement keeps the single-threaded data structures, so it runs the part of that pipeline that is free of data races on them: THREE
+// threads — insertion (the caller), segmentation, association + combination + publishing — connected by bounded single-producer
+// single-consumer queues (the producer waits when a queue is full: back-pressure, so the ring never overruns, cc.cpp:337). Results are the
+// single-threaded ones (every column still passes the stages in order). What it measures: how much of the reference's per-column work
+// overlaps when insertion (35 % of the single-threaded time), segmentation (12 %) and the rest (~ 50 %) run concurrently.
+struct Oracle::Pipe
+{
+    struct SegJob
+    {
+        int64_t gcol;
+        Iso pose;
+        float pos[3];
+    };
+    static constexpr size_t CAP = 1024; // columns in flight per queue (a small fraction of the 10-rotation ring)
+    std::vector<SegJob> seg{CAP};
+    std::vector<int64_t> assoc = std::vector<int64_t>(CAP);
+    std::atomic<uint64_t> seg_head{0}, seg_tail{0}, assoc_head{0}, assoc_tail{0};
+    std::atomic<bool> done_insert{false}, done_segment{false}, failed{false};
+    std::string error;
+};
+
+void Oracle::pipe_push_segment(int64_t gcol, const Iso& pose)
+{
+    Pipe& q = *pipe;
+    const uint64_t t = q.seg_tail.load(std::memory_order_relaxed);
+    while (t - q.seg_head.load(std::memory_order_acquire) >= Pipe::CAP && !q.failed.load())
+        std::this_thread::yield();
+    Pipe::SegJob& j = q.seg[t % Pipe::CAP];
+    j.gcol = gcol;
+    j.pose = pose;
+    for (int i = 0; i < 3; i++)
+        j.pos[i] = sensor_pos_f[i];
+    q.seg_tail.store(t + 1, std::memory_order_release);
+}
+
+void Oracle::pipe_push_associate(int64_t gcol)
+{
+    Pipe& q = *pipe;
+    const uint64_t t = q.assoc_tail.load(std::memory_order_relaxed);
+    while (t - q.assoc_head.load(std::memory_order_acquire) >= Pipe::CAP && !q.failed.load())
+        std::this_thread::yield();
+    q.assoc[t % Pipe::CAP] = gcol;
+    q.assoc_tail.store(t + 1, std::memory_order_release);
+}
+
+// runs n firings through the three-thread pipeline; returns seconds (-1: an exception, its text in o.error)
+static double run_pipeline(Oracle& o, int64_t n, const float* xyz, const uint8_t* intensity, const double* poses)
+{
+    Oracle::Pipe q;
+    o.pipe = &q;
+    auto fail = [&](const char* what)
+    {
+        if (!q.failed.exchange(true))
+            q.error = what;
+    };
+    std::thread seg_thread(
+        [&]()
+        {
+            try
+            {
+                while (true)
+                {
+                    const uint64_t h = q.seg_head.load(std::memory_order_relaxed);
+                    if (h == q.seg_tail.load(std::memory_order_acquire))
+                    {
+                        if (q.done_insert.load(std::memory_order_acquire) && h == q.seg_tail.load(std::memory_order_acquire))
+                            break;
+                        if (q.failed.load())
+                            break;
+                        std::this_thread::yield();
+                        continue;
+                    }
+                    const Oracle::Pipe::SegJob j = q.seg[h % Oracle::Pipe::CAP];
+                    q.seg_head.store(h + 1, std::memory_order_release);
+                    for (int i = 0; i < 3; i++)
+                        o.seg_pos[i] = j.pos[i];
+                    o.segment_column(j.gcol, j.pose);
+                }
+            }
+            catch (const std::exception& e)
+            {
+                fail(e.what());
+            }
+            q.done_segment.store(true, std::memory_order_release);
+        });
+    std::thread assoc_thread(
+        [&]()
+        {
+            try
+            {
+                while (true)
+                {
+                    const uint64_t h = q.assoc_head.load(std::memory_order_relaxed);
+                    if (h == q.assoc_tail.load(std::memory_order_acquire))
+                    {
+                        if (q.done_segment.load(std::memory_order_acquire) && h == q.assoc_tail.load(std::memory_order_acquire))
+                            break;
+                        if (q.failed.load())
+                            break;
+                        std::this_thread::yield();
+                        continue;
+                    }
+                    const int64_t g = q.assoc[h % Oracle::Pipe::CAP];
+                    q.assoc_head.store(h + 1, std::memory_order_release);
+                    o.associate_column(g);
+                }
+            }
+            catch (const std::exception& e)
+            {
+                fail(e.what());
+            }
+        });
+    const auto t0 = std::chrono::steady_clock::now();
+    try
+    {
+        for (int64_t i = 0; i < n && !q.failed.load(); i++)
+            o.add_firing(xyz + (size_t) i * o.num_rows * 3, intensity + (size_t) i * o.num_rows, poses + (size_t) i * 12);
+    }
+    catch (const std::exception& e)
+    {
+        fail(e.what());
+    }
+    q.done_insert.store(true, std::memory_order_release);
+    seg_thread.join();
+    assoc_thread.join();
+    const auto t1 = std::chrono::steady_clock::now();
+    o.pipe = nullptr;
+    if (q.failed.load())
+    {
+        o.error = q.error;
+        return -1.0;
+    }
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
 } // namespace
 
 extern "C" {
@@ -1033,6 +1200,23 @@ double orc_time_firings(orc_handle* h, int64_t n, const float* xyz, const uint8_
     auto t1 = std::chrono::steady_clock::now();
     o.record = rec;
     return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// Mode B of BASELINE.md 3: the same n firings through the three-thread stage pipeline (see Oracle::Pipe); recording off; seconds or -1.
+double orc_time_firings_pipeline(orc_handle* h, int64_t n, const float* xyz, const uint8_t* intensity, const double* poses)
+{
+    Oracle& o = h->o;
+    const bool rec = o.record;
+    o.record = false;
+    const double s = run_pipeline(o, n, xyz, intensity, poses);
+    o.record = rec;
+    return s;
+}
+
+// the pipeline with recording ON (tests: its events and published columns must be the single-threaded ones); CC_OK or an error code
+int orc_add_firings_pipeline(orc_handle* h, int64_t n, const float* xyz, const uint8_t* intensity, const double* poses)
+{
+    return run_pipeline(h->o, n, xyz, intensity, poses) < 0 ? CC_ERR_BOOKKEEPING : CC_OK;
 }
 
 // Mode A of BASELINE.md 3: per-call latency of addFiring (one firing = one column for KITTI-shaped streams). out_ns[i] = duration of

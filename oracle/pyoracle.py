@@ -48,6 +48,9 @@ def lib():
         L.orc_time_firings.restype = C.c_double
         L.orc_time_each_firing.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_time_each_firing.restype = C.c_double
+        L.orc_time_firings_pipeline.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_time_firings_pipeline.restype = C.c_double
+        L.orc_add_firings_pipeline.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_last_error.restype = C.c_char_p
         L.orc_last_error.argtypes = [C.c_void_p]
         L.orc_stream_state.argtypes = [C.c_void_p, C.POINTER(capi.StreamState)]
@@ -137,6 +140,20 @@ class Oracle:
         intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
         poses = np.ascontiguousarray(poses, dtype=np.float64)
         return self.L.orc_time_firings(self.h, xyz.shape[0], xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
+
+    def time_firings_pipeline(self, xyz, intensity, poses) -> float:
+        """BASELINE.md mode B: the firings through the three-thread stage pipeline (cc_oracle.cpp: Oracle::Pipe); seconds, -1 on error."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        return self.L.orc_time_firings_pipeline(self.h, xyz.shape[0], xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
+
+    def add_firings_pipeline(self, xyz, intensity, poses) -> int:
+        """The same pipeline with recording on (tests: equal to add_firings)."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        intensity = np.ascontiguousarray(intensity, dtype=np.uint8)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        return self.L.orc_add_firings_pipeline(self.h, xyz.shape[0], xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
 
     def time_each_firing(self, xyz, intensity, poses) -> np.ndarray:
         """Per-call addFiring latency in nanoseconds (BASELINE.md mode A)."""

@@ -41,7 +41,6 @@ def test_ring_wrap_host_path(name, chunks, oracle_lib):
 @pytest.mark.parametrize("name,option,value", [
     ("w_s64_240x13", "parallel_insert", 0),
     ("w_s64_240x13", "assoc_waves", 1),
-    ("w_s64_240x13", "assoc_waves", 2),
     ("w_s64_240x13", "assoc_waves", 3),
     ("w_s64_ring_wall_240x12", "assoc_waves", 1),
     ("w_s64_ring_wall_240x12", "assoc_waves", 3),

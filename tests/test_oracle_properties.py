@@ -156,3 +156,34 @@ def test_error_paths(oracle_lib):
     o2 = Oracle(cfg, 64)
     assert o2.add_firings(bad, stream.intensity[:1], stream.poses[:1]) == 0
     assert o2.state()["reset_required"] == 1
+
+
+def test_stage_pipeline_of_the_cpu_baseline_gives_the_single_threaded_results(oracle_lib):
+    """BASELINE.md mode B (bench.py: cpu_baseline.mode_b) runs the oracle's stages on three threads connected by bounded queues. It is a timing
+    harness — but it must do the same work: events and published columns equal to the depth-first single-threaded run."""
+    import numpy as np
+    from continuous_clustering_amd import capi, synth
+    from oracle.pyoracle import Oracle
+    cfg = capi.Config.kitti()
+    cfg.num_columns = 360
+    sensor = synth.SensorModel(num_rows=64, num_columns=360)
+    st = synth.make_stream(360 * 4 + 50, seed=9, sensor=sensor, motion=synth.Motion.translate())
+    a, b = Oracle(cfg, 64), Oracle(cfg, 64)
+    assert a.add_firings(st.xyz, st.intensity, st.poses) == 0
+    assert b.add_firings_pipeline(st.xyz, st.intensity, st.poses) == 0, b.last_error()
+    ea, eb = a.drain_events(), b.drain_events()
+    # the ground-view events of the pipeline come from another thread than the cluster-view ones: compare per type, in order
+    for t in (1, 2, 3):
+        assert np.array_equal(ea[ea["type"] == t], eb[eb["type"] == t]), t
+    assert a.state() == b.state()
+    fa, ta = a.published_range()
+    pa, pb = a.read_published(fa, ta), b.read_published(fa, ta)
+    for k in pa:
+        x, y = pa[k], pb[k]
+        if x.dtype.kind == "f":
+            assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(x[~np.isnan(x)], y[~np.isnan(y)]), k
+        else:
+            assert np.array_equal(x, y), k
+    c = Oracle(cfg, 64, record=False)
+    assert c.time_firings_pipeline(st.xyz, st.intensity, st.poses) > 0
+    assert c.state()["cells_published"] == a.state()["cells_published"]

@@ -32,7 +32,7 @@ for i in range(n_cases):
         over["stop_after_association_enabled"] = 0
     cfg = (cases._vls if s128 else cases._kitti)(cols, **over)
     chunks = [int(c) for c in rng.choice([1, 3, 17, 64, 97, 250, cols, 2 * cols], size=4)]
-    waves = [0, 4, 3, 2, 1][i % 5]  # default (k_assoc3 + links wavefront), pinned four / three waves, k_assoc2, k_assoc_lds
+    waves = [0, 4, 3, 1][i % 4]  # default (k_assoc3 + links wavefront), pinned four / three waves, k_assoc_lds
     batch = 0 if i % 7 == 6 else 1  # the batch-parallel kernel in front (default) or not
     rounds = [0, 2, 1, 3][i % 4]
     box = {}
