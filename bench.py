@@ -328,7 +328,7 @@ def engine_options(eng):
     for env, opt in (("CC_SUB_BATCH", "sub_batch"), ("CC_TABLE_EARLY", "table_on_insert_chain"), ("CC_PIPELINE", "pipeline"),
                      ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed"),
                      ("CC_SKIP_FALLBACKS", "skip_idle_fallbacks"), ("CC_ASSOC_ROUNDS", "assoc_rounds"), ("CC_ASSOC_BATCH", "assoc_batch"),
-                     ("CC_EGO_EARLY", "ego_on_insert_chain"), ("CC_ASSOC_COOLDOWN", "assoc_cooldown"), ("CC_SWEEP_BLOCKS", "assoc_sweep_blocks"), ("CC_INSERT_WIDE", "insert_wide_max_streams"), ("CC_INSERT_SPLIT", "insert_split_blocks"), ("CC_DEBUG_NO_ASSOC_FALLBACK", "debug_no_assoc_fallback"), ("CC_FUSE_FRONT", "fuse_front")):
+                     ("CC_EGO_EARLY", "ego_on_insert_chain"), ("CC_ASSOC_COOLDOWN", "assoc_cooldown"), ("CC_SWEEP_BLOCKS", "assoc_sweep_blocks"), ("CC_INSERT_WIDE", "insert_wide_max_streams"), ("CC_INSERT_SPLIT", "insert_split_blocks"), ("CC_DEBUG_NO_ASSOC_FALLBACK", "debug_no_assoc_fallback"), ("CC_FUSE_FRONT", "fuse_front"), ("CC_INSERT_NARROW", "insert_narrow_blocks")):
         if os.environ.get(env) not in (None, ""):
             eng.set_option(opt, int(os.environ[env]))
 
@@ -430,8 +430,13 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
     # four chains wander by +- 20 % between runs of equal throughput, and at 128 rows two kernels are within that of each other); without the
     # file, the longest HIP-event duration of this run. `launch_ms` is always this run's own HIP-event figure for that kernel.
     committed = {}
-    spath = os.path.join(ROOT, "profiles", "r03_final_kernel_stats.csv" if R == 64 else "r03_final_kernel_stats_s128.csv")
-    if os.path.exists(spath):
+    spath = ""
+    for tag in ("r04_final", "r04a", "r03_final"):  # (the newest committed summary of this build's round)
+        cand = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv" if R == 64 else f"{tag}_kernel_stats_s128.csv")
+        if os.path.exists(cand):
+            spath = cand
+            break
+    if spath:
         try:
             import csv
             calls = {}
@@ -641,6 +646,9 @@ def single_stream_report(ctx, sensor, cfg, F, xyz, inten, poses):
         try:
             # reference_api_only: nothing but the reference's calls with its default is_single_threaded = false — the class's asynchronous mode
             # (addFiring enqueues, a worker thread runs the engine and the callbacks); latency there = due time -> ground-view callback
+            # (one untimed run first: the first start of the demo binary on a fresh box pages in the libraries and loads the code objects —
+            # a 20 - 30 ms stall in the middle of a 0.3 s feed that says nothing about a running system)
+            subprocess.run([demo, path, "/dev/null", "-1", "0"], capture_output=True, text=True, timeout=300)
             for key, batch, rate in (("reference_api_only_paced_22kHz", -1, 22000), ("reference_api_only_free_running", -1, 0),
                                      ("adaptive_paced_22kHz", 0, 22000), ("adaptive_free_running", 0, 0), ("one_call_per_firing", 1, 0)):
                 r = subprocess.run([demo, path, "/dev/null", str(batch), str(rate)], capture_output=True, text=True, timeout=300)

@@ -166,7 +166,10 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
         return;
     }
 
-    __builtin_amdgcn_s_setprio(3); // latency-bound (barriers, LDS round trips): win issue arbitration against co-resident throughput kernels
+#ifndef CC_AB_PRIO
+#define CC_AB_PRIO 3
+#endif
+    __builtin_amdgcn_s_setprio(CC_AB_PRIO); // latency-bound (barriers, LDS round trips): win issue arbitration against co-resident throughput kernels
     __shared__ AbTrees T;
     __shared__ short ring[AB_RING * WAVE * RPL];
     __shared__ int s_nunf;

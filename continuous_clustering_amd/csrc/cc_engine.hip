@@ -43,7 +43,8 @@ struct cc_engine
     bool fuse_front{true};     // option "fuse_front": k_insert_par also does the per-cell part of the segmentation of the columns it fills
     int* h_par_left{nullptr};  // pinned
     int insert_split_blocks{0};      // option "insert_split_blocks": blocks per stream of k_insert_par in such launches (0 = 4 up to 40 streams, else 2; 1 = one)
-    int insert_wide_max_streams{96}; // option "insert_wide_max_streams": launches of at most this many streams run k_insert_par with 16 wavefronts
+    int insert_narrow_blocks{0};     // option "insert_narrow_blocks": above insert_wide_max_streams, blocks of 4 wavefronts, this many per stream (0 = one block of 8)
+    int insert_wide_max_streams{160}; // option "insert_wide_max_streams": launches of at most this many streams run k_insert_par with 16 wavefronts
     bool skip_idle_fallbacks{true}; // option "skip_idle_fallbacks": wait for k_insert_par and launch the other insertion kernels only if needed
     hipStream_t stream{nullptr};  // insertion chain (and everything else when not pipelined)
     hipStream_t stream2{nullptr}; // table / segmentation / window-scan chain of the pipelined throughput path
@@ -490,10 +491,21 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         int* left = gate ? e->d_par_left : (int*) nullptr;
         if (count <= e->insert_wide_max_streams)
         {
-            const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : 2);
+            // (round 4: with the segmentation fused in, a block of 8 wavefronts needs ~1.1 ms per 2200 firings by itself: up to 160 streams the
+            // GPU has room for twice the wavefronts — 128 streams 11.3 -> 15.0 G points/s — above that it is full and they only get in each other's way)
+            const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : (count <= 96 ? 2 : 1));
             hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
                                first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, ego_in);
             if (nb > 1)
+                hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
+                                   (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, fuse ? 1 : 0);
+        }
+        else if (e->insert_narrow_blocks > 0)
+        {
+            // (experiment: small blocks find room on a busy CU sooner than one block of 8 wavefronts)
+            hipLaunchKernelGGL((cck::k_insert_par<1, 4>), dim3(count, e->insert_narrow_blocks), dim3(256), 0, si, g, e->cfg, Pt, e->d_states,
+                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, ego_in);
+            if (e->insert_narrow_blocks > 1)
                 hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
                                    (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, fuse ? 1 : 0);
         }
@@ -2051,6 +2063,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     }
     else if (n == "insert_split_blocks")
         e->insert_split_blocks = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
+    else if (n == "insert_narrow_blocks")
+        e->insert_narrow_blocks = (int) value;
     else if (n == "insert_wide_max_streams")
         e->insert_wide_max_streams = (int) value;
     else if (n == "skip_idle_fallbacks")

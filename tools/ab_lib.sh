@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/ab_lib.sh [-s "<bench args>"] <lib1.so> <lib2.so> ...   same-box alternation of bench.py (256 x S64, 40 steps) over several builds of the library
-args="--steps 40 --warmup 3 --no-cpu-baseline --no-latency --no-s128 --no-verify"
+args="--steps 40 --warmup 3 --no-cpu-baseline --no-latency --no-s128 --no-few-streams --no-host-fed --no-verify"
 if [ "$1" = "-s" ]; then args="$2"; shift 2; fi
 for rep in 1 2 3; do
 for lib in "$@"; do

@@ -7,9 +7,9 @@ repo=${GRAFT_REPO_ROOT:-/root/repo}
 out=$repo/gpurun_out/round_$tag
 mkdir -p $out
 cd $repo
-python bench.py > $out/bench_line.json 2> $out/bench.err
-CC_ASSOC_ROUNDS=1 tools/prof.sh $tag --steps 40 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof.log 2>&1
-CC_ASSOC_ROUNDS=1 tools/prof.sh ${tag}_s128 --sensor s128 --firings 1700 --steps 10 --warmup 3 --no-cpu-baseline --no-latency --no-s128 > $out/prof_s128.log 2>&1
+python bench.py --steps 20 --warmup 5 > $out/bench_line.json 2> $out/bench.err
+CC_ASSOC_ROUNDS=1 tools/prof.sh $tag --steps 40 --warmup 3 --no-cpu-baseline --no-latency --no-s128 --no-few-streams --no-host-fed > $out/prof.log 2>&1
+CC_ASSOC_ROUNDS=1 tools/prof.sh ${tag}_s128 --sensor s128 --firings 1700 --steps 10 --warmup 3 --no-cpu-baseline --no-latency --no-s128 --no-few-streams --no-host-fed > $out/prof_s128.log 2>&1
 tools/pmc.sh $tag > $out/pmc.log 2>&1
 tools/pmc.sh ${tag}_s128 --sensor s128 --firings 1700 > $out/pmc_s128.log 2>&1
 tools/pmc_sq.sh $tag "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
@@ -17,12 +17,12 @@ tools/pmc_sq.sh $tag "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD 
                      "SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS_ATOMIC" \
                      "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" > $out/sq.log 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 1 --steps 20 --warmup 3 \
-  --no-cpu-baseline --no-latency --no-s128 > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
+  --no-cpu-baseline --no-latency --no-s128 --no-few-streams --no-host-fed > $out/bench_rccl_world1.json 2> $out/bench_rccl_world1.err
 # every kernel alone (pipeline 0), association with / without its links wavefront; stream-count sweep; per-wave cycle counters (instrumented build)
 CC_ASSOC_WAVES=4 python tools/kernel_times.py 2>&1 | grep "^pipeline" > $out/kernel_times_assoc_waves4.txt
 CC_ASSOC_WAVES=3 python tools/kernel_times.py 2>&1 | grep "^pipeline" > $out/kernel_times_assoc_waves3.txt
 for S in 32 64 128 256 384 512; do
-  python bench.py --streams $S --steps 30 --no-cpu-baseline --no-latency --no-verify --no-s128 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('streams', $S, 'Mpoints/s', round(d['value']), 'ms_per_step', round(d['ms_per_step'],3), 'dominant', d['roofline']['kernel'], 'launch_ms', round(d['roofline']['launch_ms'],3))"
+  python bench.py --streams $S --steps 30 --no-cpu-baseline --no-latency --no-verify --no-s128 --no-few-streams --no-host-fed 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('streams', $S, 'Mpoints/s', round(d['value']), 'ms_per_step', round(d['ms_per_step'],3), 'dominant', d['roofline']['kernel'], 'launch_ms', round(d['roofline']['launch_ms'],3))"
 done > $out/stream_sweep.txt
 [ -f continuous_clustering_amd/libcc_hip_abstats.so ] && python tools/prof_assocb.py 256 > $out/assocb_phase_clocks.txt 2>&1
 cp $repo/gpurun_out/prof_$tag/*kernel_stats.csv $out/kernel_stats_s64.csv 2>/dev/null
