@@ -718,6 +718,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     bool marked7 = false;
     int adaptive_rounds = 1;
     bool global_done = false; // k_associate's work was done inside the last k_assoc3 launch
+    // a lean small call (k_small_front in front, results mirrored): k_assocb, then ONE kernel for the serial fall-backs, the ids and the mirror
+    const bool small_tail = small_front && e->capture_mirror.state != nullptr && batch_assoc && e->assoc_waves >= 2 && rpl == 1 &&
+                            e->cfg.cluster_point_trees_every_nth_column == 1 && !e->debug_no_assoc_fallback;
     if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
     {
         const int seen = *e->h_bail_count; // (as of some earlier batch: a heuristic, not a condition of correctness)
@@ -732,8 +735,16 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             adaptive_rounds = 3;
         }
     }
+    if (small_tail)
+    {
+        launch_assocb();
+        CC_MARK(sa); // ev7
+        marked7 = true;
+        hipLaunchKernelGGL(cck::k_small_tail<1>, dim3(1), dim3(cck::A3_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, e->capture_mirror);
+        global_done = true;
+    }
     // k_assoc3 walks the finished-cluster checks of several columns at once and assumes one check per column
-    if (e->assoc_waves >= 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
+    else if (e->assoc_waves >= 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
     {
         // with or without the links wave (cc_assoc3.h: A3_THREADS): by default (assoc_waves = 0) with it while the streams are few
         // enough for the association chain to be what the step waits for
@@ -803,8 +814,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         CC_HIP_CHECK(e, hipEventRecord(e->ev_pubrdy[slot], sa));
         CC_HIP_CHECK(e, hipStreamWaitEvent(spub, e->ev_pubrdy[slot], 0));
     }
-    hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, spub, g, e->P, e->d_states, first_stream,
-                       slot, e->capture_mirror);
+    if (!small_tail)
+        hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, spub, g, e->P, e->d_states, first_stream,
+                           slot, e->capture_mirror);
     CC_MARK(spub); // ev9: publish
 #undef CC_MARK
     if (si != sa)

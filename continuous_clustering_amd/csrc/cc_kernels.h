@@ -1411,6 +1411,9 @@ __device__ __forceinline__ int par_close_stream(StreamState* st, const int slot,
             st->batch[slot].pub_begin = -1;
             st->batch[slot].pub_end = -1;
             st->batch[slot].fused = fused;
+#if !defined(CC_PROFILE_SECTIONS) && !defined(CC_A2_STATS)
+            st->dbg[4] += (unsigned long long) fused; // batches closed as fused (cc_engine_debug_counters; tests)
+#endif
             if (fused)
                 st->batch[slot].mode = st->assoc_mode; // (what k_table does first for the streams it sees)
             // (pre_seg_begin stays: if another stream makes the host launch the other insertion kernels after all, k_insert2 finds
@@ -5866,62 +5869,90 @@ struct HostMirror
     unsigned long long* d_seq; // device: [0] that number, [1] blocks of the current launch that are through
 };
 
-__global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot, HostMirror hm)
+// cluster ids of the columns the batch published (cc.cpp:1035-1092: what publishing leaves in Point::id), columns by .. ny .. strided
+__device__ __forceinline__ void publish_body(const Geometry& g, const Planes& P, const StreamState* states, const int s, const int slot, const int by,
+                                             const int ny)
 {
-    const int s = first_stream + blockIdx.x;
     const StreamState* st = &states[s];
-    if (st->batch[slot].pub_begin >= 0)
+    if (st->batch[slot].pub_begin < 0)
+        return;
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    int plc = (int) ((st->batch[slot].pub_begin + by) % RC);
+    const int plc_step = (int) ((unsigned) ny % (unsigned) RC);
+    for (long long pc = st->batch[slot].pub_begin + by; pc < st->batch[slot].pub_end;
+         pc += ny, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
     {
-        const SP p = stream_ptrs(P, g, s);
-        const int R = g.num_rows, RC = g.ring_cols;
-        int plc = (int) ((st->batch[slot].pub_begin + blockIdx.y) % RC);
-        const int plc_step = (int) (gridDim.y % (unsigned) RC);
-        for (long long pc = st->batch[slot].pub_begin + blockIdx.y; pc < st->batch[slot].pub_end;
-             pc += gridDim.y, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
+        for (int row = lane_id(); row < R; row += 64)
         {
-            for (int row = lane_id(); row < R; row += 64)
-            {
-                const int ci = plc * R + row;
-                const int r = p.root[ci];
-                p.id[ci] = r >= 0 ? p.t_cid[r] : 0u;
-            }
+            const int ci = plc * R + row;
+            const int r = p.root[ci];
+            p.id[ci] = r >= 0 ? p.t_cid[r] : 0u;
         }
     }
+}
+
+// one wavefront: the call's results into pinned host memory, the sequence number last
+__device__ __forceinline__ void mirror_results(const Geometry& g, const Planes& P, const StreamState* states, const int s, const HostMirror& hm)
+{
+    const int lane = lane_id();
+    const StreamState* s0 = &states[s];
+    const unsigned* src = (const unsigned*) s0;
+    unsigned* dst = (unsigned*) hm.state;
+    for (int i = lane; i < (int) (sizeof(StreamState) / 4); i += 64)
+        dst[i] = src[i];
+    const int ne = s0->n_events < hm.max_events ? s0->n_events : hm.max_events;
+    const unsigned* es = (const unsigned*) (P.events + (size_t) s * g.event_capacity);
+    unsigned* ed = (unsigned*) hm.events;
+    for (int i = lane; i < ne * (int) (sizeof(cc_event) / 4); i += 64)
+        ed[i] = es[i];
+    if (lane == 0)
+        *hm.remaining = *hm.d_remaining;
+    __threadfence_system();
+    if (lane == 0)
+    {
+        hm.d_seq[1] = 0ull;
+        const unsigned long long v = hm.d_seq[0] + 1ull;
+        hm.d_seq[0] = v;
+        __hip_atomic_store(hm.seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot, HostMirror hm)
+{
+    publish_body(g, P, states, first_stream + (int) blockIdx.x, slot, (int) blockIdx.y, (int) gridDim.y);
     if (hm.state)
     {
         // the LAST block of the launch to get here mirrors the call's results: every cluster id of the call has been written by then, and the
         // association chain in front of this kernel left the state final
-        const int lane = lane_id();
         __threadfence();
         unsigned long long through = 0;
-        if (lane == 0)
+        if (lane_id() == 0)
             through = atomicAdd(&hm.d_seq[1], 1ull);
         through = (unsigned long long) uniform_i64((long long) through);
         if (through == (unsigned long long) gridDim.x * gridDim.y - 1ull)
-        {
-            const StreamState* s0 = &states[first_stream];
-            const unsigned* src = (const unsigned*) s0;
-            unsigned* dst = (unsigned*) hm.state;
-            for (int i = lane; i < (int) (sizeof(StreamState) / 4); i += 64)
-                dst[i] = src[i];
-            const int ne = s0->n_events < hm.max_events ? s0->n_events : hm.max_events;
-            const unsigned* es = (const unsigned*) (P.events + (size_t) first_stream * g.event_capacity);
-            unsigned* ed = (unsigned*) hm.events;
-            for (int i = lane; i < ne * (int) (sizeof(cc_event) / 4); i += 64)
-                ed[i] = es[i];
-            if (lane == 0)
-                *hm.remaining = *hm.d_remaining;
-            __threadfence_system();
-            if (lane == 0)
-            {
-                hm.d_seq[1] = 0ull;
-                const unsigned long long v = hm.d_seq[0] + 1ull;
-                hm.d_seq[0] = v;
-                __hip_atomic_store(hm.seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
+            mirror_results(g, P, states, first_stream, hm);
     }
 }
+
+// k_small_tail — what is behind the batch-parallel association in a call of a few firings on ONE stream (the per-column latency path): the exact serial
+// kernel for whatever k_assocb left (nothing, normally), the streams that continue in global memory, the cluster ids of the published columns and
+// the results into pinned host memory — k_assoc3 + k_publish in one launch (one graph node less: ~4.5 us of a 50 us call). grid = 1, block = A3_THREADS.
+template<int RPL>
+__global__ __launch_bounds__(A3_THREADS) void k_small_tail(Geometry g, cc_config cfg, Planes P, StreamState* states, int stream, int slot, HostMirror hm)
+{
+    assoc3_stream<RPL>(g, cfg, P, states, stream, slot, 0);
+    __threadfence_block();
+    __syncthreads(); // every wavefront has left the stream (its state is in the planes again)
+    if (threadIdx.x < 64)
+        associate_stream<RPL>(g, cfg, P, states, stream, slot);
+    __syncthreads();
+    publish_body(g, P, states, stream, slot, (int) (threadIdx.x >> 6), (int) (blockDim.x >> 6));
+    __syncthreads();
+    if (hm.state && threadIdx.x < 64)
+        mirror_results(g, P, states, stream, hm);
+}
+
 
 // =====================================================================================================
 // k_scatter_info / k_scatter_apply — the frame scatter of the reference's harness (addColumnAndEvaluateFrameIfCompleted,

@@ -98,3 +98,49 @@ def test_device_call_longer_than_the_parallel_kernel_takes(oracle_lib):
             assert so[k] == se[k], (s, k)
         hi = se["first_unpublished_global_column_index"] - 1
         util.compare_columns(o.read_published(hi - 3000, hi), e.read_columns(hi - 3000, hi, stream=s), hi - 3000, mirror=False)
+
+
+def _fused_batches(e):
+    import ctypes as C
+    from continuous_clustering_amd import load_library
+    L = load_library()
+    L.cc_engine_debug_counters.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    out = np.zeros(16, dtype=np.uint64)
+    L.cc_engine_debug_counters(e.h, 0, out.ctypes.data)
+    return int(out[4])
+
+
+@pytest.mark.parametrize("chunks", [[2200], [700, 64, 1500], [100, 2100]])
+def test_fused_segmentation_is_taken_and_changes_nothing(chunks, oracle_lib):
+    """Round 4: k_insert_par also does the per-cell part of the segmentation of the columns it fills and closes a batch it took completely as
+    FUSED (no k_table / k_seg_pre for the stream). On a steady stream every batch but the first must be closed that way (debug counter 4), on a
+    stream that keeps leaving the fast shape some are and some are not — and with the option off none: the oracle's results in all three."""
+    cfg = capi.Config.kitti()
+    stream = synth.make_stream(2200 * 3 + 300, seed=21, motion=synth.Motion.translate())
+    box = {}
+    util.run_and_compare(stream, cfg, chunks=chunks, engine_setup=lambda e: box.__setitem__("e", e))
+    calls = 0
+    f = i = 0
+    while f < stream.n_firings:
+        f += min(chunks[i % len(chunks)], stream.n_firings - f)
+        i += 1
+        calls += 1
+    big = sum(1 for k in range(calls) if min(chunks[k % len(chunks)], 10 ** 9) >= 64)
+    assert _fused_batches(box["e"]) >= big - 2, (_fused_batches(box["e"]), big)   # (all calls of >= 64 firings but the first one or two)
+    util.run_and_compare(stream, cfg, chunks=chunks, engine_setup=lambda e: (e.set_option("fuse_front", 0), box.__setitem__("off", e)))
+    assert _fused_batches(box["off"]) == 0
+    rough = perturbed_stream(7)
+    util.run_and_compare(rough, cfg, chunks=[1100], engine_setup=lambda e: box.__setitem__("r", e))
+    assert 0 < _fused_batches(box["r"]) < 7
+
+
+def test_fused_segmentation_with_columns_no_firing_fills(oracle_lib):
+    """A sensor that skips every third column (firings 1.5 columns apart): the columns in between are segmented as columns without returns by
+    the wavefront of the firing in front of them (stage_gap), still inside the fused kernel."""
+    cfg = capi.Config.kitti()
+    cfg.num_columns = 720
+    sensor = synth.SensorModel(num_rows=64, num_columns=480)   # 480 firings per rotation into 720 columns
+    stream = synth.make_stream(480 * 4 + 100, seed=33, sensor=sensor, motion=synth.Motion.translate())
+    box = {}
+    s = util.run_and_compare(stream, cfg, chunks=[480, 200], engine_setup=lambda e: box.__setitem__("e", e))
+    assert s["published_columns"] > 1500 and _fused_batches(box["e"]) >= 5
