@@ -214,8 +214,9 @@ int cc_engine_set_robot_from_sensor(cc_engine* e, int stream, const double tf[12
  * associated, checked and published; events are queued in reference order.
  * Columns published during a call stay readable (cc_engine_read_columns) until the next call when
  * n <= 2 * num_columns; longer calls are split internally and may clear (cc.cpp:1091) what their first
- * part published. Calls with n <= 8 take a low-latency path: one captured hipGraph launch (H2D of the firings,
- * every kernel, D2H of state and events) and one synchronisation. */
+ * part published. Calls with n <= 8 take a low-latency path: one captured hipGraph launch — on sensors of <= 64 rows three kernels that read the
+ * firings from pinned staging and write state and events back into pinned memory, no copy node, the host spins on a sequence number
+ * (one firing per call: ~48 us p50); otherwise H2D of the firings, every kernel, D2H of state and events and one synchronisation. */
 int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz, const uint8_t* intensity,
                           const double* poses);
 
@@ -287,8 +288,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * block-parallel kernel, the serial insertion kernel continues behind it; 0: serial kernel only), "publish_off_chain" (1 (default): in the pipelined mode k_publish runs on a stream of its own instead of at the end of
  * the association chain), "table_on_insert_chain" (1 (default): in the pipelined mode k_table runs at the end of the insertion chain instead of
  * at the head of the segmentation chain (0); 2: on a stream of its own between the two), "ego_on_insert_chain" (1: k_ego next to k_table instead of in
- * front of k_seg_pre; default 0), "insert_wide_max_streams" / "insert_split_blocks" (launches of at most that many streams, default 96, run k_insert_par with 16
- * wavefronts per block and deal a stream's firings to that many blocks: 0 (default) = 4 up to 40 streams, else 2), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
+ * front of k_seg_pre; default 0), "fuse_front" (1 (default): k_insert_par also does the per-cell part of the ground segmentation of the columns it fills and closes batches it took completely as fused: k_table / k_seg_pre are only launched for streams that need them; 0: the unfused chain), "seg_small_max" (default 63: calls of at most that many firings on a sensor of <= 64 rows segment their columns with k_seg_small, one wavefront per stream with rows as lanes), "small_front" (1 (default): such a call on ONE stream outside the pipeline — cc_engine_add_firings — runs k_small_front / k_small_tail: a three-kernel graph without copy nodes, the results mirrored into pinned host memory), "insert_narrow_blocks" (experiment), "insert_wide_max_streams" / "insert_split_blocks" (launches of at most that many streams, default 160, run k_insert_par with 16
+ * wavefronts per block and deal a stream's firings to that many blocks: 0 (default) = 4 up to 40 streams, 2 up to 96, else 1), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
  * number_of_visited_neighbors, per-tree values of finished trees, the tree-link log; 0 in throughput mode), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
  * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made). */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
