@@ -30,7 +30,7 @@ __device__ __forceinline__ void assoc3_stream(const Geometry& g, const cc_config
     constexpr int A2_LEAD = a2_lead(RPL), A2_STAGE = a2_stage(RPL);
     static_assert(WIN_COLS + A2_LEAD + 1 <= WIN2_COLS && A2_LEAD + G <= A2_STAGE && A2_LEAD < A2_INFO, "ring sizes");
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = uniform_i32((int) (threadIdx.x >> 6));
     const bool lwave = blockDim.x > 192; // wave L exists
     const int nthreads = (int) blockDim.x;
     StreamState* st = &states[s];

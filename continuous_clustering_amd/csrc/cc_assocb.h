@@ -134,7 +134,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
 {
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = uniform_i32((int) (threadIdx.x >> 6));
     StreamState* st = &states[s];
     if (st->error != 0 || st->batch[slot].seg_begin < 0 || st->assoc_mode != 0 || st->batch[slot].mode != 0 ||
         st->batch[slot].acp_next >= st->batch[slot].seg_end)

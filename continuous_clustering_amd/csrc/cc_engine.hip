@@ -1430,7 +1430,39 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     int prio_lo = 0, prio_hi = 0;
     (void) hipSetDevice(device);
     (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
+    // experiment switch CC_OPT_CU_SPLIT="ins,seg,scan,assoc": the four chains of the pipelined path on disjoint sets of compute units (CU-masked
+    // streams; the mask's bits are dealt round-robin over XCDs and shader engines by the driver, so a contiguous range is spread over the chip)
+    bool cu_split = false;
+    if (const char* cs = std::getenv("CC_OPT_CU_SPLIT"))
+    {
+        int part[4] = {0, 0, 0, 0};
+        hipDeviceProp_t prop;
+        if (sscanf(cs, "%d,%d,%d,%d", &part[0], &part[1], &part[2], &part[3]) == 4 && hipGetDeviceProperties(&prop, device) == hipSuccess)
+        {
+            const int ncu = prop.multiProcessorCount;
+            const int words = (ncu + 31) / 32;
+            auto masked = [&](hipStream_t* out_stream, int from, int cnt) -> bool
+            {
+                std::vector<uint32_t> m(words, 0u);
+                for (int i = from; i < from + cnt && i < ncu; i++)
+                    m[i >> 5] |= 1u << (i & 31);
+                return hipExtStreamCreateWithCUMask(out_stream, (uint32_t) words, m.data()) == hipSuccess;
+            };
+            const int o1 = part[0], o2 = o1 + part[1], o3 = o2 + part[2];
+            cu_split = part[0] > 0 && part[1] > 0 && part[2] > 0 && part[3] > 0 && o3 + part[3] <= ncu && masked(&e->stream, 0, part[0]) &&
+                       masked(&e->stream5, 0, part[0]) && masked(&e->stream7, 0, part[0]) && masked(&e->stream2, o1, part[1]) &&
+                       masked(&e->stream4, o2, part[2]) && masked(&e->stream3, o3, part[3]) && masked(&e->stream6, o3, part[3]);
+            if (!cu_split)
+            {
+                fprintf(stderr, "cc_engine_create: CC_OPT_CU_SPLIT=%s rejected (%d compute units)\n", cs, ncu);
+                delete e;
+                return CC_ERR_INVALID_ARGUMENT;
+            }
+        }
+    }
+    if (cu_split)
+        fprintf(stderr, "cc_engine_create: chains on disjoint compute units (CC_OPT_CU_SPLIT=%s)\n", std::getenv("CC_OPT_CU_SPLIT"));
+    else if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||

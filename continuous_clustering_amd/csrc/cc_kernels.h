@@ -151,6 +151,14 @@ __device__ __forceinline__ void lds_st(T* p, T v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// element `ci` of a per-stream plane through a 32-bit BYTE offset: a wave-uniform base pointer plus a zero-extended 32-bit lane offset is the
+// addressing mode global loads / stores have (saddr + voffset) — with a 64-bit index every access pays two or three instructions of address
+// arithmetic. A stream's planes stay far below 4 GB (ring_cols * rows * 16 B).
+template<class T>
+__device__ __forceinline__ T& at32(T* base, const unsigned ci)
+{
+    return *(T*) ((char*) base + ci * (unsigned) sizeof(T));
+}
 __device__ __forceinline__ int uniform_i32(int v)
 {
     return __builtin_amdgcn_readfirstlane(v);
@@ -640,7 +648,7 @@ __device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config&
 {
     const int s = first_stream + sl;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = uniform_i32((int) (threadIdx.x >> 6));
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
@@ -1525,7 +1533,7 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = uniform_i32((int) (threadIdx.x >> 6)); // (readfirstlane: the firing index and everything addressed with it stay scalar)
     const int tid = threadIdx.x;
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
@@ -1685,12 +1693,9 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     // the current one is worked on.
     float nx_x[RPL], nx_y[RPL], nx_z[RPL];
     uint8_t nx_i[RPL];
-    double nx_pose = 0., nx_trig = 0.; // (nx_trig: translation of the NEXT firing's pose in lanes 0 - 2 = sgps_sensor_position of this column's job)
     auto load_firing = [&](const int f)
     {
         const size_t fi = fglob + (size_t) f;
-        if (fuse && f + 1 < upto)
-            nx_trig = poses[(fi + 1) * 12 + (size_t) (3 + 4 * (lane < 3 ? lane : 0))];
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -1706,8 +1711,6 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
                 nx_i[k] = inten[fi * R + row];
             }
         }
-        if (f < upto)
-            nx_pose = poses[fi * 12 + (size_t) (lane < 12 ? lane : 0)];
     };
     const int fstep = W * nby;
 #ifdef CC_IP_PRIO
@@ -1789,15 +1792,15 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
             const int row = k * 64 + lane;
             if (row >= R)
                 continue;
-            const size_t ci = (size_t) lc * R + row;
-            p.sg_x2[ci] = x2[k];
-            p.sg_uz[ci] = uz[k];
-            p.sg_w[ci] = w[k];
-            p.sg_flags[ci] = (uint8_t) flags[k];
+            const unsigned ci = (unsigned) lc * (unsigned) R + (unsigned) row;
+            at32(p.sg_x2, ci) = x2[k];
+            at32(p.sg_uz, ci) = uz[k];
+            at32(p.sg_w, ci) = w[k];
+            at32(p.sg_flags, ci) = (uint8_t) flags[k];
             if ((flags[k] & SG_NAN) && write_empty_cells)
             {
-                p.gtag[ci] = tag;
-                p.sc_rec[ci] = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+                at32(p.gtag, ci) = tag;
+                at32(p.sc_rec, ci) = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
             }
             if (flags[k] & SG_NAN)
                 any_empty = true;
@@ -1908,11 +1911,16 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
             cz[k] = nx_z[k];
             cint[k] = nx_i[k];
         }
+        // the firing's pose by SCALAR loads (f is wave-uniform): as a vector load with one lane per matrix element, prefetched with the returns, the
+        // matrix cost 30 v_readlane per firing on a GPU whose vector ALUs are what the step waits for; the scalar loads' latency is other wavefronts' time
+        const double* Tp = poses + (fglob + (size_t) f) * 12;
         double T[12]; // (wave-uniform: the matrix travels in SGPRs)
 #pragma unroll
         for (int i = 0; i < 12; i++)
-            T[i] = lane_f64(nx_pose, i);
-        const float spx = (float) lane_f64(nx_trig, 0), spy = (float) lane_f64(nx_trig, 1), spz = (float) lane_f64(nx_trig, 2);
+            T[i] = Tp[i];
+        // translation of the NEXT firing's pose = sgps_sensor_position of this column's job
+        const bool has_next = fuse && f + 1 < upto;
+        const float spx = has_next ? (float) Tp[12 + 3] : 0.f, spy = has_next ? (float) Tp[12 + 7] : 0.f, spz = has_next ? (float) Tp[12 + 11] : 0.f;
         load_firing(f + fstep);
         if (f > lds_ld(&s_bad)) // some earlier firing left the shape: nothing behind it is wanted (wave-uniform)
             break;
@@ -1946,23 +1954,23 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
         for (int k = 0; k < RPL; k++)
         {
             const int row = k * 64 + lane;
-            const size_t ci = (size_t) lc * R + row;
+            const unsigned ci = (unsigned) lc * (unsigned) R + (unsigned) row;
             const bool has = q[k].cir != PP_SKIP;
             // a cell without a return of a column segmented here is tagged like the segmentation tags it (cc.cpp:348-351) and gets the record of a
             // cell without a return (k_seg_scan completes it with the supplemented inclination): one store each for all the column's cells
             if (has | (seg_here & (row < R)))
             {
                 const float nn = __builtin_nanf("");
-                p.sc_rec[ci] = make_float4(has ? q[k].x : nn, has ? q[k].y : nn, has ? q[k].z : nn, has ? q[k].incl : nn);
-                p.gtag[ci] = tag;
+                at32(p.sc_rec, ci) = make_float4(has ? q[k].x : nn, has ? q[k].y : nn, has ? q[k].z : nn, has ? q[k].incl : nn);
+                at32(p.gtag, ci) = tag;
             }
             if (has)
             {
-                p.inten[ci] = cint[k];
-                p.src[ci] = (uint32_t) (seq0 + f);
-                p.dist[ci] = q[k].dist;
-                p.incl[ci] = q[k].incl;
-                p.incaz[ci] = q[k].incaz; // (c0 < num_columns and nothing moves on: the return's rotation is its column's)
+                at32(p.inten, ci) = cint[k];
+                at32(p.src, ci) = (uint32_t) (seq0 + f);
+                at32(p.dist, ci) = q[k].dist;
+                at32(p.incl, ci) = q[k].incl;
+                at32(p.incaz, ci) = q[k].incaz; // (c0 < num_columns and nothing moves on: the return's rotation is its column's)
             }
         }
         // columns [G_(f-1), G_f) are finished by this firing and carry its pose (cc.cpp:289-291)
@@ -2050,7 +2058,7 @@ __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, St
     (void) fbase;
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
-    const int lane = lane_id(), wave = threadIdx.x >> 6, tid = threadIdx.x;
+    const int lane = lane_id(), wave = uniform_i32((int) (threadIdx.x >> 6)), tid = threadIdx.x;
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
@@ -2120,7 +2128,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
+    const int wave = uniform_i32((int) (threadIdx.x >> 6));
     const int tid = threadIdx.x;
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
@@ -2540,7 +2548,7 @@ template<int RPL>
 __global__ __launch_bounds__(64 * TABLE_WAVES) void k_table(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
-    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int lane = lane_id(), wave = uniform_i32((int) (threadIdx.x >> 6));
     StreamState* st = &states[s];
 #ifdef CC_CHAIN2_PRIO
     __builtin_amdgcn_s_setprio(CC_CHAIN2_PRIO);
@@ -4702,9 +4710,9 @@ __global__ __launch_bounds__(256) void k_small_front(Geometry g, cc_config cfg, 
     __syncthreads();
     // D  all four wavefronts: the window scan of the call's columns (scan_body: what k_scan does with one wavefront per block)
     if (g.mirror_fields)
-        scan_body<1, true>(g, cfg, P, states, stream, slot, 0, (int) (threadIdx.x >> 6), 4);
+        scan_body<1, true>(g, cfg, P, states, stream, slot, 0, uniform_i32((int) (threadIdx.x >> 6)), 4);
     else
-        scan_body<1, false>(g, cfg, P, states, stream, slot, 0, (int) (threadIdx.x >> 6), 4);
+        scan_body<1, false>(g, cfg, P, states, stream, slot, 0, uniform_i32((int) (threadIdx.x >> 6)), 4);
 }
 
 // =====================================================================================================
@@ -5947,7 +5955,7 @@ __global__ __launch_bounds__(A3_THREADS) void k_small_tail(Geometry g, cc_config
     if (threadIdx.x < 64)
         associate_stream<RPL>(g, cfg, P, states, stream, slot);
     __syncthreads();
-    publish_body(g, P, states, stream, slot, (int) (threadIdx.x >> 6), (int) (blockDim.x >> 6));
+    publish_body(g, P, states, stream, slot, uniform_i32((int) (threadIdx.x >> 6)), (int) (blockDim.x >> 6));
     __syncthreads();
     if (hm.state && threadIdx.x < 64)
         mirror_results(g, P, states, stream, hm);
