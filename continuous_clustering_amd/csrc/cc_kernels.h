@@ -2234,7 +2234,6 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     // chunk is worked on: a chunk is a load -> ~300 instructions -> barrier chain, and two wavefronts per SIMD cannot hide the load
     float nx_x[RPL], nx_y[RPL], nx_z[RPL];
     uint8_t nx_i[RPL];
-    double nx_pose = 0.;
     auto load_firing = [&](const long long f)
     {
         const size_t fi = fglob + (size_t) f;
@@ -2253,8 +2252,6 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                 nx_i[k] = inten[fi * R + row];
             }
         }
-        if (f < n)
-            nx_pose = poses[fi * 12 + (size_t) (lane < 12 ? lane : 0)];
     };
     load_firing(cursor0 + wave);
     for (long long f0 = cursor0; f0 < n; f0 += IM_WAVES)
@@ -2273,10 +2270,13 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
             cz[k] = nx_z[k];
             cint[k] = nx_i[k];
         }
-        double T[12]; // (wave-uniform: the matrix travels in SGPRs)
+        double T[12]; // (wave-uniform: the matrix travels in SGPRs, by scalar loads — as in k_insert_par)
+        {
+            const double* Tp = poses + (fglob + (size_t) (mine ? f : cursor0)) * 12;
 #pragma unroll
-        for (int i = 0; i < 12; i++)
-            T[i] = lane_f64(nx_pose, i);
+            for (int i = 0; i < 12; i++)
+                T[i] = Tp[i];
+        }
         load_firing(f + IM_WAVES);
         // ---- prepare this wavefront's firing ------------------------------------------------------------------------------------
         int rear_cir = -1, span = 0;
@@ -2415,14 +2415,14 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                     const int crel = my_rel + oc[k];
                     const unsigned lcq = (unsigned) (lc0 + crel) / (unsigned) RC;
                     const int lc = (int) ((unsigned) (lc0 + crel) - lcq * (unsigned) RC);
-                    const size_t ci = (size_t) lc * R + row;
-                    p.sc_rec[ci] = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
-                    p.inten[ci] = cint[k];
-                    p.src[ci] = (uint32_t) (seq0 + (f - cursor0));
-                    p.dist[ci] = q[k].dist;
-                    p.incl[ci] = q[k].incl;
-                    p.incaz[ci] = q[k].incaz; // (the return's rotation, rot0 + (cir0 + crel) / num_columns, is that of its column)
-                    p.gtag[ci] = cell_tag(pass0 + (long long) lcq);
+                    const unsigned ci = (unsigned) lc * (unsigned) R + (unsigned) row;
+                    at32(p.sc_rec, ci) = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
+                    at32(p.inten, ci) = cint[k];
+                    at32(p.src, ci) = (uint32_t) (seq0 + (f - cursor0));
+                    at32(p.dist, ci) = q[k].dist;
+                    at32(p.incl, ci) = q[k].incl;
+                    at32(p.incaz, ci) = q[k].incaz; // (the return's rotation, rot0 + (cir0 + crel) / num_columns, is that of its column)
+                    at32(p.gtag, ci) = cell_tag(pass0 + (long long) lcq);
                     atomicMax(&s_rowmax[row], crel);
                 }
             }
