@@ -674,6 +674,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
     if (small_front)
         ; // (k_small_front has scanned the call's columns)
+    // (65 - 128 rows: packed by default. The lock-step form with two rows per lane — scan_packed = 0 — shortens the scan's own launch, 3.0 -> 2.35 ms at
+    // 256 x S128, but needs more vector instructions, and the step is bound by those: 11.7 -> 11.4 G points/s same-box)
     else if (e->scan_packed == 1 || (e->scan_packed < 0 && rpl > 1))
     {
         if (rpl == 1 && !g.mirror_fields)

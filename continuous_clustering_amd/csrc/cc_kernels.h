@@ -4475,7 +4475,6 @@ __device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cf
     c.max_steps_in_column = cfg.max_steps_in_column;
     c.stop_enabled = cfg.stop_after_association_enabled;
     c.stop_min_steps = cfg.stop_after_association_min_steps;
-    __shared__ int s_links[WAVE * MAX_ROWS_PER_LANE][LINK_SLOTS];
     const long long col_end = st->batch[slot].seg_end, first_column = st->first_column;
     // (ring columns advanced incrementally: a 64-bit modulo per column costs ~100 scalar instructions)
     const int first_lc = (int) (first_column % RC);
@@ -4503,7 +4502,7 @@ __device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cf
         double fin[RPL];
         unsigned long long packed[RPL];
         int reach = 0; // deepest column (steps back) any visit of this lane went to
-        if (RPL == 1)
+        if constexpr (RPL == 1)
         {
             // Rows = lanes: the scan of all 64 points of the column runs in lock step. Every lane visits the same relative cell
             // (sb columns back, d rows up or down) at the same time, in the reference's order (cc.cpp:706-769): the candidate
@@ -4604,44 +4603,138 @@ __device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cf
         }
         else
         {
-            for (int k = 0; k < RPL; k++)
+            static_assert(RPL == 2, "one or two rows per lane");
+            // Two rows per lane (65 - 128 rows), the same lock step: both of a lane's points visit the same relative cell at the same time. The
+            // candidate column is two coalesced records per lane (rows lane and 64 + lane); the cell row - d of the upper half lies in the upper
+            // half's registers of lane - d, that of the lower half in the lower half's registers of lane - d — or, for the first d lanes, in
+            // the upper half's of lane - d + 64 (mod 64 the same lane): two cross-lane reads per component and one select for the half that
+            // crosses. Round 4: the per-lane gathers of k_scan2 kept the texture addresser busy 64 clocks per visit (1.69 ms alone at 256 x S128).
+            float4 me[2];
+            float mad[2];
+            int needed[2], rooted[2], overflow[2], live_i[2], visits[2], reachk[2];
+            bool inrow[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++)
             {
                 const int row = k * 64 + lane;
+                const int ci = lc * R + (row < R ? row : 0);
+                inrow[k] = row < R;
+                me[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                mad[k] = 0.f;
+                needed[k] = -1;
                 parent[k] = -2;
                 nlinks[k] = 0;
                 fin[k] = 0.;
                 packed[k] = 0;
-                if (row >= R)
-                    continue;
-                const int ci = lc * R + row;
-                if (!p.ignored[ci])
+                rooted[k] = overflow[k] = live_i[k] = visits[k] = reachk[k] = 0;
+                if (inrow[k] && !p.ignored[ci])
                 {
+                    live_i[k] = 1;
                     parent[k] = -1;
-                    const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                    const double caz = cell_caz(cb, p.incaz[ci]);
-                    fin[k] = caz + (double) mad;
-                    bool overflow = false;
-                    int dummy_root = -1, vis = 0, rch = 0;
-                    scan_point<false, true, true>(c, lc, gc, row, bound, mad, caz, dummy_root, parent[k], s_links[row], nlinks[k], overflow, LINK_SLOTS,
-                                                  MIRROR ? &vis : nullptr, nullptr, nullptr, MIRROR ? &rch : nullptr);
-                    if (overflow)
-                        nlinks[k] = 255;
-                    if (MIRROR)
+                    me[k] = p.sc_rec[ci];
+                    mad[k] = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                    fin[k] = cell_caz(cb, p.incaz[ci]) + (double) mad[k];
+                    needed[k] = f2i_x86(__builtin_ceilf(mad[k] / c.az_width));
+                    needed[k] = needed[k] < c.max_steps_in_row ? needed[k] : c.max_steps_in_row;
+                }
+            }
+            int oc = lc;
+            for (int sb = 0;; sb++)
+            {
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    live_i[k] = (live_i[k] && sb <= needed[k]) ? 1 : 0;
+                if (!__any((live_i[0] | live_i[1]) != 0))
+                    break;
+                float4 cr[2];
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                {
+                    cr[k] = make_float4(__builtin_nanf(""), 0.f, 0.f, 0.f);
+                    if (inrow[k])
                     {
-                        p.sc_visits[ci] = sat_u16(vis);
-                        reach = rch > reach ? rch : reach;
+                        cr[k] = p.sc_rec[oc * R + k * 64 + lane];
+                        if (p.ignored[oc * R + k * 64 + lane])
+                            cr[k].x = __builtin_nanf("");
                     }
                 }
-                else if (MIRROR)
-                    p.sc_visits[ci] = 0;
-                p.sc_parent[ci] = (int16_t) parent[k];
-                p.sc_nlinks[ci] = (uint8_t) nlinks[k];
-                p.sc_fin[ci] = fin[k];
-                const int nl = nlinks[k] == 255 ? LINK_SLOTS : nlinks[k];
-                for (int j = 0; j < nl; j++)
-                    packed[k] |= (unsigned long long) (s_links[row][j] & 0xffff) << (16 * j);
-                if (nl > 0)
-                    p.sc_links[ci] = packed[k];
+                for (int down = 0; down < 2; down++) // dir = -1 (rows above), then dir = +1 (cc.cpp:712-716)
+                {
+                    if (down == 1 && sb == 0)
+                        continue;
+                    int d = (down == 1 || sb == 0) ? 1 : 0;
+                    int run[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++)
+                    {
+                        const int orow = down ? k * 64 + lane + d : k * 64 + lane - d;
+                        run[k] = (live_i[k] && orow >= 0 && orow < R && d <= c.max_steps_in_column) ? 1 : 0;
+                    }
+                    while (__any((run[0] | run[1]) != 0))
+                    {
+                        const int src = (down ? lane + d : lane - d) & 63;
+                        const float a0x = __shfl(cr[0].x, src), a0y = __shfl(cr[0].y, src), a0z = __shfl(cr[0].z, src), a0w = __shfl(cr[0].w, src);
+                        const float a1x = __shfl(cr[1].x, src), a1y = __shfl(cr[1].y, src), a1z = __shfl(cr[1].z, src), a1w = __shfl(cr[1].w, src);
+                        // (the wanted row k * 64 + lane -/+ d lies in lane (lane -/+ d) mod 64 of the half its bit 6 names)
+#pragma unroll
+                        for (int k = 0; k < 2; k++)
+                        {
+                            const int orow = down ? k * 64 + lane + d : k * 64 + lane - d;
+                            const int half = orow >> 6; // 0 or 1 where the visit is wanted (run[k]); anything else is not used
+                            const bool h1 = half == 1;
+                            const float ox = h1 ? a1x : a0x, oy = h1 ? a1y : a0y, oz = h1 ? a1z : a0z, ow = h1 ? a1w : a0w;
+                            if (MIRROR)
+                            {
+                                visits[k] += run[k]; // cc.cpp:725
+                                reachk[k] = run[k] ? sb : reachk[k];
+                            }
+                            const int cont = (run[k] && !(ccm::absf(ow - me[k].w) > mad[k])) ? 1 : 0;
+                            const float dx = me[k].x - ox, dy = me[k].y - oy, dz = me[k].z - oz;
+                            const int acc = (cont && ox == ox && dx * dx + dy * dy + dz * dz < c.maxd2) ? 1 : 0; // x = NaN: ignored / empty
+                            const int cand = (sb << 8) | (orow & 0xff);
+                            parent[k] = (acc && !rooted[k]) ? cand : parent[k];
+                            if (__any(acc && rooted[k])) // a second accepted candidate is a link (rare next to the visits: wave-uniform branch)
+                            {
+                                const int as_link = (acc && rooted[k] && nlinks[k] < LINK_SLOTS) ? 1 : 0;
+                                overflow[k] |= (acc && rooted[k] && nlinks[k] >= LINK_SLOTS) ? 1 : 0;
+                                packed[k] |= as_link ? (unsigned long long) cand << (16 * nlinks[k]) : 0ull;
+                                nlinks[k] += as_link;
+                            }
+                            rooted[k] |= acc;
+                            const int stop = (rooted[k] && c.stop_enabled && d >= c.stop_min_steps) ? 1 : 0;
+                            const int nrow = down ? orow + 1 : orow - 1;
+                            run[k] = (cont && !stop && nrow >= 0 && nrow < R && d + 1 <= c.max_steps_in_column) ? 1 : 0;
+                        }
+                        d++;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+                    if (rooted[k] && c.stop_enabled && sb >= c.stop_min_steps)
+                        live_i[k] = 0;
+                if (oc == bound)
+                    break;
+                oc = oc == 0 ? RC - 1 : oc - 1;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+            {
+                const int row = k * 64 + lane;
+                if (overflow[k])
+                    nlinks[k] = 255;
+                if (inrow[k])
+                {
+                    const int ci = lc * R + row;
+                    p.sc_parent[ci] = (int16_t) parent[k];
+                    p.sc_nlinks[ci] = (uint8_t) nlinks[k];
+                    p.sc_fin[ci] = fin[k];
+                    if (nlinks[k] > 0)
+                        p.sc_links[ci] = packed[k];
+                    if (MIRROR)
+                        p.sc_visits[ci] = sat_u16(visits[k]);
+                }
+                if (MIRROR)
+                    reach = reachk[k] > reach ? reachk[k] : reach;
             }
         }
         scan_column_epilogue<RPL, MIRROR>(p, R, lc, lane, parent, nlinks, fin, packed, reach);

@@ -112,6 +112,10 @@ def build_case(name: str):
     if name == "s128_full_1700":
         return synth.make_stream(1700 * 2 + 200, seed=19, sensor=SensorModel.s128(), start_column=40,
                                  motion=Motion.translate()), _vls(1700), None
+    if name == "s96_offsets":
+        # 96 rows: two rows per lane with a half-filled second register (lanes 32 - 63 own no second row), per-laser azimuth offsets
+        sen = SensorModel(num_rows=96, num_columns=600, incl_top_deg=12.0, incl_bottom_deg=-25.0, azimuth_offsets_deg=(-3.1, -1.0, 1.0, 3.1))
+        return synth.make_stream(600 * 3 + 40, seed=23, sensor=sen, start_column=15, motion=Motion.translate()), _vls(600), None
     if name == "s32_small_sensor":
         sen = SensorModel(num_rows=32, num_columns=512, incl_top_deg=10.0, incl_bottom_deg=-30.0)
         return synth.make_stream(512 * 3, seed=20, sensor=sen), _vls(512, max_distance=0.5), None
@@ -236,7 +240,7 @@ def build_case(name: str):
 ALL_CASES = ["s64_static", "s64_translate", "s64_turn", "s64_full_2200", "s64_forced_finish_ring", "s64_ring_with_objects",
              "s64_fog_and_ego", "s64_counterclockwise", "s64_every_2nd_column", "s64_no_early_stop", "s64_min_steps_3",
              "s64_wide_window_global_kernel", "s64_dropouts", "s64_no_supplement_no_incl_ignore", "s64_robot_tf_tilted", "s128_offsets",
-             "s128_no_offsets_translate", "s128_full_1700", "s32_small_sensor", "j_s64_jitter", "j_s64_jitter_wide", "j_s128_offsets_jitter"]
+             "s128_no_offsets_translate", "s128_full_1700", "s96_offsets", "s32_small_sensor", "j_s64_jitter", "j_s64_jitter_wide", "j_s128_offsets_jitter"]
 
 EXCEPTION_CASES = ["x_s64_slanted_gaps", "x_s64_slanted_gaps_far", "x_s64_near_jitter_gaps_3", "x_s64_refused_attach"]
 

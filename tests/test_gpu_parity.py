@@ -224,12 +224,13 @@ def test_batch_parallel_association_hands_exceptions_to_the_serial_kernel(name, 
 
 @pytest.mark.parametrize("name,option,value", [
     ("s64_translate", "scan_packed", 1), ("s64_dropouts", "scan_packed", 1), ("j_s64_jitter_wide", "scan_packed", 1),
-    ("s128_offsets", "scan_packed", 0), ("s32_small_sensor", "scan_packed", 1),
+    ("s128_offsets", "scan_packed", 0), ("s128_full_1700", "scan_packed", 0), ("s96_offsets", "scan_packed", 0), ("s32_small_sensor", "scan_packed", 1),
     ("s128_offsets", "parallel_insert", 2), ("s128_full_1700", "parallel_insert", 0), ("j_s128_offsets_jitter", "parallel_insert", 2),
     ("j_s64_jitter", "parallel_insert", 0), ("s64_full_2200", "parallel_insert", 2),
 ])
 def test_kernel_variants_give_the_same_result(name, option, value, oracle_lib):
-    """The window scan has two kernels (rows as lanes in lock step / active points packed into the lanes) and the insertion three
+    """The window scan has two kernels (rows as lanes in lock step — since round 4 also with two rows per lane — / active points packed into the
+    lanes) and the insertion three
     (block-parallel single-column, block-parallel multi-column with the collision rule checked, serial): every selection must reproduce the
     oracle. The defaults are covered by test_engine_matches_oracle; here the other choice of each option."""
     stream, cfg, tf = cases.build_case(name)

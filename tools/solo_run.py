@@ -8,10 +8,12 @@ if len(sys.argv) > 2:  # another build of the library (A/B)
 from continuous_clustering_amd import Engine, capi, synth
 import bench
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
-F, NB = 2200, 3
+s128 = os.environ.get("SOLO_SENSOR", "s64") == "s128"  # SOLO_SENSOR=s128: the 128-row workload of the bench's s128 leg
+sensor = synth.SensorModel.s128() if s128 else synth.SensorModel.s64()
+cfg = capi.Config.vls128() if s128 else capi.Config.kitti()
+F, NB = (1700 if s128 else 2200), 3
 xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
-e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", 0)
+e = Engine(cfg, sensor.num_rows, S); e.record_events(False); e.set_option("pipeline", 0)
 for b in range(NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])
 print("rc", e.sync())
