@@ -464,6 +464,28 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
             traffic = json.load(open(tpath)).get(KERNEL_OF[dom], {}).get("hbm_bytes_per_launch")
         except Exception:  # noqa: BLE001
             traffic = None
+    # vector-ALU issue: what the step is actually bound by (profiles/ROOFLINE.md R4.2). Wave-instructions per step from the committed SQ counter
+    # pass (tools/pmc_sq.sh runs tools/solo_run.py on 64 streams of the S64 workload: scaled to this run's streams x firings); a wave64 instruction
+    # occupies one of the 1024 SIMD16s for 4 clocks at 2.4 GHz.
+    valu = None
+    vpath = os.path.join(ROOT, "profiles", "r04_final_sq_lds_l2_counters.txt")
+    if R == 64 and os.path.exists(vpath):
+        try:
+            import re
+            tot = 0.0
+            for line in open(vpath):
+                m = re.match(r"(k_\w+) .*'SQ_INSTS_VALU': (\d+)", line)
+                # (kernels of a steady-state step; the start-up batch's serial kernels are not part of it)
+                if m and m.group(1) in ("k_insert_par", "k_scan", "k_seg_scan", "k_assocb", "k_assoc3", "k_publish", "k_ego", "k_begin_batch"):
+                    tot += float(m.group(2))
+            if tot > 0:
+                per_step = tot * (S * F) / (64.0 * 2200.0)
+                peak = 1024 * 2.4e9 / 4.0  # wave-instructions per second
+                valu = {"wave_instructions_per_step": per_step, "achieved": per_step / (elapsed / steps) / 1e9, "peak": peak / 1e9,
+                        "unit": "G wave-instructions/s", "frac": per_step / (elapsed / steps) / peak,
+                        "source": os.path.relpath(vpath, ROOT) + " (SQ_INSTS_VALU per kernel launch on 64 streams, scaled; not measured in this run)"}
+        except Exception:  # noqa: BLE001
+            valu = None
     res = {
         "value": cells / elapsed / 1e6,
         "ms_per_step": elapsed / steps * 1e3,
@@ -482,9 +504,11 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
             "traffic_source": (os.path.relpath(tpath, ROOT) + " (PMC passes of tools/pmc.sh on this round's build, not measured in this run)") if traffic is not None else None,
             "step_frac": cells * alg_bytes_per_cell / ctx.world / elapsed / 1e9 / HBM_PEAK_GBS,
             "dominant_by": "longest average launch in the committed rocprofv3 summary (rocprof_source)" if committed else "longest HIP-event duration of this run",
-            "note": "no kernel of the path is bandwidth-bound: each is latency / issue-bound by itself and they share the GPU on four chains of HIP "
-                    "streams (a kernel's launch_ms inside the pipeline is 1.5 - 2.5 x its duration alone, profiles/ROOFLINE.md); step_frac = "
-                    "algorithmic bytes of the whole step / step time / peak",
+            "valu": valu,
+            "note": "no kernel of the path is bandwidth-bound: the step equals the sum of the kernels' durations alone and keeps the vector ALUs "
+                    ">= 60 % busy (`valu`: VALU wave-instructions x 4 clocks / 1024 SIMDs), i.e. it is bound by vector-instruction issue; the chains of "
+                    "HIP streams time-share the ALUs (a kernel's launch_ms inside the pipeline is 1.5 - 2.5 x its duration alone, profiles/ROOFLINE.md); "
+                    "step_frac = algorithmic bytes of the whole step / step time / peak",
         },
         "verified": verified,
         "per_rank": per_rank,
