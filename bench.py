@@ -931,7 +931,8 @@ def main():
         out["host_fed"] = host_fed_report(solo, sensor, cfg, F, xyz, inten, poses)
 
     # ---- CPU baseline on this box's host cores (inputs: the bench's own streams, copied back from HBM) ------------
-    if not args.no_cpu_baseline and not stub:
+    # (the contract: on rank 0 at N = 1 only — a multi-GPU line carries the per-GPU figure of the N = 1 run)
+    if not args.no_cpu_baseline and not stub and world == 1:
         out["cpu_baseline"] = cpu_baseline_report(cfg, sensor, xyz, inten, poses, Sx, F, args)
         if s128_inputs is not None and "s128" in out:
             a2 = argparse.Namespace(**vars(args))
