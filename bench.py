@@ -423,7 +423,7 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
     # insert_ms is the serial kernel k_insert2 behind it; above 64 rows the block-parallel kernel is k_insert_multi)
     # assoc_lds_ms is k_assocb alone (the batch-parallel association); assoc_global_ms the serial kernels launched behind it (k_assoc3, k_associate:
     # in steady state they find nothing to do)
-    KERNEL_OF = {"prep_ms": "k_insert_par" if R <= 64 else "k_insert_multi", "insert_ms": "k_insert2", "scan_ms": "k_scan" if R <= 64 else "k_scan2", "assoc_lds_ms": "k_assocb",
+    KERNEL_OF = {"prep_ms": "k_insert_par" if R <= 64 else "k_insert_multi", "insert_ms": "k_insert2", "scan_ms": "k_scan2" if (R > 64 or S > 192 or os.environ.get("CC_SCAN_PACKED") == "1") and os.environ.get("CC_SCAN_PACKED") != "0" else "k_scan", "assoc_lds_ms": "k_assocb",
                  "assoc_global_ms": "k_assoc3", "publish_ms": "k_publish"}
     # Which kernel is "dominant": the one with the longest average launch in the committed rocprofv3 summary of this round (profiles/), so that the
     # line names the same kernel in every run and its frac can be re-derived from profiles/ (the HIP-event durations of kernels that overlap on
@@ -476,7 +476,7 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
             for line in open(vpath):
                 m = re.match(r"(k_\w+) .*'SQ_INSTS_VALU': (\d+)", line)
                 # (kernels of a steady-state step; the start-up batch's serial kernels are not part of it)
-                if m and m.group(1) in ("k_insert_par", "k_scan", "k_seg_scan", "k_assocb", "k_assoc3", "k_publish", "k_ego", "k_begin_batch"):
+                if m and m.group(1) in ("k_insert_par", KERNEL_OF["scan_ms"], "k_seg_scan", "k_assocb", "k_assoc3", "k_publish", "k_ego", "k_begin_batch"):
                     tot += float(m.group(2))
             if tot > 0:
                 per_step = tot * (S * F) / (64.0 * 2200.0)

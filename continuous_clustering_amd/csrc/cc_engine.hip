@@ -98,8 +98,9 @@ struct cc_engine
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
     int scan_packed{-1};                // option "scan_packed": 1 = k_scan2 (active points packed into the lanes), 0 = k_scan (rows as lanes, lock
-                                        // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch;
-                                        // at 64 rows the lock-step kernel is 3 % ahead inside the pipeline although it issues 1.5 x the instructions)
+                                        // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch)
+                                        // and, at up to 64 rows, for launches of more than 192 streams (there the step follows the number of vector
+                                        // instructions, of which k_scan2 issues 0.65 x: + 3 %; below, the lock-step kernel's shorter launch wins 1 - 2 %)
     int assoc_waves{3};                 // option "assoc_waves": 1 = k_assoc_lds, 3 / 4 = k_assoc3 (2, the retired two-wavefront kernel, selects k_assoc3)
                                         // without / with its links wavefront
     bool assoc_batch{true};             // option "assoc_batch": k_assocb in front of the serial association kernels
@@ -676,7 +677,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         ; // (k_small_front has scanned the call's columns)
     // (65 - 128 rows: packed by default. The lock-step form with two rows per lane — scan_packed = 0 — shortens the scan's own launch, 3.0 -> 2.35 ms at
     // 256 x S128, but needs more vector instructions, and the step is bound by those: 11.7 -> 11.4 G points/s same-box)
-    else if (e->scan_packed == 1 || (e->scan_packed < 0 && rpl > 1))
+    // (64 rows, end of round 4: with the insertion's uniform work on the scalar unit the step follows the vector-instruction count, and the packed
+    // scan issues 0.65 x those of the lock-step one: + 3 % at 256 streams (same-box, 3 alternations: 16.22 -> 16.72 G points/s), - 1 ... - 2 % at
+    // 32 - 128 streams where the GPU has room and the lock-step scan's shorter launch counts)
+    else if (e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192)))
     {
         if (rpl == 1 && !g.mirror_fields)
             hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);

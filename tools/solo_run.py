@@ -15,5 +15,7 @@ F, NB = (1700 if s128 else 2200), 3
 xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
 torch.cuda.synchronize()
 e = Engine(cfg, sensor.num_rows, S); e.record_events(False); e.set_option("pipeline", 0)
+# (the counter passes run on 64 streams but stand for the 256-stream bench, where the engine takes the packed window scan: pin it)
+if os.environ.get("SOLO_SCAN_PACKED", "1") == "1": e.set_option("scan_packed", 1)
 for b in range(NB): e.add_firings_device(F, xyz[b], inten[b], poses[b])
 print("rc", e.sync())
