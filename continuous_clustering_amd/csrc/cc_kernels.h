@@ -2348,7 +2348,9 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                     stop = stop < j ? stop : j;
                     break;
                 }
-                const int rc = s_rear_cir[j], sp = s_span[j];
+                // (what every thread reads here is the same for all of them: readfirstlane keeps the whole walk on the scalar unit — as vector
+                // arithmetic the three walks of a chunk were ~170 of the ~1000 vector instructions a firing costs this kernel)
+                const int rc = uniform_i32(s_rear_cir[j]), sp = uniform_i32(s_span[j]);
                 const int diff = rc - cir;
                 const bool ok = rc >= 0 && ((diff > 0 && diff <= half) || diff < -half) && sp < half; // strictly forward, also across the wrap
                 const int delta = ok ? (diff < -half ? diff + NC : diff) : 0;
@@ -2382,9 +2384,9 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                 {
                     int last = s_rowmax[row];
                     int rel = carry_rel, cir = carry_cir;
-                    for (int j = 0; j < wave; j++) // (the rear columns of the earlier firings of the chunk, recomputed: a handful of adds)
+                    for (int j = 0; j < wave; j++) // (the rear columns of the earlier firings of the chunk, recomputed: a handful of scalar adds)
                     {
-                        const int rc = s_rear_cir[j];
+                        const int rc = uniform_i32(s_rear_cir[j]);
                         const int diff = rc - cir;
                         rel += diff < -half ? diff + NC : diff;
                         cir = rc;
@@ -2400,7 +2402,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
         }
         __syncthreads();
         {
-            const int st2 = s_stop;
+            const int st2 = uniform_i32(s_stop);
             stop = st2 < stop ? st2 : stop;
         }
         // ---- accepted firings write their cells ------------------------------------------------------------------------------------
@@ -2434,7 +2436,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
         // ---- carry (the same walk over the accepted firings, in every thread) -------------------------------------------------------
         for (int j = 0; j < stop; j++)
         {
-            const int rc = s_rear_cir[j], sp = s_span[j];
+            const int rc = uniform_i32(s_rear_cir[j]), sp = uniform_i32(s_span[j]);
             const int diff = rc - carry_cir;
             carry_rel += diff < -half ? diff + NC : diff;
             carry_cir = rc;
