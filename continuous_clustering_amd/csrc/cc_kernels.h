@@ -4820,7 +4820,12 @@ __global__ __launch_bounds__(256) void k_small_front(Geometry g, cc_config cfg, 
 // column epilogue (same-column parent chains, column summary) and the coalesced stores. Same outputs as k_scan, bit for bit.
 // grid = (streams, SCAN_BLOCKS), block = 64.
 // =====================================================================================================
-constexpr int SCAN_TILE_CELLS = 256;
+// (256 cells: ~64 active points = one packed pass. 512 — fuller passes, half the tiles — is 15 % slower at 64 rows and 6 % at 128: twice the
+// LDS per one-wavefront block and longer tails of the per-lane state machines)
+#ifndef CC_SCAN_TILE_CELLS
+#define CC_SCAN_TILE_CELLS 256
+#endif
+constexpr int SCAN_TILE_CELLS = CC_SCAN_TILE_CELLS;
 
 template<int RPL, bool MIRROR>
 __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
