@@ -247,6 +247,20 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
 #else
 #define AB_PH(i)
 #endif
+    // CC_AB_STATS_W (with CC_AB_STATS): the counters are taken by worker wavefront 1 instead of the timeline wavefront
+#if defined(CC_AB_STATS) && defined(CC_AB_STATS_W)
+#undef AB_PH
+#define AB_PH(i)
+#define AB_PHW(i)                                                    \
+    if (wave == 1)                                                   \
+    {                                                                \
+        const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+        ab_t[i] += n_ - ab_mark;                                     \
+        ab_mark = n_;                                                \
+    }
+#else
+#define AB_PHW(i)
+#endif
     long long gc0 = col_begin;
     int lc0 = (int) (col_begin % RC);
     unsigned long long batch_cols = 0;
@@ -746,7 +760,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                     }
                 }
             }
+            AB_PHW(0)
             ab_barrier(); // B1
+            AB_PHW(1)
             // ---------------------------------------------------------------------------------- pointer jumping (one barrier per round)
             for (int r = 0; r < 8; r++)
             {
@@ -773,6 +789,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 if (!T.jflag[r])
                     break;
             }
+            AB_PHW(2)
             // ================================================================================== 2: records, alive words, links
         int bad = 0;
 #pragma unroll
@@ -836,6 +853,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                     atomicMax(&T.g_last[s0], cidx);
                 }
             }
+            AB_PHW(3)
             // link candidates (accepted candidates after the first, cc.cpp:693-694) that lead to another tree
             if ((lds_ld(&T.col_info[cidx]) >> 8) & 3) // (wave-uniform: the column has points with links at all)
             {
@@ -868,10 +886,12 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                     }
                 }
             }
+            AB_PHW(4)
         }
             if (__any(bad) && lane == 0)
                 T.bail = AB_BAIL_DEAD;
             ab_barrier(); // B2
+            AB_PHW(5)
             if (T.bail || T.n_ev > AB_EVENTS)
             {
                 bailed = true;
@@ -884,6 +904,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 prefetch_inputs(gc0 + ncols, l1);
             }
             ab_barrier(); // B3
+            AB_PHW(6)
             if (T.bail)
             {
                 bailed = true;
@@ -947,6 +968,10 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             }
         }
             // (no barrier here: the next group's first phase only writes ring columns, tree slots and words that nothing above reads)
+            AB_PHW(8)
+#if defined(CC_AB_STATS) && defined(CC_AB_STATS_W)
+            ab_t[7]++;
+#endif
             n_unf = s_nunf;
             gc0 += ncols;
             lc0 += ncols;
@@ -1004,11 +1029,19 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             st->n_events = n_events < g.event_capacity ? n_events : g.event_capacity;
             if (g.record_events && n_events > g.event_capacity)
                 raise_error(st, CC_ERR_CAPACITY, n_events, 0);
-#ifdef CC_AB_STATS
+#if defined(CC_AB_STATS) && !defined(CC_AB_STATS_W)
             ab_t[9] = __builtin_amdgcn_s_memtime() - ab_t0;
             for (int i = 0; i < 10; i++)
                 st->dbg[i] += ab_t[i];
 #endif
         }
     }
+#if defined(CC_AB_STATS) && defined(CC_AB_STATS_W)
+    if (wave == 1 && lane == 0)
+    {
+        ab_t[9] = __builtin_amdgcn_s_memtime() - ab_t0;
+        for (int i = 0; i < 10; i++)
+            st->dbg[i] += ab_t[i];
+    }
+#endif
 }

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -110,6 +111,10 @@ struct cc_engine
     bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 256 streams
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
+    bool streams_pooled{false};                          // the seven streams come from (and return to) the process-wide set cache
+    bool slab_planning{false};                           // alloc_plane only records (field, offset): allocate() makes ONE hipMalloc of the total
+    size_t slab_bytes{0};
+    std::vector<std::pair<void**, size_t>> slab_plan;
     std::string error;
     // staging for the single-stream host path
     float* d_stage_xyz{nullptr};
@@ -154,6 +159,8 @@ struct cc_engine
 namespace
 {
 
+constexpr size_t CC_SLAB_ALIGN = 2u << 20;
+
 #define CC_HIP_CHECK(e, call)                                                                                      \
     do                                                                                                             \
     {                                                                                                              \
@@ -165,9 +172,19 @@ namespace
         }                                                                                                          \
     } while (0)
 
+// One slab for the planes of an engine (allocate()): the planes are carved out of a single hipMalloc at 2 MiB boundaries, so that the driver
+// can back them with its largest page-table fragments whatever the allocator's free lists look like by then — sixty separate allocations
+// made after other engines of the process had come and gone ran the insertion kernel 1.3 - 1.6 x slower than the first engine's.
 template<class T>
 int alloc_plane(cc_engine* e, T** out, size_t count)
 {
+    if (e->slab_planning)
+    {
+        const size_t bytes = (count * sizeof(T) + CC_SLAB_ALIGN - 1) / CC_SLAB_ALIGN * CC_SLAB_ALIGN;
+        e->slab_plan.push_back({(void**) out, e->slab_bytes});
+        e->slab_bytes += bytes;
+        return CC_OK;
+    }
     void* p = nullptr;
     hipError_t err = hipMalloc(&p, count * sizeof(T));
     if (err != hipSuccess)
@@ -250,6 +267,9 @@ int allocate(cc_engine* e)
     const size_t T = S * (size_t) g.tree_capacity;
     Planes& P = e->P;
     int rc = CC_OK;
+    e->slab_planning = getenv("CC_NO_SLAB") == nullptr;
+    e->slab_bytes = 0;
+    e->slab_plan.clear();
 #define A(field, count)                                \
     if ((rc = alloc_plane(e, &P.field, (count))) != 0) \
         return rc;
@@ -277,6 +297,22 @@ int allocate(cc_engine* e)
         return rc;
     if ((rc = alloc_plane(e, &e->d_remaining, 1)) != 0)
         return rc;
+    const bool slab = e->slab_planning;
+    if (e->slab_planning)
+    {
+        e->slab_planning = false;
+        char* base = nullptr;
+        if ((rc = alloc_plane(e, &base, e->slab_bytes)) != 0)
+            return rc;
+        for (auto& f : e->slab_plan)
+            *f.first = base + f.second;
+        e->slab_plan.clear();
+    }
+    (void) slab;
+    // (counters the kernels only ever add to: recycled device memory is not zero)
+    CC_HIP_CHECK(e, hipMemset(e->d_bail_count, 0, sizeof(int)));
+    CC_HIP_CHECK(e, hipMemset(e->d_par_left, 0, 2 * sizeof(int)));
+    CC_HIP_CHECK(e, hipMemset(e->d_remaining, 0, sizeof(int)));
     return CC_OK;
 }
 
@@ -1362,6 +1398,81 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     e->state_cached[stream] = 1;
     return CC_OK;
 }
+
+// ---- the engine's HIP streams are a process-wide resource ---------------------------------------------------------------------------------
+// A HIP stream gets its hardware queue when it is first used, and queues are handed to the compute pipes in creation order. The four chains of
+// the pipelined path only overlap as designed when their queues sit on different pipes: the first engine of a process got that by accident
+// (four queues created back to back), every later engine got recycled queues in another order — insertion and association on one pipe — and
+// ran 10 - 15 % slower at 32 streams, 6 - 10 % at 256 (tools/step_probe.py). So a set of seven streams is created once per
+// device, its queues are materialised in a fixed order (one empty launch each: the four chains first), and the set is kept for the next engine
+// when an engine is destroyed. Two engines alive at the same time get two sets.
+__global__ void k_touch_stream() {}
+
+struct StreamSet
+{
+    hipStream_t s[7]{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // stream, stream2 .. stream7
+};
+std::mutex g_stream_sets_mu;
+std::vector<std::pair<int, StreamSet>> g_stream_sets; // (device, set) not in use by a live engine
+
+bool acquire_stream_set(int device, StreamSet* out)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_stream_sets_mu);
+        for (size_t i = 0; i < g_stream_sets.size(); i++)
+            if (g_stream_sets[i].first == device)
+            {
+                *out = g_stream_sets[i].second;
+                g_stream_sets.erase(g_stream_sets.begin() + (long) i);
+                return true;
+            }
+    }
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
+    // The serial chains (insertion, association) bound a pipelined step; the table / segmentation / scan chain between them is
+    // throughput work with slack, so it gets the low-priority queue and yields issue slots and memory bandwidth to the other two.
+    const int prio[7] = {prio_hi, prio_lo, prio_hi, prio_lo, prio_lo, prio_lo, prio_hi};
+    StreamSet set;
+    for (int i = 0; i < 7; i++)
+        if (hipStreamCreateWithPriority(&set.s[i], hipStreamNonBlocking, prio[i]) != hipSuccess)
+        {
+            for (int k = 0; k < i; k++)
+                (void) hipStreamDestroy(set.s[k]);
+            return false;
+        }
+    // queues in this order: insertion, segmentation, association, window scan (the four chains), then publish, table, preparation
+    for (int i : {0, 1, 2, 3, 5, 6, 4})
+    {
+        hipLaunchKernelGGL(k_touch_stream, dim3(1), dim3(1), 0, set.s[i]);
+        (void) hipStreamSynchronize(set.s[i]);
+    }
+    *out = set;
+    return true;
+}
+
+void release_stream_set(int device, const StreamSet& set)
+{
+    std::lock_guard<std::mutex> lock(g_stream_sets_mu);
+    g_stream_sets.push_back({device, set});
+}
+
+// (all streams idle) the pooled set goes back for the next engine of the process; CU-masked experiment streams are destroyed
+void give_back_streams(cc_engine* e)
+{
+    hipStream_t all[7] = {e->stream, e->stream2, e->stream3, e->stream4, e->stream5, e->stream6, e->stream7};
+    if (e->streams_pooled)
+    {
+        StreamSet set;
+        for (int i = 0; i < 7; i++)
+            set.s[i] = all[i];
+        release_stream_set(e->device, set);
+    }
+    else
+        for (hipStream_t st : all)
+            if (st)
+                (void) hipStreamDestroy(st);
+    e->stream = e->stream2 = e->stream3 = e->stream4 = e->stream5 = e->stream6 = e->stream7 = nullptr;
+}
 } // namespace
 
 extern "C" {
@@ -1431,11 +1542,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         return CC_ERR_NO_DEVICE;
     cc_engine* e = new cc_engine();
     e->device = device;
-    // The serial chains (insertion, association) bound a pipelined step; the table / segmentation / scan chain between them is
-    // throughput work with slack, so it gets the low-priority queue and yields issue slots and memory bandwidth to the other two.
-    int prio_lo = 0, prio_hi = 0;
     (void) hipSetDevice(device);
-    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi); // numerically lower = higher priority
     // experiment switch CC_OPT_CU_SPLIT="ins,seg,scan,assoc": the four chains of the pipelined path on disjoint sets of compute units (CU-masked
     // streams; the mask's bits are dealt round-robin over XCDs and shader engines by the driver, so a contiguous range is spread over the chip)
     bool cu_split = false;
@@ -1461,6 +1568,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
             if (!cu_split)
             {
                 fprintf(stderr, "cc_engine_create: CC_OPT_CU_SPLIT=%s rejected (%d compute units)\n", cs, ncu);
+                give_back_streams(e); // (whatever masked streams were created)
                 delete e;
                 return CC_ERR_INVALID_ARGUMENT;
             }
@@ -1468,16 +1576,16 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     }
     if (cu_split)
         fprintf(stderr, "cc_engine_create: chains on disjoint compute units (CC_OPT_CU_SPLIT=%s)\n", std::getenv("CC_OPT_CU_SPLIT"));
-    else if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithPriority(&e->stream, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream2, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream3, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream4, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream5, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream6, hipStreamNonBlocking, prio_lo) != hipSuccess ||
-        hipStreamCreateWithPriority(&e->stream7, hipStreamNonBlocking, prio_hi) != hipSuccess)
+    else
     {
-        delete e;
-        return CC_ERR_HIP;
+        StreamSet set;
+        if (hipSetDevice(device) != hipSuccess || !acquire_stream_set(device, &set))
+        {
+            delete e;
+            return CC_ERR_HIP;
+        }
+        e->stream = set.s[0], e->stream2 = set.s[1], e->stream3 = set.s[2], e->stream4 = set.s[3], e->stream5 = set.s[4], e->stream6 = set.s[5], e->stream7 = set.s[6];
+        e->streams_pooled = true;
     }
     for (int i = 0; i < 4; i++)
     {
@@ -1537,7 +1645,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
             (void) hipHostFree(e->h_par_left);
         if (e->h_bail_count)
             (void) hipHostFree(e->h_bail_count);
-        (void) hipStreamDestroy(e->stream);
+        give_back_streams(e);
         delete e;
         return rc;
     }
@@ -1586,12 +1694,6 @@ void cc_engine_destroy(cc_engine* e)
     }
     for (hipEvent_t ev : e->pev_pool)
         (void) hipEventDestroy(ev);
-    (void) hipStreamDestroy(e->stream2);
-    (void) hipStreamDestroy(e->stream3);
-    (void) hipStreamDestroy(e->stream4);
-    (void) hipStreamDestroy(e->stream6);
-    (void) hipStreamDestroy(e->stream7);
-    (void) hipStreamDestroy(e->stream5);
     for (hipEvent_t ev : e->ev_pool)
         (void) hipEventDestroy(ev);
     if (e->h_remaining)
@@ -1600,7 +1702,7 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipHostFree(e->h_par_left);
     if (e->h_bail_count)
         (void) hipHostFree(e->h_bail_count);
-    (void) hipStreamDestroy(e->stream);
+    give_back_streams(e);
     delete e;
 }
 
