@@ -21,7 +21,7 @@ from .capi import Config
 __all__ = ["Config", "Engine", "EngineError", "load_library", "capi", "IDENTITY_TF"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcc_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("CC_HIP_LIB", "libcc_hip.so"))  # (CC_HIP_LIB: another build of the same library, for A/B tools)
 _lib = None
 
 IDENTITY_TF = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], dtype=np.float64)

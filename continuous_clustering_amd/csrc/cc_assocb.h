@@ -1,23 +1,41 @@
 // Batch-parallel association + finished-cluster check (included by cc_kernels.h inside namespace cck, after cc_assoc3.h).
 //
 // k_assocb does what k_assoc3 / k_assoc_lds do (association bookkeeping cc.cpp:643-696 and 773-835, finished-cluster check :837-974, publish
-// bookkeeping :1035-1092), but not as a walk over the columns: a block of AB_WAVES wavefronts takes a GROUP of up to 64 columns of one stream
-// at a time and nothing in it is serial per column.
+// bookkeeping :1035-1092), but not as a walk over the columns: a block of AB_WAVES worker wavefronts + one timeline wavefront takes a GROUP of
+// up to 60 columns of one stream at a time and nothing in it is serial per column.
 //
 //   1  tree of every point   k_scan left, per point, where its chain of same-column parents ends (sc_term): a new root of the column or a cell
 //                            of an earlier column. Inside the group that is a forest of pointers, resolved by pointer jumping in an LDS ring
 //                            of per-cell tree slots (<= 7 rounds for 64 columns, instead of one dependent look-up per column).
-//   2  records               per column and tree that receives points: count and largest finished_at contribution (cc.cpp:666-670). What the
-//                            finished-cluster check needs of them is ONE 64-bit word per tree: bit j = "this tree alone keeps its cluster
-//                            unfinished at column j of the group" (its largest finished_at so far > the column's smallest azimuth, :884-885).
-//                            A record (column c, value f) contributes ballot(lane >= c && f > min_az[lane]) — one compare over the lanes, one
-//                            LDS atomic OR.
+//   2  records               per column and RUN of rows that lead to one tree: points and largest finished_at contribution (cc.cpp:666-670),
+//                            by one segmented DPP scan per column (no loop over the column's trees). What the finished-cluster check needs of
+//                            them is ONE 64-bit word per tree: bit j = "this tree alone keeps its cluster unfinished at column j of the group"
+//                            (its largest finished_at so far > the column's smallest azimuth, :884-885). A record (column c, value f)
+//                            contributes ballot(lane >= c && f > min_az[lane]) — one compare over the lanes, one LDS atomic OR.
 //   3  timeline (one wave)   lanes = trees. A cluster is unfinished at column j iff the OR of its trees' words has bit j set; it is finished at
 //                            the first eligible column where it has not. Tree links (cc.cpp:675-696) are the only thing that changes clusters:
 //                            the few links of a group that join two different trees are applied in column order, the columns between two such
 //                            events are one "epoch" evaluated with a single segmented OR. Ids by rank of (finish column, oldest tree),
 //                            first-unpublished column per column as the oldest tree still listed (cc.cpp:944-959), events by prefix sums.
 //   4  commit                tree roots of the group's cells, finished trees, compaction of the tree table, remap of the slot ring.
+//
+// Round 5: the groups are PIPELINED. While the workers resolve, jump and record group i, the timeline wavefront evaluates and commits group
+// i - 1 (round 4: it idled 40 % of a group waiting for the records, the workers 20 % waiting for the timeline). What makes that possible is a
+// slot numbering that does not wait for the previous group's compaction: the workers number the trees of group i as
+//     N(i) = [ survivors of the timeline pass of group i - 2, in list order ] ++ [ trees born in group i - 1 ] ++ [ trees born in group i ]
+// — the list the timeline pass of group i - 1 works on, plus the group's own new roots (how many every column starts is static: k_scan's column
+// summary). The timeline pass of group i translates: a survivor's slot is its position BEFORE the compaction of pass i - 1 (`sig`), a tree that
+// pass i - 1 finished has no lane any more; a point or link of group i that names such a tree is what the serial algorithm refuses (cc.cpp:658,
+// :688-690): points stop the kernel in front of the group (AB_BAIL_DEAD, as before), links are dropped (as before). The slot ring is renumbered
+// by the workers one iteration late (compaction of pass i - 2 before group i's pointers are written), the tree roots of group i's cells are
+// written when pass i has committed (one iteration after the workers recorded them; `a1` / `a2` keep two groups of resolved slots in registers).
+// Per-group shared state is double-buffered by group parity (AbGroup: what the workers produce; AbHeader: what the timeline plans).
+//
+// One iteration (group i for the workers, i - 1 for the timeline), two block barriers + one per pointer-jumping round:
+//     workers   points of group i requested, roots of group i - 2, ring renumbering, pointers of i | B1 | jumping (barrier per round) | records, links of i | B2
+//     timeline  first half of the pass of group i - 1 (up to the finished clusters' ids)          | B1 | (follows the rounds)        | second half, header of i + 1 | B2
+// (what a pass hands to the workers — compaction map, root cells, re-scan columns — is double-buffered too: the workers read the pass of group
+// i - 2 while the pass of group i - 1 writes)
 //
 // Exactness. The group is evaluated as if every first accepted candidate rooted its point (k_scan's assumption) and nothing in it touched a
 // finished tree. Every way the reference's sequential semantics can differ is DETECTED before anything is committed — a point whose chain ends in
@@ -33,15 +51,13 @@
 #ifndef CC_AB_WAVES
 #define CC_AB_WAVES 15
 #endif
-#ifndef CC_AB_CPW
-#define CC_AB_CPW 4
-#endif
-constexpr int AB_WAVES = CC_AB_WAVES;      // worker wavefronts (columns); one more wavefront runs the timeline
+constexpr int AB_WAVES = CC_AB_WAVES;      // worker wavefronts; one more wavefront runs the timeline
 constexpr int AB_THREADS = 64 * (AB_WAVES + 1);
-constexpr int AB_CPW = CC_AB_CPW;          // columns per worker wavefront and group
-constexpr int AB_G = AB_WAVES * AB_CPW;    // columns per group (<= 64 = lanes of the timeline wave)
-constexpr int AB_RING = 128;               // columns of the slot ring (power of two >= AB_G + WIN_COLS)
-constexpr int AB_TREES = 64;               // trees a group can see (unfinished at its start + born inside) = lanes of the timeline wave
+constexpr int AB_SUB = 4;                  // 64-row pieces of a worker wavefront's tile: 4 columns of a 64-row sensor, 2 columns of a 128-row sensor
+constexpr int AB_G_MAX = AB_WAVES * AB_SUB; // columns per group at 64 rows (<= 64 = lanes of the timeline wave); AB_WAVES * AB_SUB / RPL in general
+constexpr int AB_POINTS = AB_WAVES * 64;   // active points per group: one lane each
+constexpr int AB_RING = 128;               // columns of the slot ring at 64 rows (power of two >= columns per group + WIN_COLS); half of it at 128 rows
+constexpr int AB_TREES = 64;               // trees a group can see (unfinished two groups ago + born since) = lanes of the timeline wave
 constexpr int AB_EVENTS = 64;              // links between different trees per group
 constexpr int AB_NONE = -100, AB_DEAD = -101; // ring entries: cell without a tree / tree finished
 // why a launch handed the rest of its batch to the serial kernel (StreamState::batch_bail_reason)
@@ -54,46 +70,70 @@ enum
     AB_BAIL_LATE = 5,     // a tree receives a point after its cluster finished inside the group
     AB_BAIL_REACH = 6,    // a candidate from a column older than the first unpublished one
 };
-static_assert(AB_G <= 64 && AB_THREADS <= 1024 && AB_RING >= AB_G + WIN_COLS, "group geometry");
+static_assert(AB_G_MAX <= 64 && AB_THREADS <= 1024 && AB_RING >= AB_G_MAX + WIN_COLS, "group geometry");
+static_assert(LINK_SLOTS == 4, "the link phase reads the four candidate codes of a point at once");
 
+// what the workers produce for a group (indexed by the slots N(i)); read by the timeline one iteration later. Two buffers (group parity)
+struct AbGroup
+{
+    unsigned long long g_alive[AB_TREES]; // bit j: the group's records alone keep the tree's cluster unfinished at column j of the group
+    unsigned long long g_fin[AB_TREES];   // largest finished_at contribution of the group (bits of a non-negative double)
+    unsigned g_pts[AB_TREES];
+    int g_last[AB_TREES];                 // last column of the group (relative) that attached a point, -1 none
+    int birth[AB_TREES];                  // column of the group (relative) the tree starts in, -1: older
+    int g_cell[AB_TREES];                 // root cell of the trees born in the group
+    unsigned ev[AB_EVENTS];               // column << 16 | tree a << 8 | tree b
+    int n_ev;
+    int wbail;                            // the workers cannot take the group (nothing of it is committed)
+    int jflag[8];                         // pointer jumping: round r left pointers unresolved
+};
+// what the timeline plans for a group. Two buffers (group parity)
+struct AbHeader
+{
+    int col_base[64]; // new roots of the group's earlier columns
+    int col_info[64];
+    int ppos[64];     // active points of the group's earlier columns = where the column's points go in the packed order
+    int chunk_col[16]; // the column the first point of wavefront w belongs to
+    unsigned char colstart[AB_POINTS]; // column + 1 at the position of the column's first point, 0 elsewhere
+    double min_az[64];
+    long long gc0;    // first global column of the group
+    int lc0;
+    int ncols;
+    int nborn;
+    int tot;          // active points of the group
+    int base;         // slots in front of the group's own new roots = size of the list the previous group's timeline pass works on
+    int bail;         // the kernel stops in front of this group
+};
 struct AbTrees
 {
-    // persistent over the groups: the unfinished trees in creation order (the reference's sc_unfinished_point_trees_)
+    // persistent over the groups: the unfinished trees in creation order (the reference's sc_unfinished_point_trees_); timeline only
     int cell[AB_TREES];
     long long gcol[AB_TREES];
     unsigned long long fin[AB_TREES]; // bits of finished_at_continuous_azimuth_angle (non-negative double)
     long long last[AB_TREES];         // last global column that attached a point
     unsigned pts[AB_TREES];
     int comp[AB_TREES];               // cluster = smallest list position of its trees
-    // per group
-    unsigned long long g_alive[AB_TREES]; // bit j: the tree alone keeps its cluster unfinished at column j of the group
-    unsigned long long g_fin[AB_TREES];
-    unsigned g_pts[AB_TREES];
-    int g_last[AB_TREES];             // last column of the group (relative) that attached a point, -1 none
-    int birth[AB_TREES];              // column of the group (relative) the tree starts in, -1: older
-    int g_cell[AB_TREES];             // root cell of the trees born in the group
+    int sig[AB_TREES];                // the tree's slot in the numbering of the group the next pass evaluates (its position before the last compaction)
+    // scratch of a timeline pass
     unsigned long long k_or[AB_TREES];
     unsigned k_pts[AB_TREES];
     long long k_max[AB_TREES];
     unsigned k_cid[AB_TREES];
     long long t_gcol[AB_TREES];
-    int remap[AB_TREES];
-    int cell_old[AB_TREES];
-    unsigned ev[AB_EVENTS];           // column << 16 | tree a << 8 | tree b
-    int col_base[64];               // new roots of the group's earlier columns
-    int col_info[64];
-    double min_az[64];
+    int t_birth[AB_TREES];
+    int lane_of[AB_TREES];            // slot -> lane of the pass, -1: the tree finished in the pass before
     int col_ncl[64];
     int col_ebase[64];
-    int col_fix[64];                // >= 0: ring column of the first unpublished column while the column was associated (visit counts are re-taken)
-    int n_ev;
-    int ncols;
-    int nborn;
-    int bail;      // the group in work cannot be taken (nothing of it is committed)
-    int next_bail; // the kernel stops in front of the next group
-    int any_finished;
-    int jflag[8];  // pointer jumping: round r left pointers unresolved
-    int next_info[64]; // column summaries of the next group (link flags for the input prefetch)
+    // timeline pass -> workers: the pass of group j writes buffer j & 1 while the workers still read what the pass of group j - 1 left
+    int remap[2][AB_TREES];           // list position of the pass -> position after its compaction, -1 finished
+    int cell_by_slot[2][AB_TREES];    // slot (numbering of the pass's group) -> root cell
+    int col_fix[2][64];               // >= 0: ring column of the first unpublished column while the column was associated (visit counts are re-taken)
+    int rm_n[2];                      // size of the list the pass worked on
+    int rm_nunf[2];                   // trees it left
+    int any_finished[2];
+    int tbail;                        // the pass could not take its group (nothing of it is committed)
+    AbGroup G[2];
+    AbHeader H[2];
     // links already reported for the column a worker wavefront is at: bit b of pair[wave][a] = (column, tree a, tree b) is in the event list. Where two
     // trees of one object meet, every point along the seam reports the same pair: without this filter such a group had more events than the
     // timeline has lanes (AB_EVENTS) and the kernel stopped — the only stop ordinary streams still produced
@@ -118,6 +158,18 @@ __device__ __forceinline__ int wave_incl_add_i32(int v)
     v += dpp_mov_i32<0x143, 0xc>(0, v);
     return v;
 }
+// inclusive prefix maximum of non-negative values
+__device__ __forceinline__ int wave_incl_max_i32(int v)
+{
+    int t;
+    t = dpp_mov_i32<0x111, 0xf>(0, v); v = t > v ? t : v;
+    t = dpp_mov_i32<0x112, 0xf>(0, v); v = t > v ? t : v;
+    t = dpp_mov_i32<0x114, 0xf>(0, v); v = t > v ? t : v;
+    t = dpp_mov_i32<0x118, 0xf>(0, v); v = t > v ? t : v;
+    t = dpp_mov_i32<0x142, 0xa>(0, v); v = t > v ? t : v;
+    t = dpp_mov_i32<0x143, 0xc>(0, v); v = t > v ? t : v;
+    return v;
+}
 // the value of the lane below (wave_shr:1); lane 0 keeps its own
 __device__ __forceinline__ long long wave_shr1_i64(long long v)
 {
@@ -127,11 +179,37 @@ __device__ __forceinline__ double wave_shr1_f64(double v)
 {
     return __longlong_as_double(wave_shr1_i64(__double_as_longlong(v)));
 }
+// Maximum over the RUN of lanes [head, lane] a lane belongs to (`head` = first lane of the run, the same in all its lanes): the values are bit
+// patterns of non-negative doubles (finished_at), a source lane outside the run contributes + 0.0. One step = two DPP moves, one compare, two
+// selects, one v_max_f64; six steps cover the wavefront.
+template<int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long ab_segmax_step(long long b, const int src_lane, const int head)
+{
+    long long t = dpp_mov_i64<CTRL, ROW_MASK>(0ll, b);
+    t = src_lane >= head ? t : 0ll;
+    return __double_as_longlong(__builtin_fmax(__longlong_as_double(t), __longlong_as_double(b)));
+}
+__device__ __forceinline__ unsigned long long ab_run_max_f64_bits(unsigned long long bits, const int lane, const int head)
+{
+    long long b = (long long) bits;
+    b = ab_segmax_step<0x111, 0xf>(b, lane - 1, head);
+    b = ab_segmax_step<0x112, 0xf>(b, lane - 2, head);
+    b = ab_segmax_step<0x114, 0xf>(b, lane - 4, head);
+    b = ab_segmax_step<0x118, 0xf>(b, lane - 8, head);
+    b = ab_segmax_step<0x142, 0xa>(b, (lane & ~15) - 1, head); // (rows 1 and 3 take lane 15 / 47: everything of the row below)
+    b = ab_segmax_step<0x143, 0xc>(b, 31, head);               // (rows 2 and 3 take lane 31: everything of rows 0 - 1)
+    return (unsigned long long) b;
+}
 
 template<int RPL>
 __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
                                                        int* __restrict__ bail_count)
 {
+    constexpr int GCOLS = AB_WAVES * AB_SUB / RPL; // columns per group
+#ifdef CC_AB_STATS
+    const unsigned long long ab_entry = __builtin_amdgcn_s_memtime();
+    const unsigned long long ab_entry_rt = wall_clock64(); // (constant 100 MHz: what s_memtime ticks at, measured)
+#endif
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const int wave = uniform_i32((int) (threadIdx.x >> 6));
@@ -171,8 +249,14 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
 #endif
     __builtin_amdgcn_s_setprio(CC_AB_PRIO); // latency-bound (barriers, LDS round trips): win issue arbitration against co-resident throughput kernels
     __shared__ AbTrees T;
-    __shared__ short ring[AB_RING * WAVE * RPL];
+    constexpr int RING = AB_RING / RPL; // columns of the slot ring
+    static_assert(RING >= GCOLS + WIN_COLS, "slot ring");
+    __shared__ short ring[RING * WAVE * RPL];
     __shared__ int s_nunf;
+    __shared__ long long s_gc_final;
+    __shared__ int s_serial_cols;
+    __shared__ int s_reason;
+    __shared__ unsigned long long s_cols;
 
     const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
     long long first_unpub = st->first_unpublished, ring_start = st->ring_start;
@@ -194,6 +278,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
         T.last[i] = tg + (long long) p.t_width[cell] - 1;
         T.pts[i] = p.t_pts[cell];
         T.comp[i] = p.t_pos[p.t_uf[cell]];
+        T.sig[i] = i;
     }
     {
         // slot ring of the WIN_COLS columns before col_begin: two dependent gathers per cell (root plane, then the tree planes at the root)
@@ -208,7 +293,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 if (r >= 0)
                     v = p.t_finished[r] ? AB_DEAD : -1 - p.t_pos[r];
             }
-            ring[(int) (gcx & (AB_RING - 1)) * R + row] = (short) v;
+            ring[(int) (gcx & (RING - 1)) * R + row] = (short) v;
         }
     }
     __syncthreads();
@@ -222,543 +307,683 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             const int r2 = __shfl(rep, rep);
             rep = r2;
         }
-        T.remap[lane] = AB_TREES;
+        T.remap[0][lane] = AB_TREES;
         wave_lds_fence();
         if (lane < n_unf)
-            atomicMin(&T.remap[rep], lane);
+            atomicMin(&T.remap[0][rep], lane);
         wave_lds_fence();
         if (lane < n_unf)
-            T.comp[lane] = lds_ld(&T.remap[rep]);
+            T.comp[lane] = lds_ld(&T.remap[0][rep]);
         if (lane == 0 && st->batch[slot].pub_begin < 0)
             st->batch[slot].pub_begin = first_unpub; // first association kernel of this pass
+        if (lane == 0)
+        {
+            T.tbail = 0;
+            T.any_finished[0] = T.any_finished[1] = 0;
+        }
     }
     __syncthreads();
 
 #ifdef CC_AB_STATS
-    unsigned long long ab_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ab_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long ab_mark = __builtin_amdgcn_s_memtime();
     const unsigned long long ab_t0 = ab_mark;
-#define AB_PH(i)                                                     \
+    ab_t[13] = ab_mark - ab_entry; // prologue
+#define AB_PH_(i)                                                    \
     {                                                                \
         const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
         ab_t[i] += n_ - ab_mark;                                     \
         ab_mark = n_;                                                \
     }
 #else
-#define AB_PH(i)
+#define AB_PH_(i)
 #endif
-    // CC_AB_STATS_W (with CC_AB_STATS): the counters are taken by worker wavefront 1 instead of the timeline wavefront
+    // CC_AB_STATS: the phase clocks of the timeline wavefront; with CC_AB_STATS_W those of worker wavefront 1 instead (tools/prof_assocb.py)
 #if defined(CC_AB_STATS) && defined(CC_AB_STATS_W)
-#undef AB_PH
 #define AB_PH(i)
-#define AB_PHW(i)                                                    \
-    if (wave == 1)                                                   \
-    {                                                                \
-        const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
-        ab_t[i] += n_ - ab_mark;                                     \
-        ab_mark = n_;                                                \
-    }
+#ifndef CC_AB_STATS_WAVE
+#define CC_AB_STATS_WAVE 1
+#endif
+#define AB_PHW(i)                   \
+    if (wave == CC_AB_STATS_WAVE) \
+    AB_PH_(i)
+#elif defined(CC_AB_STATS)
+#define AB_PH(i) AB_PH_(i)
+#define AB_PHW(i)
 #else
+#define AB_PH(i)
 #define AB_PHW(i)
 #endif
-    long long gc0 = col_begin;
-    int lc0 = (int) (col_begin % RC);
-    unsigned long long batch_cols = 0;
-    bool bailed = false;
     const double mz_inf = 1.7976931348623157e308;
-    if (threadIdx.x == 0)
-        T.bail = 0;
 
-    // Two roles, one barrier schedule per group: B1 (pointers written) - one barrier per pointer-jumping round - B2 (records, links) - B3
-    // (timeline done, group committed, next header in place). The timeline wavefront and the workers run separate loops (separate register
-    // allocations: the workers hold a group of prefetched inputs, the timeline wave ~60 per-tree / per-column values) that meet at these barriers.
+    // Two roles, one barrier schedule per iteration (file header). The timeline wavefront and the workers run separate loops (separate register
+    // allocations: the workers hold a group of prefetched inputs and two groups of resolved slots, the timeline wave ~60 per-tree / per-column
+    // values) that meet at B1, the pointer-jumping rounds and B2. Both sides take the same decision behind B2 from the same LDS words:
+    //   T.tbail                                              the pass of group i - 1 failed -> stop, nothing of groups >= i - 1 is committed
+    //   group i missing / its header says stop / G.wbail     stop behind group i - 1 (the workers still write its roots)
     if (wave == 0)
     {
         // =============================================================================================== timeline wavefront
-        // column summaries of the NEXT group in registers (lanes = columns), requested a whole group ahead
-        int nx_info = 0;
+        // column summaries of the group after the next header, requested a whole iteration ahead (registers, lanes = columns)
+        int nx_info = 0, nx_act = 0;
         double nx_maz = mz_inf;
         auto load_next_info = [&](const long long g0, const int l0)
         {
             nx_info = 0;
+            nx_act = 0;
             nx_maz = mz_inf;
-            if (lane < AB_G && g0 + lane < col_end)
+            if (lane < GCOLS && g0 + lane < col_end)
             {
                 int lcj = l0 + lane;
                 lcj = lcj >= RC ? lcj - RC : lcj;
                 nx_info = p.col_info[lcj];
+                nx_act = p.col_act[lcj];
                 nx_maz = p.colminaz[lcj];
             }
         };
-        // group header: how many columns the group takes (the trees it sees must fit the lanes), what stops the kernel in front of it;
-        // then the summaries of the group after it are requested
-        auto group_header = [&](const long long g0, const int l0, const int n_before)
+        // group header: how many columns the group takes (the trees it may see must fit the lanes), what stops the kernel in front of it; the
+        // group's AbGroup buffer is wiped; then the summaries of the group after it are requested.
+        // `base` = trees the workers number in front of the group's own new roots; `oldest` = a lower bound of the column of every tree among them
+        auto group_header = [&](const int b, const long long g0, const int l0, const int base, const long long oldest)
         {
+            AbHeader& H = T.H[b];
+            AbGroup& G = T.G[b];
             const int info = nx_info;
             const double maz = nx_maz;
-            const bool valid = lane < AB_G && g0 + lane < col_end;
+            const bool valid = lane < GCOLS && g0 + lane < col_end;
             const int cnt = info & 0xff;
             const int incl = wave_incl_add_i32(cnt);
-            const unsigned long long okm = __ballot(valid && n_before + incl <= tree_limit);
+            const int pts = valid ? (nx_act & 0xff) + (nx_act >> 8) : 0;
+            const int ipts = wave_incl_add_i32(pts);
+            // (the group's points must fit the lanes of the worker wavefronts; one column always does)
+            const unsigned long long okm = __ballot(valid && base + incl <= tree_limit && ipts <= AB_POINTS);
             const int ncols = ~okm ? __builtin_ctzll(~okm) : 64;
             const unsigned long long cm = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
             int bail = (ncols == 0 && g0 < col_end) ? AB_BAIL_TREES : 0;
             if (__ballot(((info >> 8) & 1) != 0) & cm)
                 bail = AB_BAIL_LINKS; // a point with more link candidates than k_scan records (cc.cpp:693-694 would see them all)
-            // no tree or cluster of this group can reach the one-rotation limits (cc.cpp:657, 913-924) while the oldest unfinished tree is
-            // less than a rotation behind the group's last column
-            if (n_before > 0 && ncols > 0 && (g0 + ncols - lds_ld(&T.gcol[0])) >= NC)
+            // no tree or cluster of this group can reach the one-rotation limits (cc.cpp:657, 913-924) while the oldest tree that may still be
+            // unfinished is less than a rotation behind the group's last column
+            if (base > 0 && ncols > 0 && (g0 + ncols - oldest) >= NC)
                 bail = AB_BAIL_ROTATION;
-            T.col_base[lane] = incl - cnt;
-            T.col_info[lane] = info;
-            T.min_az[lane] = maz;
-            T.col_ncl[lane] = 0;
-            T.g_alive[lane] = 0ull;
-            T.g_fin[lane] = 0ull;
-            T.g_pts[lane] = 0u;
-            T.g_last[lane] = -1;
-            T.birth[lane] = -1;
+            H.col_base[lane] = incl - cnt;
+            H.col_info[lane] = info;
+            H.ppos[lane] = ipts - pts;
+            // where the columns begin in the packed order: markers for the workers' prefix maximum, and the column every wavefront starts in
+            if (lane < AB_POINTS / 16)
+                *(uint4*) &H.colstart[16 * lane] = make_uint4(0u, 0u, 0u, 0u);
+            wave_lds_fence();
+            if (lane < ncols && pts > 0)
+            {
+                H.colstart[ipts - pts] = (unsigned char) (lane + 1);
+                for (int cw = (ipts - pts + 63) >> 6; 64 * cw < ipts && cw < 16; cw++)
+                    H.chunk_col[cw] = lane;
+            }
+            H.min_az[lane] = maz;
+            G.g_alive[lane] = 0ull;
+            G.g_fin[lane] = 0ull;
+            G.g_pts[lane] = 0u;
+            G.g_last[lane] = -1;
+            G.birth[lane] = -1;
             const int nb = __builtin_amdgcn_readlane(incl, ncols > 0 ? ncols - 1 : 0);
+            const int npts = __builtin_amdgcn_readlane(ipts, ncols > 0 ? ncols - 1 : 0);
             if (lane < 8)
-                T.jflag[lane] = 0;
+                G.jflag[lane] = 0;
             if (lane == 0)
             {
-                T.n_ev = 0;
-                T.ncols = ncols;
-                T.nborn = ncols > 0 ? nb : 0;
-                T.next_bail = bail;
+                G.n_ev = 0;
+                G.wbail = 0;
+                H.gc0 = g0;
+                H.lc0 = l0;
+                H.ncols = bail ? 0 : ncols;
+                H.nborn = (ncols > 0 && !bail) ? nb : 0;
+                H.tot = (ncols > 0 && !bail) ? npts : 0;
+                H.base = base;
+                H.bail = bail;
             }
             int l1 = l0 + ncols;
             l1 = l1 >= RC ? l1 - RC : l1;
             load_next_info(g0 + ncols, l1);
         };
-        load_next_info(gc0, lc0);
-        T.next_info[lane] = nx_info;
-        ab_barrier(); // P0a: link flags of the first group for the workers' prefetch
-        group_header(gc0, lc0, n_unf);
-        ab_barrier(); // P0b
-        if (T.next_bail)
+        load_next_info(col_begin, (int) (col_begin % RC));
+        group_header(0, col_begin, (int) (col_begin % RC), n_unf, n_unf > 0 ? T.gcol[0] : col_begin);
+        wave_lds_fence();
+        ab_barrier(); // P0: header of group 0
+
+        // the group the next pass evaluates: its first column, kept from the header
+        long long tg0 = col_begin;
+        int tlc0 = (int) (col_begin % RC);
+        unsigned long long batch_cols = 0;
+        long long gc_final = col_begin;
+        int serial_cols = GCOLS; // columns the serial kernel takes behind a stop: the group that could not be taken
+        int reason = 0;
+        // the barriers in the middle of an iteration: the workers' pointers are written (B1), one per jumping round
+        auto mid_barriers = [&](const int b)
         {
-            bailed = true;
-            if (lane == 0)
-                T.bail = T.next_bail;
-        }
-        while (gc0 < col_end && !bailed)
-        {
-            AB_PH(0)
-            const int ncols = T.ncols;
-            const int nborn = T.nborn;
-            const double mz = T.min_az[lane]; // lanes = columns of the group
-            // what the trees that are older than the group contribute to the finished-cluster check of its columns
-            for (int t = 0; t < n_unf; t++)
-            {
-                const double f = __longlong_as_double((long long) lds_ld(&T.fin[t]));
-                const unsigned long long m = __ballot(f > mz);
-                if (lane == 0)
-                    T.g_alive[t] = m;
-            }
             ab_barrier(); // B1
             AB_PH(1)
             for (int r = 0; r < 8; r++)
             {
                 ab_barrier();
-                if (!T.jflag[r])
+                if (!T.G[b].jflag[r])
                     break;
             }
             AB_PH(2)
-            T.next_info[lane] = nx_info; // (requested a group ago: the workers' prefetch reads the link flags of the next group's columns)
-            ab_barrier(); // B2
-            AB_PH(4)
-            if (T.bail || T.n_ev > AB_EVENTS)
+        };
+        for (int i = 0;; i++)
+        {
+            const int b = i & 1, pb = b ^ 1;
+            const bool have_prev = i > 0; // (a group i - 1 exists whenever the loop got here)
+            // ---- the own alive words of the pass's old trees (what a tree that was listed before the group contributes to the check of
+            //      the group's columns by the finished_at it came with): lanes = columns for the ballots, lane t keeps tree t's word
+            unsigned long long alive_old = 0ull;
+            if (have_prev)
             {
-                if (lane == 0 && !T.bail)
-                    T.bail = AB_BAIL_LINKS;
-                bailed = true;
-                break;
-            }
-            // ================================================================================== 3: timeline (lanes = trees / columns)
-            {
-            const int n = n_unf + nborn;
-            const bool is_t = lane < n;
-            const bool old = lane < n_unf;
-            const int birth = is_t ? T.birth[lane] : -1;
-            const int cell = old ? T.cell[lane] : (is_t ? T.g_cell[lane] : 0);
-            const long long tg = old ? T.gcol[lane] : gc0 + birth;
-            const unsigned long long alive_w = is_t ? T.g_alive[lane] : ~0ull;
-            const int g_last = is_t ? T.g_last[lane] : -1;
-            int comp = old ? T.comp[lane] : lane;
-            int fc = 64; // column of the group (relative) whose check finishes the tree's cluster; 64 = not in this group
-            T.t_gcol[lane] = tg;
-            // rounds that can finish something: not the ones whose smallest azimuth equals the previous round's (the BFS of cc.cpp:854 then
-            // meets its own visited stamp everywhere)
-            const double prev_az = wave_shr1_f64(mz);
-            const bool alias = lane < ncols && mz == (lane == 0 ? last_min_az : prev_az);
-            const unsigned long long colmask = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
-            const unsigned long long alias_m = __ballot(alias);
-            const unsigned long long elig = ~alias_m & colmask;
-            const int nev = T.n_ev;
-            const unsigned evw = lane < nev ? T.ev[lane] : 0u;
-            const int evcol = (int) (evw >> 16), eva = (int) ((evw >> 8) & 0xff), evb = (int) (evw & 0xff);
-            bool ev_done = lane >= nev;
-            bool ev_made = false;
-            int epoch = 0;
-            while (true)
-            {
-                int m = uniform_i32(wave_min_i32(ev_done ? 64 : evcol));
-                m = m < ncols ? m : ncols;
-                if (m > epoch)
+                const double mzp = T.H[pb].min_az[lane];
+                const double f_mine = lane < n_unf ? __longlong_as_double((long long) T.fin[lane]) : 0.;
+                for (int t = 0; t < n_unf; t++)
                 {
-                    const unsigned long long rm = (m >= 64 ? ~0ull : ((1ull << m) - 1ull)) & ~((1ull << epoch) - 1ull);
-                    const bool live = is_t && fc == 64;
-                    T.k_or[lane] = 0ull;
-                    wave_lds_fence();
-                    if (live)
-                        atomicOr(&T.k_or[comp], alive_w);
-                    wave_lds_fence();
-                    const unsigned long long o = live ? lds_ld(&T.k_or[comp]) : ~0ull;
-                    const unsigned long long cand = ~o & elig & rm;
-                    if (live && cand)
-                        fc = __builtin_ctzll(cand);
-                    wave_lds_fence();
+                    const double f = lane_f64(f_mine, t);
+                    const unsigned long long m = __ballot(f > mzp);
+                    alive_old = lane == t ? m : alive_old;
                 }
-                if (m >= ncols)
-                    break;
-                // the links made in column m, in any order (a union is a union); a link to or from a finished tree is refused (cc.cpp:688-690)
-                unsigned long long em = __ballot(!ev_done && evcol == m);
-                while (em)
+            }
+            AB_PH(0)
+            // ================================================================================== 3: timeline pass of group i - 1
+            if (have_prev)
+            {
+                const AbHeader& H = T.H[pb];
+                AbGroup& G = T.G[pb];
+                const long long gc0 = tg0;
+                const int lc0 = tlc0;
+                const int ncols = H.ncols;
+                const int nborn = H.nborn;
+                const int base = H.base;
+                const double mz = H.min_az[lane]; // lanes = columns of the group
+                const int n = n_unf + nborn;
+                const bool is_t = lane < n;
+                const bool old = lane < n_unf;
+                const int sig = old ? T.sig[lane] : base + (lane - n_unf); // the tree's slot in the workers' numbering of this group
+                T.lane_of[lane] = -1;
+                wave_lds_fence();
+                if (is_t)
+                    T.lane_of[sig] = lane;
+                wave_lds_fence();
+                // a tree the pass before finished that received a point of this group: the reference refuses the attach (cc.cpp:658)
+                int tbad = (lane < base && lds_ld(&T.lane_of[lane]) < 0 && G.g_last[lane] >= 0) ? AB_BAIL_DEAD : 0;
+                const int birth = is_t ? G.birth[sig] : -1;
+                const int cell = old ? T.cell[lane] : (is_t ? G.g_cell[sig] : 0);
+                const long long tg = old ? T.gcol[lane] : gc0 + birth;
+                // (a tree is not listed before its column: nothing to finish there)
+                const unsigned long long alive_w = is_t ? (G.g_alive[sig] | alive_old | (birth > 0 ? (1ull << birth) - 1ull : 0ull)) : ~0ull;
+                const int g_last = is_t ? G.g_last[sig] : -1;
+                int comp = old ? T.comp[lane] : lane;
+                int fc = 64; // column of the group (relative) whose check finishes the tree's cluster; 64 = not in this group
+                T.t_gcol[lane] = tg;
+                T.t_birth[lane] = birth;
+                T.col_ncl[lane] = 0;
+                // rounds that can finish something: not the ones whose smallest azimuth equals the previous round's (the BFS of cc.cpp:854 then
+                // meets its own visited stamp everywhere)
+                const double prev_az = wave_shr1_f64(mz);
+                const bool alias = lane < ncols && mz == (lane == 0 ? last_min_az : prev_az);
+                const unsigned long long colmask = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
+                const unsigned long long alias_m = __ballot(alias);
+                const unsigned long long elig = ~alias_m & colmask;
+                const int nev_raw = G.n_ev;
+                const int nev = nev_raw < AB_EVENTS ? nev_raw : AB_EVENTS;
+                const unsigned evw = lane < nev ? G.ev[lane] : 0u;
+                const int evcol = (int) (evw >> 16);
+                // (slots -> lanes of this pass; a link to a tree the pass before finished is refused like any link to a finished tree, cc.cpp:688-690)
+                const int eva = lane < nev ? lds_ld(&T.lane_of[(evw >> 8) & 0xff]) : -1, evb = lane < nev ? lds_ld(&T.lane_of[evw & 0xff]) : -1;
+                bool ev_done = lane >= nev || eva < 0 || evb < 0;
+                bool ev_made = false;
+                int epoch = 0;
+                while (true)
                 {
-                    const int k = __builtin_ctzll(em);
-                    em &= em - 1ull;
-                    const int ea = __builtin_amdgcn_readlane(eva, k), eb = __builtin_amdgcn_readlane(evb, k);
-                    const int fa = __builtin_amdgcn_readlane(fc, ea), fb = __builtin_amdgcn_readlane(fc, eb);
-                    if (fa == 64 && fb == 64)
+                    int m = uniform_i32(wave_min_i32(ev_done ? 64 : evcol));
+                    m = m < ncols ? m : ncols;
+                    if (m > epoch)
                     {
-                        const int ca = __builtin_amdgcn_readlane(comp, ea), cb = __builtin_amdgcn_readlane(comp, eb);
-                        const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
-                        if (comp == hi)
-                            comp = lo;
-                        if (lane == k)
-                            ev_made = true;
+                        const unsigned long long rm = (m >= 64 ? ~0ull : ((1ull << m) - 1ull)) & ~((1ull << epoch) - 1ull);
+                        const bool live = is_t && fc == 64;
+                        T.k_or[lane] = 0ull;
+                        wave_lds_fence();
+                        if (live)
+                            atomicOr(&T.k_or[comp], alive_w);
+                        wave_lds_fence();
+                        const unsigned long long o = live ? lds_ld(&T.k_or[comp]) : ~0ull;
+                        const unsigned long long cand = ~o & elig & rm;
+                        if (live && cand)
+                            fc = __builtin_ctzll(cand);
+                        wave_lds_fence();
                     }
-                }
-                ev_done = ev_done || evcol == m;
-                epoch = m;
-            }
-            // a tree that receives a point after its cluster finished: the reference refuses the attach and scans on (cc.cpp:658)
-            int tbad = (is_t && fc < 64 && g_last > fc) ? AB_BAIL_LATE : 0;
-
-            // ---- finished clusters: points, extent, ids in the order the reference's BFS meets them (column, then oldest tree)
-            const unsigned pts_t = (old ? T.pts[lane] : 0u) + (is_t ? T.g_pts[lane] : 0u);
-            const long long last_old = old ? T.last[lane] : -1;
-            const long long last_t = (g_last >= 0 && gc0 + g_last > last_old) ? gc0 + g_last : last_old;
-            const unsigned long long fin_old = old ? T.fin[lane] : 0ull;
-            const unsigned long long fin_g = is_t ? T.g_fin[lane] : 0ull;
-            const unsigned long long fin_t = fin_g > fin_old ? fin_g : fin_old;
-            T.k_pts[lane] = 0u;
-            T.k_max[lane] = -1;
-            T.k_cid[lane] = 0u;
-            wave_lds_fence();
-            const bool fin_here = is_t && fc < 64;
-            if (fin_here)
-            {
-                atomicAdd(&T.k_pts[comp], pts_t);
-                atomicMax(&T.k_max[comp], last_t);
-            }
-            wave_lds_fence();
-            const bool is_rep = fin_here && comp == lane;
-            const unsigned cpts = lds_ld(&T.k_pts[lane]);
-            const long long cmax = lds_ld(&T.k_max[lane]);
-            const bool has_id = is_rep && cpts > 5u; // cc.cpp:936
-            const int key = has_id ? fc * 64 + lane : 0x7fffffff;
-            int rank = 0, rank_col = 0;
-            for (int i = 0; i < n; i++)
-            {
-                const int ki = __builtin_amdgcn_readlane(key, i);
-                rank += ki < key ? 1 : 0;
-                rank_col += (ki < key && (ki >> 6) == fc) ? 1 : 0;
-            }
-            const unsigned cid = (unsigned) (cluster_counter + (unsigned long long) rank);
-            const int n_ids = __popcll(__ballot(has_id));
-            if (has_id)
-            {
-                T.k_cid[lane] = cid;
-                atomicAdd(&T.col_ncl[fc], 1);
-            }
-            wave_lds_fence();
-            const unsigned cid_t = fin_here ? lds_ld(&T.k_cid[comp]) : 0u;
-
-            // ---- per column (lanes = columns): the oldest tree still listed when the column's check ends (cc.cpp:944-959)
-            int idx = -1;
-            for (int i = n - 1; i >= 0; i--)
-            {
-                const int fi = __builtin_amdgcn_readlane(fc, i);
-                if (fi >= lane)
-                    idx = i;
-            }
-            const long long gcj = gc0 + lane;
-            long long mc = gcj + 1;
-            bool listed = false;
-            if (idx >= 0)
-            {
-                const int bi = T.birth[idx];
-                if (bi <= lane)
-                {
-                    mc = T.t_gcol[idx];
-                    listed = true;
-                }
-            }
-            const long long mc_prev = wave_shr1_i64(mc);
-            const long long fu = lane == 0 ? first_unpub : mc_prev; // first unpublished column while column j is associated
-            const int info = T.col_info[lane];
-            const int reach = (info >> 16) & 0xff;
-            if (lane < ncols && (mc < fu || gcj - reach < fu))
-                tbad = AB_BAIL_REACH;
-            // (mirror) k_scan's visit counts (Point::number_of_visited_neighbors, cc.cpp:725) are only right if no scan LOOKED past the first
-            // unpublished column (cc.cpp:762-763): where one did — without accepting anything there — the counts are taken again in 4b
-            int fix = -1;
-            if (g.mirror_fields && lane < ncols && gcj - ((info >> 24) & 0x7f) < fu)
-            {
-                int lcf = lc0 + lane - (int) (gcj - fu);
-                lcf = lcf >= RC ? lcf - RC : lcf;
-                fix = lcf < 0 ? lcf + RC : lcf;
-            }
-            T.col_fix[lane] = fix; // cc.cpp:762-763: the live scan would have stopped earlier (or the bookkeeping error of :1072-1075: the serial kernel reports it)
-            const int ncl = T.col_ncl[lane];
-            const int per_col = lane < ncols ? 2 + ncl : 0;
-            const int eincl = wave_incl_add_i32(per_col);
-            T.col_ebase[lane] = n_events + eincl - per_col;
-            wave_lds_fence();
-
-            if (__any(tbad))
-            {
-                if (lane == 0)
-                    T.bail = __any(tbad == AB_BAIL_LATE) ? AB_BAIL_LATE : AB_BAIL_REACH;
-            }
-            else
-            {
-                // ============================================================================== 4a: commit (still wave 0)
-                if (g.record_events)
-                {
-                    if (lane < ncols)
+                    if (m >= ncols)
+                        break;
+                    // the links made in column m, in any order (a union is a union); a link to or from a finished tree is refused (cc.cpp:688-690)
+                    unsigned long long em = __ballot(!ev_done && evcol == m);
+                    while (em)
                     {
-                        const int e0 = T.col_ebase[lane];
-                        if (e0 < g.event_capacity)
+                        const int k = __builtin_ctzll(em);
+                        em &= em - 1ull;
+                        const int ea = __builtin_amdgcn_readlane(eva, k), eb = __builtin_amdgcn_readlane(evb, k);
+                        const int fa = __builtin_amdgcn_readlane(fc, ea), fb = __builtin_amdgcn_readlane(fc, eb);
+                        if (fa == 64 && fb == 64)
                         {
-                            cc_event e;
-                            e.type = CC_EV_GROUND_COLUMN;
-                            e.stream = s;
-                            e.a = gcj;
-                            e.b = gcj;
-                            e.c = 0;
-                            e.d = 0;
-                            e.column = gcj;
-                            p.events[e0] = e;
-                        }
-                        const int e1 = e0 + 1 + ncl;
-                        if (e1 < g.event_capacity)
-                        {
-                            cc_event e;
-                            e.type = CC_EV_PUBLISH_COLUMNS;
-                            e.stream = s;
-                            e.a = fu;
-                            e.b = mc - 1;
-                            e.c = 0;
-                            e.d = 0;
-                            e.column = gcj;
-                            p.events[e1] = e;
+                            const int ca = __builtin_amdgcn_readlane(comp, ea), cb = __builtin_amdgcn_readlane(comp, eb);
+                            const int lo = ca < cb ? ca : cb, hi = ca < cb ? cb : ca;
+                            if (comp == hi)
+                                comp = lo;
+                            if (lane == k)
+                                ev_made = true;
                         }
                     }
+                    ev_done = ev_done || evcol == m;
+                    epoch = m;
+                }
+                // a tree that receives a point after its cluster finished: the reference refuses the attach and scans on (cc.cpp:658)
+                if (is_t && fc < 64 && g_last > fc)
+                    tbad = AB_BAIL_LATE;
+
+                // ---- finished clusters: points, extent, ids in the order the reference's BFS meets them (column, then oldest tree)
+                const unsigned pts_t = (old ? T.pts[lane] : 0u) + (is_t ? G.g_pts[sig] : 0u);
+                const long long last_old = old ? T.last[lane] : -1;
+                const long long last_t = (g_last >= 0 && gc0 + g_last > last_old) ? gc0 + g_last : last_old;
+                const unsigned long long fin_old = old ? T.fin[lane] : 0ull;
+                const unsigned long long fin_g = is_t ? G.g_fin[sig] : 0ull;
+                const unsigned long long fin_t = fin_g > fin_old ? fin_g : fin_old;
+                const bool fin_here = is_t && fc < 64;
+                const bool any_fin = __any(fin_here);
+                unsigned cpts = 0u, cid = 0u, cid_t = 0u;
+                long long cmax = -1;
+                int rank_col = 0, n_ids = 0;
+                bool has_id = false;
+                if (any_fin) // (wave-uniform: most groups finish nothing)
+                {
+                    T.k_pts[lane] = 0u;
+                    T.k_max[lane] = -1;
+                    T.k_cid[lane] = 0u;
+                    wave_lds_fence();
+                    if (fin_here)
+                    {
+                        atomicAdd(&T.k_pts[comp], pts_t);
+                        atomicMax(&T.k_max[comp], last_t);
+                    }
+                    wave_lds_fence();
+                    const bool is_rep = fin_here && comp == lane;
+                    cpts = lds_ld(&T.k_pts[lane]);
+                    cmax = lds_ld(&T.k_max[lane]);
+                    has_id = is_rep && cpts > 5u; // cc.cpp:936
+                    const int key = has_id ? fc * 64 + lane : 0x7fffffff;
+                    int rank = 0;
+                    for (int q = 0; q < n; q++)
+                    {
+                        const int ki = __builtin_amdgcn_readlane(key, q);
+                        rank += ki < key ? 1 : 0;
+                        rank_col += (ki < key && (ki >> 6) == fc) ? 1 : 0;
+                    }
+                    cid = (unsigned) (cluster_counter + (unsigned long long) rank);
+                    n_ids = __popcll(__ballot(has_id));
                     if (has_id)
                     {
-                        const int e2 = T.col_ebase[fc] + 1 + rank_col;
-                        if (e2 < g.event_capacity)
+                        T.k_cid[lane] = cid;
+                        atomicAdd(&T.col_ncl[fc], 1);
+                    }
+                    wave_lds_fence();
+                    cid_t = fin_here ? lds_ld(&T.k_cid[comp]) : 0u;
+                }
+
+                AB_PH(4)
+                // ---- the second half of the pass runs next to the workers' records and links (the first half next to their packing and pointers)
+                mid_barriers(b);
+                // ---- per column (lanes = columns): the oldest tree still listed when the column's check ends (cc.cpp:944-959)
+                int idx = -1;
+                for (int q = n - 1; q >= 0; q--)
+                {
+                    const int fi = __builtin_amdgcn_readlane(fc, q);
+                    if (fi >= lane)
+                        idx = q;
+                }
+                const long long gcj = gc0 + lane;
+                long long mc = gcj + 1;
+                bool listed = false;
+                if (idx >= 0)
+                {
+                    const int bi = T.t_birth[idx];
+                    if (bi <= lane)
+                    {
+                        mc = T.t_gcol[idx];
+                        listed = true;
+                    }
+                }
+                const long long mc_prev = wave_shr1_i64(mc);
+                const long long fu = lane == 0 ? first_unpub : mc_prev; // first unpublished column while column j is associated
+                const int info = H.col_info[lane];
+                const int reach = (info >> 16) & 0xff;
+                if (lane < ncols && (mc < fu || gcj - reach < fu) && tbad != AB_BAIL_DEAD)
+                    tbad = AB_BAIL_REACH;
+                // (mirror) k_scan's visit counts (Point::number_of_visited_neighbors, cc.cpp:725) are only right if no scan LOOKED past the first
+                // unpublished column (cc.cpp:762-763): where one did — without accepting anything there — the counts are taken again in 4b
+                int fix = -1;
+                if (g.mirror_fields && lane < ncols && gcj - ((info >> 24) & 0x7f) < fu)
+                {
+                    int lcf = lc0 + lane - (int) (gcj - fu);
+                    lcf = lcf >= RC ? lcf - RC : lcf;
+                    fix = lcf < 0 ? lcf + RC : lcf;
+                }
+                const int ncl = T.col_ncl[lane];
+                const int per_col = lane < ncols ? 2 + ncl : 0;
+                const int eincl = wave_incl_add_i32(per_col);
+                T.col_ebase[lane] = n_events + eincl - per_col;
+                wave_lds_fence();
+
+                if (__any(tbad) || nev_raw > AB_EVENTS)
+                {
+                    // (an attach to a finished tree first, then a late point, then the reach)
+                    int why = nev_raw > AB_EVENTS ? AB_BAIL_LINKS : AB_BAIL_REACH;
+                    why = __any(tbad == AB_BAIL_LATE) ? AB_BAIL_LATE : why;
+                    why = __any(tbad == AB_BAIL_DEAD) ? AB_BAIL_DEAD : why;
+                    if (lane == 0)
+                        T.tbail = why;
+                }
+                else
+                {
+                    // ============================================================================== 4a: commit (still wave 0)
+                    T.col_fix[pb][lane] = fix; // cc.cpp:762-763: the live scan would have stopped earlier (or the bookkeeping error of :1072-1075: the serial kernel reports it)
+                    if (g.record_events)
+                    {
+                        if (lane < ncols)
                         {
-                            cc_event e;
-                            e.type = CC_EV_CLUSTER;
-                            e.stream = s;
-                            e.a = tg;
-                            e.b = cmax;
-                            e.c = cid;
-                            e.d = cpts;
-                            e.column = gc0 + fc;
-                            p.events[e2] = e;
+                            const int e0 = T.col_ebase[lane];
+                            if (e0 < g.event_capacity)
+                            {
+                                cc_event e;
+                                e.type = CC_EV_GROUND_COLUMN;
+                                e.stream = s;
+                                e.a = gcj;
+                                e.b = gcj;
+                                e.c = 0;
+                                e.d = 0;
+                                e.column = gcj;
+                                p.events[e0] = e;
+                            }
+                            const int e1 = e0 + 1 + ncl;
+                            if (e1 < g.event_capacity)
+                            {
+                                cc_event e;
+                                e.type = CC_EV_PUBLISH_COLUMNS;
+                                e.stream = s;
+                                e.a = fu;
+                                e.b = mc - 1;
+                                e.c = 0;
+                                e.d = 0;
+                                e.column = gcj;
+                                p.events[e1] = e;
+                            }
+                        }
+                        if (has_id)
+                        {
+                            const int e2 = T.col_ebase[fc] + 1 + rank_col;
+                            if (e2 < g.event_capacity)
+                            {
+                                cc_event e;
+                                e.type = CC_EV_CLUSTER;
+                                e.stream = s;
+                                e.a = tg;
+                                e.b = cmax;
+                                e.c = cid;
+                                e.d = cpts;
+                                e.column = gc0 + fc;
+                                p.events[e2] = e;
+                            }
+                        }
+                        n_events += __builtin_amdgcn_readlane(eincl, 63);
+                    }
+                    const long long new_unpub = lane_i64(mc, ncols - 1);
+                    cells_published += (unsigned long long) (new_unpub - first_unpub) * (unsigned long long) R;
+                    first_unpub = new_unpub;
+                    ring_start = first_unpub - NC > 0 ? first_unpub - NC : 0;
+                    cluster_counter += (unsigned long long) n_ids;
+                    clusters_finished += (unsigned long long) n_ids;
+                    alias_rounds += (unsigned long long) __popcll(alias_m & __ballot(listed)); // (counted like the serial kernels: only while trees are listed)
+                    last_min_az = lane_f64(mz, ncols - 1);
+                    // finished trees leave the list: what k_publish and the host mirror read of them
+                    if (fin_here)
+                    {
+                        p.t_finished[cell] = 1;
+                        p.t_cid[cell] = cid_t;
+                        if (g.mirror_fields)
+                        {
+                            p.t_fin[cell] = __longlong_as_double((long long) fin_t);
+                            p.t_pts[cell] = pts_t;
+                            p.t_width[cell] = (unsigned) (last_t - tg) + 1u;
                         }
                     }
-                    n_events += __builtin_amdgcn_readlane(eincl, 63);
-                }
-                const long long new_unpub = lane_i64(mc, ncols - 1);
-                cells_published += (unsigned long long) (new_unpub - first_unpub) * (unsigned long long) R;
-                first_unpub = new_unpub;
-                ring_start = first_unpub - NC > 0 ? first_unpub - NC : 0;
-                cluster_counter += (unsigned long long) n_ids;
-                clusters_finished += (unsigned long long) n_ids;
-                alias_rounds += (unsigned long long) __popcll(alias_m & __ballot(listed)); // (counted like the serial kernels: only while trees are listed)
-                last_min_az = lane_f64(mz, ncols - 1);
-                // finished trees leave the list: what k_publish and the host mirror read of them
-                if (fin_here)
-                {
-                    p.t_finished[cell] = 1;
-                    p.t_cid[cell] = cid_t;
-                    if (g.mirror_fields)
+                    if (g.mirror_fields) // Point::associated_trees of both roots (cc.cpp:693-694)
                     {
-                        p.t_fin[cell] = __longlong_as_double((long long) fin_t);
-                        p.t_pts[cell] = pts_t;
-                        p.t_width[cell] = (unsigned) (last_t - tg) + 1u;
+                        const int cell_a = __shfl(cell, eva < 0 ? 0 : eva), cell_b = __shfl(cell, evb < 0 ? 0 : evb);
+                        if (ev_made)
+                            log_link(g, st, p.link_log, cell_a, cell_b);
                     }
+                    // stable compaction of the list
+                    const bool surv = is_t && fc == 64;
+                    const unsigned long long sm = __ballot(surv);
+                    const int np = __popcll(sm & lanes_below());
+                    T.remap[pb][lane] = surv ? np : -1;
+                    if (is_t)
+                        T.cell_by_slot[pb][sig] = cell;
+                    wave_lds_fence();
+                    if (surv)
+                    {
+                        T.cell[np] = cell;
+                        T.gcol[np] = tg;
+                        T.fin[np] = fin_t;
+                        T.last[np] = last_t;
+                        T.pts[np] = pts_t;
+                        T.comp[np] = lds_ld(&T.remap[pb][comp]);
+                        T.sig[np] = lane;
+                    }
+                    const int n_left = __popcll(sm);
+                    if (lane == 0)
+                    {
+                        T.any_finished[pb] = n_left != n ? 1 : 0;
+                        T.rm_n[pb] = n;
+                        T.rm_nunf[pb] = n_left;
+                    }
+                    n_unf = n_left;
+                    batch_cols += (unsigned long long) ncols;
+                    wave_lds_fence();
                 }
-                if (g.mirror_fields) // Point::associated_trees of both roots (cc.cpp:693-694)
-                {
-                    const int cell_a = __shfl(cell, eva), cell_b = __shfl(cell, evb);
-                    if (ev_made)
-                        log_link(g, st, p.link_log, cell_a, cell_b);
-                }
-                // stable compaction of the list
-                const bool surv = is_t && fc == 64;
-                const unsigned long long sm = __ballot(surv);
-                const int np = __popcll(sm & lanes_below());
-                T.remap[lane] = surv ? np : -1;
-                T.cell_old[lane] = cell;
-                wave_lds_fence();
-                if (surv)
-                {
-                    T.cell[np] = cell;
-                    T.gcol[np] = tg;
-                    T.fin[np] = fin_t;
-                    T.last[np] = last_t;
-                    T.pts[np] = pts_t;
-                    T.comp[np] = lds_ld(&T.remap[comp]);
-                }
-                n_unf = __popcll(sm);
-                if (lane == 0)
-                {
-                    T.any_finished = n_unf != n ? 1 : 0;
-                    s_nunf = n_unf;
-                }
-                wave_lds_fence();
-                // the next group's header: by the time the other wavefronts have written this group's roots it is in place
-                int l1 = lc0 + ncols;
-                l1 = l1 >= RC ? l1 - RC : l1;
-                group_header(gc0 + ncols, l1, n_unf);
             }
+            else
+                mid_barriers(b);
+            AB_PH(6)
+            // ---- header of group i + 1 (the pass above has read everything of the buffers it reuses). `base`: what the pass left + the new roots of group i
+            const bool t_failed = have_prev && lds_ld(&T.tbail) != 0;
+            if (!t_failed)
+            {
+                const AbHeader& Hi = T.H[b];
+                const int ncols_i = Hi.ncols;
+                const long long gi0 = Hi.gc0;
+                const int li0 = Hi.lc0;
+                const int nborn_i = Hi.nborn;
+                int l1 = li0 + ncols_i;
+                l1 = l1 >= RC ? l1 - RC : l1;
+                const long long oldest = n_unf > 0 ? lds_ld(&T.gcol[0]) : gi0;
+                if (ncols_i > 0)
+                    group_header(pb, gi0 + ncols_i, l1, n_unf + nborn_i, oldest);
+                // the next pass evaluates group i
+                tg0 = gi0;
+                tlc0 = li0;
             }
             wave_lds_fence();
-            ab_barrier(); // B3
+            AB_PH(3)
+            ab_barrier(); // B2
             AB_PH(5)
-            if (T.bail)
-            {
-                bailed = true;
-                break;
-            }
 #ifdef CC_AB_STATS
             ab_t[7]++;
 #endif
-            batch_cols += (unsigned long long) ncols;
-            gc0 += ncols;
-            lc0 += ncols;
-            lc0 = lc0 >= RC ? lc0 - RC : lc0;
-            if (T.next_bail)
+            // ---- the common decision
+            if (t_failed)
             {
-                bailed = true;
-                if (lane == 0)
-                    T.bail = T.next_bail;
+                gc_final = tg0; // (not advanced above: still the first column of group i - 1)
+                reason = T.tbail;
+                serial_cols = T.H[pb].ncols; // (its header is still in place: the next one was not written)
+                break;
+            }
+            const int wb = T.G[b].wbail;
+            if (T.H[b].ncols == 0 || wb)
+            {
+                gc_final = T.H[b].gc0;
+                reason = wb ? wb : T.H[b].bail;
+                serial_cols = wb ? T.H[b].ncols : GCOLS;
+                break;
             }
         }
         if (lane == 0)
+        {
             s_nunf = n_unf;
+            s_gc_final = gc_final;
+            s_serial_cols = serial_cols;
+            s_reason = reason;
+            s_cols = batch_cols;
+        }
     }
     else
     {
         // =============================================================================================== worker wavefronts
+#ifndef CC_AB_WPRIO
+#define CC_AB_WPRIO 2
+#endif
+        __builtin_amdgcn_s_setprio(CC_AB_WPRIO); // (one below the timeline wavefront: it shares its SIMD with three workers)
+        // Round 5: everything per POINT runs on the group's ACTIVE points packed into the lanes of the block. k_scan leaves every column's active
+        // points packed in row order (pk_meta / pk_fin / pk_lk) and counts them (col_act); the header turns the counts into positions in the group's
+        // (column, row) order, and wavefront w takes points 64 w .. 64 w + 63: pointers, jumping, records, links and tree roots run once per
+        // wavefront on full lanes — a quarter to a third of the cells carries an obstacle point, so rows-as-lanes did the same work four times on
+        // mostly idle lanes — with the same load on every wavefront whatever the scene puts into which column. The kernel is bound by the vector
+        // issue of the ONE compute unit a stream's block sits on (4 wavefronts per SIMD; DPP, compare and 64-bit instructions at 4 clocks each):
+        // instructions per group, not latency, set its time.
         const int w = wave - 1;
-        // inputs of a group, requested a group ahead (the link words only where the column has links: T.next_info)
-        int pf_par[AB_CPW][RPL], pf_term[AB_CPW][RPL], pf_nl[AB_CPW][RPL];
-        double pf_fin[AB_CPW][RPL];
-        unsigned long long pf_lk[AB_CPW][RPL];
-        auto prefetch_inputs = [&](const long long g0, const int l0)
+        unsigned long long* pair = T.pair[w];
+        // the last two groups: the wavefront's points (where they lie, their resolved slots in the numbering of their own group) and where the groups
+        // lie. The tree roots of a group's cells are written when the timeline pass of the group has committed, two iterations after the slots were
+        // resolved (cells without a point got their -1 from k_scan)
+        int loc1 = -1, loc2 = -1; // column of the group | row << 6, -1: no point in this lane
+        int a1 = AB_NONE, a2 = AB_NONE;
+        long long g1_gc0 = 0, g2_gc0 = 0;
+        int g1_lc0 = 0, g2_lc0 = 0;
+        // 4b of a committed group: tree roots of its points' cells, re-taken visit counts (mirror mode)
+        auto write_roots = [&](const int tb, const int loc, const int av, const long long gc0, const int lc0)
         {
-#pragma unroll
-            for (int q = 0; q < AB_CPW; q++)
+            if (loc >= 0)
             {
-                const int cidx = w + q * AB_WAVES;
-                const bool col_links = ((T.next_info[cidx] >> 8) & 3) != 0; // (bit 1: points with links, bit 0: points whose link list overflowed)
-                int lc = l0 + cidx;
+                const int cidx = loc & 63, row = loc >> 6;
+                int lc = lc0 + cidx;
                 lc = lc >= RC ? lc - RC : lc;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
+                const int ci = lc * R + row;
+                at32(p.root, (unsigned) ci) = av > AB_NONE ? T.cell_by_slot[tb][-1 - av] : -1;
+                if (g.mirror_fields && av > AB_NONE)
                 {
-                    const int row = k * 64 + lane;
-                    pf_par[q][k] = -2;
-                    pf_term[q][k] = -1;
-                    pf_fin[q][k] = 0.;
-                    pf_nl[q][k] = 0;
-                    pf_lk[q][k] = 0ull;
-                    if (row < R && g0 + cidx < col_end)
+                    const int first_local = T.col_fix[tb][cidx];
+                    if (first_local >= 0)
                     {
-                        const int ci = lc * R + row;
-                        pf_par[q][k] = p.sc_parent[ci];
-                        pf_term[q][k] = p.sc_term[ci];
-                        pf_fin[q][k] = p.sc_fin[ci];
-                        if (col_links)
-                        {
-                            pf_nl[q][k] = p.sc_nlinks[ci];
-                            pf_lk[q][k] = p.sc_links[ci]; // (stale where the point has no links: never looked at)
-                        }
+                        const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                        int dummy_root = -1, dummy_parent = -1, dummy_n = 0, vis = 0;
+                        bool dummy_ov = false;
+                        scan_point<false, false, true>(c, lc, gc0 + cidx, row, first_local, mad, 0., dummy_root, dummy_parent, nullptr, dummy_n, dummy_ov, 0, &vis);
+                        p.sc_visits[ci] = sat_u16(vis);
                     }
                 }
             }
         };
-        ab_barrier(); // P0a
-        prefetch_inputs(gc0, lc0);
-        ab_barrier(); // P0b
-        if (T.next_bail)
-            bailed = true;
-        while (gc0 < col_end && !bailed)
+        ab_barrier(); // P0
+        int why_stop = 0, last_tb = 0; // 1: the timeline pass failed (nothing owed), 2: stop behind group i - 1 (its roots are owed)
+        for (int i = 0;; i++)
         {
-            const int ncols = T.ncols;
-            const double mz = T.min_az[lane]; // lanes = columns of the group
-            // ================================================================================== 1: initial pointers
-            int a[AB_CPW][RPL]; // ring value of the cell: >= 0 pointer (ring index), < 0 resolved (-1 - slot, AB_NONE, AB_DEAD)
-#pragma unroll
-            for (int q = 0; q < AB_CPW; q++)
+            const int b = i & 1;
+            const AbHeader& H = T.H[b];
+            AbGroup& G = T.G[b];
+            const int ncols = H.ncols;
+            const long long gc0 = H.gc0;
+            const int lc0 = H.lc0;
+            const int base = H.base;
+            // ================================================================================== 0: this wavefront's 64 points of the group: where they
+            //      lie (a marker at the position of every column's first point, prefix maximum over the lanes), their packed records requested
+            const bool act = 64 * w + lane < H.tot;
+            int cidx = 0;
+            unsigned meta = 0u;
+            double pfin_d = 0.;
+            unsigned long long plk = 0ull;
             {
-                const int cidx = w + q * AB_WAVES;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                    a[q][k] = AB_NONE;
-                if (cidx < ncols)
+                const int mk = act ? (int) H.colstart[64 * w + lane] : 0; // column + 1 where a column's points begin
+                const int cs = wave_incl_max_i32(mk);
+                cidx = cs > 0 ? cs - 1 : H.chunk_col[w];
+                if (act)
                 {
                     int lc = lc0 + cidx;
                     lc = lc >= RC ? lc - RC : lc;
-                    const long long gc = gc0 + cidx;
-                    const int base = n_unf + T.col_base[cidx];
-#pragma unroll
-                    for (int k = 0; k < RPL; k++)
+                    const unsigned pi = (unsigned) (lc * R + (64 * w + lane - H.ppos[cidx]));
+                    meta = at32(p.pk_meta, pi);
+                    pfin_d = at32(p.pk_fin, pi);
+                    if ((H.col_info[cidx] >> 8) & 3) // (the column has points with links; stale where this point has none: never looked at)
+                        plk = at32(p.pk_lk, pi);
+                }
+            }
+            AB_PHW(11)
+            // ================================================================================== 4b of group i - 2 (its pass committed in iteration i - 1)
+            if (i >= 2)
+            {
+                write_roots(b, loc2, a2, g2_gc0, g2_lc0);
+                if (T.any_finished[b])
+                {
+                    // the look-back window of group i: slots renumbered by the compaction of the pass of group i - 2 (numbering N(i - 1) -> N(i)),
+                    // finished trees marked (cells without a point hold stale values nobody follows)
+                    const int rm_n = T.rm_n[b], shift = T.rm_nunf[b] - rm_n;
+                    for (int j = threadIdx.x - 64; j < WIN_COLS * R; j += AB_THREADS - 64)
                     {
-                        const int row = k * 64 + lane;
-                        if (row < R)
+                        const int back = j / R + 1, row = j - (back - 1) * R;
+                        const int rj = (int) ((gc0 - back) & (RING - 1)) * R + row;
+                        const int v = ring[rj];
+                        if (v > AB_NONE && v < 0)
                         {
-                            const int ci = lc * R + row;
-                            const int par = pf_par[q][k];
-                            const int term = pf_term[q][k];
-                            int v = AB_NONE;
-                            if (par >= -1)
-                            {
-                                if (term >= 256)
-                                    v = (int) ((gc - (term >> 8)) & (AB_RING - 1)) * R + (term & 0xff);
-                                else if (term >= 0)
-                                    v = -1 - (base + term);
-                                if (par == -1)
-                                {
-                                    const int sl = base + term;
-                                    T.g_cell[sl] = ci;
-                                    T.birth[sl] = cidx;
-                                }
-                            }
-                            a[q][k] = v;
-                            ring[(int) (gc & (AB_RING - 1)) * R + row] = (short) v;
+                            const int sl = -1 - v;
+                            const int r = sl < rm_n ? T.remap[b][sl & (AB_TREES - 1)] : sl + shift;
+                            ring[rj] = (short) (r >= 0 ? -1 - r : AB_DEAD);
                         }
                     }
+                    // (the window's columns are written by this loop only, group i's cells by the pointers below only: B1 in front of the rounds
+                    // that read both orders them)
                 }
+            }
+            AB_PHW(8)
+            const double mz = H.min_az[lane]; // lanes = columns of the group
+            // ================================================================================== 1: initial pointers
+            const unsigned long long pfin = (unsigned long long) __double_as_longlong(pfin_d);
+            int loc = -1;
+            int a = AB_NONE; // ring value of the point's cell: >= 0 pointer (ring index), < 0 resolved (-1 - slot, AB_NONE, AB_DEAD)
+            int ri = 0;      // ring index of the point's cell
+            if (act)
+            {
+                const int row = (int) ((meta >> 16) & 127u);
+                loc = cidx | (row << 6);
+                const long long gc = gc0 + cidx;
+                const int cbase = base + H.col_base[cidx];
+                const int term = (int) (short) (meta & 0xffffu);
+                int v = AB_NONE;
+                if (term >= 256)
+                    v = (int) ((gc - (term >> 8)) & (RING - 1)) * R + (term & 0xff);
+                else if (term >= 0)
+                    v = -1 - (cbase + term);
+                if ((meta >> 26) & 1u)
+                {
+                    int lc = lc0 + cidx;
+                    lc = lc >= RC ? lc - RC : lc;
+                    const int sl = cbase + term;
+                    G.g_cell[sl] = lc * R + row;
+                    G.birth[sl] = cidx;
+                }
+                a = v;
+                ri = (int) (gc & (RING - 1)) * R + row;
+                ring[ri] = (short) v;
             }
             AB_PHW(0)
             ab_barrier(); // B1
@@ -767,221 +992,162 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             for (int r = 0; r < 8; r++)
             {
                 int pending = 0;
-#pragma unroll
-                for (int q = 0; q < AB_CPW; q++)
+                if (a >= 0)
                 {
-                    const int cidx = w + q * AB_WAVES;
-#pragma unroll
-                    for (int k = 0; k < RPL; k++)
-                        if (a[q][k] >= 0)
-                        {
-                            int b = ring[a[q][k]];
-                            if (b >= 0)
-                                b = ring[b]; // (two hops per round: a barrier costs more than an LDS round trip)
-                            a[q][k] = b;
-                            ring[(int) ((gc0 + cidx) & (AB_RING - 1)) * R + k * 64 + lane] = (short) b;
-                            pending |= b >= 0 ? 1 : 0;
-                        }
+                    int bb = ring[a];
+                    if (bb >= 0)
+                        bb = ring[bb]; // (two hops per round: a barrier costs more than an LDS round trip)
+                    a = bb;
+                    ring[ri] = (short) bb;
+                    pending = bb >= 0 ? 1 : 0;
                 }
                 if (__any(pending) && lane == 0)
-                    T.jflag[r] = 1;
+                    G.jflag[r] = 1;
                 ab_barrier();
-                if (!T.jflag[r])
+                if (!G.jflag[r])
                     break;
             }
             AB_PHW(2)
             // ================================================================================== 2: records, alive words, links
-        int bad = 0;
-#pragma unroll
-        for (int q = 0; q < AB_CPW; q++)
-        {
-            const int cidx = w + q * AB_WAVES;
-            if (cidx >= ncols)
-                continue;
-            int sl[RPL];
-            unsigned long long am = 0ull;
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
+            int me = -1;
+            int bad = 0;
+            if (act)
             {
-                sl[k] = -1;
-                if (pf_par[q][k] >= -1) // an active point
-                {
-                    if (a[q][k] <= AB_NONE)
-                        bad = 1; // its chain ends in a finished tree (attach refused, cc.cpp:658) or in a cell without a tree
-                    else
-                        sl[k] = -1 - a[q][k];
-                }
+                if (a <= AB_NONE)
+                    bad = 1; // the chain ends in a finished tree (attach refused, cc.cpp:658) or in a cell without a tree
+                else
+                    me = -1 - a;
             }
-            if (__any(bad))
-                break;
-            // per tree of the column: points, largest contribution; (two rows per lane: both halves of a tree are taken together)
-            unsigned long long todo[RPL];
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-                todo[k] = __ballot(sl[k] >= 0);
-            while (true)
+            if (!__any(bad))
             {
-                int s0 = -1;
-#pragma unroll
-                for (int k = RPL - 1; k >= 0; k--)
-                    if (todo[k])
-                        s0 = __builtin_amdgcn_readlane(sl[k], __builtin_ctzll(todo[k]));
-                if (s0 < 0)
-                    break;
-                int cnt = 0;
-                unsigned long long mine = 0ull;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
+                // ---- records: one per RUN of consecutive points of a column that lead to the same tree (a tree that shows up in several runs of a
+                //      column gets several records: the atomics below merge them). head = first lane of the lane's run, from a prefix maximum over the
+                //      lanes that start a run; the run's largest contribution by a segmented DPP maximum; its length from the lane numbers
                 {
-                    const bool in = sl[k] == s0;
-                    const unsigned long long mm = __ballot(in);
-                    cnt += __popcll(mm);
-                    todo[k] &= ~mm;
-                    const unsigned long long fb = (unsigned long long) __double_as_longlong(pf_fin[q][k]);
-                    if (in && fb > mine) // (non-negative doubles order like their bit patterns)
-                        mine = fb;
-                }
-                const unsigned long long mx = wave_max_f64_bits(mine);
-                unsigned long long m = __ballot(lane >= cidx && __longlong_as_double((long long) mx) > mz);
-                if (lane == 0)
-                {
-                    if (T.birth[s0] == cidx)
-                        m |= (1ull << cidx) - 1ull; // not listed before its column: nothing to finish there
-                    atomicOr(&T.g_alive[s0], m);
-                    atomicMax(&T.g_fin[s0], mx);
-                    atomicAdd(&T.g_pts[s0], (unsigned) cnt);
-                    atomicMax(&T.g_last[s0], cidx);
-                }
-            }
-            AB_PHW(3)
-            // link candidates (accepted candidates after the first, cc.cpp:693-694) that lead to another tree
-            if ((lds_ld(&T.col_info[cidx]) >> 8) & 3) // (wave-uniform: the column has points with links at all)
-            {
-                T.pair[w][lane] = 0ull;
-                wave_lds_fence();
-            }
-#pragma unroll
-            for (int k = 0; k < RPL; k++)
-            {
-                const int n = pf_nl[q][k] == 255 ? 0 : pf_nl[q][k];
-                if (sl[k] >= 0 && n > 0)
-                {
-                    const long long gc = gc0 + cidx;
-                    for (int j = 0; j < n; j++)
+                    const int key = me >= 0 ? cidx * 256 + me : -1;
+                    const int below = dpp_mov_i32<0x138, 0xf>(-2, key); // wave_shr:1 (lane 0 keeps the fill)
+                    const int above = dpp_mov_i32<0x130, 0xf>(-2, key); // wave_shl:1 (lane 63 keeps the fill)
+                    const bool starts = lane == 0 || below != key;
+                    const int head = wave_incl_max_i32(starts ? lane : 0);
+                    const unsigned long long mx = ab_run_max_f64_bits(me >= 0 ? pfin : 0ull, lane, head);
+                    const bool tail = me >= 0 && (lane == 63 || above != key);
+                    if (tail)
                     {
-                        const int code = (int) ((pf_lk[q][k] >> (16 * j)) & 0xffff);
-                        const int v = ring[(int) ((gc - (code >> 8)) & (AB_RING - 1)) * R + (code & 0xff)];
-                        if (v >= 0)
-                            bad = 1; // (cannot happen: every cell of the group is resolved)
-                        else if (v > AB_NONE && -1 - v != sl[k])
+                        atomicMax(&G.g_fin[me], mx);
+                        atomicAdd(&G.g_pts[me], (unsigned) (lane - head + 1));
+                        atomicMax(&G.g_last[me], cidx);
+                    }
+                    // the alive word of every record: the columns (lanes) at or behind its column whose smallest azimuth the record's value exceeds
+                    unsigned long long tm = __ballot(tail);
+                    while (tm)
+                    {
+                        const int t = __builtin_ctzll(tm);
+                        tm &= tm - 1ull;
+                        const double f = __longlong_as_double(lane_i64((long long) mx, t));
+                        const int st_ = __builtin_amdgcn_readlane(me, t);
+                        const int ct = __builtin_amdgcn_readlane(cidx, t);
+                        const unsigned long long mm = __ballot(lane >= ct && f > mz);
+                        if (lane == 0 && mm)
+                            atomicOr(&G.g_alive[st_], mm);
+                    }
+                }
+                AB_PHW(3)
+                // ---- link candidates (accepted candidates after the first, cc.cpp:693-694) that lead to another tree: the (up to four) slot-ring
+                //      entries of a point are read at once; nearly all of them name the point's own tree
+                {
+                    const int nlc = (int) ((meta >> 23) & 7u);
+                    const int n = (me >= 0 && nlc != 7) ? nlc : 0;
+                    if (__any(n > 0))
+                    {
+                        const long long gc = gc0 + cidx;
+                        int other[LINK_SLOTS];
+                        bool any_other = false;
+#pragma unroll
+                        for (int j = 0; j < LINK_SLOTS; j++)
                         {
-                            const unsigned long long bit = 1ull << (-1 - v);
-                            if (!(atomicOr(&T.pair[w][sl[k]], bit) & bit))
+                            const int code = (int) ((plk >> (16 * j)) & 0xffff);
+                            // (a lane without a j-th candidate reads its own cell)
+                            const int rj = j < n ? (int) ((gc - (code >> 8)) & (RING - 1)) * R + (code & 0xff) : ri;
+                            const int v = ring[rj];
+                            other[j] = -1;
+                            if (j < n)
                             {
-                                const int e = atomicAdd(&T.n_ev, 1);
-                                if (e < AB_EVENTS)
-                                    T.ev[e] = ((unsigned) cidx << 16) | ((unsigned) sl[k] << 8) | (unsigned) (-1 - v);
+                                if (v >= 0)
+                                    bad = 1; // (cannot happen: every cell of the group is resolved)
+                                else if (v > AB_NONE && -1 - v != me)
+                                {
+                                    other[j] = -1 - v;
+                                    any_other = true;
+                                }
                             }
                         }
-                    }
-                }
-            }
-            AB_PHW(4)
-        }
-            if (__any(bad) && lane == 0)
-                T.bail = AB_BAIL_DEAD;
-            ab_barrier(); // B2
-            AB_PHW(5)
-            if (T.bail || T.n_ev > AB_EVENTS)
-            {
-                bailed = true;
-                break;
-            }
-            {
-                // the next group's inputs travel while the timeline wave works
-                int l1 = lc0 + ncols;
-                l1 = l1 >= RC ? l1 - RC : l1;
-                prefetch_inputs(gc0 + ncols, l1);
-            }
-            ab_barrier(); // B3
-            AB_PHW(6)
-            if (T.bail)
-            {
-                bailed = true;
-                break;
-            }
-            // ================================================================================== 4b: tree roots of the group's cells, slot ring
-        const bool any_finished = T.any_finished != 0;
-#pragma unroll
-        for (int q = 0; q < AB_CPW; q++)
-        {
-            const int cidx = w + q * AB_WAVES;
-            if (cidx < ncols)
-            {
-                int lc = lc0 + cidx;
-                lc = lc >= RC ? lc - RC : lc;
-#pragma unroll
-                for (int k = 0; k < RPL; k++)
-                {
-                    const int row = k * 64 + lane;
-                    if (row < R)
-                    {
-                        const int v = a[q][k];
-                        p.root[lc * R + row] = v > AB_NONE ? T.cell_old[-1 - v] : -1;
-                    }
-                }
-                const int first_local = T.col_fix[cidx];
-                if (first_local >= 0)
-                {
-#pragma unroll
-                    for (int k = 0; k < RPL; k++)
-                    {
-                        const int row = k * 64 + lane;
-                        if (row < R && a[q][k] > AB_NONE)
+                        // rare (two trees meet): column by column, so that a pair of trees is reported once per column (and wavefront) and with that column
+                        unsigned long long todo = __ballot(any_other);
+                        while (todo)
                         {
-                            const int ci = lc * R + row;
-                            const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                            int dummy_root = -1, dummy_parent = -1, dummy_n = 0, vis = 0;
-                            bool dummy_ov = false;
-                            scan_point<false, false, true>(c, lc, gc0 + cidx, row, first_local, mad, 0., dummy_root, dummy_parent, nullptr, dummy_n, dummy_ov,
-                                                           0, &vis);
-                            p.sc_visits[ci] = sat_u16(vis);
+                            const int cc = __builtin_amdgcn_readlane(cidx, __builtin_ctzll(todo));
+                            const bool mine = any_other && cidx == cc;
+                            todo &= ~__ballot(mine);
+                            pair[lane] = 0ull;
+                            wave_lds_fence();
+                            if (mine)
+                            {
+#pragma unroll
+                                for (int j = 0; j < LINK_SLOTS; j++)
+                                    if (other[j] >= 0)
+                                    {
+                                        const unsigned long long bit = 1ull << other[j];
+                                        if (!(atomicOr(&pair[me], bit) & bit))
+                                        {
+                                            const int e = atomicAdd(&G.n_ev, 1);
+                                            if (e < AB_EVENTS)
+                                                G.ev[e] = ((unsigned) cidx << 16) | ((unsigned) me << 8) | (unsigned) other[j];
+                                        }
+                                    }
+                            }
+                            wave_lds_fence();
                         }
                     }
                 }
+                AB_PHW(4)
             }
-        }
-        if (any_finished)
-        {
-            // the look-back window of the next group: slots renumbered, finished trees marked
-            const long long nb = gc0 + ncols;
-            for (int i = threadIdx.x - 64; i < WIN_COLS * R; i += AB_THREADS - 64)
-            {
-                const int back = i / R + 1, row = i - (back - 1) * R;
-                const int ri = (int) ((nb - back) & (AB_RING - 1)) * R + row;
-                const int v = ring[ri];
-                if (v > AB_NONE)
-                {
-                    const int r = T.remap[-1 - v];
-                    ring[ri] = (short) (r >= 0 ? -1 - r : AB_DEAD);
-                }
-            }
-        }
-            // (no barrier here: the next group's first phase only writes ring columns, tree slots and words that nothing above reads)
-            AB_PHW(8)
+            if (__any(bad) && lane == 0)
+                G.wbail = AB_BAIL_DEAD;
+            if (lane == 0 && lds_ld(&G.n_ev) > AB_EVENTS)
+                atomicMax(&G.wbail, (int) AB_BAIL_LINKS); // (never over an attach to a finished tree: DEAD > LINKS)
+            ab_barrier(); // B2
+            AB_PHW(5)
 #if defined(CC_AB_STATS) && defined(CC_AB_STATS_W)
             ab_t[7]++;
 #endif
-            n_unf = s_nunf;
-            gc0 += ncols;
-            lc0 += ncols;
-            lc0 = lc0 >= RC ? lc0 - RC : lc0;
-            if (T.next_bail)
-                bailed = true;
+            // ---- the common decision (same LDS words as the timeline's)
+            if (i > 0 && T.tbail != 0)
+            {
+                why_stop = 1;
+                break;
+            }
+            // (the pass of group i - 1 committed: its roots are owed; they are written at the top of the next iteration or behind the loop)
+            loc2 = loc1, a2 = a1;
+            loc1 = loc, a1 = a;
+            g2_gc0 = g1_gc0, g2_lc0 = g1_lc0;
+            g1_gc0 = gc0, g1_lc0 = lc0;
+            if (ncols == 0 || G.wbail)
+            {
+                why_stop = 2;
+                last_tb = b ^ 1; // (the pass of group i - 1)
+                break;
+            }
         }
+        // roots of the last committed group (after the rotation above it is the older set: the newer one is the group that was not taken / does not exist)
+        if (why_stop == 2)
+            write_roots(last_tb, loc2, a2, g2_gc0, g2_lc0);
     }
 
     // ---- persist the tree state back to the global planes (the serial kernels and the next batch load it from there) ------------------
+#ifdef CC_AB_STATS
+    ab_t[14] = __builtin_amdgcn_s_memtime() - ab_entry; // entry -> end of the loop, as this wavefront saw it
+    ab_t[15] = wall_clock64() - ab_entry_rt;
+#endif
     __syncthreads();
     n_unf = s_nunf;
     if ((int) threadIdx.x < n_unf)
@@ -1003,6 +1169,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
         lb = wave_min_f64(lb);
         if (lane == 0)
         {
+            const long long gc_final = s_gc_final;
+            const int reason = s_reason;
+            const bool bailed = reason != 0;
             st->first_unpublished = first_unpub;
             st->batch[slot].pub_end = first_unpub;
             st->ring_start = ring_start;
@@ -1015,14 +1184,14 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             st->cells_published = cells_published;
             st->clusters_finished = clusters_finished;
             st->stamp_alias_rounds = alias_rounds;
-            st->batch[slot].acp_next = gc0;
+            st->batch[slot].acp_next = gc_final;
             // a limited launch of the serial kernel takes the group that could not be taken here (and no more), then this kernel is tried again
-            st->serial_until = bailed ? gc0 + AB_G : 0;
-            st->batch_columns += batch_cols;
+                        st->serial_until = bailed ? gc_final + s_serial_cols : 0;
+            st->batch_columns += s_cols;
             st->batch_bails += bailed ? 1ull : 0ull;
             if (bailed)
             {
-                st->batch_bail_reason[T.bail & 7] += 1ull;
+                st->batch_bail_reason[reason & 7] += 1ull;
                 if (bail_count)
                     atomicAdd(bail_count, 1); // (the engine launches more (batch-parallel, serial) rounds for the next batches: assoc_rounds 0)
             }
@@ -1031,16 +1200,16 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 raise_error(st, CC_ERR_CAPACITY, n_events, 0);
 #if defined(CC_AB_STATS) && !defined(CC_AB_STATS_W)
             ab_t[9] = __builtin_amdgcn_s_memtime() - ab_t0;
-            for (int i = 0; i < 10; i++)
+            for (int i = 0; i < 16; i++)
                 st->dbg[i] += ab_t[i];
 #endif
         }
     }
 #if defined(CC_AB_STATS) && defined(CC_AB_STATS_W)
-    if (wave == 1 && lane == 0)
+    if (wave == CC_AB_STATS_WAVE && lane == 0)
     {
         ab_t[9] = __builtin_amdgcn_s_memtime() - ab_t0;
-        for (int i = 0; i < 10; i++)
+        for (int i = 0; i < 16; i++)
             st->dbg[i] += ab_t[i];
     }
 #endif

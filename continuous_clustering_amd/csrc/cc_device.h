@@ -179,6 +179,10 @@ struct Planes
                          // column, 0..255 index of the chain's new root among the column's new roots, -1 point is ignored
     double* col_newfin;  // per column: minimum finished_at over the column's new roots (+inf without any)
     int32_t* col_info;   // per column: new roots | flags << 8 (1: link overflow, 2: any links) | largest delta used << 16
+    unsigned* pk_meta;   // the active points of a column packed in row order (entry j of local column lc at lc * rows + j): term | row << 16 | links << 23 | root << 26
+    double* pk_fin;      // ... their finished_at contributions
+    unsigned long long* pk_lk; // ... their link candidate codes (written where the point has any)
+    uint16_t* col_act;   // per column: active points (cells the window scan ran for) of rows 0 - 63 | of rows 64 - 127 << 8 (k_assocb packs them into lanes)
     uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS
     unsigned long long* sc_links; // LINK_SLOTS x 16-bit candidate codes packed into one word per cell
     double* sc_fin;      // continuous azimuth + max angle diff of the point (its contribution to finished_at)

@@ -280,7 +280,7 @@ int allocate(cc_engine* e)
     A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
     A(events, S * (size_t) g.event_capacity);
     A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
-    A(sc_term, C) A(col_newfin, L) A(col_info, L);
+    A(sc_term, C) A(col_newfin, L) A(col_info, L) A(col_act, L) A(pk_meta, C) A(pk_fin, C) A(pk_lk, C);
     A(sg_x2, C) A(sg_uz, C) A(sg_w, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
     A(tab_acc, S * (size_t) g.tab_tiles * (size_t) g.num_rows);
@@ -646,9 +646,12 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     const bool seg_small = !par && rpl == 1 && first_pass && n <= e->seg_small_max && !small_front;
     if (seg_small)
         need_segpre = false;
-    const bool table_early = si != sb && e->table_on_insert_chain != 0;
+    // (with the fused front half k_insert_par reads and writes the running table `curtab` on the insertion chain: k_table of a batch that is not
+    // fused has to run on that chain too, whatever the option says — elsewhere nothing would order it against the next batch's insertion)
+    const int table_opt = e->fuse_front ? 1 : e->table_on_insert_chain;
+    const bool table_early = si != sb && table_opt != 0;
     // (a stream of its own: the next batch's insertion does not queue behind it)
-    hipStream_t st_table = (table_early && e->table_on_insert_chain == 2 && !e->capturing) ? e->stream7 : si;
+    hipStream_t st_table = (table_early && table_opt == 2 && !e->capturing) ? e->stream7 : si;
     if (table_early && need_segpre)
     {
         if (st_table != si)
@@ -876,7 +879,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
 }
 
 // Begin a batch: zero the per-stream firing cursors and the early-stop counter; fix how far clearing may go.
-__global__ void k_begin_batch(StreamState* states, int first_stream, int count, int* remaining, int unlimited_clear)
+__global__ void k_begin_batch(StreamState* states, int first_stream, int count, int* remaining, int unlimited_clear, int slot)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count)
@@ -888,6 +891,8 @@ __global__ void k_begin_batch(StreamState* states, int first_stream, int count, 
         states[first_stream + i].pre_seg_begin = 0; // (k_insert2 clears it when it closes a batch; with skip_idle_fallbacks it may not have run)
         states[first_stream + i].n_events = 0; // every event of the previous call has been collected
         states[first_stream + i].n_links = 0;
+        // (the descriptor slot is four batches old: whoever closes this batch as fused sets the flag again; nothing else may find it set)
+        states[first_stream + i].batch[slot].fused = 0;
         states[first_stream + i].clear_allowed = unlimited_clear ? 0x7fffffffffffffffll : states[first_stream + i].ring_start;
     }
     if (i == 0)
@@ -1061,7 +1066,7 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
     }
     if (!use_small_front(e, count, n, pipeline)) // (k_small_front begins the batch itself)
         hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining,
-                           pipeline ? 1 : 0);
+                           pipeline ? 1 : 0, slot);
     if (prepared)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], e->stream5));
@@ -1285,7 +1290,7 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         else
         {
             ok = hipMemcpyAsync(e->d_small, e->h_small, b_xyz + b_int + b_pose, hipMemcpyHostToDevice, e->stream) == hipSuccess;
-            hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, e->stream, e->d_states, stream, 1, e->d_remaining, 0);
+            hipLaunchKernelGGL(k_begin_batch, dim3(1), dim3(64), 0, e->stream, e->d_states, stream, 1, e->d_remaining, 0, 0);
         }
         e->capturing = true;
         ok = ok && launch_batch(e, stream, 1, n, d_xyz, d_int, d_pose, true, 0, e->stream, e->stream, e->stream) == CC_OK;
@@ -1574,8 +1579,37 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
             }
         }
     }
+    // experiment switch CC_OPT_CU_ASSOC=N: the association chain alone on the last N compute units, every other chain on the rest (few streams:
+    // k_assocb is bound by the vector issue of the ONE compute unit a stream's block sits on, and wavefronts of the other chains on that unit
+    // take issue slots from it)
+    if (const char* ca = std::getenv("CC_OPT_CU_ASSOC"))
+    {
+        hipDeviceProp_t prop;
+        const int n_assoc = atoi(ca);
+        if (!cu_split && n_assoc > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && n_assoc < prop.multiProcessorCount)
+        {
+            const int ncu = prop.multiProcessorCount;
+            const int words = (ncu + 31) / 32;
+            auto masked = [&](hipStream_t* out_stream, int from, int cnt) -> bool
+            {
+                std::vector<uint32_t> m(words, 0u);
+                for (int i = from; i < from + cnt && i < ncu; i++)
+                    m[i >> 5] |= 1u << (i & 31);
+                return hipExtStreamCreateWithCUMask(out_stream, (uint32_t) words, m.data()) == hipSuccess;
+            };
+            const int rest = ncu - n_assoc;
+            cu_split = masked(&e->stream, 0, rest) && masked(&e->stream2, 0, rest) && masked(&e->stream4, 0, rest) && masked(&e->stream5, 0, rest) &&
+                       masked(&e->stream7, 0, rest) && masked(&e->stream6, 0, rest) && masked(&e->stream3, rest, n_assoc);
+            if (!cu_split)
+            {
+                give_back_streams(e);
+                delete e;
+                return CC_ERR_INVALID_ARGUMENT;
+            }
+        }
+    }
     if (cu_split)
-        fprintf(stderr, "cc_engine_create: chains on disjoint compute units (CC_OPT_CU_SPLIT=%s)\n", std::getenv("CC_OPT_CU_SPLIT"));
+        fprintf(stderr, "cc_engine_create: chains on disjoint compute units (CC_OPT_CU_SPLIT=%s CC_OPT_CU_ASSOC=%s)\n", std::getenv("CC_OPT_CU_SPLIT") ? std::getenv("CC_OPT_CU_SPLIT") : "", std::getenv("CC_OPT_CU_ASSOC") ? std::getenv("CC_OPT_CU_ASSOC") : "");
     else
     {
         StreamSet set;

@@ -342,6 +342,10 @@ struct SP
     int16_t* sc_term;
     double* col_newfin;
     int32_t* col_info;
+    uint16_t* col_act;
+    unsigned* pk_meta;
+    double* pk_fin;
+    unsigned long long* pk_lk;
     uint8_t* sc_nlinks;
     unsigned long long* sc_links;
     double* sc_fin;
@@ -397,6 +401,10 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.sc_term = P.sc_term + co;
     p.col_newfin = P.col_newfin + lo;
     p.col_info = P.col_info + lo;
+    p.col_act = P.col_act + lo;
+    p.pk_meta = P.pk_meta + co;
+    p.pk_fin = P.pk_fin + co;
+    p.pk_lk = P.pk_lk + co;
     p.sc_nlinks = P.sc_nlinks + co;
     p.sc_links = P.sc_links + co;
     p.sc_fin = P.sc_fin + co;
@@ -4388,10 +4396,12 @@ __device__ __forceinline__ void scan_column_epilogue(const SP& p, const int R, c
     int cnt_new = 0, mine[RPL];
     int max_delta = 0;
     int flags = 0;
+    int n_act = 0; // active points of the column, 8 bits per 64 rows
     double newfin = 1.7976931348623157e308;
 #pragma unroll
     for (int k = 0; k < RPL; k++)
     {
+        n_act |= __popcll(__ballot(parent[k] >= -1)) << (8 * k);
         const bool is_new = parent[k] == -1;
         const unsigned long long mask = __ballot(is_new);
         const int newidx = cnt_new + __popcll(mask & lanes_below());
@@ -4425,6 +4435,21 @@ __device__ __forceinline__ void scan_column_epilogue(const SP& p, const int R, c
         const int term = parent[k] < -1 ? -1 : (src < 64 ? lo : hi);
         if (row < R)
             p.sc_term[lc * R + row] = (int16_t) term;
+        // what the batch-parallel association reads: the column's ACTIVE points packed in row order (entry j of the column at lc * R + j), so that
+        // it works on full lanes; the cells without a point get their (absent) tree root here
+        const unsigned long long actm = __ballot(parent[k] >= -1);
+        if (parent[k] >= -1)
+        {
+            const int j = (k > 0 ? (n_act & 0xff) : 0) + __popcll(actm & lanes_below());
+            const unsigned nlc = nlinks[k] == 255 ? 7u : (unsigned) nlinks[k];
+            // sc_term (16 bits) | row << 16 | link count (0 .. 4, 7 = overflowed) << 23 | new root << 26
+            p.pk_meta[lc * R + j] = ((unsigned) term & 0xffffu) | ((unsigned) row << 16) | (nlc << 23) | (parent[k] == -1 ? 1u << 26 : 0u);
+            p.pk_fin[lc * R + j] = fin[k];
+            if (nlinks[k] > 0)
+                p.pk_lk[lc * R + j] = packed[k];
+        }
+        else if (row < R)
+            p.root[lc * R + row] = -1;
     }
     max_delta = -wave_min_i32(-max_delta); // DPP reductions, ballots: no LDS round trips
     if (MIRROR)
@@ -4436,6 +4461,7 @@ __device__ __forceinline__ void scan_column_epilogue(const SP& p, const int R, c
     {
         p.col_newfin[lc] = newfin;
         p.col_info[lc] = cnt_new | (flags << 8) | (max_delta << 16) | ((MIRROR ? reach : 0) << 24);
+        p.col_act[lc] = (uint16_t) n_act;
     }
 }
 
@@ -4775,6 +4801,7 @@ __global__ __launch_bounds__(256) void k_small_front(Geometry g, cc_config cfg, 
         st->pre_seg_begin = 0;
         st->n_events = 0;
         st->n_links = 0;
+        st->batch[slot].fused = 0;
         st->clear_allowed = st->ring_start;
         *remaining = 0;
     }

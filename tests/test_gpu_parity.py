@@ -188,7 +188,10 @@ def test_streams_made_to_provoke_refused_attaches(name, batch, oracle_lib):
             assert summary["engine_state"]["error_b"] > 0, "the exact serial replay of the refused attaches was expected"
             if batch:
                 why = box["e"].batch_counters()["bail_reasons"]
-                assert why[4] + why[5] > 0 and why[6] > 0, why  # a tree met after its cluster finished; a candidate behind the first unpublished column
+                # a tree met after its cluster finished (round 4's kernel classified two of these stops as reason 6, a candidate behind the first
+                # unpublished column; the pipelined kernel of round 5 stops at the same groups and names the late point — tools/find_reach_bail.py looks for
+                # inputs that still give reason 6)
+                assert why[4] + why[5] > 0, why
 
 
 @pytest.mark.parametrize("first_call", [132, 236, 496])
