@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -111,6 +112,8 @@ struct cc_engine
     bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 256 streams
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
+    std::function<int()> deferred_tail;                 // the chains of the last batch behind its insertion, not launched yet (launch_batch)
+    int defer_tail_max_streams{96};                      // option "defer_tail_max_streams": launches of at most this many streams defer them (0: never)
     bool streams_pooled{false};                          // the seven streams come from (and return to) the process-wide set cache
     bool slab_planning{false};                           // alloc_plane only records (field, offset): allocate() makes ONE hipMalloc of the total
     size_t slab_bytes{0};
@@ -436,6 +439,16 @@ int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const do
 
 // calls of a few firings on ONE stream outside the pipeline (cc_engine_add_firings: the per-column latency path) run everything in front of the window
 // scan in one kernel
+// Launch what launch_batch held back (below). Called before anything waits for, reads or re-orders the engine's streams.
+static int flush_deferred(cc_engine* e)
+{
+    if (!e->deferred_tail)
+        return CC_OK;
+    std::function<int()> f = std::move(e->deferred_tail);
+    e->deferred_tail = nullptr;
+    return f();
+}
+
 static bool use_small_front(const cc_engine* e, int count, int64_t n, bool pipeline)
 {
     return e->small_front && !pipeline && count == 1 && n <= e->seg_small_max && n < 64 && e->g.num_rows <= WAVE;
@@ -502,6 +515,18 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // others only if some stream's batch was not taken completely (the kernel then leaves the batch descriptor to k_insert2 as before).
     // (with the fused segmentation also outside the pipelined mode: the fused path needs the counters the gate reads)
     const bool gate = par && rpl == 1 && (si != sb || e->fuse_front) && e->skip_idle_fallbacks && n <= cck::IP_MAXF && !e->capturing;
+    // Few streams: a step is as long as its insertion chain PLUS the host's launches of the other chains, because the host waits at the gate
+    // before it launches them and the next batch's insertion only starts behind all of that. So the chains behind the gate (`tail` below) of a
+    // batch that needs nothing more on the insertion stream are held back and launched by the NEXT call, after that call has enqueued its own
+    // insertion and before it waits at its gate: the insertion kernels run back to back and the launches hide behind them. Anything that waits
+    // for or reads results launches the held-back chains first (flush_deferred in sync_all).
+    const bool may_defer = gate && first_pass && si != sb && si != sa && e->defer_tail_max_streams > 0 && count <= e->defer_tail_max_streams;
+    if (!gate)
+    {
+        int rcf = flush_deferred(e);
+        if (rcf)
+            return rcf;
+    }
     bool fallbacks = true;
     bool need_segpre = true; // some stream's batch is not closed as fused: k_table / k_seg_pre have work
     bool ego_done = false;
@@ -555,6 +580,12 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic)
             if (e->h_bail_count)
                 CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, si));
+            {
+                // (this batch's insertion is enqueued: now the chains of the previous batch that were held back)
+                int rcf = flush_deferred(e);
+                if (rcf)
+                    return rcf;
+            }
             const auto hp1 = std::chrono::steady_clock::now();
             CC_HIP_CHECK(e, hipStreamSynchronize(si));
             hp_t1 = std::chrono::steady_clock::now();
@@ -601,281 +632,305 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             fallbacks = *e->h_par_left != 0;
         }
     }
-    const bool small_front = first_pass && !prep_done && !par && use_small_front(e, count, n, si != sb);
-    if (small_front)
+    // what the held-back chains would still put on the insertion stream is put there now (time marks, the early-stop counter, the event the
+    // segmentation chain waits for): the held-back part must not touch that stream, the next batch's insertion will be on it by then
+    bool pre_done = false;
+    const bool defer = may_defer && !fallbacks && !need_segpre && !e->capture_mirror.state;
+    if (defer)
     {
-        int rcp = ensure_prep(e, (size_t) n * g.num_rows);
-        if (rcp)
-            return rcp;
-        const Planes Pf = planes_with_prep(e, e->prep_buf);
-        hipLaunchKernelGGL(cck::k_small_front, dim3(1), dim3(256), cck::insert2_lds_bytes(g.num_rows), si, g, e->cfg, Pf, e->d_states, first_stream, slot, d_xyz,
-                           d_int, d_pose, (long long) n, e->d_remaining, d_ego);
-        fallbacks = false;
-        need_segpre = false;
-    }
-    if (first_pass && !prep_done && fallbacks) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
-    {
-        int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp, e->cur_ntotal, e->cur_f0, par, first_stream);
-        if (rcp)
-            return rcp;
-    }
-    CC_MARK(sp); // ev1: prep (with k_insert_par in front of it when that is on)
-    if (sp != si)
-    {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], sp));
-        CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_prep[slot], 0));
-    }
-    const Planes Pins = planes_with_prep(e, e->prep_buf);
-    if (fallbacks)
-    {
-        const size_t lds = cck::insert2_lds_bytes(g.num_rows);
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
-                               d_int, (long long) n, e->d_remaining, (long long) e->cur_ntotal, (long long) e->cur_f0);
-        else
-            hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
-                               d_int, (long long) n, e->d_remaining, (long long) e->cur_ntotal, (long long) e->cur_f0);
-    }
-    CC_MARK(si); // ev2: insert
-    if (!e->capture_mirror.state) // (a small call's graph gets the counter through k_publish's mirror)
+        CC_MARK(sp); // ev1
+        CC_MARK(si); // ev2
         CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
-    // k_table only needs what the insertion of this batch wrote. It is a latency-bound kernel (8 wavefronts per stream) that takes 0.8 ms
-    // when it shares the GPU with the throughput kernels — on the segmentation chain, which is the longest of the three, that is a
-    // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
-    // calls of a few firings (the per-column latency path): ONE wavefront per stream segments the call's columns, rows as lanes (k_seg_small)
-    const bool seg_small = !par && rpl == 1 && first_pass && n <= e->seg_small_max && !small_front;
-    if (seg_small)
-        need_segpre = false;
-    // (with the fused front half k_insert_par reads and writes the running table `curtab` on the insertion chain: k_table of a batch that is not
-    // fused has to run on that chain too, whatever the option says — elsewhere nothing would order it against the next batch's insertion)
-    const int table_opt = e->fuse_front ? 1 : e->table_on_insert_chain;
-    const bool table_early = si != sb && table_opt != 0;
-    // (a stream of its own: the next batch's insertion does not queue behind it)
-    hipStream_t st_table = (table_early && table_opt == 2 && !e->capturing) ? e->stream7 : si;
-    if (table_early && need_segpre)
+        CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
+        pre_done = true;
+    }
+    auto tail = [=]() mutable -> int
     {
-        if (st_table != si)
+        const bool small_front = first_pass && !prep_done && !par && use_small_front(e, count, n, si != sb);
+        if (small_front)
         {
-            CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
-            CC_HIP_CHECK(e, hipStreamWaitEvent(st_table, e->ev_ins[slot], 0));
+            int rcp = ensure_prep(e, (size_t) n * g.num_rows);
+            if (rcp)
+                return rcp;
+            const Planes Pf = planes_with_prep(e, e->prep_buf);
+            hipLaunchKernelGGL(cck::k_small_front, dim3(1), dim3(256), cck::insert2_lds_bytes(g.num_rows), si, g, e->cfg, Pf, e->d_states, first_stream, slot, d_xyz,
+                               d_int, d_pose, (long long) n, e->d_remaining, d_ego);
+            fallbacks = false;
+            need_segpre = false;
         }
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, st_table, g, Pt, e->d_states, first_stream, slot);
-        else
-            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, st_table, g, Pt, e->d_states, first_stream, slot);
-    }
-    const bool ego_early = table_early && e->ego_on_insert_chain;
-    if (ego_early && !ego_done && need_segpre)
-        hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, st_table, (const StreamState*) e->d_states, first_stream,
+        if (first_pass && !prep_done && fallbacks) // relaunch passes of the same batch reuse the staged points; a pipelined caller prepared ahead
+        {
+            int rcp = launch_prep(e, count, n, d_xyz, d_pose, e->prep_buf, sp, e->cur_ntotal, e->cur_f0, par, first_stream);
+            if (rcp)
+                return rcp;
+        }
+        if (!pre_done)
+            CC_MARK(sp); // ev1: prep (with k_insert_par in front of it when that is on)
+        if (sp != si)
+        {
+            CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], sp));
+            CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_prep[slot], 0));
+        }
+        const Planes Pins = planes_with_prep(e, e->prep_buf);
+        if (fallbacks)
+        {
+            const size_t lds = cck::insert2_lds_bytes(g.num_rows);
+            if (rpl == 1)
+                hipLaunchKernelGGL(cck::k_insert2<1>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
+                                   d_int, (long long) n, e->d_remaining, (long long) e->cur_ntotal, (long long) e->cur_f0);
+            else
+                hipLaunchKernelGGL(cck::k_insert2<2>, dim3(count), dim3(128), lds, si, g, e->cfg, Pins, e->d_states, first_stream, slot,
+                                   d_int, (long long) n, e->d_remaining, (long long) e->cur_ntotal, (long long) e->cur_f0);
+        }
+        if (!pre_done)
+            CC_MARK(si); // ev2: insert
+        if (!pre_done && !e->capture_mirror.state) // (a small call's graph gets the counter through k_publish's mirror)
+            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_remaining, e->d_remaining, sizeof(int), hipMemcpyDeviceToHost, si));
+        // k_table only needs what the insertion of this batch wrote. It is a latency-bound kernel (8 wavefronts per stream) that takes 0.8 ms
+        // when it shares the GPU with the throughput kernels — on the segmentation chain, which is the longest of the three, that is a
+        // third of the chain; at the end of the insertion chain, which has slack, it costs nothing.
+        // calls of a few firings (the per-column latency path): ONE wavefront per stream segments the call's columns, rows as lanes (k_seg_small)
+        const bool seg_small = !par && rpl == 1 && first_pass && n <= e->seg_small_max && !small_front;
+        if (seg_small)
+            need_segpre = false;
+        // (with the fused front half k_insert_par reads and writes the running table `curtab` on the insertion chain: k_table of a batch that is not
+        // fused has to run on that chain too, whatever the option says — elsewhere nothing would order it against the next batch's insertion)
+        const int table_opt = e->fuse_front ? 1 : e->table_on_insert_chain;
+        const bool table_early = si != sb && table_opt != 0;
+        // (a stream of its own: the next batch's insertion does not queue behind it)
+        hipStream_t st_table = (table_early && table_opt == 2 && !e->capturing) ? e->stream7 : si;
+        if (table_early && need_segpre)
+        {
+            if (st_table != si)
+            {
+                CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
+                CC_HIP_CHECK(e, hipStreamWaitEvent(st_table, e->ev_ins[slot], 0));
+            }
+            if (rpl == 1)
+                hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, st_table, g, Pt, e->d_states, first_stream, slot);
+            else
+                hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, st_table, g, Pt, e->d_states, first_stream, slot);
+        }
+        const bool ego_early = table_early && e->ego_on_insert_chain;
+        if (ego_early && !ego_done && need_segpre)
+            hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, st_table, (const StreamState*) e->d_states, first_stream,
+                               e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
+        if (si != sb)
+        {
+            if (!pre_done)
+                CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], st_table));
+            CC_HIP_CHECK(e, hipStreamWaitEvent(sb, e->ev_ins[slot], 0));
+        }
+        // ---- table + segmentation + window-scan chain ------------------------------------------------------------
+        CC_MARK(sb); // ev3: start of the second chain
+        if (!table_early && need_segpre)
+        {
+            if (rpl == 1)
+                hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
+            else
+                hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
+        }
+        if (!ego_early && !ego_done && need_segpre)
+            hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
                            e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
-    if (si != sb)
-    {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], st_table));
-        CC_HIP_CHECK(e, hipStreamWaitEvent(sb, e->ev_ins[slot], 0));
-    }
-    // ---- table + segmentation + window-scan chain ------------------------------------------------------------
-    CC_MARK(sb); // ev3: start of the second chain
-    if (!table_early && need_segpre)
-    {
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_table<1>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
-        else
-            hipLaunchKernelGGL(cck::k_table<2>, dim3(count), dim3(64 * cck::TABLE_WAVES), 0, sb, g, Pt, e->d_states, first_stream, slot);
-    }
-    if (!ego_early && !ego_done && need_segpre)
-        hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
-                       e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
-    if (!need_segpre)
-        ;
-    else if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
-                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
-    else
-        hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
-                           first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
-    if (seg_small)
-    {
-        hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
-                           e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
-        hipLaunchKernelGGL(cck::k_seg_small, dim3((unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot, d_pose,
-                           (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
-    }
-    else if (!small_front)
-    {
-        const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
-        hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, Pt, e->d_states, first_stream, slot); // (Pt: this slot's table carries)
-    }
-    if (sc != sb)
-    {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_segscan[slot], sb));
-        CC_HIP_CHECK(e, hipStreamWaitEvent(sc, e->ev_segscan[slot], 0));
-    }
-    CC_MARK(sc); // ev4: table + segment (start of the window scan)
-    const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
-    if (small_front)
-        ; // (k_small_front has scanned the call's columns)
-    // (65 - 128 rows: packed by default. The lock-step form with two rows per lane — scan_packed = 0 — shortens the scan's own launch, 3.0 -> 2.35 ms at
-    // 256 x S128, but needs more vector instructions, and the step is bound by those: 11.7 -> 11.4 G points/s same-box)
-    // (64 rows, end of round 4: with the insertion's uniform work on the scalar unit the step follows the vector-instruction count, and the packed
-    // scan issues 0.65 x those of the lock-step one: + 3 % at 256 streams (same-box, 3 alternations: 16.22 -> 16.72 G points/s), - 1 ... - 2 % at
-    // 32 - 128 streams where the GPU has room and the lock-step scan's shorter launch counts)
-    else if (e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192)))
-    {
-        if (rpl == 1 && !g.mirror_fields)
-            hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        if (!need_segpre)
+            ;
         else if (rpl == 1)
-            hipLaunchKernelGGL((cck::k_scan2<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL(cck::k_seg_pre<1>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
+                               first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
+        else
+            hipLaunchKernelGGL(cck::k_seg_pre<2>, dim3((unsigned) count, cck::SEGPRE_BLOCKS), dim3(64), 0, sb, g, e->cfg, Pt, e->d_states,
+                               first_stream, slot, d_pose, (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
+        if (seg_small)
+        {
+            hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, sb, (const StreamState*) e->d_states, first_stream,
+                               e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
+            hipLaunchKernelGGL(cck::k_seg_small, dim3((unsigned) count), dim3(64), 0, sb, g, e->cfg, e->P, e->d_states, first_stream, slot, d_pose,
+                               (long long) e->cur_ntotal, (long long) e->cur_f0, (const double*) d_ego, (long long) n);
+        }
+        else if (!small_front)
+        {
+            const size_t lds = cck::seg_scan_lds_bytes(g.num_rows);
+            hipLaunchKernelGGL(cck::k_seg_scan, seg_grid, dim3(64), lds, sb, g, e->cfg, Pt, e->d_states, first_stream, slot); // (Pt: this slot's table carries)
+        }
+        if (sc != sb)
+        {
+            CC_HIP_CHECK(e, hipEventRecord(e->ev_segscan[slot], sb));
+            CC_HIP_CHECK(e, hipStreamWaitEvent(sc, e->ev_segscan[slot], 0));
+        }
+        CC_MARK(sc); // ev4: table + segment (start of the window scan)
+        const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
+        if (small_front)
+            ; // (k_small_front has scanned the call's columns)
+        // (65 - 128 rows: packed by default. The lock-step form with two rows per lane — scan_packed = 0 — shortens the scan's own launch, 3.0 -> 2.35 ms at
+        // 256 x S128, but needs more vector instructions, and the step is bound by those: 11.7 -> 11.4 G points/s same-box)
+        // (64 rows, end of round 4: with the insertion's uniform work on the scalar unit the step follows the vector-instruction count, and the packed
+        // scan issues 0.65 x those of the lock-step one: + 3 % at 256 streams (same-box, 3 alternations: 16.22 -> 16.72 G points/s), - 1 ... - 2 % at
+        // 32 - 128 streams where the GPU has room and the lock-step scan's shorter launch counts)
+        else if (e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192)))
+        {
+            if (rpl == 1 && !g.mirror_fields)
+                hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            else if (rpl == 1)
+                hipLaunchKernelGGL((cck::k_scan2<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            else if (!g.mirror_fields)
+                hipLaunchKernelGGL((cck::k_scan2<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            else
+                hipLaunchKernelGGL((cck::k_scan2<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        }
+        else if (rpl == 1 && !g.mirror_fields)
+            hipLaunchKernelGGL((cck::k_scan<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        else if (rpl == 1)
+            hipLaunchKernelGGL((cck::k_scan<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else if (!g.mirror_fields)
-            hipLaunchKernelGGL((cck::k_scan2<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL((cck::k_scan<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL((cck::k_scan2<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    }
-    else if (rpl == 1 && !g.mirror_fields)
-        hipLaunchKernelGGL((cck::k_scan<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    else if (rpl == 1)
-        hipLaunchKernelGGL((cck::k_scan<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    else if (!g.mirror_fields)
-        hipLaunchKernelGGL((cck::k_scan<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    else
-        hipLaunchKernelGGL((cck::k_scan<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    CC_MARK(sc); // ev5: scan
-    if (sc != sa)
-    {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_seg[slot], sc));
-        CC_HIP_CHECK(e, hipStreamWaitEvent(sa, e->ev_seg[slot], 0));
-    }
-    // ---- association + publish chain -------------------------------------------------------------------------
-    CC_MARK(sa); // ev6: start of the third chain
-    // batch-parallel association in front of the serial kernels: it takes every group of columns in which nothing can differ from the
-    // reference's sequential semantics (cc_assocb.h) and stops in front of the first group that might. With k_assoc3 behind it the pair runs
-    // assoc_rounds times: a LIMITED launch of the serial kernel takes that one group, the batch-parallel kernel continues behind it; the last
-    // serial launch takes whatever is left of the batch.
-    const bool batch_assoc = e->assoc_batch && e->cfg.cluster_point_trees_every_nth_column == 1;
-    auto launch_assocb = [&]()
-    {
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_assocb<1>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot,
-                               e->d_bail_count);
+            hipLaunchKernelGGL((cck::k_scan<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        CC_MARK(sc); // ev5: scan
+        if (sc != sa)
+        {
+            CC_HIP_CHECK(e, hipEventRecord(e->ev_seg[slot], sc));
+            CC_HIP_CHECK(e, hipStreamWaitEvent(sa, e->ev_seg[slot], 0));
+        }
+        // ---- association + publish chain -------------------------------------------------------------------------
+        CC_MARK(sa); // ev6: start of the third chain
+        // batch-parallel association in front of the serial kernels: it takes every group of columns in which nothing can differ from the
+        // reference's sequential semantics (cc_assocb.h) and stops in front of the first group that might. With k_assoc3 behind it the pair runs
+        // assoc_rounds times: a LIMITED launch of the serial kernel takes that one group, the batch-parallel kernel continues behind it; the last
+        // serial launch takes whatever is left of the batch.
+        const bool batch_assoc = e->assoc_batch && e->cfg.cluster_point_trees_every_nth_column == 1;
+        auto launch_assocb = [&]()
+        {
+            if (rpl == 1)
+                hipLaunchKernelGGL(cck::k_assocb<1>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot,
+                                   e->d_bail_count);
+            else
+                hipLaunchKernelGGL(cck::k_assocb<2>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot,
+                                   e->d_bail_count);
+        };
+        bool marked7 = false;
+        int adaptive_rounds = 1;
+        bool global_done = false; // k_associate's work was done inside the last k_assoc3 launch
+        // a lean small call (k_small_front in front, results mirrored): k_assocb, then ONE kernel for the serial fall-backs, the ids and the mirror
+        const bool small_tail = small_front && e->capture_mirror.state != nullptr && batch_assoc && e->assoc_waves >= 2 && rpl == 1 &&
+                                e->cfg.cluster_point_trees_every_nth_column == 1 && !e->debug_no_assoc_fallback;
+        if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
+        {
+            const int seen = *e->h_bail_count; // (as of some earlier batch: a heuristic, not a condition of correctness)
+            if (seen != e->bail_seen)
+            {
+                e->bail_seen = seen;
+                e->bail_cooldown = e->bail_cooldown_batches;
+            }
+            if (e->bail_cooldown > 0)
+            {
+                e->bail_cooldown--;
+                adaptive_rounds = 3;
+            }
+        }
+        if (small_tail)
+        {
+            launch_assocb();
+            CC_MARK(sa); // ev7
+            marked7 = true;
+            hipLaunchKernelGGL(cck::k_small_tail<1>, dim3(1), dim3(cck::A3_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, e->capture_mirror);
+            global_done = true;
+        }
+        // k_assoc3 walks the finished-cluster checks of several columns at once and assumes one check per column
+        else if (e->assoc_waves >= 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
+        {
+            // with or without the links wave (cc_assoc3.h: A3_THREADS): by default (assoc_waves = 0) with it while the streams are few
+            // enough for the association chain to be what the step waits for
+            #ifndef CC_LWAVE_MAX_STREAMS
+    #define CC_LWAVE_MAX_STREAMS 256
+    #endif
+            const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= CC_LWAVE_MAX_STREAMS);
+            const dim3 block(lwave ? cck::A3_THREADS : 192);
+            const int rounds = batch_assoc ? (e->assoc_rounds > 0 ? e->assoc_rounds : adaptive_rounds) : 1;
+            for (int r = 0; r < rounds; r++)
+            {
+                if (batch_assoc)
+                {
+                    launch_assocb();
+                    if (r == 0)
+                    {
+                        CC_MARK(sa); // ev7: the batch-parallel kernel alone ("assoc_lds_ms"); the serial kernels behind it count as "assoc_global_ms"
+                        marked7 = true;
+                    }
+                }
+                const int limited = r + 1 < rounds ? 1 : 0;
+                // behind k_assocb the serial kernel is a safety net that finds nothing to do: a few blocks sweep over all streams instead of one block
+                // per stream waiting for 45 KB of LDS on a busy CU. One block per stream when it is what associates, or while k_assocb has had to stop
+                // lately (adaptive_rounds > 1), or when the caller pinned the number of rounds
+                const int blocks = (batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1 && !e->capturing) ? (count < e->assoc_sweep_blocks ? count : e->assoc_sweep_blocks) : count;
+                if (batch_assoc && e->debug_no_assoc_fallback)
+                    continue;
+                if (rpl == 1)
+                    hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
+                else
+                    hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
+                global_done = limited == 0; // (the last launch of k_assoc3 takes the streams that continue in global memory with it)
+            }
+        }
         else
-            hipLaunchKernelGGL(cck::k_assocb<2>, dim3(count), dim3(cck::AB_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot,
-                               e->d_bail_count);
-    };
-    bool marked7 = false;
-    int adaptive_rounds = 1;
-    bool global_done = false; // k_associate's work was done inside the last k_assoc3 launch
-    // a lean small call (k_small_front in front, results mirrored): k_assocb, then ONE kernel for the serial fall-backs, the ids and the mirror
-    const bool small_tail = small_front && e->capture_mirror.state != nullptr && batch_assoc && e->assoc_waves >= 2 && rpl == 1 &&
-                            e->cfg.cluster_point_trees_every_nth_column == 1 && !e->debug_no_assoc_fallback;
-    if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
-    {
-        const int seen = *e->h_bail_count; // (as of some earlier batch: a heuristic, not a condition of correctness)
-        if (seen != e->bail_seen)
-        {
-            e->bail_seen = seen;
-            e->bail_cooldown = e->bail_cooldown_batches;
-        }
-        if (e->bail_cooldown > 0)
-        {
-            e->bail_cooldown--;
-            adaptive_rounds = 3;
-        }
-    }
-    if (small_tail)
-    {
-        launch_assocb();
-        CC_MARK(sa); // ev7
-        marked7 = true;
-        hipLaunchKernelGGL(cck::k_small_tail<1>, dim3(1), dim3(cck::A3_THREADS), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, e->capture_mirror);
-        global_done = true;
-    }
-    // k_assoc3 walks the finished-cluster checks of several columns at once and assumes one check per column
-    else if (e->assoc_waves >= 2 && e->cfg.cluster_point_trees_every_nth_column == 1)
-    {
-        // with or without the links wave (cc_assoc3.h: A3_THREADS): by default (assoc_waves = 0) with it while the streams are few
-        // enough for the association chain to be what the step waits for
-        #ifndef CC_LWAVE_MAX_STREAMS
-#define CC_LWAVE_MAX_STREAMS 256
-#endif
-        const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= CC_LWAVE_MAX_STREAMS);
-        const dim3 block(lwave ? cck::A3_THREADS : 192);
-        const int rounds = batch_assoc ? (e->assoc_rounds > 0 ? e->assoc_rounds : adaptive_rounds) : 1;
-        for (int r = 0; r < rounds; r++)
         {
             if (batch_assoc)
             {
                 launch_assocb();
-                if (r == 0)
-                {
-                    CC_MARK(sa); // ev7: the batch-parallel kernel alone ("assoc_lds_ms"); the serial kernels behind it count as "assoc_global_ms"
-                    marked7 = true;
-                }
+                CC_MARK(sa);
+                marked7 = true;
             }
-            const int limited = r + 1 < rounds ? 1 : 0;
-            // behind k_assocb the serial kernel is a safety net that finds nothing to do: a few blocks sweep over all streams instead of one block
-            // per stream waiting for 45 KB of LDS on a busy CU. One block per stream when it is what associates, or while k_assocb has had to stop
-            // lately (adaptive_rounds > 1), or when the caller pinned the number of rounds
-            const int blocks = (batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1 && !e->capturing) ? (count < e->assoc_sweep_blocks ? count : e->assoc_sweep_blocks) : count;
-            if (batch_assoc && e->debug_no_assoc_fallback)
-                continue;
             if (rpl == 1)
-                hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
+                hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
             else
-                hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
-            global_done = limited == 0; // (the last launch of k_assoc3 takes the streams that continue in global memory with it)
+                hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
         }
-    }
-    else
-    {
-        if (batch_assoc)
-        {
-            launch_assocb();
-            CC_MARK(sa);
-            marked7 = true;
-        }
-        if (rpl == 1)
-            hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        if (!marked7)
+            CC_MARK(sa); // ev7: assoc_lds (without the batch-parallel kernel: the serial LDS kernel)
+        // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
+        if ((batch_assoc && e->debug_no_assoc_fallback) || global_done)
+            ;
+        else if (rpl == 1)
+            hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    }
-    if (!marked7)
-        CC_MARK(sa); // ev7: assoc_lds (without the batch-parallel kernel: the serial LDS kernel)
-    // streams whose unfinished trees do not fit the LDS pool (or exotic window configs) continue in global memory
-    if ((batch_assoc && e->debug_no_assoc_fallback) || global_done)
-        ;
-    else if (rpl == 1)
-        hipLaunchKernelGGL(cck::k_associate<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    else
-        hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
-    CC_MARK(sa); // ev8: assoc_global
-    // (without the host synchronisation behind k_insert_par nobody else reads the counter of k_assocb's stops: four bytes ride along here)
-    if (batch_assoc && !gate && !gate2 && e->h_bail_count && !e->capturing)
-        CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
-    // The ids of the published columns only read what the association of THIS batch left behind (tree root of every cell, cluster id
-    // at the root cell; neither is touched again before the ring wraps), so in the pipelined mode they are written on a stream of their
-    // own and the next batch's association starts without waiting for them.
-    hipStream_t spub = (si != sa && e->publish_off_chain) ? e->stream6 : sa;
-    if (spub != sa)
-    {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_pubrdy[slot], sa));
-        CC_HIP_CHECK(e, hipStreamWaitEvent(spub, e->ev_pubrdy[slot], 0));
-    }
-    if (!small_tail)
-        hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, spub, g, e->P, e->d_states, first_stream,
-                           slot, e->capture_mirror);
-    CC_MARK(spub); // ev9: publish
+            hipLaunchKernelGGL(cck::k_associate<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+        CC_MARK(sa); // ev8: assoc_global
+        // (without the host synchronisation behind k_insert_par nobody else reads the counter of k_assocb's stops: four bytes ride along here)
+        if (batch_assoc && !gate && !gate2 && e->h_bail_count && !e->capturing)
+            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
+        // The ids of the published columns only read what the association of THIS batch left behind (tree root of every cell, cluster id
+        // at the root cell; neither is touched again before the ring wraps), so in the pipelined mode they are written on a stream of their
+        // own and the next batch's association starts without waiting for them.
+        hipStream_t spub = (si != sa && e->publish_off_chain) ? e->stream6 : sa;
+        if (spub != sa)
+        {
+            CC_HIP_CHECK(e, hipEventRecord(e->ev_pubrdy[slot], sa));
+            CC_HIP_CHECK(e, hipStreamWaitEvent(spub, e->ev_pubrdy[slot], 0));
+        }
+        if (!small_tail)
+            hipLaunchKernelGGL(cck::k_publish, dim3((unsigned) count, cck::PUBLISH_BLOCKS), dim3(64), 0, spub, g, e->P, e->d_states, first_stream,
+                               slot, e->capture_mirror);
+        CC_MARK(spub); // ev9: publish
+        if (si != sa)
+        {
+            CC_HIP_CHECK(e, hipEventRecord(e->ev_assoc[slot], spub)); // the batch descriptor slot is free again after its publish
+            e->assoc_pending[slot] = true;
+        }
+        CC_HIP_CHECK(e, hipGetLastError());
+        if (e->host_prof && hp_gated)
+        {
+            e->hp_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - hp_t1).count();
+            e->hp_calls++;
+        }
+        return CC_OK;
+    };
 #undef CC_MARK
-    if (si != sa)
+    if (defer)
     {
-        CC_HIP_CHECK(e, hipEventRecord(e->ev_assoc[slot], spub)); // the batch descriptor slot is free again after its publish
-        e->assoc_pending[slot] = true;
+        e->deferred_tail = tail;
+        return CC_OK;
     }
-    CC_HIP_CHECK(e, hipGetLastError());
-    if (e->host_prof && hp_gated)
-    {
-        e->hp_post += std::chrono::duration<double>(std::chrono::steady_clock::now() - hp_t1).count();
-        e->hp_calls++;
-    }
-    return CC_OK;
+    return tail();
 }
 
 // Begin a batch: zero the per-stream firing cursors and the early-stop counter; fix how far clearing may go.
@@ -945,6 +1000,11 @@ int resolve_timing(cc_engine* e)
 
 int sync_all(cc_engine* e)
 {
+    {
+        int rcf = flush_deferred(e);
+        if (rcf)
+            return rcf;
+    }
     if (e->idle)
         return CC_OK;
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
@@ -2226,6 +2286,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->table_on_insert_chain = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "assoc_sweep_blocks")
         e->assoc_sweep_blocks = value < 1 ? 1 : (value > 1024 ? 1024 : (int) value);
+    else if (n == "defer_tail_max_streams")
+        e->defer_tail_max_streams = value < 0 ? 0 : (int) value;
     else if (n == "assoc_cooldown")
         e->bail_cooldown_batches = value < 0 ? 0 : (value > 1000 ? 1000 : (int) value);
     else if (n == "ego_on_insert_chain")
