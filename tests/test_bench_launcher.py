@@ -46,7 +46,7 @@ def test_gpus_1_is_one_process_without_a_process_group():
     out = run_bench("--gpus", "1", "--total-streams", "3")
     assert out["n_gpus"] == 1 and out["rccl_world"] == 0
     assert out["cells_published"] == 3 * 40 * 64 * 4
-    assert out["strong_split"]["streams_per_gpu"] == [3] and out["strong_split"]["value"] == out["value"]
+    assert out["strong_split"]["streams_per_gpu"] == [3] and abs(out["strong_split"]["value"] - out["value"]) < 1e-4 * out["value"]
 
 
 def test_under_a_launcher_the_world_is_the_launchers():

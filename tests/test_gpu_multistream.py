@@ -281,3 +281,23 @@ def test_pipelined_path_at_other_row_counts(rows, oracle_lib):
         hi = se["first_unpublished_global_column_index"] - 1
         lo = max(hi - 600, se["ring_buffer_start_global_column_index"])
         util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
+
+
+@pytest.mark.gpu
+def test_bench_under_the_distributed_launcher_world_1():
+    """The driver's multi-GPU command at the one world size a box offers: bench.py under torch.distributed.run (RCCL process group, barrier,
+    max-over-ranks, all-gather of the counts) with 32 streams dealt over the job (north_star's strong split) and the oracle check of the headline."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--streams", "64", "--steps", "4", "--warmup", "3", "--total-streams", "32", "--no-s128",
+           "--no-cpu-baseline", "--no-latency", "--no-few-streams", "--no-host-fed", "--verify-streams", "2"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CC_BENCH_PIN="1")
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["rccl_world"] == 1 and out["n_gpus"] == 1
+    assert out["strong_split"]["streams_per_gpu"] == [32] and out["strong_split"]["total_streams"] == 32
+    assert out["verified_streams"] == 2
+    assert out["value"] > 0 and out["strong_split"]["value"] > 0
+    assert len(json.dumps(out)) < 6144  # (the driver keeps a few KB of the line)
