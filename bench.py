@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--no-strong-split", action="store_true")
     ap.add_argument("--no-few-streams", action="store_true")
     ap.add_argument("--no-host-fed", action="store_true")
+    ap.add_argument("--no-cluttered", action="store_true")
     ap.add_argument("--kitti-root", default=os.environ.get("SEMANTIC_KITTI_ROOT", ""),
                     help="SemanticKITTI dataset root (the directory that holds sequences/): adds the real-data acceptance leg (README.md:213-245)")
     ap.add_argument("--kitti-sequences", default="0,1,2,3,4,5,6,7,8,9,10")
@@ -120,7 +121,7 @@ def maybe_spawn(args):
     os.execv(sys.executable, cmd)
 
 
-def gen_inputs(torch, dev, sensor, seeds, n_firings, n_batches):
+def gen_inputs(torch, dev, sensor, seeds, n_firings, n_batches, scene=None):
     """[batch][stream][firing][row][3] etc., generated in HBM. Stream k of the engine is the seeded scene seeds[k]."""
     from continuous_clustering_amd import synth
     R = sensor.num_rows
@@ -129,7 +130,7 @@ def gen_inputs(torch, dev, sensor, seeds, n_firings, n_batches):
     inten = torch.empty((n_batches, n_streams, n_firings, R), dtype=torch.uint8, device=dev)
     poses = torch.empty((n_batches, n_streams, n_firings, 12), dtype=torch.float64, device=dev)
     for s, seed in enumerate(seeds):
-        st = synth.make_stream(n_firings * n_batches, seed=seed, sensor=sensor, motion=synth.Motion.translate(10.0),
+        st = synth.make_stream(n_firings * n_batches, seed=seed, sensor=sensor, scene=scene, motion=synth.Motion.translate(10.0),
                                start_column=40 if sensor.azimuth_offsets_deg else 0, xp=torch, device=dev, chunk=n_firings)
         xyz[:, s] = st.xyz.view(n_batches, n_firings, R, 3)
         inten[:, s] = st.intensity.view(n_batches, n_firings, R)
@@ -382,7 +383,7 @@ class Ctx:
         return Engine(cfg, R, S, device=self.local_rank)
 
 
-def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=None):
+def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=None, options=None):
     """One throughput leg: this rank's engine holds len(seeds) streams; `steps` timed passes of the hot path over one batch (F firings of
     every stream) each, bracketed by barrier + device sync on both sides. Returns the whole-job figures (cells of all ranks / slowest rank)."""
     torch, dist = ctx.torch, ctx.dist
@@ -393,6 +394,8 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
     eng = ctx.engine(cfg, R, S)
     eng.record_events(False)
     engine_options(eng)
+    for name, val in (options or {}).items():
+        eng.set_option(name, val)
 
     for b in range(warmup):
         eng.add_firings_device(F, xyz[b], inten[b], poses[b])
@@ -760,6 +763,41 @@ def few_streams_report(ctx, sensor, cfg, F, xyz, inten, poses, steps, counts=(32
     return out
 
 
+def cluttered_report(ctx, sensor, cfg, F, S, steps, headline_value, args):
+    """The step on streams that leave the batch-parallel association's fast path (synth.SceneModel.cluttered: vegetation over half the circle —
+    more unfinished trees side by side than k_assocb has lanes for): throughput, how often and why groups went to the serial kernel, the share of
+    columns the fast path took, the floor with the fast path switched off (assoc_batch = 0: every column by the serial kernels), and the CPU on
+    the same streams (mode C, 16 processes)."""
+    from continuous_clustering_amd import synth
+    torch = ctx.torch
+    warm, k = 3, max(4, min(steps, 12))
+    solo = Ctx(ctx.torch, ctx.dist, False, 1, 0, ctx.dev, ctx.local_rank, ctx.stub)
+    inputs = gen_inputs(torch, ctx.dev, sensor, [4321 + j for j in range(S)], F, warm + k, scene=synth.SceneModel.cluttered(0.1))
+    r, e, _ = run_throughput(solo, sensor, cfg, list(range(S)), F, k, warm, 2, inputs=inputs)
+    a = r["association"]
+    e.close()
+    r0, e0, _ = run_throughput(solo, sensor, cfg, list(range(S)), F, k, warm, 0, inputs=inputs, options={"assoc_batch": 0})
+    e0.close()
+    out = {"value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k, "streams": S,
+           "vs_headline": r["value"] / headline_value if headline_value else None,
+           "batch_bails": a["batch_bails"], "bail_reasons": a["bail_reasons"],
+           "fast_path_share_of_columns": a["batch_columns"] / float((warm + k) * S * F),
+           "exact_replay_columns": r["serial_columns"], "verified_streams": len(r["verified"]["streams"]) if r["verified"] else 0,
+           "kernel_ms_per_step": r["kernel_ms_per_step"],
+           "floor_value": r0["value"], "floor_ms_per_step": r0["ms_per_step"], "floor_vs_headline": r0["value"] / headline_value if headline_value else None}
+    if not args.no_cpu_baseline:
+        a2 = argparse.Namespace(**vars(args))
+        a2.cpu_rotations = min(args.cpu_rotations, 8)
+        a2.cpu_procs = 16
+        cb = cpu_baseline_report(cfg, sensor, *inputs, S, F, a2, sweep_sizes=(16,))
+        out["cpu_baseline_value"] = cb["value"]
+        out["cpu_baseline_cores"] = cb["cores"]
+    del inputs
+    if ctx.dev.type == "cuda":
+        torch.cuda.empty_cache()
+    return out
+
+
 def host_fed_report(ctx, sensor, cfg, F, xyz, inten, poses, steps=6):
     """The same step with the firings starting in (pinned) HOST memory, as a front-end that receives sensor packets would hold them: H2D of every
     batch's [S][F][...] arrays on a copy stream, cc_engine_add_firings_device once a batch has arrived. Never `value`: the timed region of the
@@ -974,6 +1012,10 @@ def main():
     if not args.no_host_fed and not stub:
         out["host_fed"] = host_fed_report(solo, sensor, cfg, F, xyz, inten, poses)
 
+    # ---- streams that leave the association's fast path (vegetation), and the floor without it ----
+    if not args.no_cluttered and not args.no_few_streams and not stub and world == 1:  # (--no-few-streams: the tools' "headline leg only")
+        out["cluttered"] = cluttered_report(solo, sensor, cfg, F, min(Sx, 256), args.steps, out["value"], args)
+
     # ---- CPU baseline on this box's host cores (inputs: the bench's own streams, copied back from HBM) ------------
     # (the contract: on rank 0 at N = 1 only — a multi-GPU line carries the per-GPU figure of the N = 1 run)
     if not args.no_cpu_baseline and not stub and world == 1:
@@ -1073,6 +1115,9 @@ def slim_line(o):
         line["live_multi_stream"] = {k: {kk: vv for kk, vv in v.items() if kk in ("value", "call_period_us", "call_latency_us_p50", "call_latency_us_p99",
                                                                                    "column_latency_us_p99_live", "keeps_up")}
                                      for k, v in lm.items() if isinstance(v, dict)}
+    cl = o.get("cluttered")
+    if cl:
+        line["cluttered"] = {k: v for k, v in cl.items() if k != "kernel_ms_per_step"}
     hf = o.get("host_fed")
     if hf:
         line["host_fed"] = {k: v for k, v in hf.items() if k in ("value", "ms_per_step", "pcie_GBs", "steps")}

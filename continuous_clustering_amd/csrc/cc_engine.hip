@@ -31,6 +31,8 @@ struct cc_engine
     int* d_bail_count{nullptr}; // launches of k_assocb that stopped in front of a group, ever (assoc_rounds 0 = adaptive)
     int* h_bail_count{nullptr}; // pinned; refreshed behind every batch's association chain
     int bail_seen{0}, bail_cooldown{0};
+    int chronic_seen{0}, chronic_skip{0}; // batches left in which the serial association kernels run alone (k_assocb kept stopping)
+    bool chronic_probe{false};
     int assoc_sweep_blocks{2};     // option "assoc_sweep_blocks": blocks of the serial kernel's launch while it is only the safety net behind k_assocb (16 at first: the fewer
                                    // 256-thread / 50 KB blocks have to be placed next to the other chains, the sooner the next batch's k_assocb starts: 0.2 -> 0.1 ms at 256 streams)
     int bail_cooldown_batches{4};  // option "assoc_cooldown": batches that run three (batch-parallel, serial) rounds after k_assocb had to stop (assoc_rounds 0).
@@ -798,7 +800,27 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         // reference's sequential semantics (cc_assocb.h) and stops in front of the first group that might. With k_assoc3 behind it the pair runs
         // assoc_rounds times: a LIMITED launch of the serial kernel takes that one group, the batch-parallel kernel continues behind it; the last
         // serial launch takes whatever is left of the batch.
-        const bool batch_assoc = e->assoc_batch && e->cfg.cluster_point_trees_every_nth_column == 1;
+        bool batch_assoc = e->assoc_batch && e->cfg.cluster_point_trees_every_nth_column == 1;
+        // Streams on which k_assocb keeps stopping (vegetation: more trees born per group than it has lanes for) cost a batch more with it than
+        // without: every stop is a (batch-parallel, serial) round, and a launch lasts as long as its slowest stream — the one that went serial.
+        // While at least a quarter of a launch's streams stop per batch the serial kernels run alone; every ninth batch tries again.
+        if (batch_assoc && e->assoc_rounds == 0 && e->h_bail_count && !e->capturing && count >= 8)
+        {
+            const int seen_now = *e->h_bail_count;
+            if (e->chronic_skip > 0)
+            {
+                e->chronic_skip--;
+                e->bail_seen = seen_now;
+                batch_assoc = false;
+                // (the batches that try again must not meet the two sweeping blocks the serial kernel runs as behind an idle k_assocb)
+                if (e->chronic_skip == 0)
+                    e->bail_cooldown = e->bail_cooldown_batches > 2 ? e->bail_cooldown_batches : 2;
+            }
+            else if ((seen_now - e->chronic_seen) * 4 >= count && e->chronic_probe)
+                e->chronic_skip = 8;
+            e->chronic_probe = batch_assoc; // (the counter read behind the NEXT batch tells what this one did)
+            e->chronic_seen = seen_now;
+        }
         auto launch_assocb = [&]()
         {
             if (rpl == 1)

@@ -55,6 +55,25 @@ class SceneModel:
     wall_gaps_deg: tuple = ((20.0, 32.0), (140.0, 155.0), (250.0, 262.0))
     range_noise: float = 0.01
     dropout: float = 0.02
+    # vegetation / fences: (start_deg, end_deg, r0, r1, density) — inside the world azimuth interval a ray returns, with probability `density`,
+    # from a random range in [r0, r1] instead of from what lies behind (thin returns at jittered ranges: many small trees that stay unfinished
+    # side by side, and neighbours that join them a few columns later). () = none
+    clutter: tuple = ()
+
+    @staticmethod
+    def cluttered(density: float = 0.1) -> "SceneModel":
+        """The scene of the bench with vegetation in front of it over half the circle: sparse returns at 3 .. 30 m (isolated leaves: more
+        unfinished trees side by side than the batch-parallel association has lanes for) in two sectors and a dense shell at 2 .. 8 m in a third
+        (neighbours a few columns apart keep joining trees: points with more link candidates than the window scan records)."""
+        return SceneModel(clutter=((30.0, 120.0, 3.0, 30.0, density), (200.0, 260.0, 3.0, 30.0, density), (300.0, 330.0, 2.0, 8.0, density)))
+
+    @staticmethod
+    def sparse_clutter(density: float = 0.1) -> "SceneModel":
+        return SceneModel(clutter=((0.0, 360.0, 3.0, 30.0, density),))
+
+    @staticmethod
+    def near_clutter(density: float = 0.1) -> "SceneModel":
+        return SceneModel(clutter=((0.0, 360.0, 2.0, 8.0, density),))
 
 
 @dataclass
@@ -213,6 +232,20 @@ def make_stream(n_firings: int, seed: int = 1234, sensor: SensorModel | None = N
             noise = (torch.rand((F, R), generator=g, device=device, dtype=torch.float64) * 2 - 1) * scene.range_noise
             drop = torch.rand((F, R), generator=g, device=device) < scene.dropout
             inten = torch.randint(0, 256, (F, R), generator=g, device=device, dtype=torch.uint8)
+        if scene.clutter:
+            ang = xp.arctan2(dw[..., 1], dw[..., 0]) * (180.0 / math.pi)
+            ang = xp.where(ang < 0, ang + 360.0, ang)
+            for ci, (a0, a1, r0, r1, dens) in enumerate(scene.clutter):
+                if is_np:
+                    u1, u2 = rng.uniform(0, 1, (F, R)), rng.uniform(0, 1, (F, R))
+                else:
+                    u1 = torch.rand((F, R), generator=g, device=device, dtype=torch.float64)
+                    u2 = torch.rand((F, R), generator=g, device=device, dtype=torch.float64)
+                tl = r0 + (r1 - r0) * u2
+                zl = o[..., 2] + tl * dw[..., 2]
+                ok = (ang >= a0) & (ang <= a1) & (u1 < dens) & (zl >= scene.ground_z + 0.25) & (zl <= scene.wall_top_z) & (tl < t)
+                t = xp.where(ok, tl, t)
+                hit = xp.where(ok, 3 + scene.n_objects + ci, hit)
         valid = (t < scene.max_range) & ~drop
         hit = xp.where(valid, hit, 0)
         tt = xp.where(valid, t + noise, float("nan"))

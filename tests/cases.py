@@ -221,6 +221,17 @@ def build_case(name: str):
             k += g
         st = synth.Stream(xyz=xyz, intensity=st.intensity, poses=st.poses, sensor=st.sensor, hit=st.hit)
         return jitter_azimuth(st, 270 + seed, 0.9), _kitti(720), None
+    # ---- vegetation-like scenes: what leaves the batch-parallel association's fast path on natural data --------------------------------
+    if name == "c_s64_sparse_clutter":
+        # isolated returns at 3 .. 30 m all around: more unfinished trees side by side than the kernel has lanes for (AB_BAIL_TREES)
+        return synth.make_stream(2200 * 2 + 300, seed=77, sensor=_s64(2200), scene=SceneModel.sparse_clutter(0.1), motion=Motion.translate()), _kitti(2200), None
+    if name == "c_s64_near_clutter":
+        # a shell of returns at 2 .. 8 m all around: a tree that may reach the one-rotation limits (AB_BAIL_ROTATION)
+        return synth.make_stream(2200 * 2 + 300, seed=77, sensor=_s64(2200), scene=SceneModel.near_clutter(0.1), motion=Motion.translate()), _kitti(2200), None
+    if name == "c_s64_mixed_clutter":
+        return synth.make_stream(2200 * 2 + 300, seed=78, sensor=_s64(2200), scene=SceneModel.cluttered(0.1), motion=Motion.turn(8.0, 0.15)), _kitti(2200), None
+    if name == "c_s128_sparse_clutter":
+        return synth.make_stream(1700 + 600, seed=79, sensor=_s128(1700), scene=SceneModel.sparse_clutter(0.08), motion=Motion.translate()), _vls(1700), None
     # ---- small variants kept as committed golden fixtures -------------------------------------------------------
     if name == "g_s64_translate":
         return synth.make_stream(800, seed=31, sensor=_s64(360), motion=Motion.translate()), _kitti(360), None
@@ -243,6 +254,8 @@ ALL_CASES = ["s64_static", "s64_translate", "s64_turn", "s64_full_2200", "s64_fo
              "s128_no_offsets_translate", "s128_full_1700", "s96_offsets", "s32_small_sensor", "j_s64_jitter", "j_s64_jitter_wide", "j_s128_offsets_jitter"]
 
 EXCEPTION_CASES = ["x_s64_slanted_gaps", "x_s64_slanted_gaps_far", "x_s64_near_jitter_gaps_3", "x_s64_refused_attach"]
+
+CLUTTER_CASES = ["c_s64_sparse_clutter", "c_s64_near_clutter", "c_s64_mixed_clutter", "c_s128_sparse_clutter"]
 
 RING_WRAP_CASES = ["w_s64_240x13", "w_s64_360x12_turn", "w_s64_ring_wall_240x12", "w_s128_offsets_340x12", "w_s32_256x12"]
 

@@ -194,6 +194,21 @@ def test_streams_made_to_provoke_refused_attaches(name, batch, oracle_lib):
                 assert why[4] + why[5] > 0, why
 
 
+@pytest.mark.parametrize("name,reason", [("c_s64_sparse_clutter", 1), ("c_s64_near_clutter", 3), ("c_s64_mixed_clutter", 1), ("c_s128_sparse_clutter", 1)])
+def test_vegetation_leaves_the_fast_path_and_stays_exact(name, reason, oracle_lib):
+    """Natural data that the batch-parallel association cannot take (cc.cpp:654-659, 688-690, 913-924 are what the serial kernels replay): sparse
+    leaves keep more than 64 trees unfinished side by side (reason 1), a shell of near returns all around grows a tree that may span a
+    rotation (reason 3; link lists that overflow, reason 2, need the early stop of the window scan switched off: s64_no_early_stop). The groups in question go to the serial kernel, the fast path resumes behind them, results equal the oracle's."""
+    stream, cfg, tf = cases.build_case(name)
+    box = {}
+    for chunks in ([stream.sensor.num_columns], [97, 1, 200]):
+        summary = util.run_and_compare(stream, cfg, chunks=chunks, robot_tf=tf, engine_setup=lambda e: box.__setitem__("e", e))
+        bc = box["e"].batch_counters()
+        assert bc["batch_bails"] > 0 and bc["bail_reasons"][reason] > 0, bc
+        assert bc["batch_columns"] > 0  # (and the fast path took part of the stream)
+        assert summary["clusters"] > 50
+
+
 @pytest.mark.parametrize("first_call", [132, 236, 496])
 def test_attach_to_a_tree_finished_in_an_earlier_launch(first_call, oracle_lib):
     """cc.cpp:654-659 across launches: in x_s64_refused_attach the second post of a pair joins (by 3-D distance) the first post's tree one column
