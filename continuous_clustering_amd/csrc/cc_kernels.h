@@ -649,7 +649,10 @@ __host__ inline size_t insert2_lds_bytes(int R)
 // block = 128: wavefront 0 is the consumer (the serial algorithm), wavefront 1 the loader that streams the staged points
 // of the coming firings from HBM into an LDS ring, so that the consumer never waits for a global load.
 // (a device function: k_insert2 is its kernel; k_small_front runs it behind the preparation of a small call, in the same block)
-template<int RPL>
+// NOWIN (k_small_front: a call of a few firings, where filling the LDS window of 64 columns — four dependent rounds of global loads — costs more
+// than the call's handful of cells): no distance window, the occupancy tests read the global plane; results are the same by construction (the
+// window is a cache of that plane: `res` selects between the two copies everywhere)
+template<int RPL, bool NOWIN = false>
 __device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, int first_stream, int slot,
                                              const uint8_t* __restrict__ inten, long long n, int* remaining, long long n_total, long long fbase,
                                              const int sl)
@@ -1145,7 +1148,7 @@ __device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config&
         long long rear = -1, fore = -1;
         if (need_hi >= 0)
         {
-            if (wbase < 0 || need_lo < wbase || need_hi + 1 >= wbase + WINC)
+            if (!NOWIN && (wbase < 0 || need_lo < wbase || need_hi + 1 >= wbase + WINC))
                 window_seek(need_lo, need_hi + 1);
             long long l_rear = 0x7fffffffffffffffll, l_fore = -1;
 #pragma unroll
@@ -1170,7 +1173,7 @@ __device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config&
                 }
                 const int so = slot * R + row;
                 const float d = r_d[so];
-                const bool res = gc >= wbase && gc + 1 < wbase + WINC; // both candidate columns resident in LDS
+                const bool res = !NOWIN && gc >= wbase && gc + 1 < wbase + WINC; // both candidate columns resident in LDS
                 // (two separate loads, not a select between an LDS and a global address: that becomes a flat load, whose wait
                 // drains every outstanding global store of the wave)
                 // (the LDS read is unconditional and the global one an exception, so that the two are never merged into one flat
@@ -1213,7 +1216,7 @@ __device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config&
                     p.gtag[ci] = cell_tag(pass);
 #endif
                     p.dist[ci] = d;
-                    if (gc >= wbase && gc < wbase + WINC)
+                    if (!NOWIN && gc >= wbase && gc < wbase + WINC)
                         w_dist[(int) (gc & (WINC - 1)) * R + row] = d;
                 }
                 l_rear = gc < l_rear ? gc : l_rear;
@@ -4791,6 +4794,13 @@ __global__ __launch_bounds__(256) void k_small_front(Geometry g, cc_config cfg, 
 {
     const int R = g.num_rows;
     StreamState* st = &states[stream];
+#ifdef CC_SF_STATS
+    unsigned long long sf_t[6];
+    sf_t[0] = __builtin_amdgcn_s_memtime();
+#define SF_MARK(i) sf_t[i] = __builtin_amdgcn_s_memtime();
+#else
+#define SF_MARK(i)
+#endif
     if (threadIdx.x == 0)
     {
         // k_begin_batch (cc_engine.hip) for this stream; a call on the host path never clears past what the host has seen
@@ -4821,20 +4831,33 @@ __global__ __launch_bounds__(256) void k_small_front(Geometry g, cc_config cfg, 
         P.pp_incaz[i] = q.incaz;
     }
     __syncthreads(); // (workgroup-scope release / acquire: the staging planes, the ego records and the stream state are visible to wavefronts 0 and 1)
+    SF_MARK(1)
     if (threadIdx.x < 128)
-        insert2_body<1>(g, cfg, P, states, stream, slot, inten, n, remaining, n, 0, 0);
+        insert2_body<1, true>(g, cfg, P, states, stream, slot, inten, n, remaining, n, 0, 0);
     else
         __syncthreads(); // (insert2_body has ONE block barrier, right at its start: the wavefronts that do not run it must meet it, or every
                          // barrier behind it pairs the wrong phases — the hardware only counts arrivals)
     __syncthreads();
+    SF_MARK(2)
     if (threadIdx.x < 64)
         seg_small_body(g, cfg, P, states, stream, slot, poses, n, 0, ego, n, 0);
     __syncthreads();
+    SF_MARK(3)
     // D  all four wavefronts: the window scan of the call's columns (scan_body: what k_scan does with one wavefront per block)
     if (g.mirror_fields)
         scan_body<1, true>(g, cfg, P, states, stream, slot, 0, uniform_i32((int) (threadIdx.x >> 6)), 4);
     else
         scan_body<1, false>(g, cfg, P, states, stream, slot, 0, uniform_i32((int) (threadIdx.x >> 6)), 4);
+#ifdef CC_SF_STATS
+    __syncthreads();
+    SF_MARK(4)
+    if (threadIdx.x == 0)
+    {
+        for (int i = 0; i < 4; i++)
+            st->dbg[i] += sf_t[i + 1] - sf_t[i];
+        st->dbg[4] += 1;
+    }
+#endif
 }
 
 // =====================================================================================================
