@@ -56,6 +56,10 @@ constexpr int AB_THREADS = 64 * (AB_WAVES + 1);
 constexpr int AB_SUB = 4;                  // 64-row pieces of a worker wavefront's tile: 4 columns of a 64-row sensor, 2 columns of a 128-row sensor
 constexpr int AB_G_MAX = AB_WAVES * AB_SUB; // columns per group at 64 rows (<= 64 = lanes of the timeline wave); AB_WAVES * AB_SUB / RPL in general
 constexpr int AB_POINTS = AB_WAVES * 64;   // active points per group: one lane each
+#ifndef CC_AB_HOPS
+#define CC_AB_HOPS 2
+#endif
+constexpr int AB_HOPS = CC_AB_HOPS;        // pointer hops per jumping round
 constexpr int AB_RING = 128;               // columns of the slot ring at 64 rows (power of two >= columns per group + WIN_COLS); half of it at 128 rows
 constexpr int AB_TREES = 64;               // trees a group can see (unfinished two groups ago + born since) = lanes of the timeline wave
 constexpr int AB_EVENTS = 64;              // links between different trees per group
@@ -995,8 +999,10 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
                 if (a >= 0)
                 {
                     int bb = ring[a];
-                    if (bb >= 0)
-                        bb = ring[bb]; // (two hops per round: a barrier costs more than an LDS round trip)
+#pragma unroll
+                    for (int h = 1; h < AB_HOPS; h++) // (several hops per round: a barrier costs more than an LDS round trip)
+                        if (bb >= 0)
+                            bb = ring[bb];
                     a = bb;
                     ring[ri] = (short) bb;
                     pending = bb >= 0 ? 1 : 0;

@@ -1633,7 +1633,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     // experiment switch CC_OPT_CU_SPLIT="ins,seg,scan,assoc": the four chains of the pipelined path on disjoint sets of compute units (CU-masked
     // streams; the mask's bits are dealt round-robin over XCDs and shader engines by the driver, so a contiguous range is spread over the chip)
     bool cu_split = false;
-    if (const char* cs = std::getenv("CC_OPT_CU_SPLIT"))
+    if (const char* cs = std::getenv("CC_ENABLE_ENV_OPTS") ? std::getenv("CC_OPT_CU_SPLIT") : nullptr)
     {
         int part[4] = {0, 0, 0, 0};
         hipDeviceProp_t prop;
@@ -1661,37 +1661,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
             }
         }
     }
-    // experiment switch CC_OPT_CU_ASSOC=N: the association chain alone on the last N compute units, every other chain on the rest (few streams:
-    // k_assocb is bound by the vector issue of the ONE compute unit a stream's block sits on, and wavefronts of the other chains on that unit
-    // take issue slots from it)
-    if (const char* ca = std::getenv("CC_OPT_CU_ASSOC"))
-    {
-        hipDeviceProp_t prop;
-        const int n_assoc = atoi(ca);
-        if (!cu_split && n_assoc > 0 && hipGetDeviceProperties(&prop, device) == hipSuccess && n_assoc < prop.multiProcessorCount)
-        {
-            const int ncu = prop.multiProcessorCount;
-            const int words = (ncu + 31) / 32;
-            auto masked = [&](hipStream_t* out_stream, int from, int cnt) -> bool
-            {
-                std::vector<uint32_t> m(words, 0u);
-                for (int i = from; i < from + cnt && i < ncu; i++)
-                    m[i >> 5] |= 1u << (i & 31);
-                return hipExtStreamCreateWithCUMask(out_stream, (uint32_t) words, m.data()) == hipSuccess;
-            };
-            const int rest = ncu - n_assoc;
-            cu_split = masked(&e->stream, 0, rest) && masked(&e->stream2, 0, rest) && masked(&e->stream4, 0, rest) && masked(&e->stream5, 0, rest) &&
-                       masked(&e->stream7, 0, rest) && masked(&e->stream6, 0, rest) && masked(&e->stream3, rest, n_assoc);
-            if (!cu_split)
-            {
-                give_back_streams(e);
-                delete e;
-                return CC_ERR_INVALID_ARGUMENT;
-            }
-        }
-    }
     if (cu_split)
-        fprintf(stderr, "cc_engine_create: chains on disjoint compute units (CC_OPT_CU_SPLIT=%s CC_OPT_CU_ASSOC=%s)\n", std::getenv("CC_OPT_CU_SPLIT") ? std::getenv("CC_OPT_CU_SPLIT") : "", std::getenv("CC_OPT_CU_ASSOC") ? std::getenv("CC_OPT_CU_ASSOC") : "");
+        fprintf(stderr, "cc_engine_create: chains on disjoint compute units (CC_OPT_CU_SPLIT=%s)\n", std::getenv("CC_OPT_CU_SPLIT"));
     else
     {
         StreamSet set;
@@ -1766,8 +1737,11 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         return rc;
     }
     // experiment switches for harnesses that only see the reference's class API (tests/cpp/dropin_demo): CC_OPT_<OPTION>=<value> in the environment
+    // (only where CC_ENABLE_ENV_OPTS is set: a library does not change its behaviour on stray environment variables)
     for (const char* name : {"small_front", "seg_small_max", "fuse_front", "small_graphs"})
     {
+        if (!getenv("CC_ENABLE_ENV_OPTS"))
+            break;
         std::string key = std::string("CC_OPT_") + name;
         for (auto& ch : key)
             ch = (char) toupper((unsigned char) ch);
@@ -2334,9 +2308,9 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     else if (n == "insert_split_blocks")
         e->insert_split_blocks = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
     else if (n == "insert_narrow_blocks")
-        e->insert_narrow_blocks = (int) value;
+        e->insert_narrow_blocks = value < 0 ? 0 : (value > 8 ? 8 : (int) value);
     else if (n == "insert_wide_max_streams")
-        e->insert_wide_max_streams = (int) value;
+        e->insert_wide_max_streams = value < 0 ? 0 : (value > (1 << 20) ? (1 << 20) : (int) value);
     else if (n == "skip_idle_fallbacks")
         e->skip_idle_fallbacks = value != 0;
     else if (n == "fuse_front")
@@ -2348,7 +2322,7 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     }
     else if (n == "seg_small_max")
     {
-        e->seg_small_max = (int) value;
+        e->seg_small_max = value < 0 ? 0 : (value > 63 ? 63 : (int) value);
         e->small_graphs_stale = true;
     }
     else if (n == "assoc_batch")

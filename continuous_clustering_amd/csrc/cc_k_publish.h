@@ -1,0 +1,349 @@
+// cc_k_publish.h — k_publish, k_small_tail, the frame scatter (k_scatter_info / k_scatter_apply), k_gather_clusters, k_view.
+// (part of cc_kernels.h: included there, in order, inside namespace cck)
+#pragma once
+
+// =====================================================================================================
+// k_publish — cluster ids of the columns published in this pass: Point::id = id of the finished cluster of the point's
+// tree (cc.cpp:1005). grid = (PUBLISH_BLOCKS, streams), block = 64, lanes = rows.
+// =====================================================================================================
+constexpr int PUBLISH_BLOCKS = 64;
+
+// what a small call on the host path hands back (cc_engine.hip: add_firings_small), written straight into pinned host memory by the last kernel of
+// the call instead of by three copy nodes of its graph: the stream's state, its first events, the early-stop counter
+struct HostMirror
+{
+    StreamState* state;
+    cc_event* events;
+    int max_events;
+    int* remaining;
+    const int* d_remaining;
+    unsigned long long* seq;   // pinned: the number of mirrored calls so far, written LAST (the host spins on it instead of synchronising the stream)
+    unsigned long long* d_seq; // device: [0] that number, [1] blocks of the current launch that are through
+};
+
+// cluster ids of the columns the batch published (cc.cpp:1035-1092: what publishing leaves in Point::id), columns by .. ny .. strided
+__device__ __forceinline__ void publish_body(const Geometry& g, const Planes& P, const StreamState* states, const int s, const int slot, const int by,
+                                             const int ny)
+{
+    const StreamState* st = &states[s];
+    if (st->batch[slot].pub_begin < 0)
+        return;
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    int plc = (int) ((st->batch[slot].pub_begin + by) % RC);
+    const int plc_step = (int) ((unsigned) ny % (unsigned) RC);
+    for (long long pc = st->batch[slot].pub_begin + by; pc < st->batch[slot].pub_end;
+         pc += ny, plc = (plc + plc_step >= RC ? plc + plc_step - RC : plc + plc_step))
+    {
+        for (int row = lane_id(); row < R; row += 64)
+        {
+            const int ci = plc * R + row;
+            const int r = p.root[ci];
+            p.id[ci] = r >= 0 ? p.t_cid[r] : 0u;
+        }
+    }
+}
+
+// one wavefront: the call's results into pinned host memory, the sequence number last
+__device__ __forceinline__ void mirror_results(const Geometry& g, const Planes& P, const StreamState* states, const int s, const HostMirror& hm)
+{
+    const int lane = lane_id();
+    const StreamState* s0 = &states[s];
+    const unsigned* src = (const unsigned*) s0;
+    unsigned* dst = (unsigned*) hm.state;
+    for (int i = lane; i < (int) (sizeof(StreamState) / 4); i += 64)
+        dst[i] = src[i];
+    const int ne = s0->n_events < hm.max_events ? s0->n_events : hm.max_events;
+    const unsigned* es = (const unsigned*) (P.events + (size_t) s * g.event_capacity);
+    unsigned* ed = (unsigned*) hm.events;
+    for (int i = lane; i < ne * (int) (sizeof(cc_event) / 4); i += 64)
+        ed[i] = es[i];
+    if (lane == 0)
+        *hm.remaining = *hm.d_remaining;
+    __threadfence_system();
+    if (lane == 0)
+    {
+        hm.d_seq[1] = 0ull;
+        const unsigned long long v = hm.d_seq[0] + 1ull;
+        hm.d_seq[0] = v;
+        __hip_atomic_store(hm.seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot, HostMirror hm)
+{
+    publish_body(g, P, states, first_stream + (int) blockIdx.x, slot, (int) blockIdx.y, (int) gridDim.y);
+    if (hm.state)
+    {
+        // the LAST block of the launch to get here mirrors the call's results: every cluster id of the call has been written by then, and the
+        // association chain in front of this kernel left the state final
+        __threadfence();
+        unsigned long long through = 0;
+        if (lane_id() == 0)
+            through = atomicAdd(&hm.d_seq[1], 1ull);
+        through = (unsigned long long) uniform_i64((long long) through);
+        if (through == (unsigned long long) gridDim.x * gridDim.y - 1ull)
+            mirror_results(g, P, states, first_stream, hm);
+    }
+}
+
+// k_small_tail — what is behind the batch-parallel association in a call of a few firings on ONE stream (the per-column latency path): the exact serial
+// kernel for whatever k_assocb left (nothing, normally), the streams that continue in global memory, the cluster ids of the published columns and
+// the results into pinned host memory — k_assoc3 + k_publish in one launch (one graph node less: ~4.5 us of a 50 us call). grid = 1, block = A3_THREADS.
+template<int RPL>
+__global__ __launch_bounds__(A3_THREADS) void k_small_tail(Geometry g, cc_config cfg, Planes P, StreamState* states, int stream, int slot, HostMirror hm)
+{
+    assoc3_stream<RPL>(g, cfg, P, states, stream, slot, 0);
+    __threadfence_block();
+    __syncthreads(); // every wavefront has left the stream (its state is in the planes again)
+    if (threadIdx.x < 64)
+        associate_stream<RPL>(g, cfg, P, states, stream, slot);
+    __syncthreads();
+    publish_body(g, P, states, stream, slot, uniform_i32((int) (threadIdx.x >> 6)), (int) (blockDim.x >> 6));
+    __syncthreads();
+    if (hm.state && threadIdx.x < 64)
+        mirror_results(g, P, states, stream, hm);
+}
+
+
+// =====================================================================================================
+// k_scatter_info / k_scatter_apply — the frame scatter of the reference's harness (addColumnAndEvaluateFrameIfCompleted,
+// kitti_demo.cpp:173-224) for a replayed KITTI sequence, on the device. A stream that is fed exactly num_columns pseudo-firings per frame
+// (kitti_demo.cpp:386-403) carries, per cell, the sequence number of the firing that filled it: frame = sequence / num_columns, range-image
+// column of the frame = sequence % num_columns, and the KITTI point of the cell is original_index[frame % slots][column][row]
+// (cc_kitti_frame::d_original_index of the frame's conversion). k_scatter_info gives the smallest / largest frame among the points of every
+// published column (what the harness needs to find where frame N + 1 starts, :205-209, and its two error conditions); k_scatter_apply
+// writes is_ground_point = (ground_point_label == GP_GROUND) and detection_label = id (:214-215) of the columns' points into the frames'
+// arrays in HBM, which cc_eval_frame_device then reads. grid = columns, block = 64 (lanes = rows).
+// =====================================================================================================
+__global__ __launch_bounds__(64) void k_scatter_info(Geometry g, Planes P, const StreamState* __restrict__ states, int s, long long from,
+                                                     const int* __restrict__ original_index, int slots, int* __restrict__ out_min,
+                                                     int* __restrict__ out_max)
+{
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols, NC = g.num_columns;
+    const long long gc = from + blockIdx.x;
+    const int lc = (int) (gc % RC);
+    const int* org = original_index + (size_t) s * (size_t) slots * (size_t) NC * (size_t) R;
+    int mn = 0x7fffffff, mx = -1;
+    // only published columns that are still in the ring hold what this reads (anything else: "no point", like an empty column)
+    // (clearing is deferred by one call, so what a call published stays readable behind ring_start: the lower end is what has been CLEARED)
+    const bool live = gc >= 0 && gc >= states[s].clear_done && gc < states[s].first_unpublished;
+    for (int row = lane_id(); live && row < R; row += 64)
+    {
+        const int ci = lc * R + row;
+        if (p.dist[ci] == p.dist[ci]) // the cell holds a return
+        {
+            const unsigned seq = p.src[ci];
+            const int frame = (int) (seq / (unsigned) NC), col = (int) (seq % (unsigned) NC);
+            if (org[((size_t) (frame % slots) * NC + col) * R + row] >= 0)
+            {
+                mn = frame < mn ? frame : mn;
+                mx = frame > mx ? frame : mx;
+            }
+        }
+    }
+    mn = wave_min_i32(mn);
+    mx = -wave_min_i32(-mx);
+    if (lane_id() == 0)
+    {
+        out_min[blockIdx.x] = mn;
+        out_max[blockIdx.x] = mx;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_scatter_apply(Geometry g, Planes P, const StreamState* __restrict__ states, int s, long long from,
+                                                      const int* __restrict__ original_index, int slots, unsigned char* __restrict__ is_ground,
+                                                      unsigned* __restrict__ detection, long long max_points)
+{
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols, NC = g.num_columns;
+    const long long gc = from + blockIdx.x;
+    if (gc < 0 || gc < states[s].clear_done || gc >= states[s].first_unpublished)
+        return; // (not a published column of the live ring)
+    const int lc = (int) (gc % RC);
+    const int* org = original_index + (size_t) s * (size_t) slots * (size_t) NC * (size_t) R;
+    unsigned char* gr = is_ground + (size_t) s * (size_t) slots * (size_t) max_points;
+    unsigned* det = detection + (size_t) s * (size_t) slots * (size_t) max_points;
+    for (int row = lane_id(); row < R; row += 64)
+    {
+        const int ci = lc * R + row;
+        if (p.dist[ci] == p.dist[ci])
+        {
+            const unsigned seq = p.src[ci];
+            const int frame = (int) (seq / (unsigned) NC), col = (int) (seq % (unsigned) NC);
+            const int pt = org[((size_t) (frame % slots) * NC + col) * R + row];
+            if (pt >= 0 && pt < max_points)
+            {
+                const size_t o = (size_t) (frame % slots) * (size_t) max_points + (size_t) pt;
+                gr[o] = p.ground[ci] == CC_GP_GROUND ? 1 : 0;
+                det[o] = p.id[ci];
+            }
+        }
+    }
+}
+
+// =====================================================================================================
+// k_gather_clusters — member points of finished clusters, compacted on the device (the point gathering of
+// collectPointsForCusterAndPublish, cc.cpp:985-1033): cluster i owns out[offset[i] .. offset[i] + n_points[i]) and receives its
+// points in (global column, row) order. grid = clusters, block = 64 (lanes = rows), one pass over the cluster's column range.
+// A point belongs to cluster c iff the root of its point tree carries c (t_cid, set when the cluster is finished).
+// =====================================================================================================
+struct ClusterQuery
+{
+    const unsigned* cid;       // [n] cluster ids (CC_EV_CLUSTER.c)
+    const long long* col_from; // [n] first column (CC_EV_CLUSTER.a)
+    const long long* col_to;   // [n] last column (CC_EV_CLUSTER.b)
+    const long long* offset;   // [n] first output element of the cluster
+    const unsigned* n_points;  // [n] expected number of points (CC_EV_CLUSTER.d)
+    long long* out_gcol;
+    int* out_row;
+    int* mismatch; // incremented per cluster whose point count differs from n_points (columns cleared already, wrong descriptor)
+};
+
+__global__ __launch_bounds__(64) void k_gather_clusters(Geometry g, Planes P, const StreamState* states, int s, ClusterQuery q)
+{
+    const int ci_ = blockIdx.x;
+    const SP p = stream_ptrs(P, g, s);
+    const StreamState* st = &states[s];
+    const int R = g.num_rows, RC = g.ring_cols;
+    const int lane = lane_id();
+    const unsigned cid = q.cid[ci_];
+    const long long a = q.col_from[ci_], b = q.col_to[ci_];
+    long long pos = q.offset[ci_];
+    const long long end = pos + q.n_points[ci_];
+    const bool readable = cid != 0 && a >= 0 && b >= a && b - a < RC && a >= st->clear_done && b <= st->ring_end;
+    if (readable)
+    {
+        int lc = (int) (a % RC);
+        for (long long gc = a; gc <= b; gc++, lc = (lc + 1 == RC ? 0 : lc + 1))
+            for (int r0 = 0; r0 < R; r0 += 64)
+            {
+                const int row = r0 + lane;
+                bool mine = false;
+                if (row < R)
+                {
+                    const int cell = lc * R + row;
+                    const int root = p.root[cell];
+                    mine = p.colg[lc] == gc && root >= 0 && p.t_cid[root] == cid && p.t_finished[root];
+                }
+                const unsigned long long mask = __ballot(mine);
+                if (mine)
+                {
+                    const long long o = pos + __popcll(mask & lanes_below());
+                    if (o < end)
+                    {
+                        q.out_gcol[o] = gc;
+                        q.out_row[o] = row;
+                    }
+                }
+                pos += __popcll(mask);
+            }
+    }
+    if (lane == 0 && pos != end)
+        atomicAdd(q.mismatch, 1);
+}
+
+// =====================================================================================================
+// k_view — host view of columns [from, from + ncols) of one stream (cc_engine_read_columns)
+// grid = ncols, block = 64
+// =====================================================================================================
+struct ViewOut
+{
+    float *x, *y, *z, *dist, *incl;
+    double* caz;
+    int64_t *gcol, *src, *root_gcol;
+    uint8_t *ground, *debug, *ignored;
+    uint64_t* id;
+    int32_t* root_row;
+    // the remaining clustering fields of Point (include/cc_hip.h), any of them may be null
+    double* fin;
+    uint32_t *tpts, *width, *nchild;
+    int32_t *visits, *par_row;
+    uint8_t* finished;
+    int64_t* par_gcol;
+};
+
+__global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamState* states, int s, long long from, ViewOut o, int max_back)
+{
+    const StreamState* st = &states[s];
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows, RC = g.ring_cols;
+    const long long gc = from + blockIdx.x;
+    const int lc = (int) (((gc % RC) + RC) % RC);
+    const bool in_ring = st->ring_end >= 0 && gc >= 0 && gc >= st->clear_done && gc <= st->ring_end;
+    const bool segmented = in_ring && st->first_column >= 0 && gc >= st->first_column && gc < st->first_unfinished;
+    const CazBase cb = caz_base_of_column(gc >= 0 ? gc : 0, g.num_columns);
+    const uint16_t tag = cell_tag((gc >= 0 ? gc : 0) / RC);
+    for (int row = lane_id(); row < R; row += 64)
+    {
+        const size_t ci = (size_t) lc * R + row;
+        const size_t oi = (size_t) blockIdx.x * R + row;
+        const float nanf_ = __builtin_nanf("");
+        const bool mine = p.gtag[ci] == tag; // the cell belongs to this pass over the ring (Point::global_column_index == gc)
+        const bool filled = in_ring && (segmented ? true : mine);
+        const bool has_point = filled && !(p.dist[ci] != p.dist[ci]) && mine;
+        const float4 rec = has_point ? p.sc_rec[ci] : make_float4(nanf_, nanf_, nanf_, nanf_);
+        o.x[oi] = rec.x;
+        o.y[oi] = rec.y;
+        o.z[oi] = rec.z;
+        o.dist[oi] = has_point ? p.dist[ci] : nanf_;
+        o.incl[oi] = (has_point || segmented) ? p.incl[ci] : nanf_;
+        // (a segmented cell without a return sits in the middle of its column, cc.cpp:371-372)
+        o.caz[oi] = has_point ? cell_caz(cb, p.incaz[ci]) : (segmented ? empty_cell_caz(gc, g.az_width) : __builtin_nan(""));
+        o.gcol[oi] = segmented ? gc : (has_point ? gc : -1);
+        // (the firing's sequence number, kept as its low 32 bits: it is one of the last 2^32 firings the stream consumed)
+        o.src[oi] = has_point ? (long long) (st->firings_consumed - (unsigned long long) (uint32_t) ((uint32_t) st->firings_consumed - p.src[ci])) : -1;
+        o.ground[oi] = segmented ? p.ground[ci] : (uint8_t) CC_GP_UNKNOWN;
+        o.debug[oi] = segmented ? p.debug[ci] : (uint8_t) CC_DBG_WHITE;
+        o.ignored[oi] = segmented ? p.ignored[ci] : 0;
+        const int r = segmented ? p.root[ci] : -1;
+        o.id[oi] = r >= 0 ? (uint64_t) p.t_cid[r] : 0ull;
+        o.root_gcol[oi] = r >= 0 ? p.colg[r / R] : -1;
+        o.root_row[oi] = r >= 0 ? r % R : 0;
+        // per-tree values live at the root cell (cc.cpp:666-671, 818-822, 933); everything else keeps its cleared value
+        const bool is_root = r >= 0 && (size_t) r == ci;
+        if (o.fin)
+            o.fin[oi] = is_root ? p.t_fin[ci] : 0.;
+        if (o.tpts)
+            o.tpts[oi] = is_root ? p.t_pts[ci] : 0u;
+        if (o.width)
+            o.width[oi] = is_root ? p.t_width[ci] : 0u;
+        if (o.finished)
+            o.finished[oi] = is_root ? p.t_finished[ci] : (uint8_t) 0;
+        if (o.visits)
+            o.visits[oi] = (segmented && g.mirror_fields) ? (int32_t) p.sc_visits[ci] : 0;
+        const int code = (segmented && r >= 0) ? (int) p.sc_parent[ci] : -1; // (columns back << 8) | row of the point whose child list holds this one
+        if (o.par_gcol)
+            o.par_gcol[oi] = code >= 0 ? gc - (code >> 8) : -1;
+        if (o.par_row)
+            o.par_row[oi] = code >= 0 ? (code & 0xff) : 0;
+    }
+    if (o.nchild)
+    {
+        // Point::child_points.size(): the points of this and the following columns whose parent is a cell of this column
+        __shared__ unsigned s_cnt[WAVE * MAX_ROWS_PER_LANE];
+        for (int row = lane_id(); row < R; row += 64)
+            s_cnt[row] = 0;
+        __syncthreads();
+        if (segmented)
+            for (int d = 0; d <= max_back; d++)
+            {
+                const long long gd = gc + d;
+                if (gd >= st->first_unfinished)
+                    break;
+                int ld = lc + d;
+                ld = ld >= RC ? ld - RC : ld;
+                for (int row = lane_id(); row < R; row += 64)
+                {
+                    const size_t cj = (size_t) ld * R + row;
+                    const int code = p.root[cj] >= 0 ? (int) p.sc_parent[cj] : -1;
+                    if (code >= 0 && (code >> 8) == d)
+                        atomicAdd(&s_cnt[code & 0xff], 1u);
+                }
+            }
+        __syncthreads();
+        for (int row = lane_id(); row < R; row += 64)
+            o.nchild[(size_t) blockIdx.x * R + row] = s_cnt[row];
+    }
+}

@@ -11,6 +11,7 @@ with open('/tmp/rt_in.bin', 'wb') as f:
     f.write(st.xyz.astype(np.float32).tobytes()); f.write(st.intensity.astype(np.uint8).tobytes()); f.write(st.poses.astype(np.float64).tobytes())
 P
 for rep in 1 2; do
+export CC_ENABLE_ENV_OPTS=1
 for cfg in "CC_X=0" "CC_OPT_SMALL_FRONT=0" "CC_OPT_SMALL_FRONT=0 CC_OPT_SEG_SMALL_MAX=0"; do
   echo "$cfg: $(env $cfg tests/cpp/dropin_demo /tmp/rt_in.bin /dev/null -1 22000 | grep feed)"
   echo "$cfg adaptive: $(env $cfg tests/cpp/dropin_demo /tmp/rt_in.bin /dev/null 0 22000 | grep feed)"
