@@ -710,10 +710,10 @@ def single_stream_report(ctx, sensor, cfg, F, xyz, inten, poses):
             for key, batch, rate in (("reference_api_only_paced_22kHz", -1, 22000), ("reference_api_only_free_running", -1, 0),
                                      ("adaptive_paced_22kHz", 0, 22000), ("adaptive_free_running", 0, 0), ("one_call_per_firing", 1, 0)):
                 r = subprocess.run([demo, path, "/dev/null", str(batch), str(rate)], capture_output=True, text=True, timeout=300)
-                m = re.search(r"firings_per_s=(\d+) latency_us_p50=([\d.]+) p99=([\d.]+) max=([\d.]+)", r.stdout)
+                m = re.search(r"firings_per_s=(\d+) latency_us_p50=([\d.]+) p99=([\d.]+) max=([\d.]+) p999=([\d.]+) stalls_over_2ms=(\d+)", r.stdout)
                 if r.returncode == 0 and m:
                     rt[key] = {"firings_per_s": float(m.group(1)), "latency_us_p50": float(m.group(2)), "latency_us_p99": float(m.group(3)),
-                               "latency_us_max": float(m.group(4))}
+                               "latency_us_p999": float(m.group(5)), "latency_us_max": float(m.group(4)), "stalls_over_2ms": int(m.group(6))}
         finally:
             os.unlink(path)
         rt["note"] = ("tests/cpp/dropin_demo: continuous_clustering::ContinuousClustering (C++ drop-in class over the C-ABI) with both callbacks "

@@ -1404,6 +1404,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
             destroy_small_graphs(e);
         e->small_graphs.push_back({stream, n, e->g.record_events, exec});
     }
+    if (!xyz)
+        return CC_OK; // (cc_engine_set_option "prewarm_small_graphs": the graph of this call size exists now, nothing is launched)
     memcpy(e->h_small, xyz, (size_t) n * R * 3 * sizeof(float));
     memcpy(e->h_small + b_xyz, intensity, (size_t) n * R);
     memcpy(e->h_small + b_xyz + b_int, poses, (size_t) n * 12 * sizeof(double));
@@ -2282,6 +2284,68 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->table_on_insert_chain = value < 0 ? 0 : (value > 2 ? 2 : value);
     else if (n == "assoc_sweep_blocks")
         e->assoc_sweep_blocks = value < 1 ? 1 : (value > 1024 ? 1024 : (int) value);
+    else if (n == "forget_inclination_table")
+    {
+        // sc_inclination_angles_between_lasers_ as a freshly constructed object has it (cc_engine_reset keeps it, like the reference's resize does):
+        // for callers that ran made-up data through a new engine (the drop-in class's warm-up)
+        if (value != 0)
+            CC_HIP_CHECK(e, hipMemset(e->P.curtab, 0xFF, (size_t) e->g.num_streams * (size_t) e->g.num_rows * sizeof(float)));
+    }
+    else if (n == "prewarm_small_graphs")
+    {
+        // Capturing and instantiating the graph of a call size takes milliseconds, once per size: a front-end that feeds a live sensor pays them
+        // here (the drop-in class does, in reset()), not in front of the first call of every size — with the asynchronous mode handing the engine
+        // whatever has queued up (1 .. 8 firings), eight such stalls of up to 30 ms each sat inside the first seconds of a stream
+        if (value != 0 && e->g.num_streams == 1)
+        {
+            // buffers first, sized for the largest call the drop-in class makes (a rotation of firings, when its caller ran ahead): growing them
+            // later re-allocates what the captured graphs point at, i.e. drops the graphs again
+            const size_t cap = (size_t) std::max(4096, e->g.num_columns);
+            if (e->ego_capacity < cap)
+            {
+                bool ok = true;
+                for (int i = 0; i < 4 && ok; i++)
+                    ok = alloc_plane(e, &e->d_ego[i], cap * cck::EGO_STRIDE) == CC_OK;
+                if (ok)
+                {
+                    e->ego_capacity = cap;
+                    e->small_graphs_stale = true;
+                }
+            }
+            (void) ensure_prep(e, (size_t) e->g.num_columns * (size_t) e->g.num_rows);
+            // the grow-only scratch of cc_engine_read_columns (a mirror reads a few columns per call; a device and a pinned host block) and of
+            // cc_engine_gather_cluster_points: a pinned allocation in front of the first finished cluster is a stall of milliseconds
+            {
+                const size_t vb = (size_t) 512 * e->g.num_rows * (5 * 4 + 8 + 3 * 8 + 3 + 8 + 4 + 8 + 8 + 5 * 4 + 1) + 256;
+                void* pv = nullptr;
+                if (e->view_bytes < vb && hipMalloc(&pv, vb) == hipSuccess)
+                {
+                    e->allocations.push_back(pv);
+                    e->d_view = pv;
+                    e->view_bytes = vb;
+                }
+                if (e->h_view_bytes < vb)
+                {
+                    if (e->h_view)
+                        (void) hipHostFree(e->h_view);
+                    e->h_view = nullptr;
+                    e->h_view_bytes = 0;
+                    if (hipHostMalloc((void**) &e->h_view, vb) == hipSuccess)
+                        e->h_view_bytes = vb;
+                }
+                const size_t gb = (size_t) 4 << 20;
+                void* pg = nullptr;
+                if (e->gather_bytes < gb && hipMalloc(&pg, gb) == hipSuccess)
+                {
+                    e->allocations.push_back(pg);
+                    e->d_gather = (char*) pg;
+                    e->gather_bytes = gb;
+                }
+            }
+            for (int64_t k = 1; k <= SMALL_MAX; k++)
+                (void) add_firings_small(e, 0, k, nullptr, nullptr, nullptr);
+        }
+    }
     else if (n == "defer_tail_max_streams")
         e->defer_tail_max_streams = value < 0 ? 0 : (int) value;
     else if (n == "assoc_cooldown")

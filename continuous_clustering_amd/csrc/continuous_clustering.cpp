@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace continuous_clustering
@@ -18,6 +20,15 @@ ContinuousClustering::~ContinuousClustering()
     }
     catch (...)
     {
+    }
+    if (trace_ && !trace_log_.empty())
+    {
+        std::vector<TraceEntry> v = trace_log_;
+        std::sort(v.begin(), v.end(), [](const TraceEntry& a, const TraceEntry& b) { return a.us > b.us; });
+        fprintf(stderr, "[cc async trace] %zu hand-overs; the longest:", v.size());
+        for (size_t i = 0; i < v.size() && i < 8; i++)
+            fprintf(stderr, " (t %.1f ms, %d firings, %.0f us)", v[i].at_ms, v[i].n, v[i].us);
+        fprintf(stderr, "\n");
     }
     if (engine_)
         cc_engine_destroy(engine_);
@@ -81,6 +92,11 @@ void ContinuousClustering::rethrowWorkerError()
 void ContinuousClustering::workerLoop()
 {
     std::vector<QueuedFiring> take;
+    trace_ = getenv("CC_ASYNC_TRACE") != nullptr;
+    trace_t0_ = std::chrono::steady_clock::now();
+    // the first HIP call of a host thread sets the thread up with the runtime (milliseconds): here, not in front of the first firing
+    if (engine_)
+        (void) cc_engine_sync(engine_);
     while (true)
     {
         take.clear();
@@ -101,6 +117,7 @@ void ContinuousClustering::workerLoop()
             }
             busy_ = true;
         }
+        const auto tr0 = std::chrono::steady_clock::now();
         try
         {
             for (const QueuedFiring& q : take)
@@ -115,6 +132,13 @@ void ContinuousClustering::workerLoop()
             // (the failed batch's firings are still in firing_log_, which the mirror indexes by firing number: after the error has been rethrown to
             // the caller the only consistent way on is reset(), as after the reference's own soft error, cc.cpp:252-261)
             reset_required_async_ = true;
+        }
+        if (trace_)
+        {
+            // CC_ASYNC_TRACE=1: the longest hand-overs of the run (how many firings, how long the engine call and the callbacks took, when)
+            const auto tr1 = std::chrono::steady_clock::now();
+            const double us = std::chrono::duration<double, std::micro>(tr1 - tr0).count();
+            trace_log_.push_back({std::chrono::duration<double, std::milli>(tr0 - trace_t0_).count(), (int) take.size(), us});
         }
         {
             std::lock_guard<std::mutex> lk(mu_);
@@ -194,6 +218,46 @@ void ContinuousClustering::check(int rc)
     }
 }
 
+// a wall 10 m around the sensor, fed in calls of every size class (1 .. 8 firings: one captured graph each; < 64: the small-call kernels; a few
+// hundred: the block-parallel insertion): results are thrown away
+void ContinuousClustering::warmUp()
+{
+    const int R = num_rows_, C = num_columns_;
+    const int sizes[] = {1, 2, 3, 4, 5, 6, 7, 8, 40, 200, 1, 300};
+    int total = 0;
+    for (int n : sizes)
+        total += n;
+    std::vector<float> xyz(static_cast<size_t>(total) * R * 3);
+    std::vector<uint8_t> inten(static_cast<size_t>(total) * R, 100);
+    std::vector<double> poses(static_cast<size_t>(total) * 12, 0.);
+    const double width = 2 * M_PI / C;
+    for (int f = 0; f < total; f++)
+    {
+        const double a = (f + 0.5) * width;
+        const double az = config_.range_image.sensor_is_clockwise ? M_PI - a : -M_PI + a;
+        for (int r = 0; r < R; r++)
+        {
+            const double incl = (2.0 - 26.0 * r / std::max(1, R - 1)) * M_PI / 180.0;
+            float* p = &xyz[(static_cast<size_t>(f) * R + r) * 3];
+            p[0] = static_cast<float>(10.0 * std::cos(incl) * std::cos(az));
+            p[1] = static_cast<float>(10.0 * std::cos(incl) * std::sin(az));
+            p[2] = static_cast<float>(10.0 * std::sin(incl));
+        }
+        double* T = &poses[static_cast<size_t>(f) * 12];
+        T[0] = T[5] = T[10] = 1.0;
+    }
+    const double id[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    (void) cc_engine_set_robot_from_sensor(engine_, 0, id);
+    int f = 0;
+    for (int n : sizes)
+    {
+        if (cc_engine_add_firings(engine_, 0, n, &xyz[static_cast<size_t>(f) * R * 3], &inten[static_cast<size_t>(f) * R], &poses[static_cast<size_t>(f) * 12]) != CC_OK)
+            break;
+        f += n;
+    }
+    (void) cc_engine_sync(engine_);
+}
+
 // ---- continuous_clustering.cpp:11-64 ----------------------------------------------------------------------------------
 void ContinuousClustering::reset(int num_rows)
 {
@@ -208,6 +272,7 @@ void ContinuousClustering::reset(int num_rows)
     ring_buffer_max_columns = num_columns_ * 10;
     cc_config pod;
     toPod(config_, pod);
+    const bool created = !engine_;
     if (!engine_)
         check(cc_engine_create(&engine_, device_, 1, num_rows, &pod));
     else
@@ -216,6 +281,17 @@ void ContinuousClustering::reset(int num_rows)
         check(cc_engine_reset(engine_, num_rows));
     }
     check(cc_engine_record_events(engine_, 1));
+    (void) cc_engine_set_option(engine_, "prewarm_small_graphs", 1); // (the graphs of calls of 1 .. 8 firings: built here, not in front of live data)
+    if (!config_.general.is_single_threaded && created)
+    {
+        // Asynchronous mode = a live sensor behind the front-end: everything a call pays only the first time (the first launch of every captured
+        // graph and of every kernel of the larger call sizes: 8 - 9 ms each, twice, inside the first 25 ms of a stream at 22 000 firings/s) is
+        // paid here, once per object (where its first reset() finds the asynchronous mode configured), on a made-up quarter rotation; the engine is reset behind it.
+        warmUp(); // (only on the engine this call created: it has seen nothing else)
+        check(cc_engine_reset(engine_, num_rows));
+        check(cc_engine_set_option(engine_, "forget_inclination_table", 1)); // (what reset keeps across calls, cc.cpp:46, must not keep the made-up data's)
+        check(cc_engine_record_events(engine_, 1));
+    }
     range_image_.assign(static_cast<size_t>(ring_buffer_max_columns) * num_rows, Point{});
     for (auto& p : range_image_)
         p.ground_point_label = GP_UNKNOWN; // clearColumns (cc.cpp:1125)

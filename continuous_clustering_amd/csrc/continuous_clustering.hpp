@@ -307,6 +307,7 @@ class ContinuousClustering
     // asynchronous mode (is_single_threaded = false)
     void workerLoop();
     void startWorker();
+    void warmUp();
     void stopWorker();
     void waitIdle();
     void rethrowWorkerError();
@@ -381,6 +382,15 @@ class ContinuousClustering
     std::deque<QueuedFiring> queue_;
     bool stop_{false};
     bool busy_{false};
+    struct TraceEntry
+    {
+        double at_ms;
+        int n;
+        double us;
+    };
+    bool trace_{false}; // CC_ASYNC_TRACE: the worker logs its hand-overs
+    std::chrono::steady_clock::time_point trace_t0_;
+    std::vector<TraceEntry> trace_log_;
     std::exception_ptr worker_error_;
     std::atomic<bool> reset_required_async_{false};
 };

@@ -214,8 +214,16 @@ int main(int argc, char** argv)
             lat.push_back(seen_us[(size_t) k] - due_us[(size_t) k]);
         std::sort(lat.begin(), lat.end());
         const double total_s = t * 1e-6;
-        printf("feed rate_hz=%.0f batch=%d firings=%d seconds=%.4f firings_per_s=%.0f latency_us_p50=%.1f p99=%.1f max=%.1f\n", rate_hz, batch, n,
-               total_s, n / total_s, lat[lat.size() / 2], lat[(size_t) (lat.size() * 0.99)], lat.back());
+        // stalls: runs of consecutive firings delivered more than 2 ms late (one hiccup of the feeder, the worker or the GPU delays everything queued behind it)
+        int stalls = 0;
+        for (int k = n / 10; k < n; k++)
+        {
+            const bool late = seen_us[(size_t) k] - due_us[(size_t) k] > 2000.;
+            const bool prev_late = k > n / 10 && seen_us[(size_t) k - 1] - due_us[(size_t) k - 1] > 2000.;
+            stalls += late && !prev_late ? 1 : 0;
+        }
+        printf("feed rate_hz=%.0f batch=%d firings=%d seconds=%.4f firings_per_s=%.0f latency_us_p50=%.1f p99=%.1f max=%.1f p999=%.1f stalls_over_2ms=%d\n", rate_hz, batch, n,
+               total_s, n / total_s, lat[lat.size() / 2], lat[(size_t) (lat.size() * 0.99)], lat.back(), lat[(size_t) (lat.size() * 0.999)], stalls);
     }
     int32_t tag = 3;
     fwrite(&tag, 4, 1, out);
