@@ -714,6 +714,9 @@ def single_stream_report(ctx, sensor, cfg, F, xyz, inten, poses):
                 if r.returncode == 0 and m:
                     rt[key] = {"firings_per_s": float(m.group(1)), "latency_us_p50": float(m.group(2)), "latency_us_p99": float(m.group(3)),
                                "latency_us_p999": float(m.group(5)), "latency_us_max": float(m.group(4)), "stalls_over_2ms": int(m.group(6))}
+                    tr = [l for l in r.stderr.splitlines() if "async trace" in l]  # (CC_ASYNC_TRACE=1: the worker's longest hand-overs)
+                    if tr:
+                        rt[key]["trace"] = tr[-1]
         finally:
             os.unlink(path)
         rt["note"] = ("tests/cpp/dropin_demo: continuous_clustering::ContinuousClustering (C++ drop-in class over the C-ABI) with both callbacks "
