@@ -291,7 +291,12 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * front of k_seg_pre; default 0), "fuse_front" (1 (default): k_insert_par also does the per-cell part of the ground segmentation of the columns it fills and closes batches it took completely as fused: k_table / k_seg_pre are only launched for streams that need them; 0: the unfused chain), "seg_small_max" (default 63: calls of at most that many firings on a sensor of <= 64 rows segment their columns with k_seg_small, one wavefront per stream with rows as lanes), "small_front" (1 (default): such a call on ONE stream outside the pipeline — cc_engine_add_firings — runs k_small_front / k_small_tail: a three-kernel graph without copy nodes, the results mirrored into pinned host memory), "insert_narrow_blocks" (experiment), "insert_wide_max_streams" / "insert_split_blocks" (launches of at most that many streams, default 160, run k_insert_par with 16
  * wavefronts per block and deal a stream's firings to that many blocks: 0 (default) = 4 up to 40 streams, 2 up to 96, else 1), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
  * number_of_visited_neighbors, per-tree values of finished trees, the tree-link log; 0 in throughput mode), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
- * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made). */
+ * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made), "defer_tail_max_streams" (default 96: in the pipelined mode, launches of at most
+ * that many streams leave the chains behind a batch's insertion gate — segmentation scan, window scan, association, publishing — to the NEXT call, which launches them behind its own insertion; every call that
+ * reads results, synchronises or resets flushes them first, so results are unchanged; 0: never defer), "prewarm_small_graphs" (value k in 1..8, a one-shot action, not a setting: sizes the grow-only host / device
+ * buffers of small calls and captures the hipGraphs of cc_engine_add_firings calls of 1..k firings now, without launching anything, so that the first real calls do not pay for it), "forget_inclination_table"
+ * (one-shot action: the stream's ground-segmentation inclination table — the only state cc_engine_reset keeps, like the reference's reset() — is cleared too; used by the drop-in class after its warm-up).
+ * Values out of range are clamped. Environment variables that override options (CC_ASSOC_ROUNDS, CC_DEFER_TAIL, ... as used by the A/B tools) are only read when CC_ENABLE_ENV_OPTS=1 is set. */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every
