@@ -11,6 +11,7 @@
 #include <vector>
 #include <algorithm>
 
+#define REP2(x) x x
 #define REP4(x) x x x x
 #define REP8(x) REP4(x) REP4(x)
 #define REP16(x) REP4(x) REP4(x) REP4(x) REP4(x)
@@ -55,6 +56,9 @@ KERNEL(k_cndmask_sgpr, "s_mov_b64 s[20:21], 0x5555aaaa\n" REP8(V8("v_cndmask_b32
 KERNEL(k_cndmask_other_dst, "s_mov_b64 vcc, 0x5555aaaa\n" REP8("v_cndmask_b32 v10, v20, v30, vcc\n v_cndmask_b32 v11, v21, v30, vcc\n v_cndmask_b32 v12, v22, v30, vcc\n v_cndmask_b32 v13, v23, v30, vcc\n v_cndmask_b32 v14, v20, v30, vcc\n v_cndmask_b32 v15, v21, v30, vcc\n v_cndmask_b32 v16, v22, v30, vcc\n v_cndmask_b32 v17, v23, v30, vcc\n"), CL32, "vcc", "v20", "v21", "v22", "v23")
 KERNEL(k_cmp_cndmask, REP8(REP4("v_cmp_gt_f32 vcc, v10, v30\n v_cndmask_b32 v11, v11, v30, vcc\n")), CL32, "vcc")
 KERNEL(k_cmp_sgpr_cndmask, REP8("v_cmp_gt_f32_e64 s[20:21], v10, v30\n v_cmp_gt_f32_e64 s[22:23], v11, v30\n v_cmp_gt_f32_e64 s[24:25], v12, v30\n v_cmp_gt_f32_e64 s[26:27], v13, v30\n v_cndmask_b32_e64 v14, v14, v30, s[20:21]\n v_cndmask_b32_e64 v15, v15, v30, s[22:23]\n v_cndmask_b32_e64 v16, v16, v30, s[24:25]\n v_cndmask_b32_e64 v17, v17, v30, s[26:27]\n"), CL32, "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27")
+KERNEL(k_add2_cnd2, "s_mov_b64 vcc, 0x5555aaaa\n" REP8(REP2("v_add_u32 v10, v10, v30\n v_add_u32 v12, v12, v30\n v_cndmask_b32 v11, v11, v30, vcc\n v_cndmask_b32 v13, v13, v30, vcc\n")), CL32, "vcc")
+KERNEL(k_add6_cnd2, "s_mov_b64 vcc, 0x5555aaaa\n" REP8("v_add_u32 v10, v10, v30\n v_add_u32 v12, v12, v30\n v_add_u32 v14, v14, v30\n v_add_u32 v15, v15, v30\n v_add_u32 v16, v16, v30\n v_add_u32 v17, v17, v30\n v_cndmask_b32 v11, v11, v30, vcc\n v_cndmask_b32 v13, v13, v30, vcc\n"), CL32, "vcc")
+KERNEL(k_cmp_cnd2, REP8(REP2("v_cmp_gt_f32 vcc, v10, v30\n v_cndmask_b32 v11, v11, v30, vcc\n v_cndmask_b32 v13, v13, v30, vcc\n v_add_u32 v12, v12, v30\n")), CL32, "vcc")
 KERNEL(k_add_cndmask, "s_mov_b64 vcc, 0x5555aaaa\n" REP8(REP4("v_add_u32 v10, v10, v30\n v_cndmask_b32 v11, v11, v30, vcc\n")), CL32, "vcc")
 KERNEL(k_max_f32, REP8(V8("v_max_f32", ", v30")), CL32)
 KERNEL(k_min_u32, REP8(V8("v_min_u32", ", v30")), CL32)
@@ -119,6 +123,9 @@ int main()
         {"v_cmp_gt_f32 vcc ; v_cndmask vcc (pairs)", k_cmp_cndmask, 64, ""},
         {"4 x v_cmp -> sgpr pairs ; 4 x v_cndmask_e64", k_cmp_sgpr_cndmask, 64, ""},
         {"v_add_u32 ; v_cndmask vcc (alternating)", k_add_cndmask, 64, ""},
+        {"2 x v_add_u32 ; 2 x v_cndmask vcc", k_add2_cnd2, 64, ""},
+        {"6 x v_add_u32 ; 2 x v_cndmask vcc", k_add6_cnd2, 64, ""},
+        {"v_cmp vcc ; 2 x v_cndmask vcc ; v_add_u32", k_cmp_cnd2, 64, ""},
         {"v_max_f32", k_max_f32, 64, ""},
         {"v_min_u32", k_min_u32, 64, ""},
         {"v_add_f32", k_add_f32, 64, ""},
