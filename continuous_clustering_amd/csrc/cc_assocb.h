@@ -399,8 +399,12 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
             const int incl = wave_incl_add_i32(cnt);
             const int pts = valid ? (nx_act & 0xff) + (nx_act >> 8) : 0;
             const int ipts = wave_incl_add_i32(pts);
-            // (the group's points must fit the lanes of the worker wavefronts; one column always does)
-            const unsigned long long okm = __ballot(valid && base + incl <= tree_limit && ipts <= AB_POINTS);
+            // (the group's points must fit the lanes of the worker wavefronts; one column always does.) New roots: a group takes at most HALF of the
+            // tree lanes `base` leaves (its first column aside) — the next group's `base` still contains all of this group's new roots, so a group that
+            // fills the lanes leaves the next one no room for a single column and the kernel stops (AB_BAIL_TREES: what vegetation-like streams did
+            // once per rotation); with the half rule the room shrinks geometrically and the finished trees of the passes in between give it back
+            const int born_cap = (tree_limit - base + 1) >> 1;
+            const unsigned long long okm = __ballot(valid && base + incl <= tree_limit && ipts <= AB_POINTS && (lane == 0 || incl <= born_cap));
             const int ncols = ~okm ? __builtin_ctzll(~okm) : 64;
             const unsigned long long cm = ncols >= 64 ? ~0ull : ((1ull << ncols) - 1ull);
             int bail = (ncols == 0 && g0 < col_end) ? AB_BAIL_TREES : 0;
