@@ -205,16 +205,104 @@ __device__ __forceinline__ unsigned long long ab_run_max_f64_bits(unsigned long 
     return (unsigned long long) b;
 }
 
+// the block's LDS (one object, declared by the kernel: k_small_all fills part of it before assocb_body runs)
 template<int RPL>
-__global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
-                                                       int* __restrict__ bail_count)
+struct AbShared
+{
+    AbTrees T;
+    short ring[(AB_RING / RPL) * WAVE * RPL]; // tree slot of every cell of the last AB_RING / RPL columns
+    int s_nunf;
+    long long s_gc_final;
+    int s_serial_cols;
+    int s_reason;
+    unsigned long long s_cols;
+};
+
+// what assocb_body needs of the stream's state before its first group: the persistent tree state (global planes indexed by root cell) -> LDS, list
+// position = slot, and the slot ring of the WIN_COLS columns before col_begin. Nothing of it depends on the batch that is being inserted, so
+// k_small_all lets its idle wavefronts do this (threads tid of nthreads) next to the call's front half, with col_begin predicted.
+template<int RPL>
+__device__ __forceinline__ void assocb_load_state(const Geometry& g, const SP& p, AbShared<RPL>& S, const long long col_begin, const long long first_column,
+                                                  const int n_unf, const int tid, const int nthreads)
+{
+    constexpr int RING = AB_RING / RPL;
+    const int R = g.num_rows, RC = g.ring_cols;
+    AbTrees& T = S.T;
+    for (int i = tid; i < n_unf; i += nthreads)
+    {
+        const int cell = p.ulist[i];
+        const long long tg = p.colg[cell / R];
+        T.cell[i] = cell;
+        T.gcol[i] = tg;
+        T.fin[i] = (unsigned long long) __double_as_longlong(p.t_fin[cell]);
+        T.last[i] = tg + (long long) p.t_width[cell] - 1;
+        T.pts[i] = p.t_pts[cell];
+        T.comp[i] = p.t_pos[p.t_uf[cell]];
+        T.sig[i] = i;
+    }
+    // slot ring of the WIN_COLS columns before col_begin: two dependent gathers per cell (root plane, then the tree planes at the root)
+    for (int i = tid; i < WIN_COLS * R; i += nthreads)
+    {
+        const int back = i / R + 1, row = i - (back - 1) * R;
+        const long long gcx = col_begin - back;
+        int v = AB_NONE;
+        if (gcx >= first_column && gcx >= 0 && first_column >= 0)
+        {
+            const int r = p.root[(int) (gcx % RC) * R + row];
+            if (r >= 0)
+                v = p.t_finished[r] ? AB_DEAD : -1 - p.t_pos[r];
+        }
+        S.ring[(int) (gcx & (RING - 1)) * R + row] = (short) v;
+    }
+}
+
+// one wavefront, behind assocb_load_state (and a block barrier): union-find parents -> cluster representative = the smallest list position of the
+// set (the serial kernels that may have left this state number their trees by ids from a free ring: the root of a set is its smallest ID, which
+// need not be its oldest tree)
+template<int RPL>
+__device__ __forceinline__ void assocb_representatives(AbShared<RPL>& S, const int n_unf)
+{
+    AbTrees& T = S.T;
+    const int lane = lane_id();
+    int rep = lane < n_unf ? T.comp[lane] : 0;
+    for (int it = 0; it < 6; it++)
+    {
+        const int r2 = __shfl(rep, rep);
+        rep = r2;
+    }
+    T.remap[0][lane] = AB_TREES;
+    wave_lds_fence();
+    if (lane < n_unf)
+        atomicMin(&T.remap[0][rep], lane);
+    wave_lds_fence();
+    if (lane < n_unf)
+        T.comp[lane] = lds_ld(&T.remap[0][rep]);
+    if (lane == 0)
+    {
+        T.tbail = 0;
+        T.any_finished[0] = T.any_finished[1] = 0;
+    }
+}
+
+// what k_small_all's idle wavefronts prepared of the above, and for which state: assocb_body uses it when the prediction held
+struct AbPreloaded
+{
+    int valid;
+    long long col_begin, first_column;
+    int n_unf;
+};
+
+// (a device function: k_assocb is its kernel; k_small_all runs it behind the front half of a small call, in the same block of AB_THREADS threads.
+// Every early return is taken by the whole block.)
+template<int RPL>
+__device__ __forceinline__ void assocb_body(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, const int s, const int slot,
+                                            int* __restrict__ bail_count, AbShared<RPL>& S, const AbPreloaded pre)
 {
     constexpr int GCOLS = AB_WAVES * AB_SUB / RPL; // columns per group
 #ifdef CC_AB_STATS
     const unsigned long long ab_entry = __builtin_amdgcn_s_memtime();
     const unsigned long long ab_entry_rt = wall_clock64(); // (constant 100 MHz: what s_memtime ticks at, measured)
 #endif
-    const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const int wave = uniform_i32((int) (threadIdx.x >> 6));
     StreamState* st = &states[s];
@@ -252,15 +340,15 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
 #define CC_AB_PRIO 3
 #endif
     __builtin_amdgcn_s_setprio(CC_AB_PRIO); // latency-bound (barriers, LDS round trips): win issue arbitration against co-resident throughput kernels
-    __shared__ AbTrees T;
+    AbTrees& T = S.T;
     constexpr int RING = AB_RING / RPL; // columns of the slot ring
     static_assert(RING >= GCOLS + WIN_COLS, "slot ring");
-    __shared__ short ring[RING * WAVE * RPL];
-    __shared__ int s_nunf;
-    __shared__ long long s_gc_final;
-    __shared__ int s_serial_cols;
-    __shared__ int s_reason;
-    __shared__ unsigned long long s_cols;
+    short* const ring = S.ring;
+    int& s_nunf = S.s_nunf;
+    long long& s_gc_final = S.s_gc_final;
+    int& s_serial_cols = S.s_serial_cols;
+    int& s_reason = S.s_reason;
+    unsigned long long& s_cols = S.s_cols;
 
     const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
     long long first_unpub = st->first_unpublished, ring_start = st->ring_start;
@@ -270,62 +358,17 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
     unsigned long long alias_rounds = st->stamp_alias_rounds;
     int n_events = st->n_events;
 
-    // ---- the persistent tree state (global planes indexed by root cell) -> LDS, list position = slot ---------------------------------------
-    if ((int) threadIdx.x < n_unf)
+    // ---- the persistent tree state -> LDS, the slot ring of the columns in front of the batch (unless the caller's idle wavefronts did it) -------
+    const bool preloaded = pre.valid != 0 && pre.col_begin == col_begin && pre.first_column == first_column && pre.n_unf == n_unf;
+    if (!preloaded)
     {
-        const int i = threadIdx.x;
-        const int cell = p.ulist[i];
-        const long long tg = p.colg[cell / R];
-        T.cell[i] = cell;
-        T.gcol[i] = tg;
-        T.fin[i] = (unsigned long long) __double_as_longlong(p.t_fin[cell]);
-        T.last[i] = tg + (long long) p.t_width[cell] - 1;
-        T.pts[i] = p.t_pts[cell];
-        T.comp[i] = p.t_pos[p.t_uf[cell]];
-        T.sig[i] = i;
+        assocb_load_state<RPL>(g, p, S, col_begin, first_column, n_unf, (int) threadIdx.x, AB_THREADS);
+        __syncthreads();
+        if (wave == 0)
+            assocb_representatives<RPL>(S, n_unf);
     }
-    {
-        // slot ring of the WIN_COLS columns before col_begin: two dependent gathers per cell (root plane, then the tree planes at the root)
-        for (int i = threadIdx.x; i < WIN_COLS * R; i += AB_THREADS)
-        {
-            const int back = i / R + 1, row = i - (back - 1) * R;
-            const long long gcx = col_begin - back;
-            int v = AB_NONE;
-            if (gcx >= first_column && gcx >= 0 && first_column >= 0)
-            {
-                const int r = p.root[(int) (gcx % RC) * R + row];
-                if (r >= 0)
-                    v = p.t_finished[r] ? AB_DEAD : -1 - p.t_pos[r];
-            }
-            ring[(int) (gcx & (RING - 1)) * R + row] = (short) v;
-        }
-    }
-    __syncthreads();
-    if (wave == 0)
-    {
-        // union-find parents -> cluster representative = the smallest list position of the set (the serial kernels that may have left this
-        // state number their trees by ids from a free ring: the root of a set is its smallest ID, which need not be its oldest tree)
-        int rep = lane < n_unf ? T.comp[lane] : 0;
-        for (int it = 0; it < 6; it++)
-        {
-            const int r2 = __shfl(rep, rep);
-            rep = r2;
-        }
-        T.remap[0][lane] = AB_TREES;
-        wave_lds_fence();
-        if (lane < n_unf)
-            atomicMin(&T.remap[0][rep], lane);
-        wave_lds_fence();
-        if (lane < n_unf)
-            T.comp[lane] = lds_ld(&T.remap[0][rep]);
-        if (lane == 0 && st->batch[slot].pub_begin < 0)
-            st->batch[slot].pub_begin = first_unpub; // first association kernel of this pass
-        if (lane == 0)
-        {
-            T.tbail = 0;
-            T.any_finished[0] = T.any_finished[1] = 0;
-        }
-    }
+    if (wave == 0 && lane == 0 && st->batch[slot].pub_begin < 0)
+        st->batch[slot].pub_begin = first_unpub; // first association kernel of this pass
     __syncthreads();
 
 #ifdef CC_AB_STATS
@@ -1224,3 +1267,12 @@ __global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg
     }
 #endif
 }
+
+template<int RPL>
+__global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+                                                       int* __restrict__ bail_count)
+{
+    __shared__ AbShared<RPL> S;
+    assocb_body<RPL>(g, cfg, P, states, first_stream + (int) blockIdx.x, slot, bail_count, S, AbPreloaded{0, 0, 0, 0});
+}
+

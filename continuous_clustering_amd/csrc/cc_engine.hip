@@ -43,6 +43,8 @@ struct cc_engine
     int* d_par_left{nullptr};  // [0] streams whose batch k_insert_par did not take completely (skip_idle_fallbacks), [1] streams whose batch still needs
                                // k_table / k_seg_pre (not closed as fused)
     bool small_front{true};    // option "small_front": a call of < 64 firings on one stream of a 64-row engine runs k_small_front (begin + ego + prep + insertion + segmentation in one launch)
+    bool small_all{true};      // option "small_all": such a call whose results are mirrored into pinned memory is ONE launch (k_small_all) instead of k_small_front + k_assocb + k_small_tail
+    bool small_direct{true};   // option "small_direct": calls of 9 .. 63 firings on one stream are ONE direct launch of k_small_all (up to 8: a captured one-node graph; 0: the general path)
     int seg_small_max{63};     // option "seg_small_max": calls of at most this many firings (64-row sensors) segment their columns with k_seg_small
     bool fuse_front{true};     // option "fuse_front": k_insert_par also does the per-cell part of the segmentation of the columns it fills
     int* h_par_left{nullptr};  // pinned
@@ -98,6 +100,7 @@ struct cc_engine
     unsigned long long* h_small_seq{nullptr}; // pinned: calls whose results k_publish has mirrored (the host spins on it)
     unsigned long long* d_small_seq{nullptr}; // device: that number + a block counter
     unsigned long long small_seq_expected{0};
+    unsigned long long small_tail_launches{0}; // small calls whose serial fall-backs the host launched behind k_small_all
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
@@ -655,6 +658,17 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             if (rcp)
                 return rcp;
             const Planes Pf = planes_with_prep(e, e->prep_buf);
+            // the whole call in one launch where the results go to pinned memory (the captured graph of cc_engine_add_firings' small calls): the
+            // serial fall-backs, needed once in a long while, are launched by the host when the kernel asks for them (add_firings_small)
+            const bool small_all = e->small_all && e->capture_mirror.state != nullptr && e->capture_mirror.tail_req != nullptr && e->assoc_batch &&
+                                   e->assoc_waves >= 2 && rpl == 1 && e->cfg.cluster_point_trees_every_nth_column == 1 && !e->debug_no_assoc_fallback;
+            if (small_all)
+            {
+                hipLaunchKernelGGL(cck::k_small_all, dim3(1), dim3(cck::AB_THREADS), cck::insert2_lds_bytes(g.num_rows), si, g, e->cfg, Pf, e->d_states, first_stream,
+                                   slot, d_xyz, d_int, d_pose, (long long) n, e->d_remaining, d_ego, e->d_bail_count, e->capture_mirror);
+                CC_HIP_CHECK(e, hipGetLastError());
+                return CC_OK;
+            }
             hipLaunchKernelGGL(cck::k_small_front, dim3(1), dim3(256), cck::insert2_lds_bytes(g.num_rows), si, g, e->cfg, Pf, e->d_states, first_stream, slot, d_xyz,
                                d_int, d_pose, (long long) n, e->d_remaining, d_ego);
             fallbacks = false;
@@ -1281,6 +1295,7 @@ int first_stream_error(cc_engine* e, int first_stream, int count)
 }
 
 constexpr int64_t SMALL_MAX = 8;   // firings per call served by the captured-graph path
+constexpr int64_t SMALL_STAGE = 63; // firings the pinned staging holds: calls of up to that many firings can be ONE direct launch of k_small_all
 constexpr int SMALL_EVENTS = 64;   // events copied back together with the state
 
 void destroy_small_graphs(cc_engine* e)
@@ -1294,11 +1309,14 @@ void destroy_small_graphs(cc_engine* e)
 // stream's scalar state and its first events. Returns -1 when the call is not eligible (the caller then takes the general path).
 int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, const uint8_t* intensity, const double* poses)
 {
-    if (!e->allow_graphs || e->timing || n > SMALL_MAX || e->g.debug_flags)
+    // the whole call as one kernel (k_small_all), launched directly: no graph to capture per call size, any n the small-call kernels take
+    const bool direct_ok = e->small_direct && e->small_all && use_small_front(e, 1, n, false) && e->assoc_batch && e->assoc_waves >= 2 &&
+                           e->cfg.cluster_point_trees_every_nth_column == 1 && !e->debug_no_assoc_fallback && n <= SMALL_STAGE;
+    if (!e->allow_graphs || e->timing || (n > SMALL_MAX && !direct_ok) || e->g.debug_flags)
         return -1;
     const int R = e->g.num_rows;
-    const size_t b_xyz = (size_t) SMALL_MAX * R * 3 * sizeof(float), b_int = (((size_t) SMALL_MAX * R) + 15) & ~(size_t) 15,
-                 b_pose = (size_t) SMALL_MAX * 12 * sizeof(double);
+    const size_t b_xyz = (size_t) SMALL_STAGE * R * 3 * sizeof(float), b_int = (((size_t) SMALL_STAGE * R) + 15) & ~(size_t) 15,
+                 b_pose = (size_t) SMALL_STAGE * 12 * sizeof(double);
     if (e->h_small && !e->d_small && alloc_plane(e, &e->d_small, b_xyz + b_int + b_pose) != CC_OK)
         return -1;
     if (!e->h_small)
@@ -1338,7 +1356,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
             lean = false;
         else
         {
-            *e->h_small_seq = 0;
+            e->h_small_seq[0] = 0;
+            e->h_small_seq[1] = 0; // (HostMirror::tail_req)
             e->small_seq_expected = 0;
         }
     }
@@ -1352,11 +1371,20 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         d_int = (const uint8_t*) zx + b_xyz;
         d_pose = (const double*) ((const unsigned char*) zx + b_xyz + b_int);
     }
+    // (a captured one-node graph starts ~3 us sooner than a direct launch — 36.9 against 39.6 us per one-firing call —, so the sizes that have a graph keep it)
+    const bool direct = lean && direct_ok && n > SMALL_MAX;
+    if (!direct && n > SMALL_MAX)
+        return -1;
     hipGraphExec_t exec = nullptr;
     for (auto& g : e->small_graphs)
         if (g.stream == stream && g.n == n && g.record == e->g.record_events)
             exec = g.exec;
-    if (!exec)
+    if (direct)
+    {
+        if (ensure_prep(e, (size_t) n * R) != CC_OK)
+            return -1;
+    }
+    else if (!exec)
     {
         if (ensure_prep(e, (size_t) n * R) != CC_OK)
             return -1;
@@ -1368,7 +1396,7 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         bool ok = true;
         if (lean)
             e->capture_mirror = cck::HostMirror{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
-                                                (unsigned long long*) zq, e->d_small_seq};
+                                                (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
         else
         {
             ok = hipMemcpyAsync(e->d_small, e->h_small, b_xyz + b_int + b_pose, hipMemcpyHostToDevice, e->stream) == hipSuccess;
@@ -1378,7 +1406,7 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         ok = ok && launch_batch(e, stream, 1, n, d_xyz, d_int, d_pose, true, 0, e->stream, e->stream, e->stream) == CC_OK;
         e->capturing = false;
         const bool mirrored = e->capture_mirror.state != nullptr;
-        e->capture_mirror = cck::HostMirror{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr};
+        e->capture_mirror = cck::HostMirror{nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
         if (!mirrored)
         {
             ok = ok && hipMemcpyAsync(e->h_small_state, e->d_states + stream, sizeof(StreamState), hipMemcpyDeviceToHost, e->stream) == hipSuccess;
@@ -1411,14 +1439,38 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     memcpy(e->h_small + b_xyz + b_int, poses, (size_t) n * 12 * sizeof(double));
     std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     const bool was_idle = e->idle;
-    CC_HIP_CHECK(e, hipGraphLaunch(exec, e->stream));
+    if (direct)
+    {
+        int rcf = flush_deferred(e);
+        if (rcf)
+            return rcf;
+        const cck::HostMirror hm{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                 (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
+        hipLaunchKernelGGL(cck::k_small_all, dim3(1), dim3(cck::AB_THREADS), cck::insert2_lds_bytes(R), e->stream, e->g, e->cfg, planes_with_prep(e, e->prep_buf),
+                           e->d_states, stream, 0, d_xyz, d_int, d_pose, (long long) n, e->d_remaining, e->d_ego[0], e->d_bail_count, hm);
+        CC_HIP_CHECK(e, hipGetLastError());
+    }
+    else
+        CC_HIP_CHECK(e, hipGraphLaunch(exec, e->stream));
     if (lean)
     {
         // the call's last kernel writes the results into pinned memory and then this counter: spinning on it returns as soon as they are
         // there (a stream synchronisation adds the driver's wake-up to every column); the stream itself is in order for whatever follows
         const unsigned long long want = ++e->small_seq_expected;
         const auto t0 = std::chrono::steady_clock::now();
-        bool seen = false;
+        bool seen = false, tail_launched = false;
+        // k_small_all left columns to the serial kernels (a stop of the batch-parallel association, a stream that continues in global memory): they,
+        // the cluster ids and the mirror are k_small_tail's, launched behind it on the same stream
+        auto tail_if_asked = [&]()
+        {
+            if (tail_launched || __atomic_load_n(e->h_small_seq + 1, __ATOMIC_ACQUIRE) != want)
+                return;
+            tail_launched = true;
+            const cck::HostMirror hm{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                     (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
+            hipLaunchKernelGGL(cck::k_small_tail<1>, dim3(1), dim3(cck::A3_THREADS), 0, e->stream, e->g, e->cfg, e->P, e->d_states, stream, 0, hm);
+            e->small_tail_launches++;
+        };
         for (unsigned spins = 0;; spins++)
         {
             if (__atomic_load_n(e->h_small_seq, __ATOMIC_ACQUIRE) >= want)
@@ -1426,12 +1478,16 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
                 seen = true;
                 break;
             }
+            tail_if_asked();
             if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
                 break; // (a first launch loading code, a stop in a debugger: let the driver wait)
         }
         if (!seen)
         {
             CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+            tail_if_asked();
+            if (tail_launched)
+                CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
             if (__atomic_load_n(e->h_small_seq, __ATOMIC_ACQUIRE) < want)
             {
                 e->error = "small call: the results were not mirrored";
@@ -1705,6 +1761,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     (void) hipFuncSetAttribute((const void*) cck::k_seg_scan, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_small_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void) hipFuncSetAttribute((const void*) cck::k_small_all, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     rc = allocate(e);
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, 2 * sizeof(int)) != hipSuccess)
@@ -2384,6 +2441,13 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->small_front = value != 0;
         e->small_graphs_stale = true;
     }
+    else if (n == "small_all")
+    {
+        e->small_all = value != 0;
+        e->small_graphs_stale = true;
+    }
+    else if (n == "small_direct")
+        e->small_direct = value != 0;
     else if (n == "seg_small_max")
     {
         e->seg_small_max = value < 0 ? 0 : (value > 63 ? 63 : (int) value);

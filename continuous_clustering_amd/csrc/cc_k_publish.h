@@ -19,6 +19,7 @@ struct HostMirror
     const int* d_remaining;
     unsigned long long* seq;   // pinned: the number of mirrored calls so far, written LAST (the host spins on it instead of synchronising the stream)
     unsigned long long* d_seq; // device: [0] that number, [1] blocks of the current launch that are through
+    unsigned long long* tail_req; // pinned (k_small_all): the number of the call whose serial fall-backs the host has to launch (k_small_tail), else 0
 };
 
 // cluster ids of the columns the batch published (cc.cpp:1035-1092: what publishing leaves in Point::id), columns by .. ny .. strided
@@ -49,6 +50,9 @@ __device__ __forceinline__ void mirror_results(const Geometry& g, const Planes& 
 {
     const int lane = lane_id();
     const StreamState* s0 = &states[s];
+    unsigned long long seq0 = 0ull; // (requested ahead of the copies: the last store of the call waits for nothing but the fence)
+    if (lane == 0)
+        seq0 = hm.d_seq[0];
     const unsigned* src = (const unsigned*) s0;
     unsigned* dst = (unsigned*) hm.state;
     for (int i = lane; i < (int) (sizeof(StreamState) / 4); i += 64)
@@ -64,7 +68,7 @@ __device__ __forceinline__ void mirror_results(const Geometry& g, const Planes& 
     if (lane == 0)
     {
         hm.d_seq[1] = 0ull;
-        const unsigned long long v = hm.d_seq[0] + 1ull;
+        const unsigned long long v = seq0 + 1ull;
         hm.d_seq[0] = v;
         __hip_atomic_store(hm.seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -105,6 +109,129 @@ __global__ __launch_bounds__(A3_THREADS) void k_small_tail(Geometry g, cc_config
         mirror_results(g, P, states, stream, hm);
 }
 
+// =====================================================================================================
+// k_small_all — a call of a few firings on ONE stream of a 64-row engine (the per-column latency path, cc_engine_add_firings with n < 64) in ONE
+// launch: what k_small_front, k_assocb and k_small_tail do in three. A kernel node of a captured graph costs ~4.5 us of dispatch on a call whose
+// kernels need 5 - 18 us each. grid = 1, block = AB_THREADS (k_assocb's block: 15 worker wavefronts + the timeline), dynamic LDS =
+// insert2_lds_bytes(num_rows).
+//   A - D  k_small_front's phases (begin, ego records, preparation: all threads; serial insertion: wavefronts 0 - 1; segmentation: wavefront 0;
+//          window scan: one wavefront per column) — everything they hand over goes through global memory, block barriers in between
+//   E      assocb_body: the batch-parallel association + finished-cluster check of the call's columns
+//   F      nothing left for the serial kernels (the normal case): cluster ids of the published columns, results into pinned host memory, the
+//          sequence number last. Otherwise (a stop of the batch-parallel kernel, a stream that continues in global memory) the call's number goes
+//          into HostMirror::tail_req and the host launches k_small_tail behind this kernel, which then does all of F.
+// =====================================================================================================
+__global__ __launch_bounds__(AB_THREADS) void k_small_all(Geometry g, cc_config cfg, Planes P, StreamState* states, int stream, int slot,
+                                                          const float* __restrict__ xyz, const uint8_t* __restrict__ inten, const double* __restrict__ poses,
+                                                          long long n, int* remaining, double* __restrict__ ego, int* __restrict__ bail_count, HostMirror hm)
+{
+    const int R = g.num_rows;
+    StreamState* st = &states[stream];
+    const int wave = uniform_i32((int) (threadIdx.x >> 6));
+    __shared__ AbShared<1> S;
+#ifdef CC_SF_STATS
+    unsigned long long sa_t[8];
+    sa_t[0] = __builtin_amdgcn_s_memtime();
+#define SA_MARK(i) sa_t[i] = __builtin_amdgcn_s_memtime();
+#else
+#define SA_MARK(i)
+#endif
+    // what the association will start from, as far as it can be known before the insertion has run: the call's first finished column is the
+    // stream's first unfinished one (insert2_body closes the batch descriptor with it); assocb_body checks the prediction
+    AbPreloaded pre;
+    pre.col_begin = st->first_unfinished;
+    pre.first_column = st->first_column;
+    pre.n_unf = st->n_unfinished;
+    pre.valid = (pre.n_unf >= 0 && pre.n_unf <= AB_TREES) ? 1 : 0;
+    if (threadIdx.x >= 256 && pre.valid)
+        assocb_load_state<1>(g, stream_ptrs(P, g, stream), S, pre.col_begin, pre.first_column, pre.n_unf, (int) threadIdx.x - 256, AB_THREADS - 256);
+    // (three wavefronts side by side: the batch begins — wavefront 2 —, the firings' ego records — wavefront 1, one lane per firing: two 3 x 4
+    // products in f64 behind a read of pinned host memory —, the points — wavefronts 0 - 3, wavefront 0 first. In one wavefront they ran one
+    // after the other: three round trips to host memory instead of one)
+    if (threadIdx.x == 128)
+    {
+        // k_begin_batch (cc_engine.hip) for this stream; a call on the host path never clears past what the host has seen
+        st->cursor = 0;
+        st->par_bad = 0x7fffffff;
+        st->par_upto = -1;
+        st->par_clear_done = -1;
+        st->pre_seg_begin = 0;
+        st->n_events = 0;
+        st->n_links = 0;
+        st->batch[slot].fused = 0;
+        st->clear_allowed = st->ring_start;
+        *remaining = 0;
+    }
+    for (long long f = (long long) threadIdx.x - 64; f >= 0 && f < n && threadIdx.x < 128; f += 64)
+        ego_record(states, stream, cfg, poses, n, n, 0, ego, 0, f);
+    for (long long i = threadIdx.x; i < n * R && threadIdx.x < 256; i += 256)
+    {
+        const PreppedPoint q = prep_point(xyz[i * 3 + 0], xyz[i * 3 + 1], xyz[i * 3 + 2], poses + (i / R) * 12, cfg.sensor_is_clockwise != 0, g.az_width);
+        P.pp_cir[i] = q.cir;
+        if (q.cir == PP_SKIP)
+            continue;
+        P.pp_x[i] = q.x;
+        P.pp_y[i] = q.y;
+        P.pp_z[i] = q.z;
+        P.pp_dist[i] = q.dist;
+        P.pp_incl[i] = q.incl;
+        P.pp_incaz[i] = q.incaz;
+    }
+    if (threadIdx.x == 0)
+    {
+        long long* w = insert2_sync_words<1>(R);
+        lds_st(w, 0ll);
+        lds_st(w + 1, 0ll);
+        lds_st(w + 2, -1ll);
+    }
+    __syncthreads();
+    SA_MARK(1)
+    if (threadIdx.x < 128)
+        insert2_body<1, true, true>(g, cfg, P, states, stream, slot, inten, n, remaining, n, 0, 0);
+    else if (wave == 4 && pre.valid)
+        assocb_representatives<1>(S, pre.n_unf);
+    __syncthreads();
+    SA_MARK(2)
+    if (threadIdx.x < 64)
+        seg_small_body(g, cfg, P, states, stream, slot, poses, n, 0, ego, n, 0);
+    __syncthreads();
+    SA_MARK(3)
+    if (g.mirror_fields)
+        scan_body<1, true>(g, cfg, P, states, stream, slot, 0, wave, AB_WAVES + 1);
+    else
+        scan_body<1, false>(g, cfg, P, states, stream, slot, 0, wave, AB_WAVES + 1);
+    __threadfence_block();
+    __syncthreads();
+    SA_MARK(4)
+    assocb_body<1>(g, cfg, P, states, stream, slot, bail_count, S, pre);
+    __threadfence_block();
+    __syncthreads();
+    SA_MARK(5)
+    // F: is anything left for the serial kernels (assoc3_stream / associate_stream take a stream under exactly these conditions)?
+    const bool left = uniform_i32((int) (st->error == 0 && st->batch[slot].seg_begin >= 0 && st->batch[slot].acp_next < st->batch[slot].seg_end)) != 0;
+    if (left)
+    {
+        if (threadIdx.x == 0)
+            __hip_atomic_store(hm.tail_req, hm.d_seq[0] + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    // (the mirror only carries the stream's state and events, final since assocb_body: wavefront 0 sends it while the others write the cluster ids,
+    // which stay in HBM and are complete when the kernel ends — whatever reads them is ordered behind it on the stream)
+    if (wave == 0)
+        mirror_results(g, P, states, stream, hm);
+    else
+        publish_body(g, P, states, stream, slot, wave - 1, AB_WAVES);
+#ifdef CC_SF_STATS
+    SA_MARK(6)
+    if (threadIdx.x == 0)
+    {
+        // (read by tools/sf_probe.py; the mirror above has gone out, so these reach the host with the NEXT call's state)
+        for (int i = 0; i < 6; i++)
+            st->dbg[i] += sa_t[i + 1] - sa_t[i];
+        st->dbg[6] += 1;
+    }
+#endif
+}
 
 // =====================================================================================================
 // k_scatter_info / k_scatter_apply — the frame scatter of the reference's harness (addColumnAndEvaluateFrameIfCompleted,

@@ -7,6 +7,8 @@ from continuous_clustering_amd import Engine, capi, synth
 cfg = capi.Config.kitti()
 st = synth.make_stream(2200 + 800, seed=5, motion=synth.Motion.translate())
 e = Engine(cfg, 64)
+for kv in filter(None, os.environ.get('CC_OPTS', '').split(',')):  # e.g. CC_OPTS=small_direct=0,small_all=0
+    e.set_option(kv.split('=')[0], int(kv.split('=')[1]))
 e.add_firings(st.xyz[:2200], st.intensity[:2200], st.poses[:2200]); e.drain_events()
 lat = []
 for k in range(2200, 3000):
