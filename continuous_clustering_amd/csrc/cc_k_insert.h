@@ -1017,6 +1017,14 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
+#ifdef CC_IP_STATS
+    // phase clocks of the block's wavefront 0 (tools/ip_probe.py): entry | clearing | 0 | B | D | end
+    unsigned long long ip_t[6];
+    ip_t[0] = __builtin_amdgcn_s_memtime();
+#define IP_MARK(i) ip_t[i] = __builtin_amdgcn_s_memtime();
+#else
+#define IP_MARK(i)
+#endif
     // FUSED SEGMENTATION (round 4): a firing of the run fills its column alone and the next firing finishes it, so the wavefront that has the
     // column's cells in registers also does the per-cell part of its ground segmentation (seg_pre_cells: what k_seg_pre would read back from
     // the ring) with the NEXT firing's pose (the job's pose, cc.cpp:291) and leaves each tile's last valid inclination step (k_table's phase 1)
@@ -1045,12 +1053,16 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     const int by = (int) blockIdx.y, nby = (int) gridDim.y;
     long long clear_done = st->clear_done;
     const long long clear_done_entry = clear_done;
-    if (clear_done >= 0 && by == 0)
+    if (clear_done >= 0)
     {
+        // (every block of the stream takes a share: the columns cleared here lie at or above clear_done_entry, the slots the run writes have their
+        // previous tenant below it — no block's cells can meet another block's clearing. One block alone needed 27 us for a rotation's columns, which
+        // the launch of 32 streams x 4 blocks then lasted longer than its other blocks)
         const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
-        for (long long c = clear_done + wave; c < clear_to; c += W)
+        const int cstep = W * nby;
+        int clc = (int) ((clear_done + wave + W * by) % RC);
+        for (long long c = clear_done + wave + W * by; c < clear_to; c += cstep, clc = clc + cstep >= RC ? clc + cstep - RC : clc + cstep)
         {
-            const int clc = (int) (c % RC);
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
@@ -1102,26 +1114,55 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     const int lc0 = (int) (prev_rear0 % RC);
     const long long pass0 = prev_rear0 / RC; // pass over the ring of the previous rearmost laser (cell_tag)
 
+    IP_MARK(1)
     // ---- 0: the column of every firing from its first valid return (prep_point's column arithmetic, nothing else of it)
-    for (int f = tid; f < nn; f += 64 * W)
+    // (one lane per firing: the lanes' loads are 768 B apart, a round trip to L2 / HBM each — the first rows of four rounds are requested together)
+    constexpr int IP_PF = 4;
+    for (int f0 = tid; f0 < nn; f0 += 64 * W * IP_PF)
     {
-        const size_t base = (fglob + (size_t) f) * R * 3;
-        int c = -1;
-        for (int row = 0; row < R; row++)
+        float hx[IP_PF], hy[IP_PF];
+#pragma unroll
+        for (int k = 0; k < IP_PF; k++)
         {
-            const float fx = xyz[base + (size_t) row * 3];
-            if (fx == fx)
+            const int f = f0 + k * 64 * W;
+            hx[k] = hy[k] = __builtin_nanf("");
+            if (f < nn)
             {
-                const float fy = xyz[base + (size_t) row * 3 + 1];
+                const size_t base = (fglob + (size_t) f) * R * 3;
+                hx[k] = xyz[base];
+                hy[k] = xyz[base + 1];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IP_PF; k++)
+        {
+            const int f = f0 + k * 64 * W;
+            if (f >= nn)
+                break;
+            const size_t base = (fglob + (size_t) f) * R * 3;
+            float fx = hx[k], fy = hy[k];
+            bool found = fx == fx;
+            for (int row = 1; row < R && !found; row++)
+            {
+                fx = xyz[base + (size_t) row * 3];
+                if (fx == fx)
+                {
+                    fy = xyz[base + (size_t) row * 3 + 1];
+                    found = true;
+                }
+            }
+            int c = -1;
+            if (found)
+            {
                 const float az = ccm::atan2f_exact(fy, fx);
                 const float inc_az = clockwise ? -az + CC_PI_F : az + CC_PI_F;
                 c = f2i_x86(inc_az / g.az_width);
-                break;
             }
+            s_c[f] = (short) ((c >= 0 && c < NC && c < 32768) ? c : -1);
         }
-        s_c[f] = (short) ((c >= 0 && c < NC && c < 32768) ? c : -1);
     }
     __syncthreads();
+    IP_MARK(2)
     // ---- B: column advance of every firing, its prefix sum over the batch, first firing that ends the run
     for (int base = 0; base < nn; base += 64 * W)
     {
@@ -1166,6 +1207,7 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     if (tid == 0)
         s_bad = upto;
     __syncthreads();
+    IP_MARK(3)
     // ---- D: the cells and the columns each firing finishes; wavefronts run independently. A wavefront's firings are latency chains
     // (load the returns -> ~300 instructions of arithmetic -> store the cells) and there are only two wavefronts per SIMD to hide
     // them, so the inputs of the wavefront's NEXT firing (returns, intensities, pose: one lane per matrix element) are loaded before
@@ -1483,7 +1525,17 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     }
     if (fuse)
         tl_flush();
+    IP_MARK(4)
     __syncthreads();
+#ifdef CC_IP_STATS
+    IP_MARK(5)
+    if (tid == 0 && by == 0)
+    {
+        for (int i = 0; i < 5; i++)
+            atomicAdd(&st->dbg[8 + i], ip_t[i + 1] - ip_t[i]);
+        atomicAdd(&st->dbg[13], 1ull);
+    }
+#endif
     if (nby > 1)
     {
         // several blocks per stream: leave the offsets and the two ends of the run for k_insert_par_fin
