@@ -2620,6 +2620,8 @@ int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* ba
             for (int i = 0; i < 8; i++)
                 bail_reasons[i] += s.batch_bail_reason[i];
     }
+    if (bail_reasons)
+        bail_reasons[7] = e->small_tail_launches; // (not a reason: small calls whose serial fall-backs the host launched behind k_small_all)
     if (batch_columns)
         *batch_columns = a;
     if (batch_bails)

@@ -219,6 +219,21 @@ def test_vegetation_stays_exact_on_and_off_the_fast_path(name, reason, oracle_li
             assert bc["bail_reasons"][1] > 0 and bc["batch_columns"] > 0, bc
 
 
+def test_small_calls_ask_the_host_for_the_serial_kernel(oracle_lib):
+    """Calls of a few firings are ONE launch (k_small_all); when the batch-parallel association in it has to stop (here: the refused attaches of
+    x_s64_refused_attach, cc.cpp:654-659) the kernel says so through pinned memory and the host launches the serial fall-back kernel behind it.
+    One- to three-firing calls over the whole stream: equal to the oracle, the request was made, and with small_all = 0 (three launches per call)
+    the same results without it."""
+    stream, cfg, tf = cases.build_case("x_s64_refused_attach")
+    box = {}
+    for small_all in (1, 0):
+        summary = util.run_and_compare(stream, cfg, chunks=[1, 3, 2, 17, 40], robot_tf=tf,
+                                       engine_setup=lambda e: (e.set_option("small_all", small_all), box.__setitem__("e", e)))
+        why = box["e"].batch_counters()["bail_reasons"]
+        assert summary["engine_state"]["error_b"] > 0, "the exact serial replay of the refused attaches was expected"
+        assert (why[7] > 0) == bool(small_all), why
+
+
 @pytest.mark.parametrize("first_call", [132, 236, 496])
 def test_attach_to_a_tree_finished_in_an_earlier_launch(first_call, oracle_lib):
     """cc.cpp:654-659 across launches: in x_s64_refused_attach the second post of a pair joins (by 3-D distance) the first post's tree one column
