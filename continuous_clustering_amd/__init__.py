@@ -93,6 +93,7 @@ def load_library():
     L.cc_engine_kernel_times.argtypes = [vp, C.POINTER(C.c_double * 7), C.POINTER(C.c_uint64)]
     L.cc_engine_totals.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.cc_engine_batch_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 2 + [C.POINTER(C.c_uint64 * 8)]
+    L.cc_engine_gate_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 2
     L.cc_engine_last_error.argtypes = [vp]
     L.cc_engine_last_error.restype = C.c_char_p
     _lib = L
@@ -258,6 +259,11 @@ class Engine:
         why = (C.c_uint64 * 8)()
         self._check(self.L.cc_engine_batch_counters(self.h, *[C.byref(x) for x in v], C.byref(why)))
         return {"batch_columns": v[0].value, "batch_bails": v[1].value, "bail_reasons": list(why)}
+
+    def gate_counters(self) -> dict:
+        v = [C.c_uint64(0) for _ in range(2)]
+        self._check(self.L.cc_engine_gate_counters(self.h, *[C.byref(x) for x in v]))
+        return {"lazy_batches": v[0].value, "lazy_redone": v[1].value}
 
     def output_planes(self, stream: int = 0):
         g, i = C.c_void_p(), C.c_void_p()

@@ -117,7 +117,18 @@ struct cc_engine
     bool assoc_waves_auto{true};        // ... 0 (default): k_assoc3, links wavefront while a launch has at most 256 streams
     bool assoc_pending[4]{false, false, false, false};
     std::vector<void*> allocations;
-    std::function<int()> deferred_tail;                 // the chains of the last batch behind its insertion, not launched yet (launch_batch)
+    // the chains of the last batch behind its insertion, not launched yet (launch_batch). With the lazy gate the closure first WAITS for that
+    // insertion and reads its counters; `redo` (may be null) launches the next batch's insertion again when those counters say that the one
+    // enqueued ahead of them was turned into a no-op
+    std::function<int(const std::function<int()>*)> deferred_tail;
+    int lazy_gate_max_streams{40};                       // option "lazy_gate": launches of at most this many streams (0: never) also enqueue the NEXT batch's insertion before they read this
+                                                         // one's counters (32 streams + 6 %; at 64 the chains behind the gate start later than they should: - 2 %)
+    bool lazy_ok{true};                                  // (switched off for an engine whose streams keep needing the other insertion kernels)
+    bool lazy_pending{false};                            // deferred_tail is such a closure: its batch's counters have not been read yet
+    const int* lazy_prev_left{nullptr};                  // ... and this is where they are (device)
+    int lazy_miss{0};
+    uint64_t lazy_batches{0}, lazy_redone{0};            // cc_engine_gate_counters: insertions enqueued ahead of the previous batch's counters / launched a second time
+    hipEvent_t ev_gate[4]{};
     int defer_tail_max_streams{96};                      // option "defer_tail_max_streams": launches of at most this many streams defer them (0: never)
     bool streams_pooled{false};                          // the seven streams come from (and return to) the process-wide set cache
     bool slab_planning{false};                           // alloc_plane only records (field, offset): allocate() makes ONE hipMalloc of the total
@@ -299,7 +310,7 @@ int allocate(cc_engine* e)
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
         return rc;
-    if ((rc = alloc_plane(e, &e->d_par_left, 2)) != 0)
+    if ((rc = alloc_plane(e, &e->d_par_left, 8)) != 0)
         return rc;
     if ((rc = alloc_plane(e, &e->d_bail_count, 1)) != 0)
         return rc;
@@ -319,7 +330,7 @@ int allocate(cc_engine* e)
     (void) slab;
     // (counters the kernels only ever add to: recycled device memory is not zero)
     CC_HIP_CHECK(e, hipMemset(e->d_bail_count, 0, sizeof(int)));
-    CC_HIP_CHECK(e, hipMemset(e->d_par_left, 0, 2 * sizeof(int)));
+    CC_HIP_CHECK(e, hipMemset(e->d_par_left, 0, 8 * sizeof(int)));
     CC_HIP_CHECK(e, hipMemset(e->d_remaining, 0, sizeof(int)));
     return CC_OK;
 }
@@ -445,19 +456,81 @@ int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const do
 // calls of a few firings on ONE stream outside the pipeline (cc_engine_add_firings: the per-column latency path) run everything in front of the window
 // scan in one kernel
 // Launch what launch_batch held back (below). Called before anything waits for, reads or re-orders the engine's streams.
-static int flush_deferred(cc_engine* e)
+static int flush_deferred(cc_engine* e, const std::function<int()>* redo = nullptr)
 {
     if (!e->deferred_tail)
         return CC_OK;
-    std::function<int()> f = std::move(e->deferred_tail);
+    std::function<int(const std::function<int()>*)> f = std::move(e->deferred_tail);
     e->deferred_tail = nullptr;
-    return f();
+    e->lazy_pending = false;
+    return f(redo);
+}
+
+// The lazy gate (few streams: the insertion chain is what a step waits for, and between two of its kernels the GPU idled for as long as the host
+// needs to notice the end of one and launch the next — 50 - 65 us of a 410 us step at 32 streams): a call enqueues its insertion and returns; the
+// NEXT call enqueues ITS insertion first and only then waits for the previous one's counters and launches the chains behind it. The kernels of the
+// insertion enqueued ahead read those counters themselves and do nothing if the previous batch is not complete (cc_k_insert.h: prev_left); the host
+// then launches what the previous batch still needs and the insertion again. Same conditions as the deferred tail, which it extends.
+static bool lazy_eligible(const cc_engine* e, int count, int64_t n, bool pipeline, bool prepared)
+{
+    const int rpl = (e->g.num_rows + WAVE - 1) / WAVE;
+    return pipeline && !prepared && count <= e->lazy_gate_max_streams && e->lazy_ok && e->parallel_insert && n >= 64 && n <= cck::IP_MAXF && rpl == 1 && e->fuse_front &&
+           e->skip_idle_fallbacks && !e->capturing && e->defer_tail_max_streams > 0 && count <= e->defer_tail_max_streams && !e->host_prof &&
+           !e->input_on_engine_stream && e->pipeline_depth >= 1;
 }
 
 static bool use_small_front(const cc_engine* e, int count, int64_t n, bool pipeline)
 {
     return e->small_front && !pipeline && count == 1 && n <= e->seg_small_max && n < 64 && e->g.num_rows <= WAVE;
 }
+
+// Begin a batch: zero the per-stream firing cursors and the early-stop counter; fix how far clearing may go.
+__global__ void k_begin_batch(StreamState* states, int first_stream, int count, int* remaining, int unlimited_clear, int slot,
+                              const int* __restrict__ prev_left = nullptr, int* __restrict__ gate_left = nullptr)
+{
+    if (prev_left && (prev_left[0] | prev_left[1]) != 0)
+        return; // (the lazy gate: the previous batch's insertion is not complete — this launch must not have happened, cc_k_insert.h: k_insert_par)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && gate_left)
+        gate_left[0] = gate_left[1] = 0; // (the counters k_insert_par leaves for the host's gate: zeroed here instead of by a memset node between two kernels)
+    if (i < count)
+    {
+        states[first_stream + i].cursor = 0;
+        states[first_stream + i].par_bad = 0x7fffffff;
+        states[first_stream + i].par_upto = -1;
+        states[first_stream + i].par_clear_done = -1;
+        states[first_stream + i].pre_seg_begin = 0; // (k_insert2 clears it when it closes a batch; with skip_idle_fallbacks it may not have run)
+        states[first_stream + i].n_events = 0; // every event of the previous call has been collected
+        states[first_stream + i].n_links = 0;
+        // (the descriptor slot is four batches old: whoever closes this batch as fused sets the flag again; nothing else may find it set)
+        states[first_stream + i].batch[slot].fused = 0;
+        states[first_stream + i].clear_allowed = unlimited_clear ? 0x7fffffffffffffffll : states[first_stream + i].ring_start;
+    }
+    if (i == 0)
+        *remaining = 0;
+}
+
+// what the host reads behind a batch's insertion (the gate), written into pinned memory by a kernel: three 4-byte copies through the copy
+// engine between the kernels of the insertion chain cost more than the kernels' dispatch
+__global__ void k_gate_out(const int* __restrict__ left, const int* __restrict__ bail_count, const int* __restrict__ remaining, int* __restrict__ h_left,
+                           int* __restrict__ h_bail_count, int* __restrict__ h_remaining)
+{
+    if (threadIdx.x == 0)
+    {
+        if (h_left)
+        {
+            h_left[0] = left[0];
+            h_left[1] = left[1];
+        }
+        if (h_bail_count)
+            *h_bail_count = *bail_count;
+        if (h_remaining)
+            *h_remaining = *remaining;
+        __threadfence_system();
+    }
+}
+
+int finish_batch(cc_engine* e);
 
 // One pass over a batch: insertion on `si`, table + segmentation + window scan on `sb`, association + publish on `sa`
 // (all three equal when not pipelined).
@@ -540,51 +613,107 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     Pt.tabc += (size_t) slot * (size_t) g.num_streams * (size_t) g.tab_tiles * (size_t) g.num_rows;
     // per-firing ego transforms of this batch (one buffer per descriptor slot: up to three batches are in flight)
     double* d_ego = e->d_ego[slot];
+    const bool lazy = may_defer && lazy_eligible(e, count, n, true, prep_done);
+    bool lazy_registered = false;
+    int* const gate_left = e->d_par_left + 2 * slot; // (one pair of counters per batch descriptor slot: the lazy gate reads a batch's pair while the next batch runs)
+    int* const gate_h_left = e->h_par_left + 2 * slot;
     if (par && rpl == 1) // (two rows per lane = sensors with per-laser azimuth offsets in practice: straight to k_insert_multi)
     {
         const bool fuse = gate && e->fuse_front;
-        if (fuse)
-        {
-            // the fused insertion needs the per-firing ego records: they only depend on the caller's poses
-            hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, si, (const StreamState*) e->d_states, first_stream,
-                               e->cfg, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, d_ego);
-            ego_done = true;
-        }
         const double* ego_in = fuse ? (const double*) d_ego : (const double*) nullptr;
-        if (gate)
-            CC_HIP_CHECK(e, hipMemsetAsync(e->d_par_left, 0, 2 * sizeof(int), si));
-        // few streams: the GPU is not full and the insertion chain is what a step waits for -> twice the wavefronts per block, and the firings of a
-        // stream dealt to several blocks (k_insert_par_fin then finishes the stream's state)
-        int* left = gate ? e->d_par_left : (int*) nullptr;
-        if (count <= e->insert_wide_max_streams)
+        int* left = gate ? gate_left : (int*) nullptr;
+        const long long cur_ntotal = e->cur_ntotal, cur_f0 = e->cur_f0;
+        // prev_left: the counters of the previous batch's insertion when this one is enqueued before the host has read them (lazy gate)
+        const bool gate_zeroed = gate && first_pass && si != sb && !use_small_front(e, count, n, true); // (submit's k_begin_batch zeroed the counters)
+        auto enqueue_insertion = [=](const int* prev_left, const bool with_remaining) -> int
         {
-            // (round 4: with the segmentation fused in, a block of 8 wavefronts needs ~1.1 ms per 2200 firings by itself: up to 160 streams the
-            // GPU has room for twice the wavefronts — 128 streams 11.3 -> 15.0 G points/s — above that it is full and they only get in each other's way)
-            const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : (count <= 96 ? 2 : 1));
-            hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
-                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, ego_in);
-            if (nb > 1)
-                hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
-                                   (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, fuse ? 1 : 0);
-        }
-        else if (e->insert_narrow_blocks > 0)
+            if (fuse)
+            {
+                // the fused insertion needs the per-firing ego records: they only depend on the caller's poses
+                hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, si, (const StreamState*) e->d_states, first_stream,
+                                   e->cfg, d_pose, (long long) n, cur_ntotal, cur_f0, d_ego);
+            }
+            if (gate && !gate_zeroed)
+                CC_HIP_CHECK(e, hipMemsetAsync(left, 0, 2 * sizeof(int), si));
+            // few streams: the GPU is not full and the insertion chain is what a step waits for -> twice the wavefronts per block, and the firings of a
+            // stream dealt to several blocks (k_insert_par_fin then finishes the stream's state)
+            if (count <= e->insert_wide_max_streams)
+            {
+                // (round 4: with the segmentation fused in, a block of 8 wavefronts needs ~1.1 ms per 2200 firings by itself: up to 160 streams the
+                // GPU has room for twice the wavefronts — 128 streams 11.3 -> 15.0 G points/s — above that it is full and they only get in each other's way)
+                const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : (count <= 96 ? 2 : 1));
+                hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
+                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
+                if (nb > 1)
+                    hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
+                                       cur_ntotal, cur_f0, slot, left, fuse ? 1 : 0, prev_left);
+            }
+            else if (e->insert_narrow_blocks > 0)
+            {
+                // (experiment: small blocks find room on a busy CU sooner than one block of 8 wavefronts)
+                hipLaunchKernelGGL((cck::k_insert_par<1, 4>), dim3(count, e->insert_narrow_blocks), dim3(256), 0, si, g, e->cfg, Pt, e->d_states,
+                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
+                if (e->insert_narrow_blocks > 1)
+                    hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
+                                       cur_ntotal, cur_f0, slot, left, fuse ? 1 : 0, prev_left);
+            }
+            else
+                hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
+                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
+            if (gate)
+            {
+                // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic;
+                // with the lazy gate also the early-stop counter the held-back chains would have copied)
+                hipLaunchKernelGGL(k_gate_out, dim3(1), dim3(64), 0, si, (const int*) left, (const int*) e->d_bail_count, (const int*) e->d_remaining, gate_h_left,
+                                   e->h_bail_count, with_remaining ? e->h_remaining : (int*) nullptr);
+            }
+            return CC_OK;
+        };
+        if (fuse)
+            ego_done = true;
+        if (lazy)
         {
-            // (experiment: small blocks find room on a busy CU sooner than one block of 8 wavefronts)
-            hipLaunchKernelGGL((cck::k_insert_par<1, 4>), dim3(count, e->insert_narrow_blocks), dim3(256), 0, si, g, e->cfg, Pt, e->d_states,
-                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, ego_in);
-            if (e->insert_narrow_blocks > 1)
-                hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
-                                   (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, fuse ? 1 : 0);
+            // this batch's insertion goes out before the previous one's counters have been read; what the held-back chains need of the insertion
+            // stream (the early-stop counter, the event the segmentation chain waits for) and the event the NEXT call waits for follow it
+            auto enqueue_lazy = [=](const int* prev_left) -> int
+            {
+                int rci = enqueue_insertion(prev_left, true);
+                if (rci)
+                    return rci;
+                CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
+                CC_HIP_CHECK(e, hipEventRecord(e->ev_gate[slot], si));
+                return CC_OK;
+            };
+            int rcl = enqueue_lazy(e->lazy_pending ? e->lazy_prev_left : nullptr);
+            if (rcl)
+                return rcl;
+            e->lazy_batches += e->lazy_pending ? 1 : 0;
+            CC_MARK(sp); // ev1
+            CC_MARK(si); // ev2
+            // now the previous batch: its counters, the chains behind its insertion — or, if it needs the other insertion kernels, those first and
+            // then this batch's insertion once more (the one above did nothing)
+            const std::function<int()> redo = [=]() -> int
+            {
+                hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining, 1, slot,
+                                   (const int*) nullptr, gate_left);
+                return enqueue_lazy(nullptr);
+            };
+            int rcf = flush_deferred(e, &redo);
+            if (rcf)
+                return rcf;
+            e->idle = false; // (the previous batch's closure may have gone through finish_batch / sync_all: this batch's insertion is in flight)
+            fallbacks = false; // (as far as anybody knows: the closure registered below finds out)
+            need_segpre = false;
+            lazy_registered = true;
         }
         else
-            hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
-                               first_stream, d_xyz, d_int, d_pose, (long long) n, (long long) e->cur_ntotal, (long long) e->cur_f0, slot, left, ego_in);
-        if (gate)
         {
-            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, 2 * sizeof(int), hipMemcpyDeviceToHost, si));
-            // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic)
-            if (e->h_bail_count)
-                CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, si));
+            int rci = enqueue_insertion(nullptr, false);
+            if (rci)
+                return rci;
+        }
+        if (gate && !lazy)
+        {
             {
                 // (this batch's insertion is enqueued: now the chains of the previous batch that were held back)
                 int rcf = flush_deferred(e);
@@ -600,8 +729,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 e->hp_gate += std::chrono::duration<double>(hp_t1 - hp1).count();
                 hp_gated = true;
             }
-            fallbacks = e->h_par_left[0] != 0;
-            need_segpre = e->h_par_left[1] != 0;
+            fallbacks = gate_h_left[0] != 0;
+            need_segpre = gate_h_left[1] != 0;
         }
     }
     // multi-column firings (per-laser azimuth offsets) and whatever single-column head k_insert_par did not take: block-parallel as well,
@@ -639,9 +768,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     // what the held-back chains would still put on the insertion stream is put there now (time marks, the early-stop counter, the event the
     // segmentation chain waits for): the held-back part must not touch that stream, the next batch's insertion will be on it by then
-    bool pre_done = false;
+    bool pre_done = lazy_registered;
     const bool defer = may_defer && !fallbacks && !need_segpre && !e->capture_mirror.state;
-    if (defer)
+    if (defer && !lazy_registered)
     {
         CC_MARK(sp); // ev1
         CC_MARK(si); // ev2
@@ -649,8 +778,15 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
         pre_done = true;
     }
-    auto tail = [=]() mutable -> int
+    // (the three arguments: >= 0 replaces what was known when the closure was made — the lazy gate learns them later)
+    auto tail = [=](const int fb_now, const int seg_now, const int pre_now) mutable -> int
     {
+        if (fb_now >= 0)
+            fallbacks = fb_now != 0;
+        if (seg_now >= 0)
+            need_segpre = seg_now != 0;
+        if (pre_now >= 0)
+            pre_done = pre_now != 0;
         const bool small_front = first_pass && !prep_done && !par && use_small_front(e, count, n, si != sb);
         if (small_front)
         {
@@ -961,33 +1097,49 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         return CC_OK;
     };
 #undef CC_MARK
-    if (defer)
+    if (lazy_registered)
     {
-        e->deferred_tail = tail;
+        const long long my_ntotal = e->cur_ntotal, my_f0 = e->cur_f0;
+        const int my_prep_buf = e->prep_buf;
+        e->deferred_tail = [=](const std::function<int()>* redo) mutable -> int
+        {
+            CC_HIP_CHECK(e, hipEventSynchronize(e->ev_gate[slot]));
+            const bool fb = gate_h_left[0] != 0, seg = gate_h_left[1] != 0;
+            if (!fb && !seg)
+            {
+                e->lazy_miss = 0;
+                return tail(0, 0, 1);
+            }
+            // some stream's batch was not taken completely (or is not fused): the other insertion kernels / k_table and k_seg_pre, then the chains,
+            // then — a call of limit_columns — the continuation passes; all of it with this batch's buffers, not the next one's
+            if (++e->lazy_miss >= 2)
+                e->lazy_ok = false; // (streams that are not in the steady single-column shape: the plain gate from now on)
+            const long long keep_ntotal = e->cur_ntotal, keep_f0 = e->cur_f0;
+            const int keep_buf = e->prep_buf;
+            e->cur_ntotal = my_ntotal, e->cur_f0 = my_f0, e->prep_buf = my_prep_buf;
+            int rc = tail(fb ? 1 : 0, seg ? 1 : 0, 0);
+            if (!rc && hipStreamSynchronize(si) != hipSuccess)
+                rc = CC_ERR_HIP;
+            if (!rc && *e->h_remaining != 0)
+                rc = finish_batch(e);
+            e->cur_ntotal = keep_ntotal, e->cur_f0 = keep_f0, e->prep_buf = keep_buf;
+            if (!rc && redo)
+            {
+                e->lazy_redone++;
+                rc = (*redo)();
+            }
+            return rc;
+        };
+        e->lazy_pending = true;
+        e->lazy_prev_left = gate_left;
         return CC_OK;
     }
-    return tail();
-}
-
-// Begin a batch: zero the per-stream firing cursors and the early-stop counter; fix how far clearing may go.
-__global__ void k_begin_batch(StreamState* states, int first_stream, int count, int* remaining, int unlimited_clear, int slot)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count)
+    if (defer)
     {
-        states[first_stream + i].cursor = 0;
-        states[first_stream + i].par_bad = 0x7fffffff;
-        states[first_stream + i].par_upto = -1;
-        states[first_stream + i].par_clear_done = -1;
-        states[first_stream + i].pre_seg_begin = 0; // (k_insert2 clears it when it closes a batch; with skip_idle_fallbacks it may not have run)
-        states[first_stream + i].n_events = 0; // every event of the previous call has been collected
-        states[first_stream + i].n_links = 0;
-        // (the descriptor slot is four batches old: whoever closes this batch as fused sets the flag again; nothing else may find it set)
-        states[first_stream + i].batch[slot].fused = 0;
-        states[first_stream + i].clear_allowed = unlimited_clear ? 0x7fffffffffffffffll : states[first_stream + i].ring_start;
+        e->deferred_tail = [tail](const std::function<int()>*) mutable -> int { return tail(-1, -1, -1); };
+        return CC_OK;
     }
-    if (i == 0)
-        *remaining = 0;
+    return tail(-1, -1, -1);
 }
 
 __global__ void k_clear_remaining(int* remaining)
@@ -1128,7 +1280,12 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
         }
         prepared = true;
     }
-    if (e->batch_open)
+    // (the lazy gate: this call's insertion is enqueued BEFORE the previous one's counters are read — launch_batch; a call that cannot do that
+    // settles the previous batch first)
+    const bool lazy_next = lazy_eligible(e, count, n, pipeline, prepared) && e->batch_open && e->pipelined;
+    if (e->lazy_pending && !lazy_next && (rc = flush_deferred(e)))
+        return rc;
+    if (e->batch_open && !(lazy_next && e->lazy_pending))
     {
         if (pipeline && e->pipelined)
         {
@@ -1162,7 +1319,7 @@ int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_
     }
     if (!use_small_front(e, count, n, pipeline)) // (k_small_front begins the batch itself)
         hipLaunchKernelGGL(k_begin_batch, dim3((count + 255) / 256), dim3(256), 0, si, e->d_states, first_stream, count, e->d_remaining,
-                           pipeline ? 1 : 0, slot);
+                           pipeline ? 1 : 0, slot, e->lazy_pending ? e->lazy_prev_left : (const int*) nullptr, pipeline ? e->d_par_left + 2 * slot : (int*) nullptr);
     if (prepared)
     {
         CC_HIP_CHECK(e, hipEventRecord(e->ev_prep[slot], e->stream5));
@@ -1735,6 +1892,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     for (int i = 0; i < 4; i++)
     {
         (void) hipEventCreateWithFlags(&e->ev_ins[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_gate[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_seg[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_assoc[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_segscan[i], hipEventDisableTiming);
@@ -1764,7 +1922,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     (void) hipFuncSetAttribute((const void*) cck::k_small_all, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     rc = allocate(e);
-    if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, 2 * sizeof(int)) != hipSuccess)
+    if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, 8 * sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
     {
         const char* hp = std::getenv("CC_HOST_PROF");
@@ -1833,6 +1991,7 @@ void cc_engine_destroy(cc_engine* e)
     for (int i = 0; i < 4; i++)
     {
         (void) hipEventDestroy(e->ev_ins[i]);
+        (void) hipEventDestroy(e->ev_gate[i]);
         (void) hipEventDestroy(e->ev_seg[i]);
         (void) hipEventDestroy(e->ev_assoc[i]);
         (void) hipEventDestroy(e->ev_segscan[i]);
@@ -2448,6 +2607,15 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     }
     else if (n == "small_direct")
         e->small_direct = value != 0;
+    else if (n == "lazy_gate")
+    {
+        int rcf = flush_deferred(e);
+        if (rcf)
+            return rcf;
+        e->lazy_gate_max_streams = (int) std::max<int64_t>(0, std::min<int64_t>(value, 4096));
+        e->lazy_ok = true;
+        e->lazy_miss = 0;
+    }
     else if (n == "seg_small_max")
     {
         e->seg_small_max = value < 0 ? 0 : (value > 63 ? 63 : (int) value);
@@ -2596,6 +2764,17 @@ int cc_engine_scatter_apply(cc_engine* e, int stream, int64_t from, int64_t to, 
                        d_original_index, slots, d_is_ground, d_detection, (long long) max_points);
     CC_HIP_CHECK(e, hipGetLastError());
     return CC_OK; // (asynchronous on cc_engine_hip_stream(e): cc_eval_frame_device on the same stream, or cc_engine_sync, orders behind it)
+}
+
+int cc_engine_gate_counters(cc_engine* e, uint64_t* lazy_batches, uint64_t* lazy_redone)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    if (lazy_batches)
+        *lazy_batches = e->lazy_batches;
+    if (lazy_redone)
+        *lazy_redone = e->lazy_redone;
+    return CC_OK;
 }
 
 int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* batch_bails, uint64_t bail_reasons[8])

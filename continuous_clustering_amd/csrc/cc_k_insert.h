@@ -1007,8 +1007,14 @@ template<int RPL, int W = IP_WAVES>
 __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
                                                             const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
                                                             const double* __restrict__ poses, long long n, long long n_total, long long fbase,
-                                                            int slot, int* __restrict__ left_over, const double* __restrict__ ego)
+                                                            int slot, int* __restrict__ left_over, const double* __restrict__ ego,
+                                                            const int* __restrict__ prev_left = nullptr)
 {
+    // prev_left (the engine's lazy gate, cc_engine.hip): the counters the PREVIOUS batch's insertion left behind. The host enqueues this batch's
+    // insertion before it has read them; if they say that the previous batch needs the other insertion kernels (or k_table on this chain), this
+    // launch must not have happened: it leaves without a trace and the host launches it again behind those kernels.
+    if (prev_left && (prev_left[0] | prev_left[1]) != 0)
+        return;
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
     const int lane = lane_id();
@@ -1582,8 +1588,11 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
 // what lies behind the first offending firing, then the stream state, the batch descriptor and (fused segmentation) the table. grid = streams, block = 256.
 template<int RPL>
 __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, StreamState* states, int first_stream, const float* __restrict__ xyz,
-                                                        long long n, long long n_total, long long fbase, int slot, int* __restrict__ left_over, int fuse_on)
+                                                        long long n, long long n_total, long long fbase, int slot, int* __restrict__ left_over, int fuse_on,
+                                                        const int* __restrict__ prev_left = nullptr)
 {
+    if (prev_left && (prev_left[0] | prev_left[1]) != 0)
+        return; // (see k_insert_par)
     (void) xyz;
     (void) n_total;
     (void) fbase;

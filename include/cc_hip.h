@@ -293,7 +293,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * number_of_visited_neighbors, per-tree values of finished trees, the tree-link log; 0 in throughput mode), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
  * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made), "defer_tail_max_streams" (default 96: in the pipelined mode, launches of at most
  * that many streams leave the chains behind a batch's insertion gate — segmentation scan, window scan, association, publishing — to the NEXT call, which launches them behind its own insertion; every call that
- * reads results, synchronises or resets flushes them first, so results are unchanged; 0: never defer), "small_all" (1 (default): a call of fewer than 64 firings on ONE stream of a 64-row engine whose results are mirrored into pinned memory is one launch, k_small_all, instead of
+ * reads results, synchronises or resets flushes them first, so results are unchanged; 0: never defer), "lazy_gate" (default 40: launches of at most that many streams also enqueue their insertion before the host has read the PREVIOUS batch's insertion counters —
+ * the insertion kernels of consecutive batches run back to back; they check those counters on the device and return at once if the previous batch still needs the serial insertion kernels, in which case the host
+ * launches those and then this insertion again (cc_engine_gate_counters); an engine that needed that twice in a row stops doing it; 0: never), "small_all" (1 (default): a call of fewer than 64 firings on ONE stream of a 64-row engine whose results are mirrored into pinned memory is one launch, k_small_all, instead of
  * k_small_front + k_assocb + k_small_tail; the host launches the serial fall-back kernel behind it when the kernel asks for it), "small_direct" (1 (default): such calls of 9 .. 63 firings are one direct launch of k_small_all;
  * calls of up to 8 firings replay a captured one-node graph, which starts ~3 us sooner), "prewarm_small_graphs" (value k in 1..8, a one-shot action, not a setting: sizes the grow-only host / device
  * buffers of small calls and captures the hipGraphs of cc_engine_add_firings calls of 1..k firings now, without launching anything, so that the first real calls do not pay for it), "forget_inclination_table"
@@ -318,6 +320,10 @@ int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters
  * after its cluster finished, 6 a candidate from a column older than the first unpublished one (cc.cpp:762-763); bail_reasons[7] is not a
  * reason: the number of small cc_engine_add_firings calls (one launch, k_small_all) whose serial fall-back kernel the host had to launch behind it. */
 int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* batch_bails, uint64_t bail_reasons[8]);
+/* The insertion gate of the pipelined mode (option "lazy_gate"): how many batches had their insertion enqueued before the host had read the
+ * previous batch's insertion counters, and how many of those were launched a second time because the previous batch turned out to need the
+ * serial insertion kernels first (the kernels of the first launch return at once in that case). No sync. */
+int cc_engine_gate_counters(cc_engine* e, uint64_t* lazy_batches, uint64_t* lazy_redone);
 
 /* ---- label compare (src/evaluation/kitti_evaluation.cpp) ---------------------------------------------------------------- */
 /* EvaluationResultForFrame, kitti_evaluation.hpp:38-49 */

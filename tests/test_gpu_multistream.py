@@ -254,6 +254,52 @@ def test_insertion_dealt_to_several_blocks_per_stream(S, split, oracle_lib):
             util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s2), lo, mirror=False)
 
 
+@pytest.mark.parametrize("F,limit", [(700, 0), (1100, 0), (700, 300)])
+def test_insertion_enqueued_ahead_of_the_previous_gate(F, limit, oracle_lib):
+    """Few streams (option lazy_gate, default <= 40): a call enqueues its insertion BEFORE the host has read the previous batch's insertion counters; the
+    kernels check those counters themselves and return at once when the previous batch still needs the serial insertion kernels, and the host launches
+    them again behind those (cc_engine_gate_counters). Regular batches between batches with firings out of shape (so that the engine keeps enqueueing
+    ahead), one of them the last of the run, one with the emission limit reached inside the serial kernel (continuation passes between the two launches):
+    oracle's state and published columns for every stream."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    cfg = capi.Config.kitti()
+    S, NB = 5, 9
+    streams = []
+    for s in range(S):
+        st = synth.make_stream(F * NB, seed=7100 + s, motion=synth.Motion.translate())
+        xyz, inten, poses = st.xyz.copy(), st.intensity.copy(), st.poses.copy()
+        if s in (1, 3):
+            for b in ((2, 5, 8) if s == 1 else (5,)):
+                k = b * F + 100 + 37 * s
+                xyz[k + 1], inten[k + 1], poses[k + 1] = xyz[k], inten[k], poses[k]  # the same firing twice: the second lands in occupied cells
+                xyz[k + 200, ::2] = xyz[k + 201, ::2]  # returns that straddle two columns
+                xyz[k + 300] = np.nan  # an empty firing
+        streams.append(synth.Stream(xyz=xyz, intensity=inten, poses=poses, sensor=st.sensor))
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    if limit:
+        e.set_option("limit_columns", limit)
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+    assert e.sync() == 0, e.last_error()
+    gc = e.gate_counters()
+    # (with the limit every batch needs the serial kernel: after two such batches in a row the engine stops enqueueing ahead)
+    assert gc["lazy_batches"] >= (2 if limit else NB - 3) and gc["lazy_redone"] >= 2, gc
+    for s in range(S):
+        o = Oracle(cfg, 64)
+        assert o.add_firings(streams[s].xyz, streams[s].intensity, streams[s].poses) == 0
+        so, se = o.state(), e.state(s)
+        for k in util.STATE_FIELDS:
+            assert so[k] == se[k], (s, k, so[k], se[k])
+        hi = se["first_unpublished_global_column_index"] - 1
+        lo = max(hi - 1500, se["ring_buffer_start_global_column_index"])
+        util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
+    e.close()
+
+
 @pytest.mark.parametrize("rows", [16, 48, 100])
 def test_pipelined_path_at_other_row_counts(rows, oracle_lib):
     """The throughput path (events off, chains overlapped, block-parallel insertion, batch-parallel association) at row counts between the usual ones."""

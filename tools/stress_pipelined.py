@@ -21,6 +21,8 @@ for r in range(rounds):
     F = int(np.random.default_rng(seed0 + r).choice([700, 1100, 2200]))
     NB = n // F
     e = Engine(cfg, 64, S); e.record_events(False)
+    for kv in filter(None, os.environ.get("CC_STRESS_OPTS", "").split(",")):  # e.g. CC_STRESS_OPTS=lazy_gate=0
+        e.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for b in range(NB):
         xyz = torch.from_numpy(np.stack([st.xyz[b * F:(b + 1) * F] for st in streams])).cuda()
         inten = torch.from_numpy(np.stack([st.intensity[b * F:(b + 1) * F] for st in streams])).cuda()
