@@ -129,6 +129,10 @@ struct cc_engine
     int lazy_miss{0};
     uint64_t lazy_batches{0}, lazy_redone{0};            // cc_engine_gate_counters: insertions enqueued ahead of the previous batch's counters / launched a second time
     hipEvent_t ev_gate[4]{};
+    int num_cus{256};                                    // compute units of the device
+    int insert_lds_pad_kb{0};                            // option "insert_lds_pad" (experiment, default 0): launches of at most one block per compute unit ask for this much unused LDS per insertion
+                                                         // block, so that no two of them share a CU. Measured with 81 KB at 256 streams: - 3.5 % (128 rows), - 6 % (64 rows): the blocks of the
+                                                         // other chains' kernels lose the room, and the block times of k_insert_multi did not get shorter (the spread was not CU sharing)
     int defer_tail_max_streams{96};                      // option "defer_tail_max_streams": launches of at most this many streams defer them (0: never)
     bool streams_pooled{false};                          // the seven streams come from (and return to) the process-wide set cache
     bool slab_planning{false};                           // alloc_plane only records (field, offset): allocate() makes ONE hipMalloc of the total
@@ -479,6 +483,13 @@ static bool lazy_eligible(const cc_engine* e, int count, int64_t n, bool pipelin
            !e->input_on_engine_stream && e->pipeline_depth >= 1;
 }
 
+// unused dynamic LDS that keeps a second block of the same kernel off the compute unit (see insert_lds_pad_kb)
+static unsigned insert_lds_pad(const cc_engine* e, int blocks, size_t static_bytes)
+{
+    const size_t want = (size_t) e->insert_lds_pad_kb * 1024;
+    return (e->insert_lds_pad_kb > 0 && blocks <= e->num_cus && want > static_bytes) ? (unsigned) (want - static_bytes) : 0u;
+}
+
 static bool use_small_front(const cc_engine* e, int count, int64_t n, bool pipeline)
 {
     return e->small_front && !pipeline && count == 1 && n <= e->seg_small_max && n < 64 && e->g.num_rows <= WAVE;
@@ -642,7 +653,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 // (round 4: with the segmentation fused in, a block of 8 wavefronts needs ~1.1 ms per 2200 firings by itself: up to 160 streams the
                 // GPU has room for twice the wavefronts — 128 streams 11.3 -> 15.0 G points/s — above that it is full and they only get in each other's way)
                 const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : (count <= 96 ? 2 : 1));
-                hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
+                hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), insert_lds_pad(e, count * nb, 20 * 1024), si, g, e->cfg, Pt, e->d_states,
                                    first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
                 if (nb > 1)
                     hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
@@ -658,7 +669,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                                        cur_ntotal, cur_f0, slot, left, fuse ? 1 : 0, prev_left);
             }
             else
-                hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), 0, si, g, e->cfg, Pt, e->d_states,
+                hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), insert_lds_pad(e, count, 20 * 1024), si, g, e->cfg, Pt, e->d_states,
                                    first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
             if (gate)
             {
@@ -847,7 +858,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             need_segpre = false;
         // (with the fused front half k_insert_par reads and writes the running table `curtab` on the insertion chain: k_table of a batch that is not
         // fused has to run on that chain too, whatever the option says — elsewhere nothing would order it against the next batch's insertion)
-        const int table_opt = e->fuse_front ? 1 : e->table_on_insert_chain;
+        const int table_opt = (e->fuse_front && rpl == 1) ? 1 : e->table_on_insert_chain; // (above 64 rows nothing is fused: only k_table touches the running table)
         const bool table_early = si != sb && table_opt != 0;
         // (a stream of its own: the next batch's insertion does not queue behind it)
         hipStream_t st_table = (table_early && table_opt == 2 && !e->capturing) ? e->stream7 : si;
@@ -1921,6 +1932,13 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
     (void) hipFuncSetAttribute((const void*) cck::k_small_front, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_small_all, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void) hipFuncSetAttribute((const void*) cck::k_insert2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void) hipFuncSetAttribute((const void*) (cck::k_insert_par<1, cck::IP_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    (void) hipFuncSetAttribute((const void*) (cck::k_insert_par<1, 2 * cck::IP_WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            e->num_cus = prop.multiProcessorCount;
+    }
     rc = allocate(e);
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_par_left, 8 * sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
@@ -2607,6 +2625,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     }
     else if (n == "small_direct")
         e->small_direct = value != 0;
+    else if (n == "insert_lds_pad")
+        e->insert_lds_pad_kb = (int) std::max<int64_t>(0, std::min<int64_t>(value, 120));
     else if (n == "lazy_gate")
     {
         int rcf = flush_deferred(e);

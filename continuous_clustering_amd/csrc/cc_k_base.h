@@ -98,6 +98,13 @@ __device__ __forceinline__ unsigned long long wave_max_f64_bits(unsigned long lo
 #undef CC_MAXF64
     return (unsigned long long) lane63_i64(b);
 }
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it waits for every global load in flight (prefetches) and
+// for every global store to be acknowledged. For hand-offs through LDS between the wavefronts of a block; global memory is NOT ordered by it.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Single-wavefront workgroups: LDS operations of one wave execute in issue order, so ordering LDS writes before LDS reads
 // of other lanes needs neither s_barrier nor a vmcnt drain (which __syncthreads() implies and which would expose the
 // latency of every global prefetch in flight). This is a compiler barrier plus a wait for outstanding LDS operations only.

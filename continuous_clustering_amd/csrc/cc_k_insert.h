@@ -1656,6 +1656,26 @@ __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, St
 #define CC_IM_WAVES 8
 #endif
 constexpr int IM_WAVES = CC_IM_WAVES;
+// Open columns staged in LDS (round 5). A firing's returns land in up to ~60 different columns, every one of them 4 (or 1, 2) bytes into a 32-byte
+// sector of its own that is evicted from L2 half empty long before the column's other rows arrive: seven planes x one sector per cell = 7.2 GB
+// written per 256 x 1700-firing launch for 1.9 GB of cells. The planes named here are kept in a ring of IM_W column slots in LDS instead and go out
+// when the rearmost laser has passed their column — whole columns, rows as lanes, every sector complete: distance (4 bytes), intensity (1), and one byte
+// 0x80 | (firing & 127) from which the source firing (4 bytes) and the cell's ring tag (2) follow (a cell waits fewer than IM_W + IM_WAVES < 128
+// firings). -DCC_IM_STAGE_INCAZ=1 also keeps the azimuth-in-column plane there (36 KB more LDS at 128 rows).
+#ifndef CC_IM_W
+#define CC_IM_W 72
+#endif
+#ifndef CC_IM_STAGE_INCAZ
+#define CC_IM_STAGE_INCAZ 0
+#endif
+#ifndef CC_IM_STAGE_DIST
+#define CC_IM_STAGE_DIST 1
+#endif
+#ifndef CC_IM_STAGE
+#define CC_IM_STAGE 1 // (0: every plane straight to global memory, as until round 5 — for A/B builds, tools/build_variant.sh)
+#endif
+constexpr int IM_W = CC_IM_W; // >= the widest firing accepted + the columns the rearmost laser advances within a chunk + 1
+static_assert(IM_W + IM_WAVES < 128, "the staged firing index has seven bits");
 
 template<int RPL>
 __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
@@ -1665,6 +1685,9 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
 {
     // left_over (engine option skip_idle_fallbacks, launches in which this is the first insertion kernel): a stream whose whole batch is taken here
     // gets its batch descriptor here (as in k_insert_par); every other stream is counted, and the host launches k_prep + k_insert2 only if there is one
+#ifdef CC_IM_STATS
+    const unsigned long long im_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int sl = blockIdx.x;
     const int s = first_stream + sl;
     const int lane = lane_id();
@@ -1674,31 +1697,44 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, NC = g.num_columns, RC = g.ring_cols;
     constexpr int NR = 64 * RPL;
-    __shared__ int s_rear_cir[IM_WAVES]; // column-in-rotation of the firing's rearmost laser, -1 = empty firing
-    __shared__ int s_span[IM_WAVES];     // foremost - rearmost column of the firing
+    __shared__ int2 s_pair[IM_WAVES];    // x: column-in-rotation of the firing's rearmost laser, -1 = empty firing; y: foremost - rearmost column of the firing
     __shared__ int s_col[IM_WAVES][NR];  // per row: columns ahead of the firing's rearmost laser, -1 = no return
     __shared__ int s_rowmax[NR];         // per row: last column written (relative to prev_rearmost at entry), INT_MIN = none in reach
     __shared__ int s_stop;               // first firing of the chunk whose rows clash with earlier returns
     __shared__ long long s_ring_start;
+#if CC_IM_STAGE
+#if CC_IM_STAGE_DIST
+    __shared__ float s_dist[IM_W][NR];         // the open columns: distance ...
+#endif
+    __shared__ unsigned char s_fw[IM_W][NR];   // ... 0 = not written by this launch, else 0x80 | (firing of the batch & 127)
+    __shared__ unsigned char s_int[IM_W][NR];  // ... intensity
+#if CC_IM_STAGE_INCAZ
+    __shared__ float s_incaz[IM_W][NR];
+#endif
+#else
+    __shared__ unsigned char s_fw[1][4];
+#endif
 
-    const long long cursor0 = st->cursor;
+    // (the stream's state is the same in every lane: through readfirstlane the chunk walks below stay on the scalar unit)
+    const long long cursor0 = uniform_i64(st->cursor);
     if (cursor0 >= n)
     {
         if (left_over && tid == 0)
             atomicAdd(left_over, 1); // (an empty call, or a batch another kernel closed: the serial kernel writes the descriptor)
         return;
     }
-    const long long prev_rear0 = st->prev_rearmost, prev_fore0 = st->prev_foremost, first_unf0 = st->first_unfinished;
-    const long long ring_end0 = st->ring_end;
+    const long long prev_rear0 = uniform_i64(st->prev_rearmost), prev_fore0 = uniform_i64(st->prev_foremost), first_unf0 = uniform_i64(st->first_unfinished);
+    const long long ring_end0 = uniform_i64(st->ring_end);
     if (tid == 0)
         s_ring_start = __hip_atomic_load(&st->ring_start, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const long long ring_start = s_ring_start;
+    const long long ring_start = uniform_i64(s_ring_start);
     // deferred clearColumns (cc.cpp:1094-1145), spread over the wavefronts (as in k_insert_par; nothing left to do when that kernel ran)
-    long long clear_done = st->clear_done;
+    long long clear_done = uniform_i64(st->clear_done);
     if (clear_done >= 0)
     {
-        const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
+        const long long clear_allowed = uniform_i64(st->clear_allowed);
+        const long long clear_to = ring_start < clear_allowed ? ring_start : clear_allowed;
         for (long long c = clear_done + wave; c < clear_to; c += IM_WAVES)
         {
             const int clc = (int) (c % RC);
@@ -1734,6 +1770,10 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     // what the rows have written ahead of the rearmost laser so far: the last occupied column of every row in [prev_rear0, prev_fore0]
     for (int r = tid; r < NR; r += 64 * IM_WAVES)
         s_rowmax[r] = (int) 0x80000000;
+#if CC_IM_STAGE
+    for (int i = tid; i < IM_W * NR / 4; i += 64 * IM_WAVES)
+        ((unsigned*) &s_fw[0][0])[i] = 0u;
+#endif
     __syncthreads();
     {
         const int ahead = (int) (prev_fore0 - prev_rear0);
@@ -1760,7 +1800,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     const int half = NC / 2;
     const bool clockwise = cfg.sensor_is_clockwise != 0;
     const size_t fglob = (size_t) sl * (size_t) n_total + (size_t) fbase;
-    const long long seq0 = (long long) st->firings_consumed;
+    const long long seq0 = uniform_i64((long long) st->firings_consumed);
     const long long rot0 = prev_rear0 / NC;
     const int cir0 = (int) (prev_rear0 - rot0 * NC);
     const int lc0 = (int) (prev_rear0 % RC);
@@ -1793,11 +1833,70 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
             }
         }
     };
+    // the staged columns: slot base_slot holds column base_rel (relative to prev_rear0), everything behind it has been written out
+    int base_rel = 0, base_slot = 0;
+    // write out the staged columns [base_rel, upto) — one wavefront per column, rows as lanes — and free their slots; last_frel: the batch-relative
+    // index of the last firing accepted so far (the staged seven bits are completed from it)
+    auto flush_columns = [&](const int upto, const long long last_frel)
+    {
+#if CC_IM_STAGE
+        for (int c = base_rel + wave; c < upto; c += IM_WAVES)
+        {
+            int slot = base_slot + (c - base_rel);
+            slot = slot >= IM_W ? slot - IM_W : slot;
+            const unsigned lcq = (unsigned) (lc0 + c) / (unsigned) RC;
+            const int lc = (int) ((unsigned) (lc0 + c) - lcq * (unsigned) RC);
+            const uint16_t tag = cell_tag(pass0 + (long long) lcq);
+#pragma unroll
+            for (int k = 0; k < RPL; k++)
+            {
+                const int row = k * 64 + lane;
+                const unsigned fw = s_fw[slot][row];
+                if (fw)
+                {
+                    const unsigned ci = (unsigned) lc * (unsigned) R + (unsigned) row;
+                    const long long frel = last_frel - (long long) (((unsigned) last_frel - fw) & 127u);
+#if CC_IM_STAGE_DIST
+                    at32(p.dist, ci) = s_dist[slot][row];
+#endif
+                    at32(p.inten, ci) = s_int[slot][row];
+                    at32(p.src, ci) = (uint32_t) (seq0 + frel);
+                    at32(p.gtag, ci) = tag;
+#if CC_IM_STAGE_INCAZ
+                    at32(p.incaz, ci) = s_incaz[slot][row];
+#endif
+                    s_fw[slot][row] = 0;
+                }
+            }
+        }
+#endif
+        if (upto > base_rel)
+        {
+            base_slot = (base_slot + (upto - base_rel)) % IM_W;
+            base_rel = upto;
+        }
+    };
     load_firing(cursor0 + wave);
+#ifdef CC_IM_STATS
+    // phase clocks of one wavefront (tools/im_probe.py): prepare | wait 1 | walk + collision rule | wait 2 | cells | carry + wait 3
+    unsigned long long im_acc[6] = {0, 0, 0, 0, 0, 0}, im_t = __builtin_amdgcn_s_memtime(), im_chunks = 0;
+    const unsigned long long im_prologue = im_t - im_t0; // (entry, clearing, the rows' last columns)
+#define IM_MARK(i)                                                \
+    {                                                             \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        im_acc[i] += t_ - im_t;                                   \
+        im_t = t_;                                                \
+    }
+#else
+#define IM_MARK(i)
+#endif
     for (long long f0 = cursor0; f0 < n; f0 += IM_WAVES)
     {
         const long long f = f0 + wave;
         const bool mine = f < n;
+        // the columns the previous chunk's firings left behind them are complete (behind the barrier that ended that chunk; the two barriers of this
+        // chunk lie between these reads and the next writes into the freed slots)
+        flush_columns(carry_rel, f0 - cursor0 - 1);
         PreppedPoint q[RPL];
         int oc[RPL];
         float cx[RPL], cy[RPL], cz[RPL];
@@ -1810,7 +1909,9 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
             cz[k] = nx_z[k];
             cint[k] = nx_i[k];
         }
-        double T[12]; // (wave-uniform: the matrix travels in SGPRs, by scalar loads — as in k_insert_par)
+        // (wave-uniform: the matrix travels in SGPRs, by scalar loads — as in k_insert_par. Requested one chunk ahead like the returns it made the
+        // preparation 3.8 k clocks per chunk SLOWER: scalar loads return out of order, so the first wait for any other scalar load waits for it too)
+        double T[12];
         {
             const double* Tp = poses + (fglob + (size_t) (mine ? f : cursor0)) * 12;
 #pragma unroll
@@ -1871,45 +1972,71 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
             s_col[wave][k * 64 + lane] = (mine && rear_cir >= 0) ? oc[k] : -1;
         if (lane == 0)
         {
-            s_rear_cir[wave] = rear_cir;
-            s_span[wave] = span;
+            s_pair[wave] = make_int2(rear_cir, span);
             if (wave == 0)
                 s_stop = IM_WAVES;
         }
-        __syncthreads();
-        // ---- rear column of every firing of the chunk (every thread the same scalar walk), first firing that ends the run -------------
-        int my_rel = 0, my_prev_rel = 0, stop = IM_WAVES;
+        IM_MARK(0)
+        lds_barrier();
+        IM_MARK(1)
+        // Everything the chunk's hand-off arrays hold is requested at once: lane j reads firing j's (rear column, span) pair and the values travel to
+        // scalar registers by v_readlane, the earlier firings' per-row columns and the row's running maximum sit in vector registers before the first of
+        // them is used. (Round 5, tools/im_probe.py: read inside the walks — one dependent LDS round trip per firing and step — the rear-column walk
+        // cost 4.9 k clocks per chunk and the collision rule of the chunk's last wavefront another 3.9 k, of 21 k.)
+        int rcs[IM_WAVES], sps[IM_WAVES];
         {
-            int rel = carry_rel, cir = carry_cir, fmax = fore_rel;
+            const int2 pr = s_pair[lane & (IM_WAVES - 1)];
+#pragma unroll
             for (int j = 0; j < IM_WAVES; j++)
             {
-                if (f0 + j >= n)
-                {
-                    stop = stop < j ? stop : j;
-                    break;
-                }
-                // (what every thread reads here is the same for all of them: readfirstlane keeps the whole walk on the scalar unit — as vector
-                // arithmetic the three walks of a chunk were ~170 of the ~1000 vector instructions a firing costs this kernel)
-                const int rc = uniform_i32(s_rear_cir[j]), sp = uniform_i32(s_span[j]);
+                rcs[j] = __builtin_amdgcn_readlane(pr.x, j);
+                sps[j] = __builtin_amdgcn_readlane(pr.y, j);
+            }
+        }
+        int ocj[RPL][IM_WAVES - 1], rowmax_in[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            rowmax_in[k] = s_rowmax[k * 64 + lane];
+#pragma unroll
+            for (int j = 0; j < IM_WAVES - 1; j++)
+                ocj[k][j] = s_col[j][k * 64 + lane];
+        }
+        // ---- rear column of every firing of the chunk (every thread the same scalar walk), first firing that ends the run -------------
+        int my_rel = 0, my_prev_rel = 0, stop = IM_WAVES;
+        int relj[IM_WAVES]; // rear column of firing j relative to prev_rear0 (valid below `stop`)
+        {
+            int rel = carry_rel, cir = carry_cir;
+            bool open = true;
+#pragma unroll
+            for (int j = 0; j < IM_WAVES; j++)
+            {
+                const int rc = rcs[j], sp = sps[j];
                 const int diff = rc - cir;
                 const bool ok = rc >= 0 && ((diff > 0 && diff <= half) || diff < -half) && sp < half; // strictly forward, also across the wrap
                 const int delta = ok ? (diff < -half ? diff + NC : diff) : 0;
                 const int nrel = rel + delta;
                 // taken only while the batch has emitted fewer than limit_columns columns before it (k_insert2's loop head), and while the
                 // previous tenant of every ring slot it touches is known to be cleared
-                if (!ok || (prev_rear0 + rel) - first_unf0 >= g.limit_columns || prev_rear0 + nrel + sp - RC >= clear_done)
+                // ... and while all its cells lie inside the staged window (base_rel is the rear column the previous chunk ended at)
+                const bool take = open && f0 + j < n && ok && !((prev_rear0 + rel) - first_unf0 >= g.limit_columns) && !(prev_rear0 + nrel + sp - RC >= clear_done) &&
+                                  (!CC_IM_STAGE || nrel + sp - base_rel < IM_W);
+                if (open && !take)
                 {
-                    stop = stop < j ? stop : j;
-                    break;
+                    stop = j;
+                    open = false;
                 }
-                if (j == wave)
+                relj[j] = nrel;
+                if (take && j == wave)
                 {
                     my_rel = nrel;
                     my_prev_rel = rel;
                 }
-                rel = nrel;
-                cir = rc;
-                fmax = nrel + sp > fmax ? nrel + sp : fmax;
+                if (take)
+                {
+                    rel = nrel;
+                    cir = rc;
+                }
             }
         }
         // ---- per-row collision rule: this firing's cell of a row must lie ahead of everything the row has written -----------------
@@ -1919,20 +2046,15 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
-                const int row = k * 64 + lane;
                 if (oc[k] >= 0)
                 {
-                    int last = s_rowmax[row];
-                    int rel = carry_rel, cir = carry_cir;
-                    for (int j = 0; j < wave; j++) // (the rear columns of the earlier firings of the chunk, recomputed: a handful of scalar adds)
+                    int last = rowmax_in[k];
+#pragma unroll
+                    for (int j = 0; j < IM_WAVES - 1; j++) // (the earlier firings of the chunk)
                     {
-                        const int rc = uniform_i32(s_rear_cir[j]);
-                        const int diff = rc - cir;
-                        rel += diff < -half ? diff + NC : diff;
-                        cir = rc;
-                        const int o = s_col[j][row];
-                        if (o >= 0)
-                            last = rel + o > last ? rel + o : last;
+                        const int o = ocj[k][j];
+                        if (j < wave && o >= 0)
+                            last = relj[j] + o > last ? relj[j] + o : last;
                     }
                     clash |= my_rel + oc[k] <= last;
                 }
@@ -1940,7 +2062,9 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
             if (__any(clash) && lane == 0)
                 atomicMin(&s_stop, wave);
         }
-        __syncthreads();
+        IM_MARK(2)
+        lds_barrier();
+        IM_MARK(3)
         {
             const int st2 = uniform_i32(s_stop);
             stop = st2 < stop ? st2 : stop;
@@ -1959,12 +2083,30 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                     const int lc = (int) ((unsigned) (lc0 + crel) - lcq * (unsigned) RC);
                     const unsigned ci = (unsigned) lc * (unsigned) R + (unsigned) row;
                     at32(p.sc_rec, ci) = make_float4(q[k].x, q[k].y, q[k].z, q[k].incl);
+                    at32(p.incl, ci) = q[k].incl;
+#if !CC_IM_STAGE
                     at32(p.inten, ci) = cint[k];
                     at32(p.src, ci) = (uint32_t) (seq0 + (f - cursor0));
                     at32(p.dist, ci) = q[k].dist;
-                    at32(p.incl, ci) = q[k].incl;
-                    at32(p.incaz, ci) = q[k].incaz; // (the return's rotation, rot0 + (cir0 + crel) / num_columns, is that of its column)
+                    at32(p.incaz, ci) = q[k].incaz;
                     at32(p.gtag, ci) = cell_tag(pass0 + (long long) lcq);
+#else
+                    // (distance, intensity, source firing and ring tag wait in LDS until the column is complete: flush_columns)
+                    int slot = base_slot + (crel - base_rel);
+                    slot = slot >= IM_W ? slot - IM_W : slot;
+#if CC_IM_STAGE_DIST
+                    s_dist[slot][row] = q[k].dist;
+#else
+                    at32(p.dist, ci) = q[k].dist;
+#endif
+                    s_int[slot][row] = cint[k];
+                    s_fw[slot][row] = (unsigned char) (0x80u | ((unsigned) (f - cursor0) & 127u));
+#if CC_IM_STAGE_INCAZ
+                    s_incaz[slot][row] = q[k].incaz;
+#else
+                    at32(p.incaz, ci) = q[k].incaz; // (the return's rotation, rot0 + (cir0 + crel) / num_columns, is that of its column)
+#endif
+#endif
                     atomicMax(&s_rowmax[row], crel);
                 }
             }
@@ -1973,20 +2115,41 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
             for (int jj = lane; jj < cnt; jj += 64)
                 p.trig[(int) ((unsigned) (lc0 + my_prev_rel + jj) % (unsigned) RC)] = (int) f;
         }
+        IM_MARK(4)
         // ---- carry (the same walk over the accepted firings, in every thread) -------------------------------------------------------
-        for (int j = 0; j < stop; j++)
-        {
-            const int rc = uniform_i32(s_rear_cir[j]), sp = uniform_i32(s_span[j]);
-            const int diff = rc - carry_cir;
-            carry_rel += diff < -half ? diff + NC : diff;
-            carry_cir = rc;
-            fore_rel = carry_rel + sp > fore_rel ? carry_rel + sp : fore_rel;
-        }
+#pragma unroll
+        for (int j = 0; j < IM_WAVES; j++)
+            if (j < stop)
+            {
+                carry_rel = relj[j];
+                carry_cir = rcs[j];
+                fore_rel = relj[j] + sps[j] > fore_rel ? relj[j] + sps[j] : fore_rel;
+            }
         done = f0 + stop;
         if (stop < IM_WAVES)
             break;
-        __syncthreads(); // this chunk's LDS reads and s_rowmax updates are complete before the next chunk rewrites the hand-off arrays
+        lds_barrier(); // this chunk's LDS reads and s_rowmax updates are complete before the next chunk rewrites the hand-off arrays (LDS only:
+                       // __syncthreads() would also wait for the cells' stores to be acknowledged and for the next firing's loads — 2 - 4 k clocks per chunk)
+#ifdef CC_IM_STATS
+        IM_MARK(5)
+        im_chunks++;
+#endif
     }
+    __syncthreads();
+    flush_columns(base_rel + IM_W, done - cursor0 - 1); // whatever is still staged: the open columns in front of the rearmost laser
+#ifdef CC_IM_STATS
+#ifndef CC_IM_STATS_WAVE
+#define CC_IM_STATS_WAVE 0
+#endif
+    if (wave == CC_IM_STATS_WAVE && lane == 0)
+    {
+        for (int i = 0; i < 6; i++)
+            atomicAdd(&st->dbg[8 + i], im_acc[i]);
+        atomicAdd(&st->dbg[14], im_chunks);
+        atomicAdd(&st->dbg[15], im_prologue);
+        atomicAdd(&st->dbg[5], 1ull);
+    }
+#endif
     __syncthreads();
     if (tid == 0)
     {
