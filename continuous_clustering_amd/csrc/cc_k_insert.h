@@ -1805,6 +1805,12 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
     const int cir0 = (int) (prev_rear0 - rot0 * NC);
     const int lc0 = (int) (prev_rear0 % RC);
     const long long pass0 = prev_rear0 / RC; // pass over the ring of the previous rearmost laser (cell_tag)
+    // the two 64-bit limits of the walk below as columns relative to prev_rear0 (32 bits: the walk is ~50 scalar instructions per firing on the
+    // chunk's critical path): the emission limit (k_insert2's loop head: (prev_rear0 + rel) - first_unf0 >= limit_columns ends the run) and the first
+    // column whose ring slot is not known to be cleared (prev_rear0 + rel' - RC >= clear_done)
+    auto clamp_rel = [](const long long v) { return v < -0x40000000ll ? -0x40000000ll : (v > 0x40000000ll ? 0x40000000ll : v); };
+    const int lim_rel = (int) clamp_rel((long long) g.limit_columns - (prev_rear0 - first_unf0));
+    const int clr_rel = (int) clamp_rel(clear_done + (long long) RC - prev_rear0);
     // carried from chunk to chunk (every thread keeps the same values)
     int carry_rel = 0;    // rear column of the last accepted firing, relative to prev_rear0
     int carry_cir = cir0; // its column-in-rotation
@@ -2008,6 +2014,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
         {
             int rel = carry_rel, cir = carry_cir;
             bool open = true;
+            const int in_batch = n - f0 < IM_WAVES ? (int) (n - f0) : IM_WAVES;
 #pragma unroll
             for (int j = 0; j < IM_WAVES; j++)
             {
@@ -2019,8 +2026,7 @@ __global__ __launch_bounds__(64 * IM_WAVES) void k_insert_multi(Geometry g, cc_c
                 // taken only while the batch has emitted fewer than limit_columns columns before it (k_insert2's loop head), and while the
                 // previous tenant of every ring slot it touches is known to be cleared
                 // ... and while all its cells lie inside the staged window (base_rel is the rear column the previous chunk ended at)
-                const bool take = open && f0 + j < n && ok && !((prev_rear0 + rel) - first_unf0 >= g.limit_columns) && !(prev_rear0 + nrel + sp - RC >= clear_done) &&
-                                  (!CC_IM_STAGE || nrel + sp - base_rel < IM_W);
+                const bool take = open && j < in_batch && ok && rel < lim_rel && nrel + sp < clr_rel && (!CC_IM_STAGE || nrel + sp - base_rel < IM_W);
                 if (open && !take)
                 {
                     stop = j;
