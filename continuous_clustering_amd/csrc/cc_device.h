@@ -97,8 +97,8 @@ struct StreamState
     uint64_t batch_columns;       // columns associated by the batch-parallel kernel (k_assocb)
     uint64_t batch_bails;         // launches of k_assocb that handed the rest of their batch to the serial kernel
     uint64_t batch_bail_reason[8]; // ... by reason (cc_assocb.h AB_BAIL_*)
-    int64_t par_clear_done;       // k_insert_par over several blocks: what block 0 cleared up to (becomes clear_done in k_insert_par_fin: the other
-                                  // blocks must not see it change),
+    int64_t par_clear_done;       // k_insert_par over several blocks: the clearing limit the first block to arrive fixed for all of them (-1 since
+                                  // k_begin_batch; becomes clear_done in k_insert_par_fin: the other blocks must not see clear_done change),
     int32_t par_bad;              // ... the first firing whose returns left its column (INT_MAX: none; k_begin_batch resets it),
     int32_t par_upto;             // ... and the firing the run ends at by the batch-wide conditions (the same in every block)
     int64_t serial_until;         // set by k_assocb when it stops in front of a group: a LIMITED launch of the serial kernel stops there

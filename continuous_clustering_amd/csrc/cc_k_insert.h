@@ -1064,7 +1064,22 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
         // (every block of the stream takes a share: the columns cleared here lie at or above clear_done_entry, the slots the run writes have their
         // previous tenant below it — no block's cells can meet another block's clearing. One block alone needed 27 us for a rotation's columns, which
         // the launch of 32 streams x 4 blocks then lasted longer than its other blocks)
-        const long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
+        long long clear_to = ring_start < st->clear_allowed ? ring_start : st->clear_allowed;
+        if (nby > 1)
+        {
+            // the blocks of a stream start at different times and the association chain of the previous batch may be advancing ring_start meanwhile:
+            // the first block to arrive fixes the limit for all of them (StreamState::par_clear_done, -1 since k_begin_batch). With a limit of its
+            // own a block would leave its share of [its view, block 0's view) uncleared below the clear_done block 0 reports.
+            __shared__ long long s_clear_to;
+            if (tid == 0)
+            {
+                const long long want = clear_to > clear_done ? clear_to : clear_done;
+                const unsigned long long seen = atomicCAS((unsigned long long*) &st->par_clear_done, ~0ull, (unsigned long long) want);
+                s_clear_to = seen == ~0ull ? want : (long long) seen;
+            }
+            __syncthreads();
+            clear_to = s_clear_to;
+        }
         const int cstep = W * nby;
         int clc = (int) ((clear_done + wave + W * by) % RC);
         for (long long c = clear_done + wave + W * by; c < clear_to; c += cstep, clc = clc + cstep >= RC ? clc + cstep - RC : clc + cstep)
@@ -1098,7 +1113,10 @@ __global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg
     {
         if (tid == 0 && by == 0)
         {
-            st->clear_done = clear_done;
+            // (several blocks: the others may not have read clear_done yet — a block that found the new value would skip its share of the
+            // clearing; k_insert_par_fin takes it from par_clear_done)
+            if (nby == 1)
+                st->clear_done = clear_done;
             if (left_over)
             {
                 atomicAdd(left_over, 1); // the other insertion kernels have to take this stream's batch
@@ -1605,8 +1623,8 @@ __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, St
     const int upto = st->par_upto;
     if (upto <= 0)
     {
-        if (upto == 0 && tid == 0 && st->par_clear_done >= 0)
-            st->clear_done = st->par_clear_done;
+        if (tid == 0 && st->par_clear_done >= 0)
+            st->clear_done = st->par_clear_done; // (also for a stream that was not steady: its blocks shared the clearing all the same)
         return; // (not steady, or nothing taken: block 0 of k_insert_par has counted the stream as left over)
     }
     const bool fuse = fuse_on != 0 && left_over != nullptr && st->has_robot_tf != 0;
