@@ -999,34 +999,48 @@ def main():
         return
     Sx = int(xyz.shape[1])  # streams of the inputs that are resident now (S, or this rank's share of the strong split)
 
+    # The legs below are reports beside the headline (measured above). One of them failing must not take the line away from whoever reads it:
+    # the failure is printed, named in the line (`leg_errors`) and that leg's key is left out.
+    leg_errors = {}
+
+    def leg(name, fn):
+        try:
+            return fn()
+        except (Exception, SystemExit) as ex:  # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            leg_errors[name] = f"{type(ex).__name__}: {ex}"[:300]
+            return None
+
     # ---- what one GPU says about fewer streams per GPU (the strong-split regime) ----
     if not args.no_few_streams and not stub and world == 1:
-        out["few_streams"] = few_streams_report(solo, sensor, cfg, F, xyz, inten, poses, args.steps)
+        out["few_streams"] = leg("few_streams", lambda: few_streams_report(solo, sensor, cfg, F, xyz, inten, poses, args.steps))
 
     # ---- single-stream latency (BASELINE.json configs[1] shape): one firing per call through the host API --------
     if not args.no_latency and not stub:
-        out.update(single_stream_report(solo, sensor, cfg, F, xyz, inten, poses))
+        out.update(leg("single_stream", lambda: single_stream_report(solo, sensor, cfg, F, xyz, inten, poses)) or {})
 
     # ---- configs[2], second half of the metric: live streams served with small calls (throughput and latency vs firings per call) ----
     if not args.no_latency and not stub:
-        out["live_multi_stream"] = live_multi_stream(torch, cfg, sensor, xyz, inten, poses, local_rank)
+        out["live_multi_stream"] = leg("live_multi_stream", lambda: live_multi_stream(torch, cfg, sensor, xyz, inten, poses, local_rank))
 
     # ---- the headline workload fed from pinned host memory (PCIe-inclusive; never `value`) ----
     if not args.no_host_fed and not stub:
-        out["host_fed"] = host_fed_report(solo, sensor, cfg, F, xyz, inten, poses)
+        out["host_fed"] = leg("host_fed", lambda: host_fed_report(solo, sensor, cfg, F, xyz, inten, poses))
 
     # ---- streams that leave the association's fast path (vegetation), and the floor without it ----
     if not args.no_cluttered and not args.no_few_streams and not stub and world == 1:  # (--no-few-streams: the tools' "headline leg only")
-        out["cluttered"] = cluttered_report(solo, sensor, cfg, F, min(Sx, 256), args.steps, out["value"], args)
+        out["cluttered"] = leg("cluttered", lambda: cluttered_report(solo, sensor, cfg, F, min(Sx, 256), args.steps, out["value"], args))
 
     # ---- CPU baseline on this box's host cores (inputs: the bench's own streams, copied back from HBM) ------------
     # (the contract: on rank 0 at N = 1 only — a multi-GPU line carries the per-GPU figure of the N = 1 run)
     if not args.no_cpu_baseline and not stub and world == 1:
-        out["cpu_baseline"] = cpu_baseline_report(cfg, sensor, xyz, inten, poses, Sx, F, args)
+        out["cpu_baseline"] = leg("cpu_baseline", lambda: cpu_baseline_report(cfg, sensor, xyz, inten, poses, Sx, F, args))
         if s128_inputs is not None and "s128" in out:
             a2 = argparse.Namespace(**vars(args))
             a2.cpu_rotations = min(args.cpu_rotations, 10)
-            out["s128"]["cpu_baseline"] = cpu_baseline_report(capi.Config.vls128(), synth.SensorModel.s128(), *s128_inputs, Sx, 1700, a2, sweep_sizes=(1, 64))
+            out["s128"]["cpu_baseline"] = leg("s128_cpu_baseline", lambda: cpu_baseline_report(capi.Config.vls128(), synth.SensorModel.s128(), *s128_inputs, Sx, 1700, a2,
+                                                                                             sweep_sizes=(1, 64)))
     else:
         out["cpu_baseline"] = None
     del xyz, inten, poses, s128_inputs
@@ -1035,9 +1049,11 @@ def main():
 
     # ---- BASELINE.json configs[4] shape: concurrent replay of KITTI-format sequences, end to end ----
     if not args.no_latency and not stub:
-        out["replay"] = replay_report(local_rank)
+        out["replay"] = leg("replay", lambda: replay_report(local_rank))
 
     # ---- real-data acceptance (BASELINE.json configs[0] / [4]): only where SemanticKITTI is mounted ----
+    if leg_errors:
+        out["leg_errors"] = leg_errors
     out["semantic_kitti"] = sk if sk is not None else {"skipped": "no --kitti-root / $SEMANTIC_KITTI_ROOT: the dataset is not in this image"}
 
     # The driver keeps a few KB of this line: the full record (every leg's detail and the notes on how it was taken) goes to a file, the printed
@@ -1129,6 +1145,8 @@ def slim_line(o):
         line["replay"] = {k: v for k, v in rp.items() if not isinstance(v, (str, dict, list))}
     sk = o.get("semantic_kitti")
     line["semantic_kitti"] = "skipped" if isinstance(sk, dict) and "skipped" in sk else sk
+    if o.get("leg_errors"):
+        line["leg_errors"] = o["leg_errors"]  # legs beside the headline that raised (their keys are missing above)
     line["detail"] = "gpurun_out/bench_detail.json"
     # (the contract's own scalars keep their digits: the driver cross-checks value against cells and time)
     return {k: (v if not isinstance(v, (dict, list)) else _r(v)) for k, v in line.items()}
