@@ -104,6 +104,54 @@ def test_ring_wrap_pipelined_device_path(pipeline, sub_batch, F, oracle_lib):
         util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
 
 
+@pytest.mark.parametrize("sync_every_call", [0, 1])
+def test_ring_wrap_with_streams_that_leave_the_steady_shape(sync_every_call, oracle_lib):
+    """Few streams (k_insert_par deals a stream's firings to several blocks, which share the deferred clearing of the ring) of which some
+    keep leaving the steady one-column-per-firing shape (whole calls of empty firings, repeated firings): 24 rotations through the
+    10-rotation ring. A stream that is not steady still has its share of the clearing done by every block (round 5: block 0 published
+    clear_done too early and "This column is not cleared" came up one pass over the ring later)."""
+    import torch
+    from continuous_clustering_amd import Engine
+    from oracle.pyoracle import Oracle
+    cols, rot, F = 240, 24, 240
+    sen = synth.SensorModel(num_rows=64, num_columns=cols)
+    cfg = capi.Config.kitti()
+    cfg.num_columns = cols
+    S = 7
+    motions = [synth.Motion.static(), synth.Motion.translate(), synth.Motion.turn()]
+    streams = [synth.make_stream(cols * rot, seed=900 + s, sensor=sen, motion=motions[s % 3], scene=synth.SceneModel()) for s in range(S)]
+    NB = rot
+    X = [st.xyz[:NB * F].copy() for st in streams]
+    rng = np.random.default_rng(5)
+    for s in (1, 3, 4, 6):
+        for b in rng.choice(np.arange(2, NB), size=7, replace=False):
+            if (s + b) % 2:
+                X[s][b * F:(b + 1) * F] = np.nan                                         # a call of empty firings
+            else:
+                X[s][b * F + 100:b * F + 140] = X[s][b * F + 99:b * F + 100]             # one firing 41 times: the column does not advance
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    xyz = torch.from_numpy(np.stack([x.reshape(NB, F, 64, 3) for x in X], axis=1)).cuda()
+    inten = torch.from_numpy(np.stack([st.intensity[:NB * F].reshape(NB, F, 64) for st in streams], axis=1)).cuda()
+    poses = torch.from_numpy(np.stack([st.poses[:NB * F].reshape(NB, F, 12) for st in streams], axis=1)).cuda()
+    torch.cuda.synchronize()
+    for b in range(NB):
+        e.add_firings_device(F, xyz[b], inten[b], poses[b])
+        if sync_every_call:
+            assert e.sync() == 0, e.last_error()
+    assert e.sync() == 0, e.last_error()
+    for s in range(S):
+        o = Oracle(cfg, 64)
+        assert o.add_firings(X[s], streams[s].intensity[:NB * F], streams[s].poses[:NB * F]) == 0
+        so, se = o.state(), e.state(s)
+        for k in util.STATE_FIELDS:
+            assert so[k] == se[k], (s, k, so[k], se[k])
+        hi = se["first_unpublished_global_column_index"] - 1
+        lo = se["ring_buffer_start_global_column_index"]
+        assert lo > 10 * cols
+        util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
+
+
 @pytest.mark.parametrize("chunks", [[240], [1], [977]])
 def test_deliberate_ring_overrun(chunks, oracle_lib):
     """cluster_point_trees_every_nth_column larger than the ring: nothing is ever published or cleared (cc.cpp:841-842), the eleventh
