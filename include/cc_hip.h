@@ -226,7 +226,15 @@ int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz,
  *   d_poses      [num_streams][n][12]          double
  * Launches on the engine's HIP streams and returns without synchronising. The buffers must be complete when the call is made
  * (the kernels that read them run on internal streams), unless their producer was enqueued on cc_engine_hip_stream(e) AND the
- * option "input_on_engine_stream" is set: then the engine orders its reads after that work. */
+ * option "input_on_engine_stream" is set: then the engine orders its reads after that work.
+ * LIFETIME OF THE INPUTS: the call is asynchronous and so are its reads. The three buffers must stay allocated and UNCHANGED until
+ * cc_engine_sync() (or a call that implies it: cc_engine_stream_state, cc_engine_drain_events, cc_engine_read_columns ...) has returned.
+ * With the default options a call's inputs are read for the last time while the call after the next one runs (the insertion gate makes
+ * the host wait for a batch's insertion — with the lazy gate, launches of <= 40 streams, for the PREVIOUS batch's; the poses are read
+ * by the segmentation chain behind it, and firings the serial insertion kernels have to take are read one call later still), so a
+ * caller that streams batches in without synchronising keeps its buffers in a ring of >= 6 calls (the engine has 4 batch descriptor
+ * slots: the insertion of call b waits on the device for the last chain of call b - 4). Re-using a buffer earlier is a data race, not
+ * an error the engine can detect (tools/stress_pipelined.py did exactly that until round 5: "reset_required" on healthy streams). */
 int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, const uint8_t* d_intensity,
                                  const double* d_poses);
 /* Block until everything launched so far has finished. */

@@ -23,7 +23,10 @@ for r in range(rounds):
     e = Engine(cfg, 64, S); e.record_events(False)
     for kv in filter(None, os.environ.get("CC_STRESS_OPTS", "").split(",")):  # e.g. CC_STRESS_OPTS=lazy_gate=0
         e.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    alive = []  # the calls are asynchronous: a batch's buffers stay untouched until the engine has been synchronised (include/cc_hip.h)
     for b in range(NB):
+        if os.environ.get("CC_STRESS_FREE_INPUTS") != "1":
+            alive.append((xyz, inten, poses) if b else None)
         xyz = torch.from_numpy(np.stack([st.xyz[b * F:(b + 1) * F] for st in streams])).cuda()
         inten = torch.from_numpy(np.stack([st.intensity[b * F:(b + 1) * F] for st in streams])).cuda()
         poses = torch.from_numpy(np.stack([st.poses[b * F:(b + 1) * F] for st in streams])).cuda()
