@@ -1000,7 +1000,7 @@ def main():
     Sx = int(xyz.shape[1])  # streams of the inputs that are resident now (S, or this rank's share of the strong split)
 
     # The legs below are reports beside the headline (measured above). One of them failing must not take the line away from whoever reads it:
-    # the failure is printed, named in the line (`leg_errors`) and that leg's key is left out.
+    # the failure is printed, named in the line (`leg_errors`), that leg's key is left out and the process exits with 1 AFTER the line.
     leg_errors = {}
 
     def leg(name, fn):
@@ -1064,7 +1064,9 @@ def main():
             json.dump(out, fh)
     except OSError:
         pass
-    print(json.dumps(slim_line(out)))
+    print(json.dumps(slim_line(out)), flush=True)
+    if leg_errors:
+        sys.exit(1)  # (the line is out — the headline was measured — but a failed report leg is still a failed run)
 
 
 def _r(v, nd=5):
