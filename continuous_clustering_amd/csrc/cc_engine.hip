@@ -48,7 +48,7 @@ struct cc_engine
     int seg_small_max{63};     // option "seg_small_max": calls of at most this many firings (64-row sensors) segment their columns with k_seg_small
     bool fuse_front{true};     // option "fuse_front": k_insert_par also does the per-cell part of the segmentation of the columns it fills
     int* h_par_left{nullptr};  // pinned
-    int insert_split_blocks{0};      // option "insert_split_blocks": blocks per stream of k_insert_par in such launches (0 = 4 up to 40 streams, 3 up to 64, else 2; 1 = one)
+    int insert_split_blocks{0};      // option "insert_split_blocks": blocks per stream of k_insert_par in such launches (0 = 8 up to 24 streams, 6 up to 32, 4 up to 40, 3 up to 64, else 2; 1 = one)
     int insert_narrow_blocks{0};     // option "insert_narrow_blocks": above insert_wide_max_streams, blocks of 4 wavefronts, this many per stream (0 = one block of 8)
     int insert_wide_max_streams{160}; // option "insert_wide_max_streams": launches of at most this many streams run k_insert_par with 16 wavefronts
     bool skip_idle_fallbacks{true}; // option "skip_idle_fallbacks": wait for k_insert_par and launch the other insertion kernels only if needed
@@ -654,7 +654,11 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 // GPU has room for twice the wavefronts — 128 streams 11.3 -> 15.0 G points/s — above that it is full and they only get in each other's way)
                 // (blocks per stream, same-box alternations over 40 steps: 4 up to 40 streams; 3 up to 64 — 48 streams 12.3 -> 12.9 - 13.0 G points/s and 64 streams
                 // 14.0 - 14.2 -> 14.4 - 14.6 against 2 blocks, 4 blocks at 64 streams - 5 %; 2 up to 96 — at 80 streams 3 blocks are 5 - 8 % slower than 2)
-                const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks : (count <= 40 ? 4 : (count <= 64 ? 3 : (count <= 96 ? 2 : 1)));
+                // A block of 16 wavefronts wants a compute unit it does not share with a block of k_assocb (one per stream, 16 wavefronts too): blocks x streams + streams <= 256
+                // is where more blocks stop paying — 32 streams: 4 / 6 / 7 / 8 blocks 11.3 / 11.7 - 12.0 / 11.6 - 12.0 / 9.7 G points/s; 24 and 16 streams: 8 blocks + 1 .. + 3 % against 4;
+                // 40 streams: 5 blocks - 3 .. - 5 % against 4 (the rule is not exact: measured points decide)
+                const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks
+                                                          : (count <= 24 ? 8 : (count <= 32 ? 6 : (count <= 40 ? 4 : (count <= 64 ? 3 : (count <= 96 ? 2 : 1)))));
                 hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), insert_lds_pad(e, count * nb, 20 * 1024), si, g, e->cfg, Pt, e->d_states,
                                    first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
                 if (nb > 1)

@@ -297,7 +297,7 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * the association chain), "table_on_insert_chain" (1 (default): in the pipelined mode k_table runs at the end of the insertion chain instead of
  * at the head of the segmentation chain (0); 2: on a stream of its own between the two), "ego_on_insert_chain" (1: k_ego next to k_table instead of in
  * front of k_seg_pre; default 0), "fuse_front" (1 (default): k_insert_par also does the per-cell part of the ground segmentation of the columns it fills and closes batches it took completely as fused: k_table / k_seg_pre are only launched for streams that need them; 0: the unfused chain), "seg_small_max" (default 63: calls of at most that many firings on a sensor of <= 64 rows segment their columns with k_seg_small, one wavefront per stream with rows as lanes), "small_front" (1 (default): such a call on ONE stream outside the pipeline — cc_engine_add_firings — runs k_small_front / k_small_tail: a three-kernel graph without copy nodes, the results mirrored into pinned host memory), "insert_narrow_blocks" (experiment), "insert_wide_max_streams" / "insert_split_blocks" (launches of at most that many streams, default 160, run k_insert_par with 16
- * wavefronts per block and deal a stream's firings to that many blocks: 0 (default) = 4 up to 40 streams, 3 up to 64, 2 up to 96, else 1), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
+ * wavefronts per block and deal a stream's firings to that many blocks: 0 (default) = 8 up to 24 streams, 6 up to 32, 4 up to 40, 3 up to 64, 2 up to 96, else 1), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
  * number_of_visited_neighbors, per-tree values of finished trees, the tree-link log; 0 in throughput mode), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
  * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made), "defer_tail_max_streams" (default 96: in the pipelined mode, launches of at most
  * that many streams leave the chains behind a batch's insertion gate — segmentation scan, window scan, association, publishing — to the NEXT call, which launches them behind its own insertion; every call that

@@ -214,10 +214,10 @@ def test_pipelined_path_with_streams_the_batch_parallel_association_stops_at(fir
         util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
 
 
-@pytest.mark.parametrize("S,split", [(48, 0), (48, 1), (24, 3), (72, 0), (100, 0)])
+@pytest.mark.parametrize("S,split", [(48, 0), (48, 1), (24, 3), (24, 0), (30, 0), (38, 0), (72, 0), (100, 0)])
 def test_insertion_dealt_to_several_blocks_per_stream(S, split, oracle_lib):
-    """Launches of at most 96 streams run k_insert_par with 16 wavefronts per block and deal a stream's firings to several blocks (4 up to 40 streams,
-    3 up to 64, else 2; option insert_split_blocks pins the number), k_insert_par_fin closes the stream's state; above 96 streams one block of 8 wavefronts takes a
+    """Launches of at most 96 streams run k_insert_par with 16 wavefronts per block and deal a stream's firings to several blocks (8 up to 24 streams,
+    6 up to 32, 4 up to 40, 3 up to 64, else 2; option insert_split_blocks pins the number), k_insert_par_fin closes the stream's state; above 96 streams one block of 8 wavefronts takes a
     stream. Streams with firings out of shape (duplicated / empty / backwards: the run ends there and later blocks' cells are taken back) next to regular
     ones, pipelined device path: every stream ends in the oracle's state with the oracle's published columns."""
     import torch
