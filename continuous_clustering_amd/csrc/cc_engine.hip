@@ -123,6 +123,8 @@ struct cc_engine
     std::function<int(const std::function<int()>*)> deferred_tail;
     int lazy_gate_max_streams{40};                       // option "lazy_gate": launches of at most this many streams (0: never) also enqueue the NEXT batch's insertion before they read this
                                                          // one's counters (32 streams + 6 %; at 64 the chains behind the gate start later than they should: - 2 %)
+    int lazy_gate_from_streams{80};                      // option "lazy_gate_from": ... and launches of at least this many streams (0: none). Same-box alternations over 40 steps: 96 streams + 8 .. + 10 %,
+                                                         // 128 / 160 / 192 + 0 .. + 2 %, 256 + 2 .. + 5 %, 384 + 2 .. + 4 %; 48 streams - 1 %, 64 streams +- 0 (and - 2 % before the round's last changes)
     bool lazy_ok{true};                                  // (switched off for an engine whose streams keep needing the other insertion kernels)
     bool lazy_pending{false};                            // deferred_tail is such a closure: its batch's counters have not been read yet
     const int* lazy_prev_left{nullptr};                  // ... and this is where they are (device)
@@ -475,11 +477,16 @@ static int flush_deferred(cc_engine* e, const std::function<int()>* redo = nullp
 // NEXT call enqueues ITS insertion first and only then waits for the previous one's counters and launches the chains behind it. The kernels of the
 // insertion enqueued ahead read those counters themselves and do nothing if the previous batch is not complete (cc_k_insert.h: prev_left); the host
 // then launches what the previous batch still needs and the insertion again. Same conditions as the deferred tail, which it extends.
+static bool lazy_many_streams(const cc_engine* e, int count)
+{
+    return e->lazy_gate_from_streams > 0 && count >= e->lazy_gate_from_streams;
+}
+
 static bool lazy_eligible(const cc_engine* e, int count, int64_t n, bool pipeline, bool prepared)
 {
     const int rpl = (e->g.num_rows + WAVE - 1) / WAVE;
-    return pipeline && !prepared && count <= e->lazy_gate_max_streams && e->lazy_ok && e->parallel_insert && n >= 64 && n <= cck::IP_MAXF && rpl == 1 && e->fuse_front &&
-           e->skip_idle_fallbacks && !e->capturing && e->defer_tail_max_streams > 0 && count <= e->defer_tail_max_streams && !e->host_prof &&
+    return pipeline && !prepared && (count <= e->lazy_gate_max_streams || lazy_many_streams(e, count)) && e->lazy_ok && e->parallel_insert && n >= 64 && n <= cck::IP_MAXF && rpl == 1 && e->fuse_front &&
+           e->skip_idle_fallbacks && !e->capturing && e->defer_tail_max_streams > 0 && (count <= e->defer_tail_max_streams || lazy_many_streams(e, count)) && !e->host_prof &&
            !e->input_on_engine_stream && e->pipeline_depth >= 1;
 }
 
@@ -609,7 +616,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     // batch that needs nothing more on the insertion stream are held back and launched by the NEXT call, after that call has enqueued its own
     // insertion and before it waits at its gate: the insertion kernels run back to back and the launches hide behind them. Anything that waits
     // for or reads results launches the held-back chains first (flush_deferred in sync_all).
-    const bool may_defer = gate && first_pass && si != sb && si != sa && e->defer_tail_max_streams > 0 && count <= e->defer_tail_max_streams;
+    // (launches of many streams only defer together with the lazy gate: that pair is what was measured there)
+    const bool may_defer = gate && first_pass && si != sb && si != sa && e->defer_tail_max_streams > 0 &&
+                           (count <= e->defer_tail_max_streams || (lazy_many_streams(e, count) && lazy_eligible(e, count, n, true, prep_done)));
     if (!gate)
     {
         int rcf = flush_deferred(e);
@@ -2639,6 +2648,15 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         if (rcf)
             return rcf;
         e->lazy_gate_max_streams = (int) std::max<int64_t>(0, std::min<int64_t>(value, 4096));
+        e->lazy_ok = true;
+        e->lazy_miss = 0;
+    }
+    else if (n == "lazy_gate_from")
+    {
+        int rcf = flush_deferred(e);
+        if (rcf)
+            return rcf;
+        e->lazy_gate_from_streams = (int) std::max<int64_t>(0, std::min<int64_t>(value, 1 << 20));
         e->lazy_ok = true;
         e->lazy_miss = 0;
     }

@@ -230,7 +230,7 @@ int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz,
  * LIFETIME OF THE INPUTS: the call is asynchronous and so are its reads. The three buffers must stay allocated and UNCHANGED until
  * cc_engine_sync() (or a call that implies it: cc_engine_stream_state, cc_engine_drain_events, cc_engine_read_columns ...) has returned.
  * With the default options a call's inputs are read for the last time while the call after the next one runs (the insertion gate makes
- * the host wait for a batch's insertion — with the lazy gate, launches of <= 40 streams, for the PREVIOUS batch's; the poses are read
+ * the host wait for a batch's insertion — with the lazy gate, launches of <= 40 or >= 80 streams of <= 64 rows, for the PREVIOUS batch's; the poses are read
  * by the segmentation chain behind it, and firings the serial insertion kernels have to take are read one call later still), so a
  * caller that streams batches in without synchronising keeps its buffers in a ring of >= 6 calls (the engine has 4 batch descriptor
  * slots: the insertion of call b waits on the device for the last chain of call b - 4). Re-using a buffer earlier is a data race, not
@@ -303,7 +303,7 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  * that many streams leave the chains behind a batch's insertion gate — segmentation scan, window scan, association, publishing — to the NEXT call, which launches them behind its own insertion; every call that
  * reads results, synchronises or resets flushes them first, so results are unchanged; 0: never defer), "lazy_gate" (default 40: launches of at most that many streams also enqueue their insertion before the host has read the PREVIOUS batch's insertion counters —
  * the insertion kernels of consecutive batches run back to back; they check those counters on the device and return at once if the previous batch still needs the serial insertion kernels, in which case the host
- * launches those and then this insertion again (cc_engine_gate_counters); an engine that needed that twice in a row stops doing it; 0: never), "small_all" (1 (default): a call of fewer than 64 firings on ONE stream of a 64-row engine whose results are mirrored into pinned memory is one launch, k_small_all, instead of
+ * launches those and then this insertion again (cc_engine_gate_counters); an engine that needed that twice in a row stops doing it; 0: never), "lazy_gate_from" (default 80: ... and launches of at least that many streams, together with the deferred tail; 0: none. Measured: 96 streams + 8 .. + 10 %, 256 + 2 .. + 5 %, nothing between 41 and 79), "small_all" (1 (default): a call of fewer than 64 firings on ONE stream of a 64-row engine whose results are mirrored into pinned memory is one launch, k_small_all, instead of
  * k_small_front + k_assocb + k_small_tail; the host launches the serial fall-back kernel behind it when the kernel asks for it), "small_direct" (1 (default): such calls of 9 .. 63 firings are one direct launch of k_small_all;
  * calls of up to 8 firings replay a captured one-node graph, which starts ~3 us sooner), "prewarm_small_graphs" (value k in 1..8, a one-shot action, not a setting: sizes the grow-only host / device
  * buffers of small calls and captures the hipGraphs of cc_engine_add_firings calls of 1..k firings now, without launching anything, so that the first real calls do not pay for it), "forget_inclination_table"
