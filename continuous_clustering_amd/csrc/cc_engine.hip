@@ -124,7 +124,7 @@ struct cc_engine
     int lazy_gate_max_streams{40};                       // option "lazy_gate": launches of at most this many streams (0: never) also enqueue the NEXT batch's insertion before they read this
                                                          // one's counters (32 streams + 6 %; at 64 the chains behind the gate start later than they should: - 2 %)
     int lazy_gate_from_streams{80};                      // option "lazy_gate_from": ... and launches of at least this many streams (0: none). Same-box alternations over 40 steps: 96 streams + 8 .. + 10 %,
-                                                         // 128 / 160 / 192 + 0 .. + 2 %, 256 + 2 .. + 5 %, 384 + 2 .. + 4 %; 48 streams - 1 %, 64 streams +- 0 (and - 2 % before the round's last changes)
+                                                         // 128 / 160 / 192 + 0 .. + 2 %, 256 + 2 .. + 5 % (20 steps from an empty pipeline: + 0.5 .. + 0.9 %), 384 + 2 .. + 4 %; 48 streams - 1 %, 64 streams +- 0 (and - 2 % before the round's last changes)
     bool lazy_ok{true};                                  // (switched off for an engine whose streams keep needing the other insertion kernels)
     bool lazy_pending{false};                            // deferred_tail is such a closure: its batch's counters have not been read yet
     const int* lazy_prev_left{nullptr};                  // ... and this is where they are (device)
