@@ -17,6 +17,11 @@
 
 #include "cc_kernels.h"
 
+// launches of at most this many streams run k_assoc3 with its links wavefront when the number of association wavefronts is automatic
+#ifndef CC_LWAVE_MAX_STREAMS
+#define CC_LWAVE_MAX_STREAMS 256
+#endif
+
 using namespace ccd;
 
 struct cc_engine
@@ -129,6 +134,7 @@ struct cc_engine
     bool lazy_pending{false};                            // deferred_tail is such a closure: its batch's counters have not been read yet
     const int* lazy_prev_left{nullptr};                  // ... and this is where they are (device)
     int lazy_miss{0};
+    int lazy_clean{0};                                   // batches in the steady shape seen by the plain gate since lazy_ok went off (eight re-arm it)
     uint64_t lazy_batches{0}, lazy_redone{0};            // cc_engine_gate_counters: insertions enqueued ahead of the previous batch's counters / launched a second time
     hipEvent_t ev_gate[4]{};
     int num_cus{256};                                    // compute units of the device
@@ -393,6 +399,14 @@ int reset_state(cc_engine* e, bool keep_table)
     e->batch_open = false;
     for (bool& b : e->assoc_pending)
         b = false;
+    // the lazy gate starts afresh with every epoch: a stream's first batches are never in the steady shape, and an engine reused for
+    // another sequence must not inherit "two misses in a row" from the previous one (throughput would depend on history)
+    e->deferred_tail = nullptr;
+    e->lazy_pending = false;
+    e->lazy_prev_left = nullptr;
+    e->lazy_miss = 0;
+    e->lazy_clean = 0;
+    e->lazy_ok = true;
     return CC_OK;
 }
 
@@ -757,6 +771,14 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             }
             fallbacks = gate_h_left[0] != 0;
             need_segpre = gate_h_left[1] != 0;
+            // an engine that lost the lazy gate (two misses in a row: start-up, sub-rotation batches) gets it back after eight batches in the
+            // steady shape; one more miss then switches it off again at once
+            if (!e->lazy_ok)
+            {
+                e->lazy_clean = (fallbacks || need_segpre) ? 0 : e->lazy_clean + 1;
+                if (e->lazy_clean >= 8)
+                    e->lazy_ok = true, e->lazy_miss = 1, e->lazy_clean = 0;
+            }
         }
     }
     // multi-column firings (per-laser azimuth offsets) and whatever single-column head k_insert_par did not take: block-parallel as well,
@@ -1039,9 +1061,6 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         {
             // with or without the links wave (cc_assoc3.h: A3_THREADS): by default (assoc_waves = 0) with it while the streams are few
             // enough for the association chain to be what the step waits for
-            #ifndef CC_LWAVE_MAX_STREAMS
-    #define CC_LWAVE_MAX_STREAMS 256
-    #endif
             const bool lwave = e->assoc_waves == 4 || (e->assoc_waves_auto && count <= CC_LWAVE_MAX_STREAMS);
             const dim3 block(lwave ? cck::A3_THREADS : 192);
             const int rounds = batch_assoc ? (e->assoc_rounds > 0 ? e->assoc_rounds : adaptive_rounds) : 1;
@@ -2017,6 +2036,8 @@ void cc_engine_destroy(cc_engine* e)
     (void) hipStreamSynchronize(e->stream6);
     (void) hipStreamSynchronize(e->stream7);
     (void) hipStreamSynchronize(e->stream5);
+    e->deferred_tail = nullptr; // (chains a pipelined call left to "the next call": there is none)
+    e->lazy_pending = false;
     destroy_small_graphs(e);
     free_all(e); // also the pinned small-call staging
     if (e->h_view)
@@ -2092,6 +2113,12 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     if (rc)
         return rc;
     (void) hipSetDevice(e->device);
+    // A pipelined call may have left the chains behind its insertion to the next call (deferred tail / lazy gate): that closure holds the OLD
+    // geometry, plane pointers and batch slot by value. Launch it now, against the state it belongs to, so that nothing of the old epoch
+    // survives the reset (it would run on freed planes after a change of shape and mark a slot of the new epoch as pending).
+    rc = flush_deferred(e);
+    if (rc)
+        return rc;
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
@@ -2100,6 +2127,7 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream6));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream7));
     e->batch_open = false;
+    e->idle = true;
     const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
     if (!same_shape)
     {

@@ -43,6 +43,7 @@ void ContinuousClustering::startWorker()
     if (worker_.joinable())
         return;
     stop_ = false;
+    busy_ = true; // (until the worker's warm-up call on the engine has returned: workerLoop)
     worker_ = std::thread([this] { workerLoop(); });
 }
 
@@ -94,9 +95,16 @@ void ContinuousClustering::workerLoop()
     std::vector<QueuedFiring> take;
     trace_ = getenv("CC_ASYNC_TRACE") != nullptr;
     trace_t0_ = std::chrono::steady_clock::now();
-    // the first HIP call of a host thread sets the thread up with the runtime (milliseconds): here, not in front of the first firing
+    // the first HIP call of a host thread sets the thread up with the runtime (milliseconds): here, not in front of the first firing.
+    // busy_ is set by startWorker() before the thread exists and cleared here: a caller that goes through waitIdle() right behind reset()
+    // (setTransformRobotFrameFromSensorFrame) waits for this call instead of racing with it on the engine, which is not thread-safe.
     if (engine_)
         (void) cc_engine_sync(engine_);
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        busy_ = false;
+    }
+    cv_idle_.notify_all();
     while (true)
     {
         take.clear();
@@ -281,7 +289,6 @@ void ContinuousClustering::reset(int num_rows)
         check(cc_engine_reset(engine_, num_rows));
     }
     check(cc_engine_record_events(engine_, 1));
-    (void) cc_engine_set_option(engine_, "prewarm_small_graphs", 1); // (the graphs of calls of 1 .. 8 firings: built here, not in front of live data)
     if (!config_.general.is_single_threaded && created)
     {
         // Asynchronous mode = a live sensor behind the front-end: everything a call pays only the first time (the first launch of every captured
@@ -292,6 +299,9 @@ void ContinuousClustering::reset(int num_rows)
         check(cc_engine_set_option(engine_, "forget_inclination_table", 1)); // (what reset keeps across calls, cc.cpp:46, must not keep the made-up data's)
         check(cc_engine_record_events(engine_, 1));
     }
+    // the graphs of calls of 1 .. 8 firings: built here, not in front of live data — and LAST: cc_engine_reset, cc_engine_record_events and every
+    // cc_engine_set_option drop captured graphs (they bake configuration, geometry and plane pointers)
+    (void) cc_engine_set_option(engine_, "prewarm_small_graphs", 1);
     range_image_.assign(static_cast<size_t>(ring_buffer_max_columns) * num_rows, Point{});
     for (auto& p : range_image_)
         p.ground_point_label = GP_UNKNOWN; // clearColumns (cc.cpp:1125)

@@ -275,40 +275,71 @@ int cc_engine_output_planes(cc_engine* e, int stream, const uint8_t** d_ground_l
 int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const uint32_t* cluster_ids, const int64_t* col_from,
                                     const int64_t* col_to, const uint32_t* n_points, int64_t* h_gcol, int32_t* h_row);
 
-/* Engine tuning / test hooks. Names: "lds_tree_limit" (unfinished point trees per stream kept in LDS before the stream
- * continues in the global-memory association kernel, 1..256), "limit_columns" (columns one launch may emit per stream before
- * it hands back to the host), "pipeline" (0: run the kernel chains of cc_engine_add_firings_device back to back on one
- * HIP stream; 1: overlap consecutive batches on three chains (insertion | table, segmentation, window scan | association); 2 (default):
- * the window scan on a fourth chain), "assoc_waves" (cooperating wavefronts per stream in the association kernel. 0 (default): k_assoc3 —
- * resolve / records / apply wavefronts — plus its links wavefront while a launch has at most 256 streams; 3 / 4: k_assoc3 without / with
- * the links wavefront; 1: the one-wavefront kernel, which is also what
- * cluster_point_trees_every_nth_column != 1 uses), "skip_idle_fallbacks" (1 (default): in the pipelined mode the
- * host waits for the block-parallel insertion kernel of a batch and launches the other insertion kernels only if some stream's batch was not
- * taken completely (k_insert_par up to 64 rows, k_insert_multi above); 0: always launch them), "assoc_rounds" (1..8; 0 (default): adaptive — one
- * (batch-parallel, serial) association kernel pair per batch, three for the 4 batches ("assoc_cooldown") after the batch-parallel kernel had to stop, the serial kernel as "assoc_sweep_blocks" (default 2) blocks that look for streams
- * with columns left while it is only the safety net; all
- * but the last serial launch only take the group of columns the batch-parallel kernel stopped in front of), "assoc_batch" (1 (default): the batch-parallel association kernel runs in front of the
- * serial one and takes every group of columns that cannot differ from the sequential semantics, see cc_engine_batch_counters; 0: serial
- * kernels only), "sub_batch" (firings
- * per pipelined sub-batch of one cc_engine_add_firings_device call; 0 (default): the whole call is one batch), "graphs" (0: never
- * use the captured-hipGraph low-latency path of small cc_engine_add_firings calls), "debug_flags" (experiment switches, 0 in
- * production), "parallel_insert" (1 (default): the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a
- * block-parallel kernel, the serial insertion kernel continues behind it; 0: serial kernel only), "publish_off_chain" (1 (default): in the pipelined mode k_publish runs on a stream of its own instead of at the end of
- * the association chain), "table_on_insert_chain" (1 (default): in the pipelined mode k_table runs at the end of the insertion chain instead of
- * at the head of the segmentation chain (0); 2: on a stream of its own between the two), "ego_on_insert_chain" (1: k_ego next to k_table instead of in
- * front of k_seg_pre; default 0), "fuse_front" (1 (default): k_insert_par also does the per-cell part of the ground segmentation of the columns it fills and closes batches it took completely as fused: k_table / k_seg_pre are only launched for streams that need them; 0: the unfused chain), "seg_small_max" (default 63: calls of at most that many firings on a sensor of <= 64 rows segment their columns with k_seg_small, one wavefront per stream with rows as lanes), "small_front" (1 (default): such a call on ONE stream outside the pipeline — cc_engine_add_firings — runs k_small_front / k_small_tail: a three-kernel graph without copy nodes, the results mirrored into pinned host memory), "insert_narrow_blocks" (experiment), "insert_wide_max_streams" / "insert_split_blocks" (launches of at most that many streams, default 160, run k_insert_par with 16
- * wavefronts per block and deal a stream's firings to that many blocks: 0 (default) = 8 up to 24 streams, 6 up to 32, 4 up to 40, 3 up to 64, 2 up to 96, else 1), "mirror_fields" (1 (default while events are recorded): also produce the per-point values only a host mirror of range_image_ shows —
- * number_of_visited_neighbors, per-tree values of finished trees, the tree-link log; 0 in throughput mode), "input_on_engine_stream" (1: the device buffers handed to cc_engine_add_firings_device are produced by work enqueued on
- * cc_engine_hip_stream(e), e.g. cc_kitti_convert_frames; 0 (default): they are complete when the call is made), "defer_tail_max_streams" (default 96: in the pipelined mode, launches of at most
- * that many streams leave the chains behind a batch's insertion gate — segmentation scan, window scan, association, publishing — to the NEXT call, which launches them behind its own insertion; every call that
- * reads results, synchronises or resets flushes them first, so results are unchanged; 0: never defer), "lazy_gate" (default 40: launches of at most that many streams also enqueue their insertion before the host has read the PREVIOUS batch's insertion counters —
- * the insertion kernels of consecutive batches run back to back; they check those counters on the device and return at once if the previous batch still needs the serial insertion kernels, in which case the host
- * launches those and then this insertion again (cc_engine_gate_counters); an engine that needed that twice in a row stops doing it; 0: never), "lazy_gate_from" (default 80: ... and launches of at least that many streams, together with the deferred tail; 0: none. Measured: 96 streams + 8 .. + 10 %, 256 + 2 .. + 5 %, nothing between 41 and 79), "small_all" (1 (default): a call of fewer than 64 firings on ONE stream of a 64-row engine whose results are mirrored into pinned memory is one launch, k_small_all, instead of
- * k_small_front + k_assocb + k_small_tail; the host launches the serial fall-back kernel behind it when the kernel asks for it), "small_direct" (1 (default): such calls of 9 .. 63 firings are one direct launch of k_small_all;
- * calls of up to 8 firings replay a captured one-node graph, which starts ~3 us sooner), "prewarm_small_graphs" (value k in 1..8, a one-shot action, not a setting: sizes the grow-only host / device
- * buffers of small calls and captures the hipGraphs of cc_engine_add_firings calls of 1..k firings now, without launching anything, so that the first real calls do not pay for it), "forget_inclination_table"
- * (one-shot action: the stream's ground-segmentation inclination table — the only state cc_engine_reset keeps, like the reference's reset() — is cleared too; used by the drop-in class after its warm-up).
- * Values out of range are clamped. Environment variables that override options (CC_ASSOC_ROUNDS, CC_DEFER_TAIL, ... as used by the A/B tools) are only read when CC_ENABLE_ENV_OPTS=1 is set. */
+/* Engine tuning / test hooks: one option per line, `name` (default) meaning. Values out of range are clamped. Environment variables that override
+ * options (CC_ASSOC_ROUNDS, CC_DEFER_TAIL, ... as used by the A/B tools) are only read when CC_ENABLE_ENV_OPTS=1 is set. Every setting gives the
+ * same results (the parity tests run over them, tests/test_gpu_stress.py walks random combinations); they only move work between kernels and streams.
+ *
+ *  -- pipeline shape of cc_engine_add_firings_device ------------------------------------------------------------------------------------------
+ *  "pipeline"                (2)   0: the kernel chains of a batch back to back on one HIP stream; 1: consecutive batches overlap on three chains
+ *                                  (insertion | table, segmentation, window scan | association); 2: the window scan on a fourth chain
+ *  "sub_batch"               (0)   firings per pipelined sub-batch of one call; 0: the whole call is one batch
+ *  "limit_columns"                 columns one launch may emit per stream before it hands back to the host (continuation passes)
+ *  "publish_off_chain"       (1)   pipelined mode: k_publish on a stream of its own instead of at the end of the association chain
+ *  "table_on_insert_chain"   (1)   pipelined mode: k_table at the end of the insertion chain; 0: at the head of the segmentation chain; 2: own stream
+ *  "ego_on_insert_chain"     (0)   1: k_ego next to k_table instead of in front of k_seg_pre
+ *  "input_on_engine_stream"  (0)   1: the caller's device buffers are produced by work enqueued on cc_engine_hip_stream(e) (cc_kitti_convert_frames)
+ *  "defer_tail_max_streams"  (96)  launches of at most that many streams leave the chains behind a batch's insertion gate to the NEXT call, which
+ *                                  launches them behind its own insertion; every call that reads, synchronises or resets flushes them first; 0: never
+ *  "lazy_gate"               (40)  launches of at most that many streams enqueue their insertion before the host has read the PREVIOUS batch's
+ *                                  insertion counters; the kernels check them on the device and return if that batch still needs the serial insertion
+ *                                  kernels (the host then launches those and this insertion again: cc_engine_gate_counters). Two misses in a row
+ *                                  switch it off, eight clean batches or cc_engine_reset switch it on again; 0: never
+ *  "lazy_gate_from"          (80)  ... and launches of at least that many streams (96 streams + 8 .. 10 %, 256 + 2 .. 5 %, nothing at 41 .. 79); 0: none
+ *  -- insertion ----------------------------------------------------------------------------------------------------------------------------------
+ *  "parallel_insert"         (1)   the head of every batch of >= 64 firings that has the single-column firing shape is inserted by a block-parallel
+ *                                  kernel (k_insert_par up to 64 rows, k_insert_multi above), the serial kernel continues behind it; 0: serial only
+ *  "skip_idle_fallbacks"     (1)   pipelined mode: the host waits for the block-parallel insertion kernel of a batch and launches the other insertion
+ *                                  kernels only if some stream's batch was not taken completely; 0: always launch them
+ *  "fuse_front"              (1)   k_insert_par also does the per-cell part of the ground segmentation of the columns it fills and closes batches it
+ *                                  took completely as fused (k_table / k_seg_pre only for streams that need them); 0: the unfused chain
+ *  "insert_wide_max_streams" (160) launches of at most that many streams run k_insert_par with 16 wavefronts per block ...
+ *  "insert_split_blocks"     (0)   ... and deal a stream's firings to that many blocks; 0: 8 up to 24 streams, 6 up to 32, 4 up to 40, 3 up to 64,
+ *                                  2 up to 96, else 1
+ *  "insert_narrow_blocks"    (0)   experiment: that many 4-wavefront blocks per stream above insert_wide_max_streams
+ *  "insert_lds_pad"          (0)   experiment: KB of unused dynamic LDS that keep a second insertion block off a compute unit
+ *  -- segmentation, window scan ------------------------------------------------------------------------------------------------------------------
+ *  "seg_small_max"           (63)  calls of at most that many firings on a sensor of <= 64 rows segment with k_seg_small (rows as lanes)
+ *  "scan_packed"                   1: the packed window scan k_scan2 (default from 128 streams per launch and at 128 rows); 0: k_scan
+ *  -- association -----------------------------------------------------------------------------------------------------------------------------------
+ *  "assoc_batch"             (1)   the batch-parallel kernel k_assocb runs in front of the serial one and takes every group of columns that cannot
+ *                                  differ from the sequential semantics (cc_engine_batch_counters); 0: serial kernels only
+ *  "assoc_rounds"            (0)   1..8 (batch-parallel, serial) kernel pairs per batch; 0: adaptive — one pair, three for "assoc_cooldown" batches
+ *                                  after k_assocb had to stop; all but the last serial launch only take the group k_assocb stopped in front of
+ *  "assoc_cooldown"          (4)   see assoc_rounds
+ *  "assoc_sweep_blocks"      (2)   blocks of the serial kernel while it is only the safety net behind k_assocb (they sweep over all streams)
+ *  "assoc_waves"             (0)   wavefronts per stream of the serial kernel. 0: k_assoc3 (resolve / records / apply) plus its links wavefront while a
+ *                                  launch has <= 256 streams; 3 / 4: without / with the links wavefront; 1: the one-wavefront kernel (also what
+ *                                  cluster_point_trees_every_nth_column != 1 uses)
+ *  "lds_tree_limit"                unfinished point trees per stream kept in LDS before the stream continues in the global-memory kernel, 1..256
+ *  "mirror_fields"                 1 (default while events are recorded): also produce what only a host mirror of range_image_ shows
+ *                                  (number_of_visited_neighbors, per-tree values of finished trees, the tree-link log); 0 in throughput mode
+ *  -- small calls of cc_engine_add_firings (per-column latency path) -----------------------------------------------------------------------------
+ *  "graphs"                  (1)   0: never use the captured-hipGraph path of small calls
+ *  "small_front"             (1)   a call of < 64 firings on ONE stream outside the pipeline runs k_small_front / k_small_tail, results mirrored into
+ *                                  pinned host memory
+ *  "small_all"               (1)   ... as ONE launch, k_small_all, on a 64-row engine; the host launches the serial fall-back behind it when asked
+ *  "small_direct"            (1)   calls of 9 .. 63 firings are one direct launch of k_small_all; up to 8 firings replay a captured one-node graph
+ *  "resident"                (0)   1: calls of 1 .. 8 firings on a 1-stream 64-row engine are handed to a RESIDENT kernel through a pinned-memory
+ *                                  doorbell (no dispatch per call); started by the first such call, stopped by anything else that touches the engine
+ *  "prewarm_small_graphs"          one-shot action (value k in 1..8): size the grow-only buffers of small calls and capture the graphs of calls of
+ *                                  1..k firings now, without launching anything
+ *  "forget_inclination_table"      one-shot action: clear the ground-segmentation inclination table too (the only state cc_engine_reset keeps, like
+ *                                  the reference's reset(), cc.cpp:46); used by the drop-in class after its warm-up
+ *  -- debugging --------------------------------------------------------------------------------------------------------------------------------------
+ *  "debug_flags"             (0)   experiment switches
+ *  "debug_no_assoc_fallback" (0)   1: do not launch the serial kernels behind k_assocb (tools only: shows what k_assocb alone covers)
+ *  "poison_released_inputs"  (0)   1: cc_engine_inputs_released overwrites every input buffer it reports as released with NaN / 0xFF, so that a
+ *                                  caller which re-reads or re-uses "its" data too early fails loudly instead of racing */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every
