@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=80)  # (a timed region fills and drains a three-deep pipeline once: 40 steps read 5 % low)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3, help="repeats of the headline leg inside one run: the line carries the median and the spread")
     ap.add_argument("--streams", type=int, default=256, help="sensor streams per GPU")
     ap.add_argument("--firings", type=int, default=2200, help="firings per stream per step (2200 = one rotation)")
     ap.add_argument("--sensor", default="s64", choices=["s64", "s128"])
@@ -459,7 +460,7 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
     # file, the longest HIP-event duration of this run. `launch_ms` is always this run's own HIP-event figure for that kernel.
     committed = {}
     spath = ""
-    for tag in ("r05_final", "r04_final", "r03_final"):  # (the newest committed summary of this build's round)
+    for tag in ("r06_final", "r05_final", "r04_final", "r03_final"):  # (the newest committed summary of this build's round)
         cand = os.path.join(ROOT, "profiles", f"{tag}_kernel_stats.csv" if R == 64 else f"{tag}_kernel_stats_s128.csv")
         if os.path.exists(cand):
             spath = cand
@@ -498,7 +499,7 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
     # firings). `frac` is against the 2-clock roof, `frac_4clk` against the 4-clock class most of the path's instructions belong to.
     valu = None
     vpath = ""
-    for tag in ("r05_final", "r04_final"):
+    for tag in ("r06_final", "r05_final", "r04_final"):
         cand = os.path.join(ROOT, "profiles", f"{tag}_sq_lds_l2_counters.txt")
         if os.path.exists(cand):
             vpath = cand
@@ -752,9 +753,14 @@ def few_streams_report(ctx, sensor, cfg, F, xyz, inten, poses, steps, counts=(32
             continue
         sub = (xyz[:warm + k, :n].contiguous(), inten[:warm + k, :n].contiguous(), poses[:warm + k, :n].contiguous())
         solo = Ctx(ctx.torch, ctx.dist, False, 1, 0, ctx.dev, ctx.local_rank, ctx.stub)
-        r, e, _ = run_throughput(solo, sensor, cfg, list(range(n)), F, k, warm, 0, inputs=sub)
-        e.close()
-        out[str(n)] = {"streams": n, "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k}
+        rs = []
+        for _ in range(3 if n <= 64 else 1):  # (a 20-step leg of 32 streams is 8 ms: median of three, the spread beside it)
+            r, e, _ = run_throughput(solo, sensor, cfg, list(range(n)), F, k, warm, 0, inputs=sub)
+            e.close()
+            rs.append(r)
+        r = sorted(rs, key=lambda q: q["value"])[(len(rs) - 1) // 2]
+        out[str(n)] = {"streams": n, "value": r["value"], "ms_per_step": r["ms_per_step"], "steps": k,
+                       "value_min": min(q["value"] for q in rs), "value_max": max(q["value"] for q in rs)}
         del sub
         if steady_steps > k and n <= 64:
             r2, e2, own = run_throughput(solo, sensor, cfg, [1234 + j for j in range(n)], F, steady_steps, warm, 0)
@@ -896,12 +902,27 @@ def main():
 
     # ================= legs every rank takes part in =================
     # ---- headline: weak scaling, S streams per GPU (BASELINE.json configs[2] per GPU) ----
-    res, eng, (xyz, inten, poses) = run_throughput(ctx, sensor, cfg, [1234 + rank * S + k for k in range(S)], F, args.steps, args.warmup, n_verify)
+    # The timed region of the driver's shape (--steps 20) is ~42 ms and the boxes of the pool differ by +- 5 %: the leg runs `--repeats` times
+    # (default 3) on the same resident inputs with a new engine each time; the line carries the MEDIAN repeat (value, ms_per_step, kernel times
+    # and roofline all of that one repeat) and the spread next to it (value_min / value_max / value_repeats).
+    seeds = [1234 + rank * S + k for k in range(S)]
+    res, eng, (xyz, inten, poses) = run_throughput(ctx, sensor, cfg, seeds, F, args.steps, args.warmup, n_verify)
+    reps = [res]
+    for _ in range(max(1, args.repeats) - 1):
+        eng.close()
+        r_more, eng, _ = run_throughput(ctx, sensor, cfg, seeds, F, args.steps, args.warmup, 0, inputs=(xyz, inten, poses))
+        r_more["verified"] = res["verified"]  # (the first repeat checked the streams against the oracle: same inputs, same results)
+        reps.append(r_more)
+    res = sorted(reps, key=lambda r: r["value"])[(len(reps) - 1) // 2]
     out = None
     if rank == 0:
         out = {
             "metric": "Mpoints/s clustered (64-beam streams)" if R == 64 else f"Mpoints/s clustered ({R}-beam streams)",
             "value": res["value"],
+            "value_min": min(r["value"] for r in reps),
+            "value_max": max(r["value"] for r in reps),
+            "value_repeats": [r["value"] for r in reps],
+            "value_is": f"median of {len(reps)} repeats of the timed leg ({args.steps} steps each, same inputs, a new engine per repeat)",
             "unit": "Mpoints/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -1088,8 +1109,8 @@ def slim_line(o):
             d = d.get(k)
         return d
 
-    line = {k: o.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                                  "dtype", "data")}
+    line = {k: o.get(k) for k in ("metric", "value", "value_min", "value_max", "value_repeats", "value_is", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                  "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
     cfgd = dict(o.get("config") or {})
     line["config"] = cfgd
     rf = dict(o.get("roofline") or {})
@@ -1139,6 +1160,7 @@ def slim_line(o):
     cl = o.get("cluttered")
     if cl:
         line["cluttered"] = {k: v for k, v in cl.items() if k != "kernel_ms_per_step"}
+    line["cluttered_value"] = g(cl, "value")  # (vegetation-like scenes: the nearest thing to north_star's "SemanticKITTI streams" this image allows)
     hf = o.get("host_fed")
     if hf:
         line["host_fed"] = {k: v for k, v in hf.items() if k in ("value", "ms_per_step", "pcie_GBs", "steps")}

@@ -78,6 +78,7 @@ def load_library():
     L.cc_engine_add_firings.argtypes = [vp, i32, i64, vp, vp, vp]
     L.cc_engine_add_firings_device.argtypes = [vp, i64, vp, vp, vp]
     L.cc_engine_sync.argtypes = [vp]
+    L.cc_engine_inputs_released.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.cc_engine_hip_stream.argtypes = [vp]
     L.cc_engine_hip_stream.restype = vp
     L.cc_engine_record_events.argtypes = [vp, i32]
@@ -176,8 +177,16 @@ class Engine:
         return self.L.cc_engine_add_firings(self.h, stream, n, xyz.ctypes.data, intensity.ctypes.data, poses.ctypes.data)
 
     def add_firings_device(self, n: int, d_xyz, d_intensity, d_poses):
-        """Device-resident buffers laid out [num_streams][n][...]; asynchronous."""
+        """Device-resident buffers laid out [num_streams][n][...]; asynchronous — and so are the engine's reads: the three buffers must stay
+        allocated and unchanged until ``inputs_released()`` reports this call (calls are numbered 1, 2, ...) or ``sync()`` has returned.
+        A caller that streams batches in keeps its buffers in a ring and asks before it overwrites one (include/cc_hip.h)."""
         self._check(self.L.cc_engine_add_firings_device(self.h, n, _ptr(d_xyz), _ptr(d_intensity), _ptr(d_poses)))
+
+    def inputs_released(self) -> tuple:
+        """(last call of add_firings_device whose input buffers will not be read again, calls made so far); never waits."""
+        rel, sub = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.cc_engine_inputs_released(self.h, C.byref(rel), C.byref(sub)))
+        return int(rel.value), int(sub.value)
 
     def sync(self) -> int:
         return self.L.cc_engine_sync(self.h)

@@ -51,6 +51,9 @@
 #ifndef CC_AB_WAVES
 #define CC_AB_WAVES 15
 #endif
+#ifndef CC_AB_MIN_WAVES_PER_SIMD
+#define CC_AB_MIN_WAVES_PER_SIMD 1
+#endif
 constexpr int AB_WAVES = CC_AB_WAVES;      // worker wavefronts; one more wavefront runs the timeline
 constexpr int AB_THREADS = 64 * (AB_WAVES + 1);
 constexpr int AB_SUB = 4;                  // 64-row pieces of a worker wavefront's tile: 4 columns of a 64-row sensor, 2 columns of a 128-row sensor
@@ -1269,7 +1272,7 @@ __device__ __forceinline__ void assocb_body(const Geometry& g, const cc_config& 
 }
 
 template<int RPL>
-__global__ __launch_bounds__(AB_THREADS) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
+__global__ __launch_bounds__(AB_THREADS, CC_AB_MIN_WAVES_PER_SIMD) void k_assocb(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot,
                                                        int* __restrict__ bail_count)
 {
     __shared__ AbShared<RPL> S;

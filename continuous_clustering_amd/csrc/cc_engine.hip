@@ -78,6 +78,28 @@ struct cc_engine
         int32_t* cir;
     } pp[2]{};
     uint64_t batch_seq{0};        // batches submitted since reset; slot = batch_seq & 3
+    // ---- lifetime of the caller's device buffers (cc_engine_inputs_released, include/cc_hip.h) --------------------------------------------
+    // A call of cc_engine_add_firings_device has a number (1, 2, ...). Its inputs are read for the last time by kernels that are all ordered in
+    // front of the end of the batch's publishing chain, so an event recorded behind that chain (ev_rel, a ring of REL_RING) says "released";
+    // a full synchronisation at the API level releases everything submitted. Nothing here waits.
+    static constexpr int REL_RING = 8;
+    uint64_t call_seq{0};               // calls of cc_engine_add_firings_device so far (never reset: the numbers stay unique over cc_engine_reset)
+    uint64_t released_seq{0};           // ... whose inputs will not be read again, as far as the host has noticed
+    hipEvent_t ev_rel[REL_RING]{};
+    uint64_t rel_recorded[REL_RING]{};  // the call whose end the event was last recorded behind (0: none)
+    bool in_submit{false};              // inside cc_engine_add_firings_device: a synchronisation in there does not release the call being submitted
+    bool cur_call_last{true};           // the sub-batch being submitted is the last one of its call
+    int check_input_lifetime{0};        // option "check_input_lifetime": 1 checksum at submission and at release, 2 also poison on release
+    struct InputRec
+    {
+        uint64_t seq;
+        const void *xyz, *inten, *pose;
+        size_t b_xyz, b_int, b_pose;
+        unsigned long long sum;
+    };
+    std::vector<InputRec> live_inputs;  // (only with check_input_lifetime)
+    unsigned long long* d_input_sum{nullptr};
+    unsigned long long* h_input_sum{nullptr};
     bool pipelined{false};        // last submitted batch used all three streams
     bool allow_pipeline{true};    // option "pipeline"
     bool publish_off_chain{true}; // option "publish_off_chain"
@@ -272,6 +294,10 @@ int free_all(cc_engine* e)
     e->gather_bytes = 0;
     e->d_small = nullptr;
     e->d_small_seq = nullptr; // (freed with the allocations above; the pinned counter below goes with it)
+    e->d_input_sum = nullptr;
+    if (e->h_input_sum)
+        (void) hipHostFree(e->h_input_sum);
+    e->h_input_sum = nullptr;
     e->small_seq_expected = 0;
     // the pinned staging of the small-call path is sized for the row count it was created with
     if (e->h_small)
@@ -826,6 +852,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         CC_HIP_CHECK(e, hipEventRecord(e->ev_ins[slot], si));
         pre_done = true;
     }
+    // the call this batch is the end of (0: a continuation pass, a sub-batch that is not its call's last, a call on the host path)
+    const uint64_t rel_seq = (first_pass && e->in_submit && e->cur_call_last) ? e->call_seq : 0ull;
     // (the three arguments: >= 0 replaces what was known when the closure was made — the lazy gate learns them later)
     auto tail = [=](const int fb_now, const int seg_now, const int pre_now) mutable -> int
     {
@@ -1132,6 +1160,12 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         {
             CC_HIP_CHECK(e, hipEventRecord(e->ev_assoc[slot], spub)); // the batch descriptor slot is free again after its publish
             e->assoc_pending[slot] = true;
+            if (rel_seq)
+            {
+                // every kernel that reads the call's input buffers is ordered in front of this point (insertion -> segmentation -> association -> publish)
+                CC_HIP_CHECK(e, hipEventRecord(e->ev_rel[rel_seq % cc_engine::REL_RING], spub));
+                e->rel_recorded[rel_seq % cc_engine::REL_RING] = rel_seq;
+            }
         }
         CC_HIP_CHECK(e, hipGetLastError());
         if (e->host_prof && hp_gated)
@@ -1253,8 +1287,105 @@ int sync_all(cc_engine* e)
     return CC_OK;
 }
 
+// ---- lifetime of the caller's input buffers -----------------------------------------------------------------------------------------------
+// option "check_input_lifetime": a position-weighted 64-bit sum of the three buffers of a call, taken when the call is made and again when the
+// engine reports the buffers as released. A caller that re-uses a buffer too early (a data race the engine cannot see otherwise: the symptom is
+// "reset_required" on a healthy stream) changes the sum: the release then fails with CC_ERR_INVALID_ARGUMENT and says which call.
+__global__ __launch_bounds__(256) void k_input_sum(const unsigned* __restrict__ w, unsigned long long nwords, const unsigned char* __restrict__ tail, int ntail,
+                                                   unsigned long long* __restrict__ out)
+{
+    unsigned long long acc = 0ull;
+    for (unsigned long long i = (unsigned long long) blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (unsigned long long) gridDim.x * blockDim.x)
+        acc += (unsigned long long) w[i] * (2ull * i + 1ull);
+    if (blockIdx.x == 0 && (int) threadIdx.x < ntail)
+        acc += (unsigned long long) tail[threadIdx.x] * (2ull * (nwords + threadIdx.x) + 1ull);
+    for (int off = 32; off > 0; off >>= 1)
+        acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0 && acc)
+        atomicAdd(out, acc);
+}
+
+static int input_sum(cc_engine* e, const cc_engine::InputRec& r, unsigned long long* sum)
+{
+    if (!e->h_input_sum)
+    {
+        CC_HIP_CHECK(e, hipHostMalloc((void**) &e->h_input_sum, 64));
+        int rca = alloc_plane(e, &e->d_input_sum, 8);
+        if (rca)
+            return rca;
+    }
+    CC_HIP_CHECK(e, hipMemsetAsync(e->d_input_sum, 0, sizeof(unsigned long long), e->stream));
+    const struct
+    {
+        const void* p;
+        size_t b;
+    } parts[3] = {{r.xyz, r.b_xyz}, {r.inten, r.b_int}, {r.pose, r.b_pose}};
+    for (const auto& q : parts)
+    {
+        const unsigned long long nw = q.b / 4;
+        const int blocks = (int) std::min<unsigned long long>(4096ull, (nw + 255ull) / 256ull + 1ull);
+        hipLaunchKernelGGL(k_input_sum, dim3(blocks), dim3(256), 0, e->stream, (const unsigned*) q.p, nw, (const unsigned char*) q.p + nw * 4, (int) (q.b % 4), e->d_input_sum);
+    }
+    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_input_sum, e->d_input_sum, sizeof(unsigned long long), hipMemcpyDeviceToHost, e->stream));
+    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    *sum = *e->h_input_sum;
+    return CC_OK;
+}
+
+// the inputs of every call up to `upto` will not be read again
+static int note_released(cc_engine* e, uint64_t upto)
+{
+    if (upto <= e->released_seq)
+        return CC_OK;
+    e->released_seq = upto;
+    if (e->live_inputs.empty())
+        return CC_OK;
+    int rc = CC_OK;
+    std::vector<cc_engine::InputRec> keep;
+    for (const auto& r : e->live_inputs)
+    {
+        if (r.seq > upto)
+        {
+            keep.push_back(r);
+            continue;
+        }
+        unsigned long long now = 0ull;
+        int rcs = input_sum(e, r, &now);
+        if (rcs)
+            return rcs;
+        if (now != r.sum && rc == CC_OK)
+        {
+            e->error = "cc_engine_add_firings_device: the input buffers of call " + std::to_string(r.seq) +
+                       " were modified before the engine released them (cc_engine_inputs_released / cc_engine_sync): a data race in the caller";
+            rc = CC_ERR_INVALID_ARGUMENT;
+        }
+        if (e->check_input_lifetime >= 2)
+        {
+            // poison: whoever still reads "its" old data from here (or handed the engine a buffer twice) meets NaN coordinates, 0xFF intensities, NaN poses
+            CC_HIP_CHECK(e, hipMemsetAsync(const_cast<void*>(r.xyz), 0xFF, r.b_xyz, e->stream));
+            CC_HIP_CHECK(e, hipMemsetAsync(const_cast<void*>(r.inten), 0xFF, r.b_int, e->stream));
+            CC_HIP_CHECK(e, hipMemsetAsync(const_cast<void*>(r.pose), 0xFF, r.b_pose, e->stream));
+            CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+        }
+    }
+    e->live_inputs.swap(keep);
+    return rc;
+}
+
+int finish_batch_inner(cc_engine* e);
+
 // Wait for everything in flight; run continuation passes while some stream stopped early (limit_columns reached).
 int finish_batch(cc_engine* e)
+{
+    int rc = finish_batch_inner(e);
+    if (rc)
+        return rc;
+    // everything enqueued so far is complete and nothing is held back: every call's inputs are released — but for the call that is being submitted
+    // right now, if this is a synchronisation inside cc_engine_add_firings_device (the previous batch's continuation passes, a lazy-gate miss)
+    return note_released(e, e->call_seq - ((e->in_submit && e->call_seq > 0) ? 1ull : 0ull));
+}
+
+int finish_batch_inner(cc_engine* e)
 {
     if (!e->batch_open)
         return sync_all(e);
@@ -1943,6 +2074,8 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         (void) hipEventCreateWithFlags(&e->ev_segscan[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_pubrdy[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_rel[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_rel[i + 4], hipEventDisableTiming);
         if (i == 0)
             (void) hipEventCreateWithFlags(&e->ev_input, hipEventDisableTiming);
 
@@ -2051,6 +2184,8 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipEventDestroy(e->ev_segscan[i]);
         (void) hipEventDestroy(e->ev_prep[i]);
         (void) hipEventDestroy(e->ev_pubrdy[i]);
+        (void) hipEventDestroy(e->ev_rel[i]);
+        (void) hipEventDestroy(e->ev_rel[i + 4]);
         if (i == 0)
             (void) hipEventDestroy(e->ev_input);
     }
@@ -2128,6 +2263,9 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream7));
     e->batch_open = false;
     e->idle = true;
+    rc = note_released(e, e->call_seq); // (nothing of the old epoch reads the callers' buffers any more)
+    if (rc)
+        return rc;
     const bool same_shape = num_rows == e->g.num_rows && e->cfg.num_columns == e->g.num_columns;
     if (!same_shape)
     {
@@ -2225,6 +2363,23 @@ int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, co
     // pipeline one after the other: same work, but the last firing of the call leaves the pipeline a sub-batch (not a whole
     // call) after it entered.
     const bool pipeline = e->g.record_events == 0 && e->allow_pipeline;
+    // the call's number (cc_engine_inputs_released); with "check_input_lifetime" also what its buffers hold right now
+    e->call_seq++;
+    if (e->check_input_lifetime)
+    {
+        const size_t cells = (size_t) e->g.num_streams * (size_t) n * (size_t) e->g.num_rows;
+        cc_engine::InputRec r{e->call_seq, d_xyz, d_intensity, d_poses, cells * 3 * sizeof(float), cells, (size_t) e->g.num_streams * (size_t) n * 12 * sizeof(double), 0ull};
+        int rcs = input_sum(e, r, &r.sum);
+        if (rcs)
+            return rcs;
+        e->live_inputs.push_back(r);
+    }
+    struct InSubmit
+    {
+        cc_engine* e;
+        explicit InSubmit(cc_engine* e_) : e(e_) { e->in_submit = true; }
+        ~InSubmit() { e->in_submit = false, e->cur_call_last = true; }
+    } guard(e);
     // (measured: per-launch fixed costs outweigh the shorter fill / drain at 2200-firing calls, so it is off unless asked for)
     int64_t sub = e->sub_batch > 0 ? e->sub_batch : n;
     if (!pipeline || sub >= n)
@@ -2232,11 +2387,39 @@ int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, co
     for (int64_t f0 = 0; f0 < n; f0 += sub)
     {
         const int64_t m = std::min<int64_t>(sub, n - f0);
+        e->cur_call_last = f0 + m >= n;
         int rc = submit(e, 0, e->g.num_streams, m, d_xyz, d_intensity, d_poses, true, n, f0);
         if (rc)
             return rc;
     }
     return CC_OK;
+}
+
+int cc_engine_inputs_released(cc_engine* e, uint64_t* released_call, uint64_t* submitted_calls)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    (void) hipSetDevice(e->device);
+    // newest first: the events sit on one in-order stream, so the first one that has completed releases every older call as well
+    uint64_t upto = e->released_seq;
+    for (uint64_t q = e->call_seq; q > e->released_seq && q + cc_engine::REL_RING > e->call_seq; q--)
+    {
+        const int i = (int) (q % cc_engine::REL_RING);
+        if (e->rel_recorded[i] != q)
+            continue; // (its chains are still held back — deferred tail, lazy gate —, or it went through a path that only a synchronisation releases)
+        if (hipEventQuery(e->ev_rel[i]) == hipSuccess)
+        {
+            upto = q;
+            break;
+        }
+    }
+    (void) hipGetLastError(); // (hipErrorNotReady of a query is not an error of the engine)
+    int rc = note_released(e, upto);
+    if (released_call)
+        *released_call = e->released_seq;
+    if (submitted_calls)
+        *submitted_calls = e->call_seq;
+    return rc;
 }
 
 int cc_engine_sync(cc_engine* e)
@@ -2670,6 +2853,14 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->small_direct = value != 0;
     else if (n == "insert_lds_pad")
         e->insert_lds_pad_kb = (int) std::max<int64_t>(0, std::min<int64_t>(value, 120));
+    else if (n == "check_input_lifetime")
+    {
+        int rcf = finish_batch(e);
+        if (rcf)
+            return rcf;
+        e->check_input_lifetime = (int) std::max<int64_t>(0, std::min<int64_t>(value, 2));
+        e->live_inputs.clear();
+    }
     else if (n == "lazy_gate")
     {
         int rcf = flush_deferred(e);

@@ -1001,10 +1001,15 @@ __device__ __forceinline__ void table_from_partials(const SP& p, const int R, co
 #define CC_IP_WAVES 8
 #endif
 constexpr int IP_WAVES = CC_IP_WAVES;
+// register budget of the kernel as "wavefronts per SIMD it must leave room for" (512 VGPRs per lane and SIMD): what decides which of the other
+// chains' blocks fit next to an insertion block on a compute unit (profiles/r06_kernel_resources.txt)
+#ifndef CC_IP_MIN_WAVES_PER_SIMD
+#define CC_IP_MIN_WAVES_PER_SIMD 1
+#endif
 
 // (W wavefronts per block: IP_WAVES next to the other chains' kernels; twice as many when a launch has few streams and the GPU is otherwise empty)
 template<int RPL, int W = IP_WAVES>
-__global__ __launch_bounds__(64 * W) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
+__global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream,
                                                             const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
                                                             const double* __restrict__ poses, long long n, long long n_total, long long fbase,
                                                             int slot, int* __restrict__ left_over, const double* __restrict__ ego,

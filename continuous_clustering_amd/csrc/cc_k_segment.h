@@ -412,6 +412,10 @@ __global__ __launch_bounds__(64) void k_seg_pre(Geometry g, cc_config cfg, Plane
 // The look-back of the state machine (cc.cpp:513-535) walks down from a new obstacle over the ground cells right below it: rarely more than a few
 // rows. The tile keeps the azimuth-plane distance of two chunks (the current one and the one below) and reads deeper rows from the staging plane.
 // Row counts that are not a multiple of 16 take the round-2 form (every lane reads its own column, 8 rows at a time; 16 rows of look-back in LDS).
+// register budget of k_seg_scan as wavefronts per SIMD it must leave room for (2: 150 VGPRs, no spills; 4: 128 VGPRs, 18 spilled to scratch)
+#ifndef CC_SEGSCAN_MIN_WAVES_PER_SIMD
+#define CC_SEGSCAN_MIN_WAVES_PER_SIMD 2
+#endif
 constexpr int SEG_X2_RING = 16;
 constexpr int SEG_CH = 16; // rows per chunk of the tiled form
 constexpr int SEG_FEW = 4; // tiles of at most this many columns are loaded whole (3 * SEG_FEW * rows floats fit the chunk buffers up to 341 rows)
@@ -443,7 +447,7 @@ enum
 };
 
 // (20 KB of LDS per wavefront: two of them per SIMD at most — the register budget that goes with that, not 128)
-__global__ __launch_bounds__(64, 2) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(64, CC_SEGSCAN_MIN_WAVES_PER_SIMD) void k_seg_scan(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
     const int s = first_stream + blockIdx.x;
     StreamState* st = &states[s];

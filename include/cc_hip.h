@@ -227,16 +227,24 @@ int cc_engine_add_firings(cc_engine* e, int stream, int64_t n, const float* xyz,
  * Launches on the engine's HIP streams and returns without synchronising. The buffers must be complete when the call is made
  * (the kernels that read them run on internal streams), unless their producer was enqueued on cc_engine_hip_stream(e) AND the
  * option "input_on_engine_stream" is set: then the engine orders its reads after that work.
- * LIFETIME OF THE INPUTS: the call is asynchronous and so are its reads. The three buffers must stay allocated and UNCHANGED until
- * cc_engine_sync() (or a call that implies it: cc_engine_stream_state, cc_engine_drain_events, cc_engine_read_columns ...) has returned.
- * With the default options a call's inputs are read for the last time while the call after the next one runs (the insertion gate makes
- * the host wait for a batch's insertion — with the lazy gate, launches of <= 40 or >= 80 streams of <= 64 rows, for the PREVIOUS batch's; the poses are read
- * by the segmentation chain behind it, and firings the serial insertion kernels have to take are read one call later still), so a
- * caller that streams batches in without synchronising keeps its buffers in a ring of >= 6 calls (the engine has 4 batch descriptor
- * slots: the insertion of call b waits on the device for the last chain of call b - 4). Re-using a buffer earlier is a data race, not
- * an error the engine can detect (tools/stress_pipelined.py did exactly that until round 5: "reset_required" on healthy streams). */
+ * LIFETIME OF THE INPUTS: the call is asynchronous and so are its reads. The three buffers must stay allocated and UNCHANGED until the
+ * engine has released them: cc_engine_inputs_released() (below; it never waits) reports the last call whose buffers will not be read again,
+ * and cc_engine_sync() — or any call that implies it: cc_engine_stream_state, cc_engine_drain_events, cc_engine_read_columns,
+ * cc_engine_reset ... — releases everything submitted before it. A caller that streams batches in without synchronising keeps its buffers
+ * in a ring and, before it overwrites a buffer, asks cc_engine_inputs_released whether that buffer's call is through (in steady state a
+ * call's inputs are read for the last time while the second or third call after it runs, later after a lazy-gate miss: do not count calls,
+ * ask). Re-using a buffer earlier is a data race the engine cannot see by itself — the symptom is "reset_required" on a healthy stream —
+ * unless the option "check_input_lifetime" is set (a debugging aid: it checksums every call's inputs at submission and at release and
+ * fails the release with CC_ERR_INVALID_ARGUMENT, naming the call, when they differ; 2: released buffers are also overwritten with 0xFF). */
 int cc_engine_add_firings_device(cc_engine* e, int64_t n, const float* d_xyz, const uint8_t* d_intensity,
                                  const double* d_poses);
+/* Which input buffers of cc_engine_add_firings_device may be re-used. Calls are numbered 1, 2, ... per engine (the numbers run on over
+ * cc_engine_reset). *released_call = the last call whose d_xyz / d_intensity / d_poses the engine will not read again (0: none yet),
+ * *submitted_calls = calls made so far; either pointer may be NULL. Never waits and launches nothing (it queries events recorded behind
+ * each call's last kernel chain); the answer only grows. A call whose chains the engine still holds back (deferred tail, lazy gate) or
+ * that went through the non-pipelined path is reported once a later call or a synchronisation has put it through. With the option
+ * "check_input_lifetime" this is also where a buffer that changed while the engine owned it is reported (CC_ERR_INVALID_ARGUMENT). */
+int cc_engine_inputs_released(cc_engine* e, uint64_t* released_call, uint64_t* submitted_calls);
 /* Block until everything launched so far has finished. */
 int cc_engine_sync(cc_engine* e);
 /* The hipStream_t all engine work is enqueued on (for hipEvent timing by the caller). */
@@ -338,8 +346,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  -- debugging --------------------------------------------------------------------------------------------------------------------------------------
  *  "debug_flags"             (0)   experiment switches
  *  "debug_no_assoc_fallback" (0)   1: do not launch the serial kernels behind k_assocb (tools only: shows what k_assocb alone covers)
- *  "poison_released_inputs"  (0)   1: cc_engine_inputs_released overwrites every input buffer it reports as released with NaN / 0xFF, so that a
- *                                  caller which re-reads or re-uses "its" data too early fails loudly instead of racing */
+ *  "check_input_lifetime"    (0)   1: checksum the inputs of every cc_engine_add_firings_device call at submission and again at release
+ *                                  (cc_engine_inputs_released, cc_engine_sync ...): a caller that re-used a buffer too early gets
+ *                                  CC_ERR_INVALID_ARGUMENT naming the call instead of a silent race; 2: released buffers are also filled with 0xFF */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
 /* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every

@@ -15,3 +15,224 @@ def test_randomised_parity_sweep(oracle_lib):
                        timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "failures: 0" in r.stdout
+
+
+# ---- the pipelined multi-stream path under perturbed inputs -------------------------------
+# Two real bugs of round 5 (shared deferred clearing across blocks, stale input buffers) were found by bench.py's replay leg and by
+# tools/stress_pipelined.py, not by this suite. What that tool does is a test now: S perturbed streams (duplicated / empty / backwards /
+# skipped / straddling firings) through cc_engine_add_firings_device — deferred tail, lazy gate, several insertion blocks per stream —
+# against one oracle per stream, with the caller's buffers in a ring that is gated by cc_engine_inputs_released.
+def _perturbed(seed, sensor=None):
+    from test_gpu_parallel_insert import perturbed_stream
+    return perturbed_stream(seed)
+
+
+def _feed_pipelined(e, streams, F, ring=4, calls=None, stats=None):
+    """Calls of F firings of every stream through the device entry. The device buffers live in a ring of `ring` slots; a slot is overwritten
+    only after cc_engine_inputs_released has reported the call that used it (spinning without synchronising; a synchronisation only if the
+    engine holds the chains back for more than 5 s, which is counted)."""
+    import time
+
+    import numpy as np
+    import torch
+    n = min(st.n_firings for st in streams)
+    NB = n // F if calls is None else min(calls, n // F)
+    slots = [None] * ring
+    base = e.inputs_released()[1]
+    for b in range(NB):
+        k = b % ring
+        if slots[k] is not None:
+            need = base + b + 1 - ring  # the call that used this slot
+            t0 = time.perf_counter()
+            while e.inputs_released()[0] < need:
+                if time.perf_counter() - t0 > 5.0:
+                    assert e.sync() == 0, e.last_error()
+                    if stats is not None:
+                        stats["sync_fallbacks"] = stats.get("sync_fallbacks", 0) + 1
+                    break
+            assert e.inputs_released()[0] >= need
+            if stats is not None:
+                stats["asked"] = stats.get("asked", 0) + 1
+        hx = np.stack([st.xyz[b * F:(b + 1) * F] for st in streams])
+        hi = np.stack([st.intensity[b * F:(b + 1) * F] for st in streams])
+        hp = np.stack([st.poses[b * F:(b + 1) * F] for st in streams])
+        if slots[k] is None:
+            slots[k] = (torch.from_numpy(hx).cuda(), torch.from_numpy(hi).cuda(), torch.from_numpy(hp).cuda())
+        else:
+            slots[k][0].copy_(torch.from_numpy(hx))
+            slots[k][1].copy_(torch.from_numpy(hi))
+            slots[k][2].copy_(torch.from_numpy(hp))
+        torch.cuda.synchronize()
+        e.add_firings_device(F, slots[k][0].data_ptr(), slots[k][1].data_ptr(), slots[k][2].data_ptr())
+        rel, sub = e.inputs_released()
+        assert sub == base + b + 1 and rel <= sub
+    return NB, slots
+
+
+def _compare_with_oracles(e, cfg, streams, NB, F, rows=64):
+    import util
+    from oracle.pyoracle import Oracle
+    bad = []
+    for s, st in enumerate(streams):
+        o = Oracle(cfg, rows)
+        assert o.add_firings(st.xyz[:NB * F], st.intensity[:NB * F], st.poses[:NB * F]) == 0
+        so, se = o.state(), e.state(s)
+        diff = {k: (so[k], se[k]) for k in util.STATE_FIELDS if so[k] != se[k]}
+        if diff:
+            bad.append((s, diff))
+            continue
+        hi = se["first_unpublished_global_column_index"] - 1
+        lo = max(se["ring_buffer_start_global_column_index"], hi - 1200)
+        try:
+            util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
+        except AssertionError as ex:
+            bad.append((s, str(ex)[:200]))
+    return bad
+
+
+@pytest.mark.parametrize("seed,lazy", [(4100, 1), (4100, 0), (5200, 1), (5200, 0)])
+def test_pipelined_perturbed_streams_with_a_gated_input_ring(seed, lazy, oracle_lib):
+    import numpy as np
+    from continuous_clustering_amd import Engine, capi
+    cfg = capi.Config.kitti()
+    S = 40
+    streams = [_perturbed(seed + s) for s in range(S)]
+    F = int(np.random.default_rng(seed).choice([700, 1100, 2200]))
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    if not lazy:
+        e.set_option("lazy_gate", 0)
+        e.set_option("lazy_gate_from", 0)
+    stats = {}
+    NB, _slots = _feed_pipelined(e, streams, F, ring=4, stats=stats)
+    assert e.sync() == 0, e.last_error()
+    rel, sub = e.inputs_released()
+    assert rel == sub == NB  # a synchronisation releases everything
+    bad = _compare_with_oracles(e, cfg, streams, NB, F)
+    e.close()
+    assert not bad, bad[:3]
+    assert stats.get("sync_fallbacks", 0) == 0, stats  # the ring never had to wait for a synchronisation
+
+
+def test_random_walk_over_engine_options(oracle_lib):
+    """Every option setting must give the oracle's results: a seeded walk over combinations of the options that move work between kernels
+    and streams, changed BETWEEN pipelined calls (cc_engine_set_option finishes what is in flight first)."""
+    import time
+
+    import numpy as np
+    from continuous_clustering_amd import Engine, capi
+    cfg = capi.Config.kitti()
+    choices = {"pipeline": [0, 1, 2], "lazy_gate": [0, 40], "lazy_gate_from": [0, 8, 80], "defer_tail_max_streams": [0, 96], "fuse_front": [0, 1],
+               "skip_idle_fallbacks": [0, 1], "parallel_insert": [0, 1, 2], "insert_split_blocks": [0, 1, 3, 8], "insert_wide_max_streams": [0, 160],
+               "assoc_batch": [0, 1], "assoc_rounds": [0, 1, 2], "assoc_sweep_blocks": [1, 2, 16], "assoc_waves": [0, 1, 3, 4], "scan_packed": [0, 1],
+               "publish_off_chain": [0, 1], "table_on_insert_chain": [0, 1, 2], "ego_on_insert_chain": [0, 1], "sub_batch": [0, 300], "limit_columns": [600, 1 << 20]}
+    t0 = time.perf_counter()
+    rounds = 0
+    for seed in (7001, 7002, 7003, 7004, 7005, 7006):
+        if time.perf_counter() - t0 > 90.0:
+            break
+        rng = np.random.default_rng(seed)
+        S = int(rng.choice([3, 12, 24]))
+        streams = [_perturbed(seed * 10 + s) for s in range(S)]
+        F = int(rng.choice([550, 1100]))
+        e = Engine(cfg, 64, S)
+        e.record_events(False)
+        n = min(st.n_firings for st in streams)
+        NB = n // F
+        import torch
+        keep = []
+        applied = []
+        for b in range(NB):
+            for name in rng.choice(sorted(choices), size=3, replace=False):
+                v = int(rng.choice(choices[name]))
+                e.set_option(str(name), v)
+                applied.append((b, str(name), v))
+            bufs = (torch.from_numpy(np.stack([st.xyz[b * F:(b + 1) * F] for st in streams])).cuda(),
+                    torch.from_numpy(np.stack([st.intensity[b * F:(b + 1) * F] for st in streams])).cuda(),
+                    torch.from_numpy(np.stack([st.poses[b * F:(b + 1) * F] for st in streams])).cuda())
+            keep.append(bufs)
+            torch.cuda.synchronize()
+            e.add_firings_device(F, bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
+        assert e.sync() == 0, (e.last_error(), applied)
+        bad = _compare_with_oracles(e, cfg, streams, NB, F)
+        e.close()
+        assert not bad, (seed, bad[:2], applied)
+        rounds += 1
+    assert rounds >= 2
+
+
+def test_reset_without_sync_behind_pipelined_calls(oracle_lib):
+    """a pipelined call leaves the chains behind its insertion to the next call (deferred tail, lazy gate); cc_engine_reset
+    must put that closure through against the OLD state before it wipes it — same shape and a different number of rows — and the engine must then
+    behave like a new one."""
+    from continuous_clustering_amd import Engine, capi, synth, IDENTITY_TF
+    cfg = capi.Config.kitti()
+    S, F = 24, 1100
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    first = [_perturbed(8100 + s) for s in range(S)]
+    _feed_pipelined(e, first, F, ring=8, calls=3)  # no synchronisation: the last call's chains are still held back
+    e.reset()
+    e.set_robot_from_sensor(IDENTITY_TF)
+    second = [_perturbed(8200 + s) for s in range(S)]
+    NB, _ = _feed_pipelined(e, second, F, ring=8)
+    assert e.sync() == 0, e.last_error()
+    bad = _compare_with_oracles(e, cfg, second, NB, F)
+    assert not bad, bad[:3]
+    # again, into another shape: the planes are re-allocated (the held-back closure holds the old pointers by value)
+    _feed_pipelined(e, first, F, ring=8, calls=2)
+    e.reset(32)
+    e.set_robot_from_sensor(IDENTITY_TF)
+    sen = synth.SensorModel(num_rows=32, num_columns=2200, incl_top_deg=10.0, incl_bottom_deg=-30.0)
+    third = [synth.make_stream(2200 * 2 + 300, seed=8300 + s, sensor=sen, motion=synth.Motion.translate()) for s in range(S)]
+    NB, _ = _feed_pipelined(e, third, F, ring=8)
+    assert e.sync() == 0, e.last_error()
+    bad = _compare_with_oracles(e, cfg, third, NB, F, rows=32)
+    e.close()
+    assert not bad, bad[:3]
+
+
+def test_reusing_an_input_buffer_too_early_is_reported(oracle_lib):
+    """Option check_input_lifetime: the engine checksums a call's inputs at submission and at release. A caller that overwrites its only buffer
+    right behind every call (the race tools/stress_pipelined.py had for four rounds) gets CC_ERR_INVALID_ARGUMENT naming the call; a caller
+    that asks cc_engine_inputs_released first does not."""
+    import numpy as np
+    import torch
+    from continuous_clustering_amd import Engine, EngineError, capi
+    cfg = capi.Config.kitti()
+    S, F = 8, 1100
+    streams = [_perturbed(8400 + s) for s in range(S)]
+    # the well-behaved caller
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    e.set_option("check_input_lifetime", 2)
+    NB, slots = _feed_pipelined(e, streams, F, ring=3)
+    assert e.sync() == 0, e.last_error()
+    assert not _compare_with_oracles(e, cfg, streams, NB, F)
+    assert all(bool(torch.isnan(s[0]).all()) for s in slots)  # 2: released buffers are poisoned
+    e.close()
+    # the racing caller
+    e = Engine(cfg, 64, S)
+    e.record_events(False)
+    e.set_option("check_input_lifetime", 1)
+    buf = None
+    code, msg = 0, ""
+    try:
+        for b in range(4):
+            hx = np.stack([st.xyz[b * F:(b + 1) * F] for st in streams])
+            hi = np.stack([st.intensity[b * F:(b + 1) * F] for st in streams])
+            hp = np.stack([st.poses[b * F:(b + 1) * F] for st in streams])
+            if buf is None:
+                buf = (torch.from_numpy(hx).cuda(), torch.from_numpy(hi).cuda(), torch.from_numpy(hp).cuda())
+            else:
+                buf[0].copy_(torch.from_numpy(hx))  # without asking
+                buf[1].copy_(torch.from_numpy(hi))
+                buf[2].copy_(torch.from_numpy(hp))
+            torch.cuda.synchronize()
+            e.add_firings_device(F, buf[0].data_ptr(), buf[1].data_ptr(), buf[2].data_ptr())
+        code = e.sync()
+        msg = e.last_error()
+    except EngineError as ex:
+        code, msg = ex.code, str(ex)
+    e.close()
+    assert code == capi.CC_ERR_INVALID_ARGUMENT and "modified before the engine released them" in msg, (code, msg)
