@@ -95,6 +95,7 @@ def load_library():
     L.cc_engine_totals.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 4
     L.cc_engine_batch_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 2 + [C.POINTER(C.c_uint64 * 8)]
     L.cc_engine_gate_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 2
+    L.cc_engine_resident_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L.cc_engine_last_error.argtypes = [vp]
     L.cc_engine_last_error.restype = C.c_char_p
     _lib = L
@@ -268,6 +269,12 @@ class Engine:
         why = (C.c_uint64 * 8)()
         self._check(self.L.cc_engine_batch_counters(self.h, *[C.byref(x) for x in v], C.byref(why)))
         return {"batch_columns": v[0].value, "batch_bails": v[1].value, "bail_reasons": list(why)}
+
+    def resident_counters(self) -> dict:
+        """Option "resident": launches of the resident kernel, calls it has answered (as of its last exit), whether it is running now."""
+        a, b, r = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+        self._check(self.L.cc_engine_resident_counters(self.h, C.byref(a), C.byref(b), C.byref(r)))
+        return {"launches": int(a.value), "calls": int(b.value), "running": bool(r.value)}
 
     def gate_counters(self) -> dict:
         v = [C.c_uint64(0) for _ in range(2)]

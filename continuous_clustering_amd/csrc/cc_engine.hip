@@ -128,6 +128,12 @@ struct cc_engine
     unsigned long long* d_small_seq{nullptr}; // device: that number + a block counter
     unsigned long long small_seq_expected{0};
     unsigned long long small_tail_launches{0}; // small calls whose serial fall-backs the host launched behind k_small_all
+    // ---- the resident single-stream kernel (option "resident", cc_k_publish.h: k_resident) ----
+    bool resident_opt{false};              // option "resident"
+    bool res_running{false};               // k_resident sits on `stream`: nothing else may be enqueued there before stop_resident()
+    cck::ResidentCtl* h_res_ctl{nullptr};  // pinned: doorbell, stop flag, exit reason
+    int res_idle_ms{20};                   // option "resident_idle_ms": the kernel's watchdog (it leaves by itself after that long without a call)
+    unsigned long long res_launches{0}, res_calls{0};
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
@@ -295,6 +301,9 @@ int free_all(cc_engine* e)
     e->d_small = nullptr;
     e->d_small_seq = nullptr; // (freed with the allocations above; the pinned counter below goes with it)
     e->d_input_sum = nullptr;
+    if (e->h_res_ctl)
+        (void) hipHostFree(e->h_res_ctl);
+    e->h_res_ctl = nullptr;
     if (e->h_input_sum)
         (void) hipHostFree(e->h_input_sum);
     e->h_input_sum = nullptr;
@@ -501,6 +510,32 @@ int launch_prep(cc_engine* e, int count, int64_t n, const float* d_xyz, const do
 
 // calls of a few firings on ONE stream outside the pipeline (cc_engine_add_firings: the per-column latency path) run everything in front of the window
 // scan in one kernel
+// The resident single-stream kernel (k_resident) occupies `stream` until it is told to leave: every entry point that enqueues work there, writes
+// engine state from the host or changes what the kernel's arguments bake in calls this first. Read-only queries (cc_engine_read_columns,
+// cc_engine_gather_cluster_points, drains of the mirrored events) do not: they run on query_stream() beside the idling kernel, whose writes are
+// released to the device behind every call (mirror_results' system-scope fence).
+static int stop_resident(cc_engine* e)
+{
+    if (!e->res_running)
+        return CC_OK;
+    __atomic_store_n(&e->h_res_ctl->stop, 1ull, __ATOMIC_RELEASE);
+    const hipError_t err = hipStreamSynchronize(e->stream);
+    e->res_calls += __atomic_load_n(&e->h_res_ctl->calls, __ATOMIC_ACQUIRE);
+    e->res_running = false;
+    __atomic_store_n(&e->h_res_ctl->stop, 0ull, __ATOMIC_RELEASE);
+    if (err != hipSuccess)
+    {
+        e->error = std::string("stopping the resident kernel: ") + hipGetErrorString(err);
+        return CC_ERR_HIP;
+    }
+    return CC_OK;
+}
+
+static hipStream_t query_stream(const cc_engine* e)
+{
+    return e->res_running ? e->stream2 : e->stream;
+}
+
 // Launch what launch_batch held back (below). Called before anything waits for, reads or re-orders the engine's streams.
 static int flush_deferred(cc_engine* e, const std::function<int()>* redo = nullptr)
 {
@@ -1273,7 +1308,12 @@ int sync_all(cc_engine* e)
             return rcf;
     }
     if (e->idle)
-        return CC_OK;
+        return CC_OK; // (a resident kernel idling on `stream` is not work in flight: it stays)
+    {
+        int rcs = stop_resident(e);
+        if (rcs)
+            return rcs;
+    }
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream2));
     CC_HIP_CHECK(e, hipStreamSynchronize(e->stream3));
@@ -1416,6 +1456,11 @@ int finish_batch_inner(cc_engine* e)
 int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose,
            bool pipeline, int64_t n_total = 0, int64_t f0 = 0)
 {
+    {
+        int rcs = stop_resident(e);
+        if (rcs)
+            return rcs;
+    }
     const auto hp_e0 = std::chrono::steady_clock::now();
     std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     if (n_total <= 0)
@@ -1704,17 +1749,27 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         d_int = (const uint8_t*) zx + b_xyz;
         d_pose = (const double*) ((const unsigned char*) zx + b_xyz + b_int);
     }
+    // option "resident": no launch per call at all — the call is handed to k_resident through a doorbell in pinned memory (cc_k_publish.h)
+    const bool resident = lean && direct_ok && e->resident_opt && e->g.num_streams == 1 && xyz != nullptr;
+    if (!resident)
+    {
+        int rcs = stop_resident(e);
+        if (rcs)
+            return rcs;
+    }
     // (a captured one-node graph starts ~3 us sooner than a direct launch — 36.9 against 39.6 us per one-firing call —, so the sizes that have a graph keep it)
-    const bool direct = lean && direct_ok && n > SMALL_MAX;
-    if (!direct && n > SMALL_MAX)
+    const bool direct = lean && direct_ok && n > SMALL_MAX && !resident;
+    if (!direct && !resident && n > SMALL_MAX)
         return -1;
     hipGraphExec_t exec = nullptr;
-    for (auto& g : e->small_graphs)
-        if (g.stream == stream && g.n == n && g.record == e->g.record_events)
-            exec = g.exec;
-    if (direct)
+    if (!resident)
+        for (auto& g : e->small_graphs)
+            if (g.stream == stream && g.n == n && g.record == e->g.record_events)
+                exec = g.exec;
+    if (direct || resident)
     {
-        if (ensure_prep(e, (size_t) n * R) != CC_OK)
+        // (the resident kernel bakes the staging planes' pointers in: sized for the largest call it takes, once)
+        if (ensure_prep(e, (size_t) (resident ? SMALL_STAGE : n) * R) != CC_OK)
             return -1;
     }
     else if (!exec)
@@ -1772,7 +1827,53 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     memcpy(e->h_small + b_xyz + b_int, poses, (size_t) n * 12 * sizeof(double));
     std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     const bool was_idle = e->idle;
-    if (direct)
+    auto launch_resident = [&]() -> int
+    {
+        if (!e->h_res_ctl)
+        {
+            CC_HIP_CHECK(e, hipHostMalloc((void**) &e->h_res_ctl, sizeof(cck::ResidentCtl)));
+            memset(e->h_res_ctl, 0, sizeof(cck::ResidentCtl));
+        }
+        void* zc = nullptr;
+        CC_HIP_CHECK(e, hipHostGetDevicePointer(&zc, e->h_res_ctl, 0));
+        __atomic_store_n(&e->h_res_ctl->exited, 0ull, __ATOMIC_RELEASE);
+        __atomic_store_n(&e->h_res_ctl->stop, 0ull, __ATOMIC_RELEASE);
+        __atomic_store_n(&e->h_res_ctl->calls, 0ull, __ATOMIC_RELEASE);
+        const cck::HostMirror hm{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                 (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
+        hipLaunchKernelGGL(cck::k_resident, dim3(1), dim3(cck::AB_THREADS), cck::insert2_lds_bytes(R), e->stream, e->g, e->cfg, planes_with_prep(e, e->prep_buf),
+                           e->d_states, stream, 0, d_xyz, d_int, d_pose, e->d_remaining, e->d_ego[0], e->d_bail_count, hm, (cck::ResidentCtl*) zc,
+                           (unsigned long long) e->res_idle_ms * 100000ull);
+        CC_HIP_CHECK(e, hipGetLastError());
+        e->res_running = true;
+        e->res_launches++;
+        return CC_OK;
+    };
+    // the kernel has left by itself (watchdog, or the call before needed the host): the stream is free again once it has retired
+    auto reap_resident = [&]() -> int
+    {
+        if (e->res_running && __atomic_load_n(&e->h_res_ctl->exited, __ATOMIC_ACQUIRE) != 0ull)
+        {
+            CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+            e->res_calls += __atomic_load_n(&e->h_res_ctl->calls, __ATOMIC_ACQUIRE);
+            e->res_running = false;
+        }
+        return CC_OK;
+    };
+    if (resident)
+    {
+        int rcr = reap_resident();
+        if (rcr)
+            return rcr;
+        if (!e->res_running)
+        {
+            if ((rcr = flush_deferred(e)) != CC_OK || (rcr = launch_resident()) != CC_OK)
+                return rcr;
+        }
+        // the doorbell: the firings are in the pinned staging (the memcpys above), the call's number and size go out last
+        __atomic_store_n(&e->h_res_ctl->bell, ((e->small_seq_expected + 1ull) << 8) | (unsigned long long) n, __ATOMIC_RELEASE);
+    }
+    else if (direct)
     {
         int rcf = flush_deferred(e);
         if (rcf)
@@ -1812,10 +1913,30 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
                 break;
             }
             tail_if_asked();
-            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20))
+            if (resident && (spins & 31u) == 31u && !tail_launched && __atomic_load_n(&e->h_res_ctl->exited, __ATOMIC_ACQUIRE) != 0ull &&
+                __atomic_load_n(e->h_small_seq, __ATOMIC_ACQUIRE) < want && __atomic_load_n(e->h_small_seq + 1, __ATOMIC_ACQUIRE) != want)
+            {
+                // the kernel left without taking this call (its watchdog fired as the bell rang): launch it again, the bell still stands
+                int rcr = reap_resident();
+                if (!rcr)
+                    rcr = launch_resident();
+                if (rcr)
+                    return rcr;
+            }
+            if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(resident ? 2000 : 20))
                 break; // (a first launch loading code, a stop in a debugger: let the driver wait)
         }
-        if (!seen)
+        if (!seen && resident)
+        {
+            // (a stream synchronisation would wait for a kernel that waits for us)
+            (void) stop_resident(e);
+            if (__atomic_load_n(e->h_small_seq, __ATOMIC_ACQUIRE) < want)
+            {
+                e->error = "resident kernel: a call was not answered within 2 s";
+                return CC_ERR_HIP;
+            }
+        }
+        else if (!seen)
         {
             CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
             tail_if_asked();
@@ -1831,6 +1952,14 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     else
         CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
     e->idle = was_idle; // (capturing the graph went through launch_batch; replaying it only touches `stream`, which is drained again)
+    if (resident)
+    {
+        // a call that needed the host (serial fall-backs, continuation passes) or left an error made the kernel leave: reap it now, so that
+        // whatever follows finds the stream free
+        int rcr = (*e->h_remaining != 0 || e->h_small_state->error != 0) ? stop_resident(e) : reap_resident();
+        if (rcr)
+            return rcr;
+    }
     if (*e->h_remaining != 0)
     {
         // the kernels stopped early (limit_columns): continue on the general path, which also collects the events
@@ -2159,6 +2288,7 @@ void cc_engine_destroy(cc_engine* e)
     if (!e)
         return;
     (void) hipSetDevice(e->device);
+    (void) stop_resident(e);
     if (e->host_prof && e->hp_calls > 0)
         fprintf(stderr, "[cc host_prof] gated calls %lld: entry->launch_batch %.1f us, launch_batch->gate %.1f us, gate wait %.1f us, gate->return %.1f us (per call)\n",
                 e->hp_calls, e->hp_entry / e->hp_calls * 1e6, e->hp_pre / e->hp_calls * 1e6, e->hp_gate / e->hp_calls * 1e6, e->hp_post / e->hp_calls * 1e6);
@@ -2211,6 +2341,9 @@ int cc_engine_set_config(cc_engine* e, const cc_config* cfg)
     int rc = validate(e, cfg, e->g.num_rows, e->g.num_streams);
     if (rc)
         return rc;
+    (void) hipSetDevice(e->device);
+    if ((rc = stop_resident(e)) != CC_OK) // (so does the resident kernel)
+        return rc;
     rc = finish_batch(e);
     if (rc)
         return rc;
@@ -2248,6 +2381,8 @@ int cc_engine_reset(cc_engine* e, int num_rows)
     if (rc)
         return rc;
     (void) hipSetDevice(e->device);
+    if ((rc = stop_resident(e)) != CC_OK)
+        return rc;
     // A pipelined call may have left the chains behind its insertion to the next call (deferred tail / lazy gate): that closure holds the OLD
     // geometry, plane pointers and batch slot by value. Launch it now, against the state it belongs to, so that nothing of the old epoch
     // survives the reset (it would run on freed planes after a change of shape and mark a slot of the new epoch as pending).
@@ -2286,7 +2421,10 @@ int cc_engine_set_robot_from_sensor(cc_engine* e, int stream, const double tf[12
     if (!e || !tf || stream < -1 || stream >= e->g.num_streams)
         return CC_ERR_INVALID_ARGUMENT;
     (void) hipSetDevice(e->device);
-    int rc = finish_batch(e);
+    int rc = stop_resident(e); // (the host writes the streams' state below)
+    if (rc)
+        return rc;
+    rc = finish_batch(e);
     if (rc)
         return rc;
     const int first = stream < 0 ? 0 : stream, count = stream < 0 ? e->g.num_streams : 1;
@@ -2435,6 +2573,8 @@ int cc_engine_sync(cc_engine* e)
 
 void* cc_engine_hip_stream(cc_engine* e)
 {
+    if (e)
+        (void) stop_resident(e); // (whoever asks for the stream is about to enqueue work on it)
     return e ? (void*) e->stream : nullptr;
 }
 
@@ -2444,7 +2584,10 @@ int cc_engine_record_events(cc_engine* e, int enable)
         return CC_ERR_INVALID_ARGUMENT;
     destroy_small_graphs(e);
     (void) hipSetDevice(e->device);
-    int rc = finish_batch(e);
+    int rc = stop_resident(e);
+    if (rc)
+        return rc;
+    rc = finish_batch(e);
     if (rc)
         return rc;
     const int want = enable ? 1 : 0;
@@ -2604,13 +2747,13 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
         o.nchild = nullptr;
     int max_back = e->cfg.max_steps_in_row < e->g.ring_cols - 1 ? e->cfg.max_steps_in_row : e->g.ring_cols - 1;
     max_back = max_back < 0 ? 0 : (max_back > 255 ? 255 : max_back);
-    hipLaunchKernelGGL(cck::k_view, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, e->d_states, stream,
+    hipLaunchKernelGGL(cck::k_view, dim3((unsigned) (to - from + 1)), dim3(64), 0, query_stream(e), e->g, e->P, e->d_states, stream,
                        (long long) from, o, max_back);
     CC_HIP_CHECK(e, hipGetLastError());
     // one copy of the whole staging block (a call per field costs more than the bytes for the few columns a live mirror reads)
     const size_t used = (size_t) ((char*) o.finished + n - base);
-    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_view, base, used, hipMemcpyDeviceToHost, e->stream));
-    CC_HIP_CHECK(e, hipStreamSynchronize(e->stream));
+    CC_HIP_CHECK(e, hipMemcpyAsync(e->h_view, base, used, hipMemcpyDeviceToHost, query_stream(e)));
+    CC_HIP_CHECK(e, hipStreamSynchronize(query_stream(e)));
 #define COPY(dst, srcp, T)                                                                        \
     if (v->dst)                                                                                   \
         memcpy(v->dst, e->h_view + ((const char*) (srcp) - base), n * sizeof(T));
@@ -2678,22 +2821,22 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
     q.out_gcol = (long long*) b;
     b += (size_t) total * 8;
     q.out_row = (int*) b;
-    if (hipMemcpyAsync((void*) q.col_from, col_from, (size_t) n * 8, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemcpyAsync((void*) q.col_to, col_to, (size_t) n * 8, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemcpyAsync((void*) q.offset, offs.data(), (size_t) n * 8, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemcpyAsync((void*) q.cid, cluster_ids, (size_t) n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemcpyAsync((void*) q.n_points, n_points, (size_t) n * 4, hipMemcpyHostToDevice, e->stream) != hipSuccess ||
-        hipMemsetAsync(q.mismatch, 0, 64, e->stream) != hipSuccess)
+    if (hipMemcpyAsync((void*) q.col_from, col_from, (size_t) n * 8, hipMemcpyHostToDevice, query_stream(e)) != hipSuccess ||
+        hipMemcpyAsync((void*) q.col_to, col_to, (size_t) n * 8, hipMemcpyHostToDevice, query_stream(e)) != hipSuccess ||
+        hipMemcpyAsync((void*) q.offset, offs.data(), (size_t) n * 8, hipMemcpyHostToDevice, query_stream(e)) != hipSuccess ||
+        hipMemcpyAsync((void*) q.cid, cluster_ids, (size_t) n * 4, hipMemcpyHostToDevice, query_stream(e)) != hipSuccess ||
+        hipMemcpyAsync((void*) q.n_points, n_points, (size_t) n * 4, hipMemcpyHostToDevice, query_stream(e)) != hipSuccess ||
+        hipMemsetAsync(q.mismatch, 0, 64, query_stream(e)) != hipSuccess)
     {
         e->error = "cc_engine_gather_cluster_points: copy failed";
         return fail(CC_ERR_HIP);
     }
-    hipLaunchKernelGGL(cck::k_gather_clusters, dim3((unsigned) n), dim3(64), 0, e->stream, e->g, e->P, e->d_states, stream, q);
+    hipLaunchKernelGGL(cck::k_gather_clusters, dim3((unsigned) n), dim3(64), 0, query_stream(e), e->g, e->P, e->d_states, stream, q);
     int mismatch = 0;
-    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&mismatch, q.mismatch, 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
-        (total > 0 && (hipMemcpyAsync(h_gcol, q.out_gcol, (size_t) total * 8, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
-                       hipMemcpyAsync(h_row, q.out_row, (size_t) total * 4, hipMemcpyDeviceToHost, e->stream) != hipSuccess)) ||
-        hipStreamSynchronize(e->stream) != hipSuccess)
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(&mismatch, q.mismatch, 4, hipMemcpyDeviceToHost, query_stream(e)) != hipSuccess ||
+        (total > 0 && (hipMemcpyAsync(h_gcol, q.out_gcol, (size_t) total * 8, hipMemcpyDeviceToHost, query_stream(e)) != hipSuccess ||
+                       hipMemcpyAsync(h_row, q.out_row, (size_t) total * 4, hipMemcpyDeviceToHost, query_stream(e)) != hipSuccess)) ||
+        hipStreamSynchronize(query_stream(e)) != hipSuccess)
     {
         e->error = "cc_engine_gather_cluster_points: launch / copy failed";
         return fail(CC_ERR_HIP);
@@ -2723,11 +2866,18 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         return CC_ERR_INVALID_ARGUMENT;
     destroy_small_graphs(e);
     (void) hipSetDevice(e->device);
-    int rc = finish_batch(e);
+    int rc = stop_resident(e); // (the resident kernel bakes options, geometry and plane pointers in, like a captured graph)
+    if (rc)
+        return rc;
+    rc = finish_batch(e);
     if (rc)
         return rc;
     const std::string n(name);
-    if (n == "debug_flags")
+    if (n == "resident")
+        e->resident_opt = value != 0;
+    else if (n == "resident_idle_ms")
+        e->res_idle_ms = (int) std::max<int64_t>(1, std::min<int64_t>(value, 10000));
+    else if (n == "debug_flags")
         e->g.debug_flags = (int32_t) value;
     else if (n == "lds_tree_limit")
         e->g.lds_tree_limit = (int32_t) (value < 1 ? 1 : (value > TREE_SLOTS ? TREE_SLOTS : value));
@@ -2909,7 +3059,10 @@ int cc_engine_enable_timing(cc_engine* e, int enable)
     if (!e)
         return CC_ERR_INVALID_ARGUMENT;
     (void) hipSetDevice(e->device);
-    int rc = finish_batch(e);
+    int rc = stop_resident(e);
+    if (rc)
+        return rc;
+    rc = finish_batch(e);
     if (rc)
         return rc;
     e->timing = enable != 0;
@@ -2971,7 +3124,10 @@ int cc_engine_scatter_info(cc_engine* e, int n, const int32_t* streams, const in
     if (!e || n < 0 || slots < 1 || (n > 0 && (!streams || !from || !to || !d_original_index || !h_min_frame || !h_max_frame)))
         return CC_ERR_INVALID_ARGUMENT;
     (void) hipSetDevice(e->device);
-    int rc = finish_batch(e);
+    int rc = stop_resident(e);
+    if (rc)
+        return rc;
+    rc = finish_batch(e);
     if (rc)
         return rc;
     size_t total = 0;
@@ -3020,13 +3176,29 @@ int cc_engine_scatter_apply(cc_engine* e, int stream, int64_t from, int64_t to, 
     if (to < from)
         return CC_OK;
     (void) hipSetDevice(e->device);
-    int rc = finish_batch(e);
+    int rc = stop_resident(e);
+    if (rc)
+        return rc;
+    rc = finish_batch(e);
     if (rc)
         return rc;
     hipLaunchKernelGGL(cck::k_scatter_apply, dim3((unsigned) (to - from + 1)), dim3(64), 0, e->stream, e->g, e->P, (const StreamState*) e->d_states, stream, (long long) from,
                        d_original_index, slots, d_is_ground, d_detection, (long long) max_points);
     CC_HIP_CHECK(e, hipGetLastError());
     return CC_OK; // (asynchronous on cc_engine_hip_stream(e): cc_eval_frame_device on the same stream, or cc_engine_sync, orders behind it)
+}
+
+int cc_engine_resident_counters(cc_engine* e, uint64_t* launches, uint64_t* calls, int* running)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    if (launches)
+        *launches = e->res_launches;
+    if (calls)
+        *calls = e->res_calls + (e->res_running ? __atomic_load_n(&e->h_res_ctl->calls, __ATOMIC_ACQUIRE) : 0ull);
+    if (running)
+        *running = (e->res_running && __atomic_load_n(&e->h_res_ctl->exited, __ATOMIC_ACQUIRE) == 0ull) ? 1 : 0;
+    return CC_OK;
 }
 
 int cc_engine_gate_counters(cc_engine* e, uint64_t* lazy_batches, uint64_t* lazy_redone)

@@ -121,14 +121,16 @@ __global__ __launch_bounds__(A3_THREADS) void k_small_tail(Geometry g, cc_config
 //          sequence number last. Otherwise (a stop of the batch-parallel kernel, a stream that continues in global memory) the call's number goes
 //          into HostMirror::tail_req and the host launches k_small_tail behind this kernel, which then does all of F.
 // =====================================================================================================
-__global__ __launch_bounds__(AB_THREADS) void k_small_all(Geometry g, cc_config cfg, Planes P, StreamState* states, int stream, int slot,
-                                                          const float* __restrict__ xyz, const uint8_t* __restrict__ inten, const double* __restrict__ poses,
-                                                          long long n, int* remaining, double* __restrict__ ego, int* __restrict__ bail_count, HostMirror hm)
+// the whole call (phases A - F above) as a device function: k_small_all is one invocation of it, k_resident a loop over it. Returns (to every
+// thread alike) 0 when the call's results have been mirrored into pinned host memory, 1 when the serial fall-backs are needed: HostMirror::tail_req
+// then names the call and whoever launched this must launch k_small_tail behind it.
+__device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config& cfg, const Planes& P, StreamState* states, const int stream, const int slot,
+                                              const float* xyz, const uint8_t* inten, const double* poses, const long long n, int* remaining, double* ego,
+                                              int* bail_count, const HostMirror& hm, AbShared<1>& S)
 {
     const int R = g.num_rows;
     StreamState* st = &states[stream];
     const int wave = uniform_i32((int) (threadIdx.x >> 6));
-    __shared__ AbShared<1> S;
 #ifdef CC_SF_STATS
     unsigned long long sa_t[8];
     sa_t[0] = __builtin_amdgcn_s_memtime();
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(AB_THREADS) void k_small_all(Geometry g, cc_config 
     {
         if (threadIdx.x == 0)
             __hip_atomic_store(hm.tail_req, hm.d_seq[0] + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
+        return 1;
     }
     // (the mirror only carries the stream's state and events, final since assocb_body: wavefront 0 sends it while the others write the cluster ids,
     // which stay in HBM and are complete when the kernel ends — whatever reads them is ordered behind it on the stream)
@@ -231,6 +233,111 @@ __global__ __launch_bounds__(AB_THREADS) void k_small_all(Geometry g, cc_config 
         st->dbg[6] += 1;
     }
 #endif
+    return 0;
+}
+
+__global__ __launch_bounds__(AB_THREADS) void k_small_all(Geometry g, cc_config cfg, Planes P, StreamState* states, int stream, int slot,
+                                                          const float* __restrict__ xyz, const uint8_t* __restrict__ inten, const double* __restrict__ poses,
+                                                          long long n, int* remaining, double* __restrict__ ego, int* __restrict__ bail_count, HostMirror hm)
+{
+    __shared__ AbShared<1> S;
+    (void) small_all_body(g, cfg, P, states, stream, slot, xyz, inten, poses, n, remaining, ego, bail_count, hm, S);
+}
+
+// =====================================================================================================
+// k_resident — the synchronous calling pattern of the reference (is_single_threaded: addFiring returns when the firing's columns are through,
+// thread_pool.hpp:58-64, cc.cpp:88-93; kitti_demo.cpp:280,403) without a kernel dispatch per call: ONE block of AB_THREADS threads stays on a
+// compute unit and runs small_all_body once per doorbell. Host and kernel talk through pinned host memory (ResidentCtl):
+//   host    copies the call's firings into the pinned staging (xyz / inten / poses, the same buffers k_small_all reads), then stores
+//           bell = call number << 8 | n  (release, system scope) and spins on HostMirror::seq / tail_req / ResidentCtl::exited
+//   kernel  thread 0 polls `bell` (one load over PCIe per ~1 us) until it names the next call; the block runs the call; results go to the pinned
+//           mirror as in k_small_all, the sequence number last. Writes to the planes are released to the device (the system-scope fence in
+//           mirror_results writes the L2 back), so read-only queries on ANOTHER stream (k_view, k_gather_clusters) see them while this kernel idles.
+// The kernel leaves (ResidentCtl::exited = reason, system scope, last store) when
+//   1  the host asked for it (ResidentCtl::stop: reset, set_config, set_option, a call of another shape, destroy ...)
+//   2  a call needs the serial fall-backs (tail_req names it: the host launches k_small_tail behind this kernel, in stream order)
+//   3  a call stopped early (limit_columns: the host runs the continuation passes) or left an error on the stream
+//   4  WATCHDOG: no doorbell for `idle_limit` ticks of the 100 MHz wall clock (a host thread that died or went away must not pin a compute
+//      unit and a PCIe poll loop forever); the next call simply launches the kernel again
+// and the host waits for the kernel's end on the stream before it launches anything else there. A doorbell that arrives while the kernel is
+// leaving is not lost: `bell` keeps its value and the next launch of the kernel takes it.
+// grid = 1, block = AB_THREADS, dynamic LDS = insert2_lds_bytes(num_rows).
+// =====================================================================================================
+struct ResidentCtl
+{
+    unsigned long long bell;   // host -> kernel: call number << 8 | firings (1 .. 63)
+    unsigned long long pad0[7];
+    unsigned long long stop;   // host -> kernel: leave now
+    unsigned long long pad1[7];
+    unsigned long long exited; // kernel -> host: 0 while it runs, else the reason it left
+    unsigned long long calls;  // kernel -> host: calls this launch of the kernel has run (statistics)
+    unsigned long long pad2[6];
+};
+
+__global__ __launch_bounds__(AB_THREADS) void k_resident(Geometry g, cc_config cfg, Planes P, StreamState* states, int stream, int slot, const float* xyz,
+                                                         const uint8_t* inten, const double* poses, int* remaining, double* ego, int* bail_count, HostMirror hm,
+                                                         ResidentCtl* ctl, unsigned long long idle_limit)
+{
+    __shared__ AbShared<1> S;
+    __shared__ long long s_cmd; // > 0: firings of the next call; < 0: leave with reason -s_cmd
+    unsigned long long calls = 0ull;
+    for (;;)
+    {
+        if (threadIdx.x == 0)
+        {
+            const unsigned long long want = hm.d_seq[0] + 1ull; // (written by this block's own mirror_results, or by the launch before)
+            const unsigned long long t0 = wall_clock64();
+            long long cmd = 0;
+            for (unsigned spin = 0;; spin++)
+            {
+                const unsigned long long b = __hip_atomic_load(&ctl->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((b >> 8) == want && (b & 255ull) != 0ull)
+                {
+                    cmd = (long long) (b & 255ull);
+                    break;
+                }
+                if (__hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull)
+                {
+                    cmd = -1;
+                    break;
+                }
+                if ((spin & 15u) == 15u && wall_clock64() - t0 > idle_limit)
+                {
+                    cmd = -4;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
+            s_cmd = cmd;
+        }
+        __syncthreads();
+        const long long cmd = uniform_i64(s_cmd);
+        int reason = cmd < 0 ? (int) -cmd : 0;
+        if (reason == 0)
+        {
+            // acquire at system scope, every wavefront: what the host wrote before it rang the bell (the firings in pinned memory) is read from
+            // memory, not from a cache line of the previous call, and no load of the call is moved in front of the poll
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+            __builtin_amdgcn_s_dcache_inv();
+            const int left = small_all_body(g, cfg, P, states, stream, slot, xyz, inten, poses, cmd, remaining, ego, bail_count, hm, S);
+            calls++;
+            __syncthreads(); // (S and the insertion's LDS words are re-used by the next call)
+            if (left)
+                reason = 2;
+            else if (uniform_i32((int) (*remaining != 0 || states[stream].error != 0)) != 0)
+                reason = 3;
+        }
+        if (reason)
+        {
+            if (threadIdx.x == 0)
+            {
+                __hip_atomic_store(&ctl->calls, calls, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+                __hip_atomic_store(&ctl->exited, (unsigned long long) reason, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+    }
 }
 
 // =====================================================================================================

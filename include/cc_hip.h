@@ -337,8 +337,12 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *                                  pinned host memory
  *  "small_all"               (1)   ... as ONE launch, k_small_all, on a 64-row engine; the host launches the serial fall-back behind it when asked
  *  "small_direct"            (1)   calls of 9 .. 63 firings are one direct launch of k_small_all; up to 8 firings replay a captured one-node graph
- *  "resident"                (0)   1: calls of 1 .. 8 firings on a 1-stream 64-row engine are handed to a RESIDENT kernel through a pinned-memory
- *                                  doorbell (no dispatch per call); started by the first such call, stopped by anything else that touches the engine
+ *  "resident"                (0)   1: calls of 1 .. 63 firings on a 1-stream 64-row engine are handed to a RESIDENT kernel (k_resident: one block that
+ *                                  stays on a compute unit) through a doorbell in pinned memory — no dispatch per call. Started by the first such
+ *                                  call; read-only queries (cc_engine_read_columns, cc_engine_gather_cluster_points, the event drains) run beside
+ *                                  it on another stream; everything else (reset, set_config, set_option, larger calls, destroy ...) stops it first
+ *  "resident_idle_ms"        (20)  the kernel's watchdog: it leaves by itself after that long without a call (a host thread that went away must
+ *                                  not pin a compute unit); the next call launches it again
  *  "prewarm_small_graphs"          one-shot action (value k in 1..8): size the grow-only buffers of small calls and capture the graphs of calls of
  *                                  1..k firings now, without launching anything
  *  "forget_inclination_table"      one-shot action: clear the ground-segmentation inclination table too (the only state cc_engine_reset keeps, like
@@ -368,6 +372,11 @@ int cc_engine_totals(cc_engine* e, uint64_t* cells_published, uint64_t* clusters
  * after its cluster finished, 6 a candidate from a column older than the first unpublished one (cc.cpp:762-763); bail_reasons[7] is not a
  * reason: the number of small cc_engine_add_firings calls (one launch, k_small_all) whose serial fall-back kernel the host had to launch behind it. */
 int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* batch_bails, uint64_t bail_reasons[8]);
+/* The resident single-stream kernel (option "resident"): launches of k_resident so far, calls it has answered, and whether it sits on the
+ * engine's stream right now (it leaves by itself after "resident_idle_ms" without a call, and whenever a call needs the host). The number of
+ * calls of a launch that is still running is as of its last exit report (0 until then). Any pointer may be NULL. Never waits. */
+int cc_engine_resident_counters(cc_engine* e, uint64_t* launches, uint64_t* calls, int* running);
+
 /* The insertion gate of the pipelined mode (option "lazy_gate"): how many batches had their insertion enqueued before the host had read the
  * previous batch's insertion counters, and how many of those were launched a second time because the previous batch turned out to need the
  * serial insertion kernels first (the kernels of the first launch return at once in that case). No sync. */
