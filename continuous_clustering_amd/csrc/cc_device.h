@@ -189,6 +189,10 @@ struct Planes
     uint16_t* sc_visits; // Point::number_of_visited_neighbors (cc.cpp:725), only with Geometry::mirror_fields
     int2* link_log;      // [stream][link_capacity] (root cell, root cell) of every tree link made in the current call (cc.cpp:693-694), only
                          // with Geometry::mirror_fields: the host rebuilds Point::associated_trees from it
+    // long scans of the packed window scan (cc_k_scan.h: k_scan2<.., SPLIT> -> k_scan2_long -> k_scan2_epi)
+    void* sl_rec;     // [stream][SL_CAP] ScanLongRec: points that were still scanning after SCAN_CAP visits
+    int32_t* sl_ctl;  // [stream][4] records | next record to hand out | deferred columns | blocks of k_scan2_epi that are through
+    int32_t* sl_cols; // [stream][ring_cols] local columns whose epilogue waits for k_scan2_long
     int32_t* par_off; // [stream][IP_MAXF] column offset of every firing of the batch (k_insert_par over several blocks -> k_insert_par_fin)
     float* curtab;    // [stream][num_rows] sc_inclination_angles_between_lasers_ after the last emitted column
     unsigned long long* tab_acc; // [stream][Geometry::tab_tiles][num_rows] (column + 1) << 32 | bits of the last valid inclination step inside a tile, as the

@@ -137,6 +137,7 @@ struct cc_engine
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
+    bool scan_split{true};              // option "scan_split": the packed window scan hands long scans to k_scan2_long (cc_k_scan.h)
     int scan_packed{-1};                // option "scan_packed": 1 = k_scan2 (active points packed into the lanes), 0 = k_scan (rows as lanes, lock
                                         // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch)
                                         // and, at up to 64 rows, for launches of more than 192 streams (there the step follows the number of vector
@@ -354,6 +355,9 @@ int allocate(cc_engine* e)
     A(tabc, (size_t) BATCH_SLOTS * S * (size_t) g.tab_tiles * (size_t) g.num_rows);
     A(sc_visits, C);
     A(link_log, S * (size_t) g.link_capacity);
+    A(sl_ctl, S * 4) A(sl_cols, L);
+    if ((rc = alloc_plane(e, (unsigned long long**) &P.sl_rec, S * (size_t) cck::SL_CAP * sizeof(cck::ScanLongRec) / sizeof(unsigned long long))) != 0)
+        return rc;
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
         return rc;
@@ -401,6 +405,7 @@ int reset_state(cc_engine* e, bool keep_table)
     CC_HIP_CHECK(e, hipMemsetAsync(P.ignored, 0, C, e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.root, 0xFF, C * sizeof(int32_t), e->stream));
     CC_HIP_CHECK(e, hipMemsetAsync(P.tab_acc, 0, S * (size_t) g.tab_tiles * (size_t) g.num_rows * sizeof(unsigned long long), e->stream));
+    CC_HIP_CHECK(e, hipMemsetAsync(P.sl_ctl, 0, S * 4 * sizeof(int32_t), e->stream));
     if (!keep_table)
         CC_HIP_CHECK(e, hipMemsetAsync(P.curtab, 0xFF, S * (size_t) g.num_rows * sizeof(float), e->stream));
     std::vector<StreamState> init(S);
@@ -1032,7 +1037,25 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         // 32 - 128 streams where the GPU has room and the lock-step scan's shorter launch counts)
         else if (e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192)))
         {
-            if (rpl == 1 && !g.mirror_fields)
+            if (!g.mirror_fields && e->scan_split)
+            {
+                // long scans apart (cc_k_scan.h): the packed scan hands points that are still scanning after SCAN_CAP visits to k_scan2_long, which
+                // keeps every lane busy with one of them; k_scan2_epi finishes the columns that had such a point
+                const dim3 long_grid((unsigned) count, cck::SCAN_LONG_BLOCKS), epi_grid((unsigned) count, cck::SCAN_EPI_BLOCKS);
+                if (rpl == 1)
+                {
+                    hipLaunchKernelGGL((cck::k_scan2<1, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_long<1>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_epi<1>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot);
+                }
+                else
+                {
+                    hipLaunchKernelGGL((cck::k_scan2<2, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_long<2>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_epi<2>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot);
+                }
+            }
+            else if (rpl == 1 && !g.mirror_fields)
                 hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
             else if (rpl == 1)
                 hipLaunchKernelGGL((cck::k_scan2<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
@@ -3038,6 +3061,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_batch = value != 0;
     else if (n == "assoc_rounds")
         e->assoc_rounds = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
+    else if (n == "scan_split")
+        e->scan_split = value != 0;
     else if (n == "scan_packed")
     {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);

@@ -340,6 +340,7 @@ struct SP
     float4* sc_rec;
     uint16_t* sc_visits;
     int2* link_log;
+    int32_t* sl_cols;
 };
 
 __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, int s)
@@ -401,5 +402,6 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.sc_rec = P.sc_rec + co;
     p.sc_visits = P.sc_visits + co;
     p.link_log = P.link_log + (size_t) s * (size_t) g.link_capacity;
+    p.sl_cols = P.sl_cols + lo;
     return p;
 }

@@ -416,9 +416,136 @@ __global__ __launch_bounds__(256) void k_small_front(Geometry g, cc_config cfg, 
 #endif
 constexpr int SCAN_TILE_CELLS = CC_SCAN_TILE_CELLS;
 
-template<int RPL, bool MIRROR>
+// ---- the per-lane state machine of one point's window scan (cc.cpp:706-769), shared by k_scan2 and k_scan2_long ----------------------------------
+// column offset sb, direction (0 = rows above, 1 = rows below), vertical step d; one visit per call of step()
+struct ScanCfg
+{
+    int R, RC, max_col_steps, stop_min;
+    bool stop_enabled;
+    float maxd2;
+};
+
+struct ScanPoint
+{
+    float4 me;
+    float mad;
+    int row, needed, bound;
+    int sb, down, d, oc, orow;
+    int rooted, parent, nlinks, overflow, visits, reach;
+    unsigned long long packed;
+    bool run;
+
+    __device__ __forceinline__ void next_column(const ScanCfg& c) // the end of a column's visits: cc.cpp:756-769
+    {
+        if ((rooted && c.stop_enabled && sb >= c.stop_min) || oc == bound || sb + 1 > needed)
+            run = false;
+        else
+        {
+            sb++;
+            oc = oc == 0 ? c.RC - 1 : oc - 1;
+            down = 0;
+            d = 0;
+            orow = row; // (the cell in the same row always passes the loop condition: d = 0, row inside the image)
+        }
+    }
+    __device__ __forceinline__ void next_direction(const ScanCfg& c) // a direction ended (break or loop condition false)
+    {
+        if (down == 0 && sb > 0)
+        {
+            down = 1;
+            d = 1;
+            orow = row + 1;
+            if (!(orow < c.R && d <= c.max_col_steps))
+                next_column(c);
+        }
+        else
+            next_column(c);
+    }
+    // position on the first cell that passes the while-condition of cc.cpp:718-719, or finish
+    __device__ __forceinline__ void start(const ScanCfg& c, const bool have, const int lc)
+    {
+        sb = 0, down = 0, d = 1, oc = lc, orow = row - 1;
+        rooted = 0, parent = -1, nlinks = 0, overflow = 0, visits = 0, reach = 0;
+        packed = 0;
+        run = have;
+        if (run && !(orow >= 0 && d <= c.max_col_steps))
+            next_direction(c); // row 0 has nothing above it in its own column
+    }
+    template<bool MIRROR>
+    __device__ __forceinline__ void step(const ScanCfg& c, const SP& p)
+    {
+        const float4 o = p.sc_rec[oc * c.R + orow];
+        const unsigned char oign = p.ignored[oc * c.R + orow]; // (issued with the record: one round trip per visit)
+        if (MIRROR)
+        {
+            visits++; // cc.cpp:725
+            reach = sb;
+        }
+        if (ccm::absf(o.w - me.w) > mad) // cc.cpp:728: the inclination window is left
+            next_direction(c);
+        else
+        {
+            const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
+            if (!oign && dx * dx + dy * dy + dz * dz < c.maxd2) // (a cell without a return is ignored, and its x is NaN)
+            {
+                const int cand = (sb << 8) | orow;
+                if (!rooted)
+                    parent = cand;
+                else if (nlinks < LINK_SLOTS)
+                {
+                    packed |= (unsigned long long) cand << (16 * nlinks);
+                    nlinks++;
+                }
+                else
+                    overflow = 1;
+                rooted = 1;
+            }
+            if (rooted && c.stop_enabled && d >= c.stop_min) // cc.cpp:746-749
+                next_direction(c);
+            else
+            {
+                d++;
+                orow = down ? orow + 1 : orow - 1;
+                if (!(orow >= 0 && orow < c.R && d <= c.max_col_steps))
+                    next_direction(c);
+            }
+        }
+    }
+};
+
+// ---- long scans (round 6) -----------------------------------------------------------------------------------------------------------------------
+// Nearly every scan is over after four visits, but a point that finds no neighbour (vegetation, spray, the edge of an object) visits every cell
+// of its inclination window in up to max_steps_in_row + 1 columns: hundreds of visits (p99 331, max 840 on the bench's vegetation scenes; p99 5,
+// max 200 on its street scene). In a wavefront whose lanes run one point each, 63 lanes then wait for that one: 5 % of the lanes did a visit per
+// iteration on vegetation, 32 % on the street scene (tools/scan_model.py, from the oracle's visit counts). So a lane that is still scanning after
+// SCAN_CAP visits hands its state to the stream's LONG-SCAN LIST (Planes::sl_rec) and k_scan2 goes on; k_scan2_long then runs those points with
+// every lane busy — a lane whose point is done takes the next one from the list —, and k_scan2_epi runs the column epilogue of the columns that
+// had such a point (k_scan2 does it at once for the others: 97 % of the columns on the street scene, 58 % on vegetation). Same visits in the same
+// order per point, so the same results bit for bit. Only without Geometry::mirror_fields (the visit counts and the scan reach of the host mirror
+// stay with the one-pass form).
+constexpr int SL_CAP = 8192; // records of a stream's long-scan list per batch; a lane that finds it full finishes its scan where it is
+struct ScanLongRec
+{
+    int ci;            // the point's cell (local column * rows + row)
+    int oc;            // ring column of the next visit
+    short orow, sb, d, needed;
+    short parent;
+    unsigned char down, rooted, nlinks, flags; // flags: 1 link overflow, 2 the scan must stop at the stream's first column (bound)
+    float mad;
+    unsigned long long packed;
+};
+static_assert(sizeof(ScanLongRec) == 40, "long-scan record");
+// per stream: Planes::sl_ctl[4] = {records, next record to hand out, deferred columns, blocks of k_scan2_epi that are through}
+
+#ifndef CC_SCAN_CAP
+#define CC_SCAN_CAP 6
+#endif
+constexpr int SCAN_CAP = CC_SCAN_CAP; // visits a lane of k_scan2 spends on its point before it hands it to the long-scan list (SPLIT)
+
+template<int RPL, bool MIRROR, bool SPLIT = false>
 __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
 {
+    static_assert(!(SPLIT && MIRROR), "the long-scan list does not carry the mirror's visit counts");
     const int s = first_stream + blockIdx.x;
     const int lane = lane_id();
     const StreamState* st = &states[s];
@@ -426,18 +553,23 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
         return;
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    const float maxd2 = g.max_distance_squared;
-    const int max_row_steps = cfg.max_steps_in_row, max_col_steps = cfg.max_steps_in_column;
-    const bool stop_enabled = cfg.stop_after_association_enabled != 0;
-    const int stop_min = cfg.stop_after_association_min_steps;
+    ScanCfg sc;
+    sc.R = R, sc.RC = RC;
+    sc.maxd2 = g.max_distance_squared;
+    sc.max_col_steps = cfg.max_steps_in_column;
+    sc.stop_enabled = cfg.stop_after_association_enabled != 0;
+    sc.stop_min = cfg.stop_after_association_min_steps;
+    const int max_row_steps = cfg.max_steps_in_row;
     const int TC = SCAN_TILE_CELLS / (RPL * 64); // columns per tile: 4 at <= 64 rows, 2 at <= 128
     __shared__ unsigned short s_list[SCAN_TILE_CELLS];  // tile-local cell (column in tile * RPL * 64 + row) of every active point
-    __shared__ short s_parent[SCAN_TILE_CELLS];
+    __shared__ short s_parent[SCAN_TILE_CELLS];         // (SPLIT: -3 = the point waits in the long-scan list)
     __shared__ unsigned char s_nlinks[SCAN_TILE_CELLS];
-    __shared__ unsigned short s_visits[SCAN_TILE_CELLS];
-    __shared__ unsigned char s_reach[SCAN_TILE_CELLS];
+    __shared__ unsigned short s_visits[MIRROR ? SCAN_TILE_CELLS : 1];
+    __shared__ unsigned char s_reach[MIRROR ? SCAN_TILE_CELLS : 1];
     __shared__ double s_fin[SCAN_TILE_CELLS];
     __shared__ unsigned long long s_links[SCAN_TILE_CELLS];
+    int* const sl_ctl = P.sl_ctl + (size_t) s * 4;
+    ScanLongRec* const sl_rec = (ScanLongRec*) P.sl_rec + (size_t) s * SL_CAP;
     const long long col_begin = st->batch[slot].acp_next, col_end = st->batch[slot].seg_end, first_column = st->first_column;
     const int first_lc = (int) (first_column % RC);
     const long long n_tiles = (col_end - col_begin + TC - 1) / TC;
@@ -477,6 +609,7 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
         }
         wave_lds_fence();
         // ---- B: one point per lane ---------------------------------------------------------------------------------------------
+        unsigned deferred = 0; // SPLIT: bit tc = a point of the tile's column tc went to the long-scan list
         for (int base = 0; base < n_act; base += 64)
         {
             const bool have = base + lane < n_act;
@@ -486,106 +619,77 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
             int lc = lc0 + tc;
             lc = lc >= RC ? lc - RC : lc;
             const int ci = lc * R + row;
-            float4 me = make_float4(0.f, 0.f, 0.f, 0.f);
-            float mad = 0.f;
+            ScanPoint q;
+            q.me = make_float4(0.f, 0.f, 0.f, 0.f);
+            q.mad = 0.f;
+            q.row = row;
             double fin = 0.;
-            int needed = -1;
+            q.needed = -1;
             if (have)
             {
-                me = p.sc_rec[ci];
-                mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
-                fin = cell_caz(caz_base_of_rotation(rot0 + (cir0 + tc >= g.num_columns ? 1 : 0)), p.incaz[ci]) + (double) mad;
-                needed = f2i_x86(__builtin_ceilf(mad / g.az_width));
-                needed = needed < max_row_steps ? needed : max_row_steps;
+                q.me = p.sc_rec[ci];
+                q.mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
+                fin = cell_caz(caz_base_of_rotation(rot0 + (cir0 + tc >= g.num_columns ? 1 : 0)), p.incaz[ci]) + (double) q.mad;
+                q.needed = f2i_x86(__builtin_ceilf(q.mad / g.az_width));
+                q.needed = q.needed < max_row_steps ? q.needed : max_row_steps;
             }
             // never look at columns older than the first column ever segmented (their planes are uninitialised)
-            const int bound = (gc - first_column) <= (long long) max_row_steps + 1 ? first_lc : -1;
-            // state of the scan (cc.cpp:706-769): column offset sb, direction (0 = rows above, 1 = rows below), vertical step d
-            int sb = 0, down = 0, d = 1, oc = lc, orow = row - 1;
-            int rooted = 0, parent = -1, nlinks = 0, overflow = 0, visits = 0, reach = 0;
-            unsigned long long packed = 0;
-            // position on the first cell that passes the while-condition of cc.cpp:718-719, or finish
-            bool run = have;
-            auto next_column = [&]() // the end of a column's visits: cc.cpp:756-769
+            q.bound = (gc - first_column) <= (long long) max_row_steps + 1 ? first_lc : -1;
+            q.start(sc, have, lc);
+            bool pending = false;
+            if (SPLIT)
             {
-                if ((rooted && stop_enabled && sb >= stop_min) || oc == bound || sb + 1 > needed)
-                    run = false;
-                else
+                for (int it = 0; it < SCAN_CAP && __any(q.run); it++)
+                    if (q.run)
+                        q.template step<false>(sc, p);
+                const unsigned long long m = __ballot(q.run);
+                if (m)
                 {
-                    sb++;
-                    oc = oc == 0 ? RC - 1 : oc - 1;
-                    down = 0;
-                    d = 0;
-                    orow = row; // (the cell in the same row always passes the loop condition: d = 0, row inside the image)
-                }
-            };
-            auto next_direction = [&]() // a direction ended (break or loop condition false)
-            {
-                if (down == 0 && sb > 0)
-                {
-                    down = 1;
-                    d = 1;
-                    orow = row + 1;
-                    if (!(orow < R && d <= max_col_steps))
-                        next_column();
-                }
-                else
-                    next_column();
-            };
-            if (run && !(orow >= 0 && d <= max_col_steps))
-                next_direction(); // row 0 has nothing above it in its own column
-            while (__any(run))
-            {
-                if (run)
-                {
-                    const float4 o = p.sc_rec[oc * R + orow];
-                    const unsigned char oign = p.ignored[oc * R + orow]; // (issued with the record: one round trip per visit)
-                    if (MIRROR)
+                    // the points that are still scanning go to the stream's long-scan list (one atomic per wavefront), as far as it has room
+                    int lbase = 0;
+                    if (lane == (int) __ffsll((long long) m) - 1)
+                        lbase = atomicAdd(&sl_ctl[0], (int) __popcll(m));
+                    lbase = __shfl(lbase, (int) __ffsll((long long) m) - 1);
+                    const int idx = lbase + (int) __popcll(m & lanes_below());
+                    if (q.run && idx < SL_CAP)
                     {
-                        visits++; // cc.cpp:725
-                        reach = sb;
+                        ScanLongRec r;
+                        r.ci = ci, r.oc = q.oc;
+                        r.orow = (short) q.orow, r.sb = (short) q.sb, r.d = (short) q.d, r.needed = (short) q.needed;
+                        r.parent = (short) q.parent;
+                        r.down = (unsigned char) q.down, r.rooted = (unsigned char) q.rooted, r.nlinks = (unsigned char) q.nlinks;
+                        r.flags = (unsigned char) ((q.overflow ? 1 : 0) | (q.bound >= 0 ? 2 : 0));
+                        r.mad = q.mad;
+                        r.packed = q.packed;
+                        sl_rec[idx] = r;
+                        pending = true;
+                        q.run = false;
                     }
-                    if (ccm::absf(o.w - me.w) > mad) // cc.cpp:728: the inclination window is left
-                        next_direction();
-                    else
-                    {
-                        const float dx = me.x - o.x, dy = me.y - o.y, dz = me.z - o.z;
-                        if (!oign && dx * dx + dy * dy + dz * dz < maxd2) // (a cell without a return is ignored, and its x is NaN)
-                        {
-                            const int cand = (sb << 8) | orow;
-                            if (!rooted)
-                                parent = cand;
-                            else if (nlinks < LINK_SLOTS)
-                            {
-                                packed |= (unsigned long long) cand << (16 * nlinks);
-                                nlinks++;
-                            }
-                            else
-                                overflow = 1;
-                            rooted = 1;
-                        }
-                        if (rooted && stop_enabled && d >= stop_min) // cc.cpp:746-749
-                            next_direction();
-                        else
-                        {
-                            d++;
-                            orow = down ? orow + 1 : orow - 1;
-                            if (!(orow >= 0 && orow < R && d <= max_col_steps))
-                                next_direction();
-                        }
-                    }
+                    while (__any(q.run)) // (a full list: finish here)
+                        if (q.run)
+                            q.template step<false>(sc, p);
                 }
+                // which of the tile's columns have a waiting point
+                for (int t2 = 0; t2 < TC; t2++)
+                    if (__any(pending && tc == t2))
+                        deferred |= 1u << t2;
+            }
+            else
+            {
+                while (__any(q.run))
+                    if (q.run)
+                        q.template step<MIRROR>(sc, p);
             }
             if (have)
             {
-                s_parent[tl] = (short) parent;
-                s_nlinks[tl] = (unsigned char) (overflow ? 255 : nlinks);
+                s_parent[tl] = (short) (pending ? -3 : q.parent);
+                s_nlinks[tl] = (unsigned char) (q.overflow ? 255 : q.nlinks);
                 s_fin[tl] = fin;
-                s_links[tl] = packed;
+                s_links[tl] = q.packed;
                 if (MIRROR)
                 {
-                    s_visits[tl] = sat_u16(visits);
-                    s_reach[tl] = (unsigned char) reach;
+                    s_visits[tl] = sat_u16(q.visits);
+                    s_reach[tl] = (unsigned char) q.reach;
                 }
             }
         }
@@ -599,6 +703,7 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
             double fin[RPL];
             unsigned long long packed[RPL];
             int reach = 0;
+            const bool later = SPLIT && ((deferred >> tc) & 1u) != 0; // the column waits for k_scan2_long: k_scan2_epi finishes it
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
@@ -613,17 +718,151 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
                 if (row < R)
                 {
                     const int ci = lc * R + row;
-                    p.sc_parent[ci] = (int16_t) parent[k];
-                    p.sc_nlinks[ci] = (uint8_t) nlinks[k];
                     p.sc_fin[ci] = fin[k];
-                    if (nlinks[k] > 0)
-                        p.sc_links[ci] = packed[k];
+                    if (!(later && parent[k] == -3)) // (a waiting point's parent and links are written by k_scan2_long)
+                    {
+                        p.sc_parent[ci] = (int16_t) parent[k];
+                        p.sc_nlinks[ci] = (uint8_t) nlinks[k];
+                        if (nlinks[k] > 0)
+                            p.sc_links[ci] = packed[k];
+                    }
                     if (MIRROR)
                         p.sc_visits[ci] = s_visits[tl];
                 }
             }
-            scan_column_epilogue<RPL, MIRROR>(p, R, lc, lane, parent, nlinks, fin, packed, reach);
+            if (later)
+            {
+                if (lane == 0)
+                    p.sl_cols[atomicAdd(&sl_ctl[2], 1)] = lc;
+            }
+            else
+                scan_column_epilogue<RPL, MIRROR>(p, R, lc, lane, parent, nlinks, fin, packed, reach);
         }
         wave_lds_fence(); // the tile's LDS arrays are rewritten by the next tile
+    }
+}
+
+// k_scan2_long — the points k_scan2<.., SPLIT> handed over, one per lane, every lane busy: a lane whose point is done writes its results
+// (Planes::sc_parent / sc_nlinks / sc_links of the point's cell) and takes the next record. grid = (streams, SCAN_LONG_BLOCKS), block = 64.
+#ifndef CC_SCAN_LONG_BLOCKS
+#define CC_SCAN_LONG_BLOCKS 16
+#endif
+constexpr int SCAN_LONG_BLOCKS = CC_SCAN_LONG_BLOCKS;
+constexpr int SCAN_EPI_BLOCKS = 16;
+
+template<int RPL>
+__global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+{
+    const int s = first_stream + blockIdx.x;
+    int* const sl_ctl = P.sl_ctl + (size_t) s * 4;
+    int n = sl_ctl[0];
+    if (n <= 0)
+        return;
+    n = n < SL_CAP ? n : SL_CAP;
+    const StreamState* st = &states[s];
+    const int lane = lane_id();
+    const SP p = stream_ptrs(P, g, s);
+    const ScanLongRec* const sl_rec = (ScanLongRec*) P.sl_rec + (size_t) s * SL_CAP;
+    const int R = g.num_rows, RC = g.ring_cols;
+    ScanCfg sc;
+    sc.R = R, sc.RC = RC;
+    sc.maxd2 = g.max_distance_squared;
+    sc.max_col_steps = cfg.max_steps_in_column;
+    sc.stop_enabled = cfg.stop_after_association_enabled != 0;
+    sc.stop_min = cfg.stop_after_association_min_steps;
+    const int first_lc = (int) (st->first_column % RC);
+    ScanPoint q;
+    q.run = false;
+    q.me = make_float4(0.f, 0.f, 0.f, 0.f);
+    q.mad = 0.f, q.row = 0, q.needed = 0, q.bound = -1, q.sb = 0, q.down = 0, q.d = 0, q.oc = 0, q.orow = 0;
+    q.rooted = 0, q.parent = -1, q.nlinks = 0, q.overflow = 0, q.visits = 0, q.reach = 0, q.packed = 0ull;
+    int ci = 0;
+    bool more = true; // (wave-uniform) the list may still have records nobody has taken
+    for (;;)
+    {
+        const unsigned long long idle = __ballot(!q.run);
+        if (more && idle)
+        {
+            int lbase = 0;
+            if (lane == (int) __ffsll((long long) idle) - 1)
+                lbase = atomicAdd(&sl_ctl[1], (int) __popcll(idle));
+            lbase = __shfl(lbase, (int) __ffsll((long long) idle) - 1);
+            const int idx = lbase + (int) __popcll(idle & lanes_below());
+            if (!q.run && idx < n)
+            {
+                const ScanLongRec r = sl_rec[idx];
+                ci = r.ci;
+                q.me = p.sc_rec[ci];
+                q.mad = r.mad;
+                q.row = ci % R;
+                q.needed = r.needed;
+                q.bound = (r.flags & 2) ? first_lc : -1;
+                q.sb = r.sb, q.down = r.down, q.d = r.d, q.oc = r.oc, q.orow = r.orow;
+                q.rooted = r.rooted, q.parent = r.parent, q.nlinks = r.nlinks, q.overflow = r.flags & 1;
+                q.packed = r.packed;
+                q.run = true;
+            }
+            more = lbase + (int) __popcll(idle) < n;
+        }
+        if (!__any(q.run))
+            break;
+        for (int it = 0; it < 8; it++) // (a few visits between two looks at the list)
+            if (q.run)
+            {
+                q.template step<false>(sc, p);
+                if (!q.run)
+                {
+                    p.sc_parent[ci] = (int16_t) q.parent;
+                    p.sc_nlinks[ci] = (uint8_t) (q.overflow ? 255 : q.nlinks);
+                    if (q.nlinks > 0)
+                        p.sc_links[ci] = q.packed;
+                }
+            }
+    }
+}
+
+// k_scan2_epi — the column epilogue of the columns that waited for k_scan2_long: their per-cell scan results are complete in the planes now.
+// The last block through clears the stream's long-scan counters for the next batch. grid = (streams, SCAN_EPI_BLOCKS), block = 64.
+template<int RPL>
+__global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
+{
+    const int s = first_stream + blockIdx.x;
+    int* const sl_ctl = P.sl_ctl + (size_t) s * 4;
+    const int nd = sl_ctl[2];
+    if (nd <= 0 && sl_ctl[0] <= 0)
+        return;
+    const int lane = lane_id();
+    const SP p = stream_ptrs(P, g, s);
+    const int R = g.num_rows;
+    for (int i = blockIdx.y; i < nd; i += gridDim.y)
+    {
+        const int lc = p.sl_cols[i];
+        int parent[RPL], nlinks[RPL];
+        double fin[RPL];
+        unsigned long long packed[RPL];
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            parent[k] = -2, nlinks[k] = 0, fin[k] = 0., packed[k] = 0ull;
+            if (row < R)
+            {
+                const int ci = lc * R + row;
+                parent[k] = p.sc_parent[ci];
+                nlinks[k] = p.sc_nlinks[ci];
+                fin[k] = p.sc_fin[ci];
+                if (nlinks[k] > 0)
+                    packed[k] = p.sc_links[ci];
+            }
+        }
+        scan_column_epilogue<RPL, false>(p, R, lc, lane, parent, nlinks, fin, packed, 0);
+    }
+    __threadfence();
+    if (lane == 0 && atomicAdd(&sl_ctl[3], 1) == (int) gridDim.y - 1)
+    {
+        sl_ctl[0] = 0;
+        sl_ctl[1] = 0;
+        sl_ctl[2] = 0;
+        sl_ctl[3] = 0;
     }
 }

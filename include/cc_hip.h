@@ -317,7 +317,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  "insert_lds_pad"          (0)   experiment: KB of unused dynamic LDS that keep a second insertion block off a compute unit
  *  -- segmentation, window scan ------------------------------------------------------------------------------------------------------------------
  *  "seg_small_max"           (63)  calls of at most that many firings on a sensor of <= 64 rows segment with k_seg_small (rows as lanes)
- *  "scan_packed"                   1: the packed window scan k_scan2 (default from 128 streams per launch and at 128 rows); 0: k_scan
+ *  "scan_packed"                   1: the packed window scan k_scan2 (default above 192 streams per launch and at 128 rows); 0: k_scan
+ *  "scan_split"              (1)   throughput mode: a point of the packed scan that is still scanning after 6 visits (it found no neighbour:
+ *                                  vegetation, spray) is handed to k_scan2_long, which runs such points with every lane busy; 0: one pass
  *  -- association -----------------------------------------------------------------------------------------------------------------------------------
  *  "assoc_batch"             (1)   the batch-parallel kernel k_assocb runs in front of the serial one and takes every group of columns that cannot
  *                                  differ from the sequential semantics (cc_engine_batch_counters); 0: serial kernels only
