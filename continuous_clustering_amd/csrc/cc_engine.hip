@@ -64,6 +64,8 @@ struct cc_engine
     hipStream_t stream7{nullptr}; // k_table with table_on_insert_chain = 2
     hipStream_t stream6{nullptr}; // k_publish of a pipelined batch: off the association chain, which is the longest of the three
     hipEvent_t ev_pubrdy[4]{};
+    hipEvent_t ev_ego[4]{};       // k_ego of the slot's batch on the preparation stream (option "ego_off_chain")
+    bool ego_off_chain{true};
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
     hipEvent_t ev_input{};            // option "input_on_engine_stream": recorded on `stream` when a device call arrives
@@ -137,7 +139,9 @@ struct cc_engine
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
-    bool scan_split{true};              // option "scan_split": the packed window scan hands long scans to k_scan2_long (cc_k_scan.h)
+    int scan_split{2};                  // option "scan_split": the packed window scan hands long scans to k_scan2_long (cc_k_scan.h); 2 = while there are many
+    bool split_on{false};               // ... the automatic mode's current choice, from the counters k_scan2_epi leaves in d_bail_count[1 .. 2]
+    unsigned split_cols_seen{0}, split_rec_seen{0}, split_probe{0};
     int scan_packed{-1};                // option "scan_packed": 1 = k_scan2 (active points packed into the lanes), 0 = k_scan (rows as lanes, lock
                                         // step), -1 (default) = k_scan2 for sensors with more than 64 rows (measured: S128 3.7 -> 2.0 ms per batch)
                                         // and, at up to 64 rows, for launches of more than 192 streams (there the step follows the number of vector
@@ -282,6 +286,8 @@ void fill_geometry(cc_engine* e, int num_rows)
     g.tab_tiles = g.ring_cols / 64 + 2; // (a pass never emits more than a ring of columns)
     if (g.lds_tree_limit <= 0 || g.lds_tree_limit > TREE_SLOTS)
         g.lds_tree_limit = TREE_SLOTS;
+    if (g.sl_cap <= 0 || g.sl_cap > cck::SL_CAP)
+        g.sl_cap = cck::SL_CAP;
 }
 
 int free_all(cc_engine* e)
@@ -363,7 +369,7 @@ int allocate(cc_engine* e)
         return rc;
     if ((rc = alloc_plane(e, &e->d_par_left, 8)) != 0)
         return rc;
-    if ((rc = alloc_plane(e, &e->d_bail_count, 1)) != 0)
+    if ((rc = alloc_plane(e, &e->d_bail_count, 4)) != 0) // [0] stops of k_assocb, [1] long-scan records, [2] columns scanned with the long scans apart
         return rc;
     if ((rc = alloc_plane(e, &e->d_remaining, 1)) != 0)
         return rc;
@@ -380,7 +386,7 @@ int allocate(cc_engine* e)
     }
     (void) slab;
     // (counters the kernels only ever add to: recycled device memory is not zero)
-    CC_HIP_CHECK(e, hipMemset(e->d_bail_count, 0, sizeof(int)));
+    CC_HIP_CHECK(e, hipMemset(e->d_bail_count, 0, 4 * sizeof(int)));
     CC_HIP_CHECK(e, hipMemset(e->d_par_left, 0, 8 * sizeof(int)));
     CC_HIP_CHECK(e, hipMemset(e->d_remaining, 0, sizeof(int)));
     return CC_OK;
@@ -621,7 +627,11 @@ __global__ void k_gate_out(const int* __restrict__ left, const int* __restrict__
             h_left[1] = left[1];
         }
         if (h_bail_count)
-            *h_bail_count = *bail_count;
+        {
+            h_bail_count[0] = bail_count[0];
+            h_bail_count[1] = bail_count[1]; // (long-scan statistics of the window scan: cc_k_scan.h, k_scan2_epi)
+            h_bail_count[2] = bail_count[2];
+        }
         if (h_remaining)
             *h_remaining = *remaining;
         __threadfence_system();
@@ -729,9 +739,22 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         {
             if (fuse)
             {
-                // the fused insertion needs the per-firing ego records: they only depend on the caller's poses
-                hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, si, (const StreamState*) e->d_states, first_stream,
+                // the fused insertion needs the per-firing ego records: they only depend on the caller's poses (and the robot transform, which the
+                // host writes between batches) — so not on the insertion chain, which is what a step waits for: on the preparation stream (idle while the
+                // block-parallel insertion takes the batches), where they run beside the PREVIOUS batch's insertion; the insertion waits for the
+                // event. The records' buffer belongs to the batch-descriptor slot: its last readers (segmentation chain of four batches ago) are
+                // in front of that slot's publishing event.
+                const bool off = e->ego_off_chain && si != sb && !e->capturing;
+                hipStream_t se = off ? e->stream5 : si;
+                if (off)
+                    CC_HIP_CHECK(e, hipStreamWaitEvent(se, e->ev_assoc[slot], 0));
+                hipLaunchKernelGGL(cck::k_ego, dim3((unsigned) ((n + 255) / 256), (unsigned) count), dim3(256), 0, se, (const StreamState*) e->d_states, first_stream,
                                    e->cfg, d_pose, (long long) n, cur_ntotal, cur_f0, d_ego);
+                if (off)
+                {
+                    CC_HIP_CHECK(e, hipEventRecord(e->ev_ego[slot], se));
+                    CC_HIP_CHECK(e, hipStreamWaitEvent(si, e->ev_ego[slot], 0));
+                }
             }
             if (gate && !gate_zeroed)
                 CC_HIP_CHECK(e, hipMemsetAsync(left, 0, 2 * sizeof(int), si));
@@ -867,7 +890,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         {
             CC_HIP_CHECK(e, hipMemcpyAsync(e->h_par_left, e->d_par_left, sizeof(int), hipMemcpyDeviceToHost, si));
             if (e->h_bail_count)
-                CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, si));
+                CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, 3 * sizeof(int), hipMemcpyDeviceToHost, si));
             const auto hp1 = std::chrono::steady_clock::now();
             CC_HIP_CHECK(e, hipStreamSynchronize(si));
             hp_t1 = std::chrono::steady_clock::now();
@@ -1037,7 +1060,24 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         // 32 - 128 streams where the GPU has room and the lock-step scan's shorter launch counts)
         else if (e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192)))
         {
-            if (!g.mirror_fields && e->scan_split)
+            // the long scans apart? 1: always; 2 (default): while the streams have many of them — vegetation: ~1 long scan per column, street: 0.04.
+            // On a street scene the split costs chain time (the longest single scan, ~200 dependent visits, stands alone behind k_scan2 instead of
+            // beside its other tiles: - 8 % at 256 streams), on vegetation it is + 60 %. Every 32nd batch is scanned with the split, which counts;
+            // the rate of the batches counted since the last look decides (hysteresis 0.30 / 0.15 long scans per column).
+            bool split = !g.mirror_fields && e->scan_split != 0;
+            if (split && e->scan_split == 2 && e->h_bail_count && !e->capturing)
+            {
+                const unsigned rec = (unsigned) e->h_bail_count[1], cols = (unsigned) e->h_bail_count[2];
+                const unsigned dc = cols - e->split_cols_seen, dr = rec - e->split_rec_seen;
+                if (dc >= 1024u)
+                {
+                    const double rate = (double) dr / (double) dc;
+                    e->split_on = e->split_on ? rate > 0.15 : rate > 0.30;
+                    e->split_cols_seen = cols, e->split_rec_seen = rec;
+                }
+                split = e->split_on || (e->split_probe++ & 31u) == 0u;
+            }
+            if (split)
             {
                 // long scans apart (cc_k_scan.h): the packed scan hands points that are still scanning after SCAN_CAP visits to k_scan2_long, which
                 // keeps every lane busy with one of them; k_scan2_epi finishes the columns that had such a point
@@ -1046,13 +1086,13 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 {
                     hipLaunchKernelGGL((cck::k_scan2<1, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
                     hipLaunchKernelGGL(cck::k_scan2_long<1>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-                    hipLaunchKernelGGL(cck::k_scan2_epi<1>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_epi<1>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
                 else
                 {
                     hipLaunchKernelGGL((cck::k_scan2<2, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
                     hipLaunchKernelGGL(cck::k_scan2_long<2>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-                    hipLaunchKernelGGL(cck::k_scan2_epi<2>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_epi<2>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
             }
             else if (rpl == 1 && !g.mirror_fields)
@@ -1200,7 +1240,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         CC_MARK(sa); // ev8: assoc_global
         // (without the host synchronisation behind k_insert_par nobody else reads the counter of k_assocb's stops: four bytes ride along here)
         if (batch_assoc && !gate && !gate2 && e->h_bail_count && !e->capturing)
-            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, sizeof(int), hipMemcpyDeviceToHost, sa));
+            CC_HIP_CHECK(e, hipMemcpyAsync(e->h_bail_count, e->d_bail_count, 3 * sizeof(int), hipMemcpyDeviceToHost, sa));
         // The ids of the published columns only read what the association of THIS batch left behind (tree root of every cell, cluster id
         // at the root cell; neither is touched again before the ring wraps), so in the pipelined mode they are written on a stream of their
         // own and the next batch's association starts without waiting for them.
@@ -2227,6 +2267,7 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         (void) hipEventCreateWithFlags(&e->ev_prep[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_pubrdy[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_rel[i], hipEventDisableTiming);
+        (void) hipEventCreateWithFlags(&e->ev_ego[i], hipEventDisableTiming);
         (void) hipEventCreateWithFlags(&e->ev_rel[i + 4], hipEventDisableTiming);
         if (i == 0)
             (void) hipEventCreateWithFlags(&e->ev_input, hipEventDisableTiming);
@@ -2265,10 +2306,10 @@ int cc_engine_create(cc_engine** out, int device, int num_streams, int num_rows,
         const char* hp = std::getenv("CC_HOST_PROF");
         e->host_prof = hp && hp[0] == '1';
     }
-    if (rc == CC_OK && hipHostMalloc((void**) &e->h_bail_count, sizeof(int)) != hipSuccess)
+    if (rc == CC_OK && hipHostMalloc((void**) &e->h_bail_count, 4 * sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
     if (rc == CC_OK)
-        *e->h_bail_count = 0;
+        e->h_bail_count[0] = e->h_bail_count[1] = e->h_bail_count[2] = e->h_bail_count[3] = 0;
     if (rc == CC_OK && hipHostMalloc((void**) &e->h_remaining, sizeof(int)) != hipSuccess)
         rc = CC_ERR_HIP;
     if (rc == CC_OK)
@@ -2338,6 +2379,7 @@ void cc_engine_destroy(cc_engine* e)
         (void) hipEventDestroy(e->ev_prep[i]);
         (void) hipEventDestroy(e->ev_pubrdy[i]);
         (void) hipEventDestroy(e->ev_rel[i]);
+        (void) hipEventDestroy(e->ev_ego[i]);
         (void) hipEventDestroy(e->ev_rel[i + 4]);
         if (i == 0)
             (void) hipEventDestroy(e->ev_input);
@@ -3061,8 +3103,12 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_batch = value != 0;
     else if (n == "assoc_rounds")
         e->assoc_rounds = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
+    else if (n == "ego_off_chain")
+        e->ego_off_chain = value != 0;
     else if (n == "scan_split")
-        e->scan_split = value != 0;
+        e->scan_split = (int) std::max<int64_t>(0, std::min<int64_t>(value, 2));
+    else if (n == "scan_long_records")
+        e->g.sl_cap = (int) std::max<int64_t>(1, std::min<int64_t>(value, cck::SL_CAP));
     else if (n == "scan_packed")
     {
         e->scan_packed = value < 0 ? -1 : (value != 0 ? 1 : 0);

@@ -651,7 +651,7 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
                         lbase = atomicAdd(&sl_ctl[0], (int) __popcll(m));
                     lbase = __shfl(lbase, (int) __ffsll((long long) m) - 1);
                     const int idx = lbase + (int) __popcll(m & lanes_below());
-                    if (q.run && idx < SL_CAP)
+                    if (q.run && idx < g.sl_cap)
                     {
                         ScanLongRec r;
                         r.ci = ci, r.oc = q.oc;
@@ -758,7 +758,7 @@ __global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Pl
     int n = sl_ctl[0];
     if (n <= 0)
         return;
-    n = n < SL_CAP ? n : SL_CAP;
+    n = n < g.sl_cap ? n : g.sl_cap;
     const StreamState* st = &states[s];
     const int lane = lane_id();
     const SP p = stream_ptrs(P, g, s);
@@ -824,14 +824,24 @@ __global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Pl
 // k_scan2_epi — the column epilogue of the columns that waited for k_scan2_long: their per-cell scan results are complete in the planes now.
 // The last block through clears the stream's long-scan counters for the next batch. grid = (streams, SCAN_EPI_BLOCKS), block = 64.
 template<int RPL>
-__global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, Planes P, StreamState* states, int first_stream, int slot, int* __restrict__ stat)
 {
     const int s = first_stream + blockIdx.x;
     int* const sl_ctl = P.sl_ctl + (size_t) s * 4;
     const int nd = sl_ctl[2];
+    const int lane = lane_id();
+    // what the engine's automatic mode looks at (cc_engine.hip: scan_split 2): long scans and columns of the batches scanned this way
+    if (stat && blockIdx.y == 0 && lane == 0)
+    {
+        const StreamState* st = &states[s];
+        if (st->error == 0 && st->batch[slot].seg_begin >= 0 && st->batch[slot].mode == 0)
+        {
+            atomicAdd(&stat[1], sl_ctl[0] < g.sl_cap ? sl_ctl[0] : g.sl_cap);
+            atomicAdd(&stat[2], (int) (st->batch[slot].seg_end - st->batch[slot].acp_next));
+        }
+    }
     if (nd <= 0 && sl_ctl[0] <= 0)
         return;
-    const int lane = lane_id();
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows;
     for (int i = blockIdx.y; i < nd; i += gridDim.y)

@@ -295,6 +295,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  "publish_off_chain"       (1)   pipelined mode: k_publish on a stream of its own instead of at the end of the association chain
  *  "table_on_insert_chain"   (1)   pipelined mode: k_table at the end of the insertion chain; 0: at the head of the segmentation chain; 2: own stream
  *  "ego_on_insert_chain"     (0)   1: k_ego next to k_table instead of in front of k_seg_pre
+ *  "ego_off_chain"           (1)   pipelined mode with the fused front half: k_ego of a batch runs on the preparation stream, beside the previous
+ *                                  batch's insertion, instead of in front of its own insertion on the insertion chain
  *  "input_on_engine_stream"  (0)   1: the caller's device buffers are produced by work enqueued on cc_engine_hip_stream(e) (cc_kitti_convert_frames)
  *  "defer_tail_max_streams"  (96)  launches of at most that many streams leave the chains behind a batch's insertion gate to the NEXT call, which
  *                                  launches them behind its own insertion; every call that reads, synchronises or resets flushes them first; 0: never
@@ -318,8 +320,11 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  -- segmentation, window scan ------------------------------------------------------------------------------------------------------------------
  *  "seg_small_max"           (63)  calls of at most that many firings on a sensor of <= 64 rows segment with k_seg_small (rows as lanes)
  *  "scan_packed"                   1: the packed window scan k_scan2 (default above 192 streams per launch and at 128 rows); 0: k_scan
- *  "scan_split"              (1)   throughput mode: a point of the packed scan that is still scanning after 6 visits (it found no neighbour:
- *                                  vegetation, spray) is handed to k_scan2_long, which runs such points with every lane busy; 0: one pass
+ *  "scan_split"              (2)   throughput mode: a point of the packed scan that is still scanning after 6 visits (it found no neighbour:
+ *                                  vegetation, spray) is handed to k_scan2_long, which runs such points with every lane busy, and k_scan2_epi
+ *                                  finishes its column. 1: always; 0: one pass; 2: while the streams have many such points (every 32nd batch is
+ *                                  scanned this way and counted: on at > 0.30 long scans per column, off again below 0.15)
+ *  "scan_long_records"       (8192) room of a stream's list of such points per batch (a lane that finds it full finishes its scan in place)
  *  -- association -----------------------------------------------------------------------------------------------------------------------------------
  *  "assoc_batch"             (1)   the batch-parallel kernel k_assocb runs in front of the serial one and takes every group of columns that cannot
  *                                  differ from the sequential semantics (cc_engine_batch_counters); 0: serial kernels only

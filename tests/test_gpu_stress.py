@@ -69,12 +69,12 @@ def _feed_pipelined(e, streams, F, ring=4, calls=None, stats=None):
     return NB, slots
 
 
-def _compare_with_oracles(e, cfg, streams, NB, F, rows=64):
+def _compare_with_oracles(e, cfg, streams, NB, F, rows=64, tf=None):
     import util
-    from oracle.pyoracle import Oracle
+    from oracle.pyoracle import Oracle, IDENTITY_TF
     bad = []
     for s, st in enumerate(streams):
-        o = Oracle(cfg, rows)
+        o = Oracle(cfg, rows, IDENTITY_TF if tf is None else tf)
         assert o.add_firings(st.xyz[:NB * F], st.intensity[:NB * F], st.poses[:NB * F]) == 0
         so, se = o.state(), e.state(s)
         diff = {k: (so[k], se[k]) for k in util.STATE_FIELDS if so[k] != se[k]}
@@ -124,7 +124,8 @@ def test_random_walk_over_engine_options(oracle_lib):
     cfg = capi.Config.kitti()
     choices = {"pipeline": [0, 1, 2], "lazy_gate": [0, 40], "lazy_gate_from": [0, 8, 80], "defer_tail_max_streams": [0, 96], "fuse_front": [0, 1],
                "skip_idle_fallbacks": [0, 1], "parallel_insert": [0, 1, 2], "insert_split_blocks": [0, 1, 3, 8], "insert_wide_max_streams": [0, 160],
-               "assoc_batch": [0, 1], "assoc_rounds": [0, 1, 2], "assoc_sweep_blocks": [1, 2, 16], "assoc_waves": [0, 1, 3, 4], "scan_packed": [0, 1],
+               "assoc_batch": [0, 1], "assoc_rounds": [0, 1, 2], "assoc_sweep_blocks": [1, 2, 16], "assoc_waves": [0, 1, 3, 4], "scan_packed": [0, 1], "scan_split": [0, 1],
+               "scan_long_records": [1, 40, 8192],
                "publish_off_chain": [0, 1], "table_on_insert_chain": [0, 1, 2], "ego_on_insert_chain": [0, 1], "sub_batch": [0, 300], "limit_columns": [600, 1 << 20]}
     t0 = time.perf_counter()
     rounds = 0
@@ -236,3 +237,30 @@ def test_reusing_an_input_buffer_too_early_is_reported(oracle_lib):
         code, msg = ex.code, str(ex)
     e.close()
     assert code == capi.CC_ERR_INVALID_ARGUMENT and "modified before the engine released them" in msg, (code, msg)
+
+
+# ---- the packed window scan with the long scans apart (k_scan2<SPLIT> -> k_scan2_long -> k_scan2_epi) -----------------------------------------
+@pytest.mark.parametrize("name,records", [(n, 8192) for n in ("c_s64_sparse_clutter", "c_s64_near_clutter", "c_s64_mixed_clutter", "c_s128_sparse_clutter",
+                                                              "s64_full_2200", "s128_offsets", "s64_forced_finish_ring", "x_s64_slanted_gaps",
+                                                              "s64_min_steps_3", "s32_small_sensor", "s96_offsets", "j_s64_jitter_wide")] +
+                         [("c_s64_mixed_clutter", 3), ("c_s128_sparse_clutter", 1), ("c_s64_near_clutter", 64)])
+def test_packed_scan_with_long_scans_apart(name, records, oracle_lib):
+    """Throughput mode (events off: no mirror fields), packed scan forced on: points that find no neighbour leave k_scan2 after 6 visits and are
+    finished by k_scan2_long; the columns they sit in get their epilogue from k_scan2_epi. With a list of 1 / 3 / 64 records most of them find
+    it full and finish in place. Two engine streams of the same input: the list and its counters are per stream."""
+    import cases
+    from continuous_clustering_amd import Engine, IDENTITY_TF
+    stream, cfg, tf = cases.build_case(name)
+    rows = stream.sensor.num_rows
+    e = Engine(cfg, rows, 2, 0, IDENTITY_TF if tf is None else tf)
+    e.record_events(False)
+    e.set_option("scan_packed", 1)
+    e.set_option("scan_split", 1)
+    e.set_option("scan_long_records", records)
+    F = max(64, min(700, stream.n_firings // 3))
+    streams = [stream, stream]
+    NB, _ = _feed_pipelined(e, streams, F, ring=8)
+    assert e.sync() == 0, e.last_error()
+    bad = _compare_with_oracles(e, cfg, streams, NB, F, rows=rows, tf=tf)
+    e.close()
+    assert not bad, bad[:2]
