@@ -353,7 +353,7 @@ def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args, sweep_sizes=
 # ---------------------------------------------------------------------------------------------------------------------------
 def engine_options(eng):
     for env, opt in (("CC_SUB_BATCH", "sub_batch"), ("CC_TABLE_EARLY", "table_on_insert_chain"), ("CC_PIPELINE", "pipeline"),
-                     ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed"), ("CC_SCAN_SPLIT", "scan_split"), ("CC_EGO_OFF_CHAIN", "ego_off_chain"),
+                     ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed"), ("CC_SCAN_SPLIT", "scan_split"), ("CC_EGO_OFF_CHAIN", "ego_off_chain"), ("CC_FIN_MERGE", "insert_fin_merge"),
                      ("CC_SKIP_FALLBACKS", "skip_idle_fallbacks"), ("CC_ASSOC_ROUNDS", "assoc_rounds"), ("CC_ASSOC_BATCH", "assoc_batch"),
                      ("CC_EGO_EARLY", "ego_on_insert_chain"), ("CC_ASSOC_COOLDOWN", "assoc_cooldown"), ("CC_SWEEP_BLOCKS", "assoc_sweep_blocks"), ("CC_INSERT_WIDE", "insert_wide_max_streams"), ("CC_INSERT_SPLIT", "insert_split_blocks"), ("CC_DEBUG_NO_ASSOC_FALLBACK", "debug_no_assoc_fallback"), ("CC_FUSE_FRONT", "fuse_front"), ("CC_DEFER_TAIL", "defer_tail_max_streams"), ("CC_LAZY_GATE", "lazy_gate"), ("CC_LAZY_GATE_FROM", "lazy_gate_from"), ("CC_INSERT_LDS_PAD", "insert_lds_pad"), ("CC_INSERT_NARROW", "insert_narrow_blocks")):
         if os.environ.get(env) not in (None, ""):
@@ -669,8 +669,12 @@ def single_stream_report(ctx, sensor, cfg, F, xyz, inten, poses):
     local_rank, R = ctx.local_rank, sensor.num_rows
     out = {}
     # ---- single-stream latency (BASELINE.json configs[1] shape): one firing per call through the host API --------
-    if True:
+    # (twice: a kernel launch per call — k_small_all —, and the resident kernel, engine option "resident": no dispatch per call, a doorbell in
+    # pinned memory; the drop-in class switches it on in its synchronous mode)
+    for key, resident in (("latency_us_per_column_single_stream", 0), ("latency_us_per_column_single_stream_resident", 1)):
         e1 = Engine(cfg, R, 1, device=local_rank)
+        if resident:
+            e1.set_option("resident", 1)
         hx = xyz[0, 0].cpu().numpy()
         hi = inten[0, 0].cpu().numpy()
         hp = poses[0, 0].cpu().numpy()
@@ -681,8 +685,11 @@ def single_stream_report(ctx, sensor, cfg, F, xyz, inten, poses):
             e1.add_firings(hx[k:k + 1], hi[k:k + 1], hp[k:k + 1])
             lat.append(time.perf_counter() - t1)
         lat = np.array(lat) * 1e6
-        out["latency_us_per_column_single_stream"] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)),
-                                                      "mode": "1 firing per cc_engine_add_firings call (H2D + all kernels of the path + sync + event read-back)"}
+        out[key] = {"p50": float(np.percentile(lat, 50)), "p99": float(np.percentile(lat, 99)), "p999": float(np.percentile(lat, 99.9)), "max": float(lat.max()),
+                    "mode": "1 firing per cc_engine_add_firings call (firing into pinned memory + all kernels of the path + results mirrored back)" +
+                            (", resident kernel" if resident else ", one launch per call")}
+        if resident:
+            out[key].update({k2: v2 for k2, v2 in e1.resident_counters().items() if k2 != "running"})
         e1.close()
 
     # ---- the same single stream through the C++ drop-in class, fed like a live HDL-64E (22 000 firings per second): a call per firing
@@ -1140,6 +1147,7 @@ def slim_line(o):
                     "roofline": {k: g(s128, "roofline", k) for k in ("kernel", "achieved", "frac", "traffic", "step_frac", "launch_ms")},
                     "cpu_baseline_value": g(s128, "cpu_baseline", "value"), "cpu_baseline_cores": g(s128, "cpu_baseline", "cores")}
     line["latency_us_per_column_single_stream"] = {k: v for k, v in (o.get("latency_us_per_column_single_stream") or {}).items() if k != "mode"}
+    line["latency_us_per_column_single_stream_resident"] = {k: v for k, v in (o.get("latency_us_per_column_single_stream_resident") or {}).items() if k != "mode"}
     for k in ("verified_streams", "rccl_world", "cells_published", "clusters_finished", "serial_columns", "association", "kernel_ms_per_step", "per_rank_value", "per_rank", "numa_pin"):
         line[k] = o.get(k)
     ss = o.get("strong_split")

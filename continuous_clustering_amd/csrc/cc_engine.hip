@@ -65,7 +65,8 @@ struct cc_engine
     hipStream_t stream6{nullptr}; // k_publish of a pipelined batch: off the association chain, which is the longest of the three
     hipEvent_t ev_pubrdy[4]{};
     hipEvent_t ev_ego[4]{};       // k_ego of the slot's batch on the preparation stream (option "ego_off_chain")
-    bool ego_off_chain{true};
+    bool insert_fin_merge{true};  // option "insert_fin_merge": k_insert_par's last blocks do k_insert_par_fin's and k_gate_out's work
+    bool ego_off_chain{false};    // (measured, round 6: 32 streams - 8 % in the 20-step leg and - 12 % steady with it on — the cross-stream event costs more than the kernel's ~10 us on the chain —, 256 streams + 0)
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
     hipEvent_t ev_input{};            // option "input_on_engine_stream": recorded on `stream` when a device call arrives
@@ -367,7 +368,7 @@ int allocate(cc_engine* e)
 #undef A
     if ((rc = alloc_plane(e, &e->d_states, S)) != 0)
         return rc;
-    if ((rc = alloc_plane(e, &e->d_par_left, 8)) != 0)
+    if ((rc = alloc_plane(e, &e->d_par_left, 16)) != 0) // (2 gate counters per batch slot; [8 + slot]: the in-kernel gate's count of streams that are through)
         return rc;
     if ((rc = alloc_plane(e, &e->d_bail_count, 4)) != 0) // [0] stops of k_assocb, [1] long-scan records, [2] columns scanned with the long scans apart
         return rc;
@@ -387,7 +388,7 @@ int allocate(cc_engine* e)
     (void) slab;
     // (counters the kernels only ever add to: recycled device memory is not zero)
     CC_HIP_CHECK(e, hipMemset(e->d_bail_count, 0, 4 * sizeof(int)));
-    CC_HIP_CHECK(e, hipMemset(e->d_par_left, 0, 8 * sizeof(int)));
+    CC_HIP_CHECK(e, hipMemset(e->d_par_left, 0, 16 * sizeof(int)));
     CC_HIP_CHECK(e, hipMemset(e->d_remaining, 0, sizeof(int)));
     return CC_OK;
 }
@@ -758,6 +759,12 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             }
             if (gate && !gate_zeroed)
                 CC_HIP_CHECK(e, hipMemsetAsync(left, 0, 2 * sizeof(int), si));
+            // round 6: the stream's last block of k_insert_par finishes the stream (k_insert_par_fin's work) and the launch's last stream writes what the
+            // host reads at the gate into pinned memory (k_gate_out's work): up to two kernels less on the chain a step waits for
+            const bool in_kernel_gate = gate && e->insert_fin_merge && e->insert_narrow_blocks == 0;
+            const cck::ParGate gt = in_kernel_gate ? cck::ParGate{e->d_par_left + 8 + slot, (const int*) e->d_bail_count, (const int*) e->d_remaining, gate_h_left, e->h_bail_count,
+                                                                  with_remaining ? e->h_remaining : (int*) nullptr, 1}
+                                                   : cck::ParGate{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             // few streams: the GPU is not full and the insertion chain is what a step waits for -> twice the wavefronts per block, and the firings of a
             // stream dealt to several blocks (k_insert_par_fin then finishes the stream's state)
             if (count <= e->insert_wide_max_streams)
@@ -772,8 +779,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks
                                                           : (count <= 24 ? 8 : (count <= 32 ? 6 : (count <= 40 ? 4 : (count <= 64 ? 3 : (count <= 96 ? 2 : 1)))));
                 hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), insert_lds_pad(e, count * nb, 20 * 1024), si, g, e->cfg, Pt, e->d_states,
-                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
-                if (nb > 1)
+                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left, gt);
+                if (nb > 1 && !in_kernel_gate)
                     hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
                                        cur_ntotal, cur_f0, slot, left, fuse ? 1 : 0, prev_left);
             }
@@ -788,8 +795,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             }
             else
                 hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), insert_lds_pad(e, count, 20 * 1024), si, g, e->cfg, Pt, e->d_states,
-                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
-            if (gate)
+                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left, gt);
+            if (gate && !in_kernel_gate)
             {
                 // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic;
                 // with the lazy gate also the early-stop counter the held-back chains would have copied)
@@ -1071,7 +1078,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 const unsigned dc = cols - e->split_cols_seen, dr = rec - e->split_rec_seen;
                 if (dc >= 1024u)
                 {
-                    const double rate = (double) dr / (double) dc;
+                    const double rate = (double) dr / ((double) dc * (double) rpl); // (per column of 64 rows)
                     e->split_on = e->split_on ? rate > 0.15 : rate > 0.30;
                     e->split_cols_seen = cols, e->split_rec_seen = rec;
                 }
@@ -3103,6 +3110,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_batch = value != 0;
     else if (n == "assoc_rounds")
         e->assoc_rounds = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
+    else if (n == "insert_fin_merge")
+        e->insert_fin_merge = value != 0;
     else if (n == "ego_off_chain")
         e->ego_off_chain = value != 0;
     else if (n == "scan_split")

@@ -973,6 +973,82 @@ __device__ __forceinline__ void table_from_partials(const SP& p, const int R, co
     }
 }
 
+// what the host reads behind a batch's insertion (the gate), and where: the last block of the launch writes it into pinned memory itself
+// (round 6: k_gate_out was one more kernel on the chain a step waits for)
+struct ParGate
+{
+    int* ctr;               // device: blocks / streams of this launch that are through (reset by the last one); nullptr: no in-kernel gate
+    const int* bail_count;  // device: [0] stops of k_assocb, [1 .. 2] long-scan statistics
+    const int* remaining;   // device: the early-stop counter
+    int* h_left;            // pinned: left_over[0 .. 1]
+    int* h_bail_count;      // pinned
+    int* h_remaining;       // pinned (nullptr: not wanted)
+    int fin_in_kernel;      // several blocks per stream: the stream's last block does k_insert_par_fin's work
+};
+
+__device__ __forceinline__ void par_gate_out(const ParGate& gt, const int* left_over, const int n_streams)
+{
+    // (one thread per stream calls this, after everything it wrote for the stream)
+    __threadfence();
+    if (atomicAdd(gt.ctr, 1) != n_streams - 1)
+        return;
+    __threadfence();
+    *gt.ctr = 0;
+    if (gt.h_left && left_over)
+    {
+        gt.h_left[0] = __hip_atomic_load(&left_over[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gt.h_left[1] = __hip_atomic_load(&left_over[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (gt.h_bail_count)
+    {
+        gt.h_bail_count[0] = __hip_atomic_load(&gt.bail_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gt.h_bail_count[1] = __hip_atomic_load(&gt.bail_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gt.h_bail_count[2] = __hip_atomic_load(&gt.bail_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (gt.h_remaining)
+        *gt.h_remaining = __hip_atomic_load(gt.remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+}
+
+// what one block of k_insert_par does behind its phase D, for launches that dealt a stream's firings to several blocks: take back what lies behind
+// the first offending firing, then the stream state, the batch descriptor and (fused segmentation) the table. NW wavefronts, every thread of them.
+template<int RPL>
+__device__ __forceinline__ void par_fin_body(const Geometry& g, const SP& p, StreamState* st, const long long n, const int slot, int* __restrict__ left_over,
+                                             const int fuse_on, const int nwaves, int* s_fused)
+{
+    const int lane = lane_id(), wave = uniform_i32((int) (threadIdx.x >> 6)), tid = threadIdx.x;
+    const int R = g.num_rows, RC = g.ring_cols;
+    const int upto = st->par_upto;
+    if (upto <= 0)
+    {
+        if (tid == 0 && st->par_clear_done >= 0)
+            st->clear_done = st->par_clear_done; // (also for a stream that was not steady: its blocks shared the clearing all the same)
+        return; // (not steady, or nothing taken: block 0 of k_insert_par has counted the stream as left over)
+    }
+    const bool fuse = fuse_on != 0 && left_over != nullptr && st->has_robot_tf != 0;
+    const int bad = st->par_bad;
+    const int done = bad < upto ? bad : upto;
+    const long long prev_rear0 = st->prev_rearmost, first_unf0 = st->first_unfinished, ring_end0 = st->ring_end;
+    const int lc0 = (int) (prev_rear0 % RC);
+    const long long seq0 = (long long) st->firings_consumed;
+    if (done < upto)
+        par_take_back<RPL>(p, R, RC, lc0, p.par_off[done], p.par_off[upto - 1], wave, nwaves, lane);
+    const bool whole = done == (int) n && done > 0;
+    __syncthreads(); // (everybody has read the state thread 0 is about to replace)
+    if (tid == 0)
+    {
+        st->clear_done = st->par_clear_done;
+#ifndef CC_A2_STATS
+        st->dbg[6] += (unsigned long long) done;
+        st->dbg[7] += 1;
+#endif
+        *s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0, done > 0 ? (long long) p.par_off[done - 1] : 0);
+    }
+    __syncthreads();
+    if (fuse && wave == 0)
+        table_from_partials<RPL>(p, R, *s_fused != 0, (p.par_off[upto - 1] >> 6) + 1, *s_fused ? ((p.par_off[done - 1] + 63) >> 6) : 0, lane);
+}
+
 // =====================================================================================================
 // k_insert_par — insertFiringIntoRangeImage (cc.cpp:105-292) for the head of a batch, all firings at once, straight from the
 // caller's buffers (the per-point preparation is done inline: what this kernel takes never touches the staging planes).
@@ -1013,7 +1089,7 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
                                                             const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
                                                             const double* __restrict__ poses, long long n, long long n_total, long long fbase,
                                                             int slot, int* __restrict__ left_over, const double* __restrict__ ego,
-                                                            const int* __restrict__ prev_left = nullptr)
+                                                            const int* __restrict__ prev_left = nullptr, ParGate gt = ParGate{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0})
 {
     // prev_left (the engine's lazy gate, cc_engine.hip): the counters the PREVIOUS batch's insertion left behind. The host enqueues this batch's
     // insertion before it has read them; if they say that the previous batch needs the other insertion kernels (or k_table on this chain), this
@@ -1128,6 +1204,33 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
                 atomicAdd(left_over + 1, 1); // ... and k_table / k_seg_pre its segmentation
             }
             st->par_upto = -1;
+        }
+        if (gt.ctr)
+        {
+            // (the in-kernel gate: this stream is through as far as this kernel goes)
+            __shared__ int s_last0;
+            bool last = nby == 1;
+            if (nby > 1)
+            {
+                __threadfence();
+                __syncthreads();
+                if (tid == 0)
+                    s_last0 = atomicAdd(&st->par_blocks, 1) == nby - 1 ? 1 : 0;
+                __syncthreads();
+                last = s_last0 != 0;
+                if (last)
+                {
+                    __threadfence();
+                    if (tid == 0)
+                    {
+                        st->par_blocks = 0;
+                        if (gt.fin_in_kernel && st->par_clear_done >= 0)
+                            st->clear_done = st->par_clear_done; // (par_fin_body for a stream that is not steady)
+                    }
+                }
+            }
+            if (last && tid == 0)
+                par_gate_out(gt, left_over, (int) gridDim.x);
         }
         return;
     }
@@ -1585,6 +1688,26 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
                 }
             }
         }
+        if (gt.ctr && gt.fin_in_kernel)
+        {
+            // round 6: the stream's LAST block through does k_insert_par_fin's work itself (one kernel less on the chain a step waits for, and the
+            // streams that are through early finish beside the others' insertion), and the launch's last stream writes the host's gate
+            __shared__ int s_last1, s_fused1;
+            __threadfence(); // (release: this thread's cells, offsets, table partials)
+            __syncthreads();
+            if (tid == 0)
+                s_last1 = atomicAdd(&st->par_blocks, 1) == nby - 1 ? 1 : 0;
+            __syncthreads();
+            if (!s_last1)
+                return;
+            __threadfence(); // (acquire: what the stream's other blocks left — par_upto, par_bad, par_clear_done, par_off, the partials)
+            if (tid == 0)
+                st->par_blocks = 0;
+            par_fin_body<RPL>(g, p, st, n, slot, left_over, fuse ? 1 : 0, W, &s_fused1);
+            __syncthreads();
+            if (tid == 0)
+                par_gate_out(gt, left_over, (int) gridDim.x);
+        }
         return;
     }
     const int done = s_bad < upto ? s_bad : upto;
@@ -1605,10 +1728,12 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
     __syncthreads(); // (also: every wavefront's table partials have reached Planes::tab_acc)
     if (fuse && wave == 0 && upto > 0)
         table_from_partials<RPL>(p, R, s_fused != 0, ((int) s_off[upto - 1] >> 6) + 1, s_fused ? (int) ((s_off[done - 1] + 63) >> 6) : 0, lane);
+    if (gt.ctr && tid == 0)
+        par_gate_out(gt, left_over, (int) gridDim.x); // (the counters this stream contributes to the gate were added by thread 0, above)
 }
 
-// k_insert_par_fin — what one block of k_insert_par does behind its phase D, for launches that dealt a stream's firings to several blocks: take back
-// what lies behind the first offending firing, then the stream state, the batch descriptor and (fused segmentation) the table. grid = streams, block = 256.
+// k_insert_par_fin — par_fin_body as a kernel of its own (option "insert_fin_merge" = 0; by default the stream's last block of k_insert_par does
+// it). grid = streams, block = 256.
 template<int RPL>
 __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, StreamState* states, int first_stream, const float* __restrict__ xyz,
                                                         long long n, long long n_total, long long fbase, int slot, int* __restrict__ left_over, int fuse_on,
@@ -1619,42 +1744,9 @@ __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, St
     (void) xyz;
     (void) n_total;
     (void) fbase;
-    const int sl = blockIdx.x;
-    const int s = first_stream + sl;
-    const int lane = lane_id(), wave = uniform_i32((int) (threadIdx.x >> 6)), tid = threadIdx.x;
-    StreamState* st = &states[s];
-    const SP p = stream_ptrs(P, g, s);
-    const int R = g.num_rows, RC = g.ring_cols;
-    const int upto = st->par_upto;
-    if (upto <= 0)
-    {
-        if (tid == 0 && st->par_clear_done >= 0)
-            st->clear_done = st->par_clear_done; // (also for a stream that was not steady: its blocks shared the clearing all the same)
-        return; // (not steady, or nothing taken: block 0 of k_insert_par has counted the stream as left over)
-    }
-    const bool fuse = fuse_on != 0 && left_over != nullptr && st->has_robot_tf != 0;
-    const int bad = st->par_bad;
-    const int done = bad < upto ? bad : upto;
-    const long long prev_rear0 = st->prev_rearmost, first_unf0 = st->first_unfinished, ring_end0 = st->ring_end;
-    const int lc0 = (int) (prev_rear0 % RC);
-    const long long seq0 = (long long) st->firings_consumed;
-    if (done < upto)
-        par_take_back<RPL>(p, R, RC, lc0, p.par_off[done], p.par_off[upto - 1], wave, 4, lane);
-    const bool whole = done == (int) n && done > 0;
+    const int s = first_stream + (int) blockIdx.x;
     __shared__ int s_fused;
-    __syncthreads(); // (everybody has read the state thread 0 is about to replace)
-    if (tid == 0)
-    {
-        st->clear_done = st->par_clear_done;
-#ifndef CC_A2_STATS
-        st->dbg[6] += (unsigned long long) done;
-        st->dbg[7] += 1;
-#endif
-        s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0, done > 0 ? (long long) p.par_off[done - 1] : 0);
-    }
-    __syncthreads();
-    if (fuse && wave == 0)
-        table_from_partials<RPL>(p, R, s_fused != 0, (p.par_off[upto - 1] >> 6) + 1, s_fused ? ((p.par_off[done - 1] + 63) >> 6) : 0, lane);
+    par_fin_body<RPL>(g, stream_ptrs(P, g, s), &states[s], n, slot, left_over, fuse_on, 4, &s_fused);
 }
 
 // =====================================================================================================

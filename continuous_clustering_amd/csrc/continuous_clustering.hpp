@@ -289,6 +289,9 @@ class ContinuousClustering
     void setAdaptiveBatching(int max_firings = 8, int max_wait_us = 150);
     void flush();                              // process buffered firings now
     void setDevice(int hip_device);            // before the first reset(); default 0
+    // synchronous mode: hand small calls to the engine's resident kernel (no kernel launch per addFiring; it holds one compute unit while firings
+    // keep coming and leaves by itself 20 ms after the last one). Default on; takes effect at the next reset()
+    void setResidentKernel(bool on) { use_resident_ = on; }
 
   public:
     // range image (implemented as ring buffer) — continuous_clustering.hpp:246-251
@@ -332,6 +335,7 @@ class ContinuousClustering
     int device_{0};
     int batch_size_{1};
     bool adaptive_{false};
+    bool use_resident_{true};
     int max_wait_us_{150};
     std::chrono::steady_clock::time_point first_buffered_at_{}, last_process_end_{};
     bool reset_required_{false};

@@ -295,8 +295,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  "publish_off_chain"       (1)   pipelined mode: k_publish on a stream of its own instead of at the end of the association chain
  *  "table_on_insert_chain"   (1)   pipelined mode: k_table at the end of the insertion chain; 0: at the head of the segmentation chain; 2: own stream
  *  "ego_on_insert_chain"     (0)   1: k_ego next to k_table instead of in front of k_seg_pre
- *  "ego_off_chain"           (1)   pipelined mode with the fused front half: k_ego of a batch runs on the preparation stream, beside the previous
- *                                  batch's insertion, instead of in front of its own insertion on the insertion chain
+ *  "ego_off_chain"           (0)   experiment: pipelined mode with the fused front half: k_ego of a batch on the preparation stream, beside the previous
+ *                                  batch's insertion, instead of in front of its own insertion (32 streams - 8 .. - 12 %: the event costs more than the kernel)
  *  "input_on_engine_stream"  (0)   1: the caller's device buffers are produced by work enqueued on cc_engine_hip_stream(e) (cc_kitti_convert_frames)
  *  "defer_tail_max_streams"  (96)  launches of at most that many streams leave the chains behind a batch's insertion gate to the NEXT call, which
  *                                  launches them behind its own insertion; every call that reads, synchronises or resets flushes them first; 0: never
@@ -315,6 +315,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  "insert_wide_max_streams" (160) launches of at most that many streams run k_insert_par with 16 wavefronts per block ...
  *  "insert_split_blocks"     (0)   ... and deal a stream's firings to that many blocks; 0: 8 up to 24 streams, 6 up to 32, 4 up to 40, 3 up to 64,
  *                                  2 up to 96, else 1
+ *  "insert_fin_merge"        (1)   the last block of k_insert_par that is through for a stream finishes the stream (k_insert_par_fin's work) and the
+ *                                  launch's last stream writes the gate's counters into pinned memory (k_gate_out's work); 0: those two kernels
  *  "insert_narrow_blocks"    (0)   experiment: that many 4-wavefront blocks per stream above insert_wide_max_streams
  *  "insert_lds_pad"          (0)   experiment: KB of unused dynamic LDS that keep a second insertion block off a compute unit
  *  -- segmentation, window scan ------------------------------------------------------------------------------------------------------------------
