@@ -65,7 +65,8 @@ struct cc_engine
     hipStream_t stream6{nullptr}; // k_publish of a pipelined batch: off the association chain, which is the longest of the three
     hipEvent_t ev_pubrdy[4]{};
     hipEvent_t ev_ego[4]{};       // k_ego of the slot's batch on the preparation stream (option "ego_off_chain")
-    bool insert_fin_merge{true};  // option "insert_fin_merge": k_insert_par's last blocks do k_insert_par_fin's and k_gate_out's work
+    bool insert_fin_merge{false}; // option "insert_fin_merge": k_insert_par's last blocks do k_insert_par_fin's and k_gate_out's work (measured, round 6: the
+                                  // agent-scope fences the hand-over between blocks needs write the XCD's whole L2 back — 32 / 64 streams - 22 %, 256 streams - 1 %)
     bool ego_off_chain{false};    // (measured, round 6: 32 streams - 8 % in the 20-step leg and - 12 % steady with it on — the cross-stream event costs more than the kernel's ~10 us on the chain —, 256 streams + 0)
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
@@ -1067,20 +1068,21 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         // 32 - 128 streams where the GPU has room and the lock-step scan's shorter launch counts)
         else if (e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192)))
         {
-            // the long scans apart? 1: always; 2 (default): while the streams have many of them — vegetation: ~1 long scan per column, street: 0.04.
-            // On a street scene the split costs chain time (the longest single scan, ~200 dependent visits, stands alone behind k_scan2 instead of
-            // beside its other tiles: - 8 % at 256 streams), on vegetation it is + 60 %. Every 32nd batch is scanned with the split, which counts;
-            // the rate of the batches counted since the last look decides (hysteresis 0.30 / 0.15 long scans per column).
+            // the long scans apart? 1: always; 2 (default): while they are a large part of the scan's work. The visits k_scan2_long makes per column
+            // (of 64 rows) say so: vegetation ~150, the 128-row bench scene ~15, the street scene ~4. Where they are few the split costs chain time
+            // (two more launches whose blocks wait for wave slots, the longest single scan standing alone: street scene - 8 % at 256 streams, the
+            // 128-row scene - 2 %), on vegetation it is + 60 .. + 70 %. Every 32nd batch is scanned with the split, which counts; the batches
+            // counted since the last look decide (on above 40 visits per column, off again below 20).
             bool split = !g.mirror_fields && e->scan_split != 0;
             if (split && e->scan_split == 2 && e->h_bail_count && !e->capturing)
             {
-                const unsigned rec = (unsigned) e->h_bail_count[1], cols = (unsigned) e->h_bail_count[2];
-                const unsigned dc = cols - e->split_cols_seen, dr = rec - e->split_rec_seen;
+                const unsigned vis = (unsigned) e->h_bail_count[1], cols = (unsigned) e->h_bail_count[2];
+                const unsigned dc = cols - e->split_cols_seen, dv = vis - e->split_rec_seen;
                 if (dc >= 1024u)
                 {
-                    const double rate = (double) dr / ((double) dc * (double) rpl); // (per column of 64 rows)
-                    e->split_on = e->split_on ? rate > 0.15 : rate > 0.30;
-                    e->split_cols_seen = cols, e->split_rec_seen = rec;
+                    const double rate = (double) dv / ((double) dc * (double) rpl); // (per column of 64 rows)
+                    e->split_on = e->split_on ? rate > 20.0 : rate > 40.0;
+                    e->split_cols_seen = cols, e->split_rec_seen = vis;
                 }
                 split = e->split_on || (e->split_probe++ & 31u) == 0u;
             }
@@ -1092,13 +1094,13 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 if (rpl == 1)
                 {
                     hipLaunchKernelGGL((cck::k_scan2<1, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-                    hipLaunchKernelGGL(cck::k_scan2_long<1>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_long<1>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                     hipLaunchKernelGGL(cck::k_scan2_epi<1>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
                 else
                 {
                     hipLaunchKernelGGL((cck::k_scan2<2, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
-                    hipLaunchKernelGGL(cck::k_scan2_long<2>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL(cck::k_scan2_long<2>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                     hipLaunchKernelGGL(cck::k_scan2_epi<2>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
             }

@@ -751,7 +751,7 @@ constexpr int SCAN_LONG_BLOCKS = CC_SCAN_LONG_BLOCKS;
 constexpr int SCAN_EPI_BLOCKS = 16;
 
 template<int RPL>
-__global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot)
+__global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot, int* __restrict__ stat)
 {
     const int s = first_stream + blockIdx.x;
     int* const sl_ctl = P.sl_ctl + (size_t) s * 4;
@@ -777,6 +777,7 @@ __global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Pl
     q.mad = 0.f, q.row = 0, q.needed = 0, q.bound = -1, q.sb = 0, q.down = 0, q.d = 0, q.oc = 0, q.orow = 0;
     q.rooted = 0, q.parent = -1, q.nlinks = 0, q.overflow = 0, q.visits = 0, q.reach = 0, q.packed = 0ull;
     int ci = 0;
+    int nvis = 0; // visits this lane made (the engine's automatic mode weighs the long scans by them)
     bool more = true; // (wave-uniform) the list may still have records nobody has taken
     for (;;)
     {
@@ -810,6 +811,7 @@ __global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Pl
             if (q.run)
             {
                 q.template step<false>(sc, p);
+                nvis++;
                 if (!q.run)
                 {
                     p.sc_parent[ci] = (int16_t) q.parent;
@@ -818,6 +820,13 @@ __global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Pl
                         p.sc_links[ci] = q.packed;
                 }
             }
+    }
+    if (stat)
+    {
+        for (int off = 32; off > 0; off >>= 1)
+            nvis += __shfl_down(nvis, off, 64);
+        if (lane == 0 && nvis > 0)
+            atomicAdd(&stat[1], nvis);
     }
 }
 
@@ -836,7 +845,6 @@ __global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, Planes P, StreamSt
         const StreamState* st = &states[s];
         if (st->error == 0 && st->batch[slot].seg_begin >= 0 && st->batch[slot].mode == 0)
         {
-            atomicAdd(&stat[1], sl_ctl[0] < g.sl_cap ? sl_ctl[0] : g.sl_cap);
             atomicAdd(&stat[2], (int) (st->batch[slot].seg_end - st->batch[slot].acp_next));
         }
     }

@@ -315,8 +315,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  "insert_wide_max_streams" (160) launches of at most that many streams run k_insert_par with 16 wavefronts per block ...
  *  "insert_split_blocks"     (0)   ... and deal a stream's firings to that many blocks; 0: 8 up to 24 streams, 6 up to 32, 4 up to 40, 3 up to 64,
  *                                  2 up to 96, else 1
- *  "insert_fin_merge"        (1)   the last block of k_insert_par that is through for a stream finishes the stream (k_insert_par_fin's work) and the
- *                                  launch's last stream writes the gate's counters into pinned memory (k_gate_out's work); 0: those two kernels
+ *  "insert_fin_merge"        (0)   experiment: the last block of k_insert_par that is through for a stream finishes the stream (k_insert_par_fin's work)
+ *                                  and the launch's last stream writes the gate's counters into pinned memory (k_gate_out's work). Exact, but the
+ *                                  agent-scope fences of the hand-over write the whole L2 back: - 22 % at 32 / 64 streams
  *  "insert_narrow_blocks"    (0)   experiment: that many 4-wavefront blocks per stream above insert_wide_max_streams
  *  "insert_lds_pad"          (0)   experiment: KB of unused dynamic LDS that keep a second insertion block off a compute unit
  *  -- segmentation, window scan ------------------------------------------------------------------------------------------------------------------
@@ -324,8 +325,8 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  "scan_packed"                   1: the packed window scan k_scan2 (default above 192 streams per launch and at 128 rows); 0: k_scan
  *  "scan_split"              (2)   throughput mode: a point of the packed scan that is still scanning after 6 visits (it found no neighbour:
  *                                  vegetation, spray) is handed to k_scan2_long, which runs such points with every lane busy, and k_scan2_epi
- *                                  finishes its column. 1: always; 0: one pass; 2: while the streams have many such points (every 32nd batch is
- *                                  scanned this way and counted: on at > 0.30 long scans per column, off again below 0.15)
+ *                                  finishes its column. 1: always; 0: one pass; 2: while such scans are a large part of the work (every 32nd batch
+ *                                  is scanned this way and counted: on above 40 visits of k_scan2_long per column of 64 rows, off again below 20)
  *  "scan_long_records"       (8192) room of a stream's list of such points per batch (a lane that finds it full finishes its scan in place)
  *  -- association -----------------------------------------------------------------------------------------------------------------------------------
  *  "assoc_batch"             (1)   the batch-parallel kernel k_assocb runs in front of the serial one and takes every group of columns that cannot
