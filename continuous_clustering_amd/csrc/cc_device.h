@@ -221,6 +221,7 @@ struct Geometry
                              // parent of live-replayed points, per-tree values of finished trees, the tree-link log)
     int32_t link_capacity;
     int32_t tab_tiles;       // tiles of 64 columns a batch can have: entries of Planes::tabc per stream and batch-descriptor slot
+    int32_t scan_cap;        // visits a lane of the packed window scan spends on its point before it hands it to the long-scan list (option "scan_cap")
     int32_t sl_cap;          // records of a stream's long-scan list the packed window scan may use (<= SL_CAP; option "scan_long_records": tests shrink it)
 };
 

@@ -290,6 +290,8 @@ void fill_geometry(cc_engine* e, int num_rows)
         g.lds_tree_limit = TREE_SLOTS;
     if (g.sl_cap <= 0 || g.sl_cap > cck::SL_CAP)
         g.sl_cap = cck::SL_CAP;
+    if (g.scan_cap <= 0)
+        g.scan_cap = cck::SCAN_CAP;
 }
 
 int free_all(cc_engine* e)
@@ -3118,6 +3120,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->ego_off_chain = value != 0;
     else if (n == "scan_split")
         e->scan_split = (int) std::max<int64_t>(0, std::min<int64_t>(value, 2));
+    else if (n == "scan_cap")
+        e->g.scan_cap = (int) std::max<int64_t>(1, std::min<int64_t>(value, 1 << 20));
     else if (n == "scan_long_records")
         e->g.sl_cap = (int) std::max<int64_t>(1, std::min<int64_t>(value, cck::SL_CAP));
     else if (n == "scan_packed")

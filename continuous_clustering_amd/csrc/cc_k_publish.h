@@ -266,9 +266,9 @@ __global__ __launch_bounds__(AB_THREADS) void k_small_all(Geometry g, cc_config 
 struct ResidentCtl
 {
     unsigned long long bell;   // host -> kernel: call number << 8 | firings (1 .. 63)
-    unsigned long long pad0[7];
-    unsigned long long stop;   // host -> kernel: leave now
-    unsigned long long pad1[7];
+    unsigned long long stop;   // host -> kernel: leave now (next to the bell: the kernel reads both with ONE 16-byte load over PCIe)
+    unsigned long long pad0[6];
+    unsigned long long pad1[8];
     unsigned long long exited; // kernel -> host: 0 while it runs, else the reason it left
     unsigned long long calls;  // kernel -> host: calls this launch of the kernel has run (statistics)
     unsigned long long pad2[6];
@@ -288,25 +288,33 @@ __global__ __launch_bounds__(AB_THREADS) void k_resident(Geometry g, cc_config c
             const unsigned long long want = hm.d_seq[0] + 1ull; // (written by this block's own mirror_results, or by the launch before)
             const unsigned long long t0 = wall_clock64();
             long long cmd = 0;
-            for (unsigned spin = 0;; spin++)
+            // A poll is a read of host memory over PCIe (~1.5 us there and back). Four are kept in flight, a quarter of a microsecond apart: the
+            // bell is seen one trip after the host's store instead of one and a half to two (one read at a time, bell and stop flag one after the other)
+            typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4* bp = (const u32x4*) &ctl->bell;
+            for (unsigned spin = 0; cmd == 0; spin++)
             {
-                const unsigned long long b = __hip_atomic_load(&ctl->bell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                if ((b >> 8) == want && (b & 255ull) != 0ull)
+                u32x4 v[4];
+                // (volatile or atomic loads in C are waited for one by one; four system-coherent loads in flight need the instruction sequence spelled out)
+                asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\ts_sleep 4\n\t"
+                             "global_load_dwordx4 %1, %4, off sc0 sc1\n\ts_sleep 4\n\t"
+                             "global_load_dwordx4 %2, %4, off sc0 sc1\n\ts_sleep 4\n\t"
+                             "global_load_dwordx4 %3, %4, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                             : "v"(bp)
+                             : "memory");
+#pragma unroll
+                for (int k = 0; k < 4; k++)
                 {
-                    cmd = (long long) (b & 255ull);
-                    break;
+                    const unsigned long long b = (unsigned long long) v[k].x | ((unsigned long long) v[k].y << 32);
+                    const unsigned long long stopv = (unsigned long long) v[k].z | ((unsigned long long) v[k].w << 32);
+                    if (cmd == 0 && (b >> 8) == want && (b & 255ull) != 0ull)
+                        cmd = (long long) (b & 255ull);
+                    if (cmd == 0 && stopv != 0ull)
+                        cmd = -1;
                 }
-                if (__hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull)
-                {
-                    cmd = -1;
-                    break;
-                }
-                if ((spin & 15u) == 15u && wall_clock64() - t0 > idle_limit)
-                {
+                if (cmd == 0 && (spin & 7u) == 7u && wall_clock64() - t0 > idle_limit)
                     cmd = -4;
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
             }
             s_cmd = cmd;
         }

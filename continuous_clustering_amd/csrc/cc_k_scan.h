@@ -639,7 +639,7 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
             bool pending = false;
             if (SPLIT)
             {
-                for (int it = 0; it < SCAN_CAP && __any(q.run); it++)
+                for (int it = 0; it < g.scan_cap && __any(q.run); it++)
                     if (q.run)
                         q.template step<false>(sc, p);
                 const unsigned long long m = __ballot(q.run);

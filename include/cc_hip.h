@@ -327,6 +327,7 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *                                  vegetation, spray) is handed to k_scan2_long, which runs such points with every lane busy, and k_scan2_epi
  *                                  finishes its column. 1: always; 0: one pass; 2: while such scans are a large part of the work (every 32nd batch
  *                                  is scanned this way and counted: on above 40 visits of k_scan2_long per column of 64 rows, off again below 20)
+ *  "scan_cap"                (6)   ... the number of visits after which a point is handed over
  *  "scan_long_records"       (8192) room of a stream's list of such points per batch (a lane that finds it full finishes its scan in place)
  *  -- association -----------------------------------------------------------------------------------------------------------------------------------
  *  "assoc_batch"             (1)   the batch-parallel kernel k_assocb runs in front of the serial one and takes every group of columns that cannot
