@@ -133,6 +133,13 @@ struct cc_engine
     unsigned long long small_seq_expected{0};
     unsigned long long small_tail_launches{0}; // small calls whose serial fall-backs the host launched behind k_small_all
     // ---- the resident single-stream kernel (option "resident", cc_k_publish.h: k_resident) ----
+    // ---- the call's column views in the mirror (cc_k_publish.h: HostMirror::view) ----
+    long long* h_small_view_hdr{nullptr};  // pinned: [0] call number, [1] columns, [2 .. 2 + MV_COLS) their global indices
+    char* h_small_view{nullptr};           // pinned: view_layout(.., MV_COLS * rows)
+    bool small_view_ok{false};             // the last small call's views are what the planes hold (nothing has changed the stream since)
+    int small_view_stream{-1};
+    bool mirror_views{true};               // option "mirror_views"
+    unsigned long long view_hits{0}, view_misses{0};
     bool resident_opt{false};              // option "resident"
     bool res_running{false};               // k_resident sits on `stream`: nothing else may be enqueued there before stop_resident()
     cck::ResidentCtl* h_res_ctl{nullptr};  // pinned: doorbell, stop flag, exit reason
@@ -315,6 +322,13 @@ int free_all(cc_engine* e)
     if (e->h_res_ctl)
         (void) hipHostFree(e->h_res_ctl);
     e->h_res_ctl = nullptr;
+    if (e->h_small_view_hdr)
+        (void) hipHostFree(e->h_small_view_hdr);
+    if (e->h_small_view)
+        (void) hipHostFree(e->h_small_view);
+    e->h_small_view_hdr = nullptr;
+    e->h_small_view = nullptr;
+    e->small_view_ok = false;
     if (e->h_input_sum)
         (void) hipHostFree(e->h_input_sum);
     e->h_input_sum = nullptr;
@@ -400,6 +414,7 @@ int allocate(cc_engine* e)
 // sc_inclination_angles_between_lasers_ values when the size does not change (cc.cpp:46).
 int reset_state(cc_engine* e, bool keep_table)
 {
+    e->small_view_ok = false;
     std::fill(e->state_cached.begin(), e->state_cached.end(), 0);
     const Geometry& g = e->g;
     const size_t S = (size_t) g.num_streams;
@@ -1530,6 +1545,7 @@ int finish_batch_inner(cc_engine* e)
 int submit(cc_engine* e, int first_stream, int count, int64_t n, const float* d_xyz, const uint8_t* d_int, const double* d_pose,
            bool pipeline, int64_t n_total = 0, int64_t f0 = 0)
 {
+    e->small_view_ok = false; // (the streams move on: what the last small call mirrored is history)
     {
         int rcs = stop_resident(e);
         if (rcs)
@@ -1823,6 +1839,30 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         d_int = (const uint8_t*) zx + b_xyz;
         d_pose = (const double*) ((const unsigned char*) zx + b_xyz + b_int);
     }
+    // the views of the call's columns ride along with the mirrored results (HostMirror::view): pinned planes of MV_COLS * rows cells + a header
+    e->small_view_ok = false;
+    long long* zvh = nullptr;
+    char* zvb = nullptr;
+    if (lean && e->mirror_views && e->g.record_events)
+    {
+        size_t vbytes = 0;
+        (void) cck::view_layout(nullptr, (size_t) cck::MV_COLS * R, &vbytes);
+        if (!e->h_small_view_hdr && (hipHostMalloc((void**) &e->h_small_view_hdr, 256) != hipSuccess || hipHostMalloc((void**) &e->h_small_view, vbytes + 64) != hipSuccess))
+            return -1;
+        void *a = nullptr, *b = nullptr;
+        if (hipHostGetDevicePointer(&a, e->h_small_view_hdr, 0) == hipSuccess && hipHostGetDevicePointer(&b, e->h_small_view, 0) == hipSuccess)
+            zvh = (long long*) a, zvb = (char*) b;
+    }
+    auto with_views = [&](cck::HostMirror hm) -> cck::HostMirror
+    {
+        hm.view_hdr = zvh;
+        if (zvh)
+        {
+            hm.view = cck::view_layout(zvb, (size_t) cck::MV_COLS * R);
+            hm.view.nchild = nullptr;
+        }
+        return hm;
+    };
     // option "resident": no launch per call at all — the call is handed to k_resident through a doorbell in pinned memory (cc_k_publish.h)
     const bool resident = lean && direct_ok && e->resident_opt && e->g.num_streams == 1 && xyz != nullptr;
     if (!resident)
@@ -1857,8 +1897,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
             return -1;
         bool ok = true;
         if (lean)
-            e->capture_mirror = cck::HostMirror{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
-                                                (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
+            e->capture_mirror = with_views(cck::HostMirror{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                                           (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1});
         else
         {
             ok = hipMemcpyAsync(e->d_small, e->h_small, b_xyz + b_int + b_pose, hipMemcpyHostToDevice, e->stream) == hipSuccess;
@@ -1913,8 +1953,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         __atomic_store_n(&e->h_res_ctl->exited, 0ull, __ATOMIC_RELEASE);
         __atomic_store_n(&e->h_res_ctl->stop, 0ull, __ATOMIC_RELEASE);
         __atomic_store_n(&e->h_res_ctl->calls, 0ull, __ATOMIC_RELEASE);
-        const cck::HostMirror hm{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
-                                 (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
+        const cck::HostMirror hm = with_views(cck::HostMirror{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                 (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1});
         hipLaunchKernelGGL(cck::k_resident, dim3(1), dim3(cck::AB_THREADS), cck::insert2_lds_bytes(R), e->stream, e->g, e->cfg, planes_with_prep(e, e->prep_buf),
                            e->d_states, stream, 0, d_xyz, d_int, d_pose, e->d_remaining, e->d_ego[0], e->d_bail_count, hm, (cck::ResidentCtl*) zc,
                            (unsigned long long) e->res_idle_ms * 100000ull);
@@ -1952,8 +1992,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
         int rcf = flush_deferred(e);
         if (rcf)
             return rcf;
-        const cck::HostMirror hm{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
-                                 (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
+        const cck::HostMirror hm = with_views(cck::HostMirror{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                 (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1});
         hipLaunchKernelGGL(cck::k_small_all, dim3(1), dim3(cck::AB_THREADS), cck::insert2_lds_bytes(R), e->stream, e->g, e->cfg, planes_with_prep(e, e->prep_buf),
                            e->d_states, stream, 0, d_xyz, d_int, d_pose, (long long) n, e->d_remaining, e->d_ego[0], e->d_bail_count, hm);
         CC_HIP_CHECK(e, hipGetLastError());
@@ -1974,8 +2014,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
             if (tail_launched || __atomic_load_n(e->h_small_seq + 1, __ATOMIC_ACQUIRE) != want)
                 return;
             tail_launched = true;
-            const cck::HostMirror hm{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
-                                     (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1};
+            const cck::HostMirror hm = with_views(cck::HostMirror{(StreamState*) zs, (cc_event*) zev, e->g.record_events ? SMALL_EVENTS : 0, (int*) zr, e->d_remaining,
+                                     (unsigned long long*) zq, e->d_small_seq, (unsigned long long*) zq + 1});
             hipLaunchKernelGGL(cck::k_small_tail<1>, dim3(1), dim3(cck::A3_THREADS), 0, e->stream, e->g, e->cfg, e->P, e->d_states, stream, 0, hm);
             e->small_tail_launches++;
         };
@@ -2077,6 +2117,9 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     }
     e->state_cache[stream] = st; // (n_events / n_links are not part of what cc_engine_stream_state reports)
     e->state_cached[stream] = 1;
+    // the views of the columns this call's events name came with the results (unless the serial fall-backs finished the call, or they were too many)
+    e->small_view_ok = zvh != nullptr && e->h_small_view_hdr[0] == (long long) e->small_seq_expected && e->h_small_view_hdr[1] > 0;
+    e->small_view_stream = stream;
     return CC_OK;
 }
 
@@ -2770,6 +2813,46 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     int rc = finish_batch(e);
     if (rc)
         return rc;
+    // Served from what the last small call mirrored with its results (HostMirror::view: the columns it segmented and the columns it published), if
+    // that covers the request: no kernel, no copy engine, no synchronisation — the per-firing read of a front-end that keeps a mirror of range_image_
+    if (e->small_view_ok && stream == e->small_view_stream && !v->number_of_child_points && to - from < cck::MV_COLS)
+    {
+        const long long* hdr = e->h_small_view_hdr;
+        const int nv = (int) hdr[1];
+        const size_t R = (size_t) e->g.num_rows;
+        int slot_of[cck::MV_COLS];
+        bool all = nv > 0 && nv <= cck::MV_COLS;
+        for (int64_t gcx = from; all && gcx <= to; gcx++)
+        {
+            int j = 0;
+            while (j < nv && hdr[2 + j] != gcx)
+                j++;
+            all = j < nv;
+            slot_of[gcx - from] = j;
+        }
+        if (all)
+        {
+            const cck::ViewOut m = cck::view_layout(e->h_small_view, (size_t) cck::MV_COLS * R);
+            for (int64_t gcx = from; gcx <= to; gcx++)
+            {
+                const size_t so = (size_t) slot_of[gcx - from] * R, dofs = (size_t) (gcx - from) * R;
+#define VCOPY(dst, srcp, T)  \
+    if (v->dst)              \
+        memcpy(v->dst + dofs, (srcp) + so, R * sizeof(T));
+                VCOPY(x, m.x, float) VCOPY(y, m.y, float) VCOPY(z, m.z, float) VCOPY(distance, m.dist, float) VCOPY(inclination_angle, m.incl, float);
+                VCOPY(continuous_azimuth_angle, m.caz, double) VCOPY(global_column_index, m.gcol, int64_t) VCOPY(source_firing, m.src, int64_t);
+                VCOPY(ground_point_label, m.ground, uint8_t) VCOPY(debug_ground_point_label, m.debug, uint8_t) VCOPY(is_ignored, m.ignored, uint8_t);
+                VCOPY(id, m.id, uint64_t) VCOPY(tree_root_global_column, m.root_gcol, int64_t) VCOPY(tree_root_row, m.root_row, int32_t);
+                VCOPY(finished_at_continuous_azimuth_angle, m.fin, double) VCOPY(tree_num_points, m.tpts, uint32_t) VCOPY(cluster_width, m.width, uint32_t);
+                VCOPY(number_of_visited_neighbors, m.visits, int32_t) VCOPY(belongs_to_finished_cluster, m.finished, uint8_t);
+                VCOPY(tree_parent_global_column, m.par_gcol, int64_t) VCOPY(tree_parent_row, m.par_row, int32_t);
+#undef VCOPY
+            }
+            e->view_hits++;
+            return CC_OK;
+        }
+    }
+    e->view_misses++;
     const size_t n = (size_t) (to - from + 1) * e->g.num_rows;
     // one staging block: 5 float + 1 double + 3 int64 + 3 u8 + 1 u64 + 1 i32 planes, + 1 double + 1 int64 + 5 x 4-byte + 1 u8 of the
     // remaining clustering fields
@@ -2951,6 +3034,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
     const std::string n(name);
     if (n == "resident")
         e->resident_opt = value != 0;
+    else if (n == "mirror_views")
+        e->mirror_views = value != 0;
     else if (n == "resident_idle_ms")
         e->res_idle_ms = (int) std::max<int64_t>(1, std::min<int64_t>(value, 10000));
     else if (n == "debug_flags")

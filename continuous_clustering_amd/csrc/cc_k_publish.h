@@ -8,6 +8,113 @@
 // =====================================================================================================
 constexpr int PUBLISH_BLOCKS = 64;
 
+struct ViewOut
+{
+    float *x, *y, *z, *dist, *incl;
+    double* caz;
+    int64_t *gcol, *src, *root_gcol;
+    uint8_t *ground, *debug, *ignored;
+    uint64_t* id;
+    int32_t* root_row;
+    // the remaining clustering fields of Point (include/cc_hip.h), any of them may be null
+    double* fin;
+    uint32_t *tpts, *width, *nchild;
+    int32_t *visits, *par_row;
+    uint8_t* finished;
+    int64_t* par_gcol;
+};
+
+
+// the host view of ONE column gc of a stream into column slot `oc` of the output arrays (k_view's body without the child counts; one wavefront)
+__device__ __forceinline__ void view_column(const Geometry& g, const SP& p, const StreamState* st, const long long gc, const int oc, const ViewOut& o)
+{
+    const int R = g.num_rows, RC = g.ring_cols;
+    const int lc = (int) (((gc % RC) + RC) % RC);
+    const bool in_ring = st->ring_end >= 0 && gc >= 0 && gc >= st->clear_done && gc <= st->ring_end;
+    const bool segmented = in_ring && st->first_column >= 0 && gc >= st->first_column && gc < st->first_unfinished;
+    const CazBase cb = caz_base_of_column(gc >= 0 ? gc : 0, g.num_columns);
+    const uint16_t tag = cell_tag((gc >= 0 ? gc : 0) / RC);
+    for (int row = lane_id(); row < R; row += 64)
+    {
+        const size_t ci = (size_t) lc * R + row;
+        const size_t oi = (size_t) oc * R + row;
+        const float nanf_ = __builtin_nanf("");
+        const bool mine = p.gtag[ci] == tag; // the cell belongs to this pass over the ring (Point::global_column_index == gc)
+        const bool filled = in_ring && (segmented ? true : mine);
+        const bool has_point = filled && !(p.dist[ci] != p.dist[ci]) && mine;
+        const float4 rec = has_point ? p.sc_rec[ci] : make_float4(nanf_, nanf_, nanf_, nanf_);
+        o.x[oi] = rec.x;
+        o.y[oi] = rec.y;
+        o.z[oi] = rec.z;
+        o.dist[oi] = has_point ? p.dist[ci] : nanf_;
+        o.incl[oi] = (has_point || segmented) ? p.incl[ci] : nanf_;
+        // (a segmented cell without a return sits in the middle of its column, cc.cpp:371-372)
+        o.caz[oi] = has_point ? cell_caz(cb, p.incaz[ci]) : (segmented ? empty_cell_caz(gc, g.az_width) : __builtin_nan(""));
+        o.gcol[oi] = segmented ? gc : (has_point ? gc : -1);
+        // (the firing's sequence number, kept as its low 32 bits: it is one of the last 2^32 firings the stream consumed)
+        o.src[oi] = has_point ? (long long) (st->firings_consumed - (unsigned long long) (uint32_t) ((uint32_t) st->firings_consumed - p.src[ci])) : -1;
+        o.ground[oi] = segmented ? p.ground[ci] : (uint8_t) CC_GP_UNKNOWN;
+        o.debug[oi] = segmented ? p.debug[ci] : (uint8_t) CC_DBG_WHITE;
+        o.ignored[oi] = segmented ? p.ignored[ci] : 0;
+        const int r = segmented ? p.root[ci] : -1;
+        o.id[oi] = r >= 0 ? (uint64_t) p.t_cid[r] : 0ull;
+        o.root_gcol[oi] = r >= 0 ? p.colg[r / R] : -1;
+        o.root_row[oi] = r >= 0 ? r % R : 0;
+        // per-tree values live at the root cell (cc.cpp:666-671, 818-822, 933); everything else keeps its cleared value
+        const bool is_root = r >= 0 && (size_t) r == ci;
+        if (o.fin)
+            o.fin[oi] = is_root ? p.t_fin[ci] : 0.;
+        if (o.tpts)
+            o.tpts[oi] = is_root ? p.t_pts[ci] : 0u;
+        if (o.width)
+            o.width[oi] = is_root ? p.t_width[ci] : 0u;
+        if (o.finished)
+            o.finished[oi] = is_root ? p.t_finished[ci] : (uint8_t) 0;
+        if (o.visits)
+            o.visits[oi] = (segmented && g.mirror_fields) ? (int32_t) p.sc_visits[ci] : 0;
+        const int code = (segmented && r >= 0) ? (int) p.sc_parent[ci] : -1; // (columns back << 8) | row of the point whose child list holds this one
+        if (o.par_gcol)
+            o.par_gcol[oi] = code >= 0 ? gc - (code >> 8) : -1;
+        if (o.par_row)
+            o.par_row[oi] = code >= 0 ? (code & 0xff) : 0;
+    }
+}
+
+// where the planes of a ViewOut lie in one staging block of n cells (8-byte planes first to keep alignment); `bytes` = what is used of it
+__host__ __device__ inline ViewOut view_layout(char* base, const size_t n, size_t* bytes = nullptr)
+{
+    ViewOut o;
+    o.caz = (double*) base;
+    o.gcol = (int64_t*) (base + n * 8);
+    o.src = (int64_t*) (base + n * 16);
+    o.root_gcol = (int64_t*) (base + n * 24);
+    o.id = (uint64_t*) (base + n * 32);
+    o.fin = (double*) (base + n * 40);
+    o.par_gcol = (int64_t*) (base + n * 48);
+    char* b4 = base + n * 56;
+    o.x = (float*) b4;
+    o.y = (float*) (b4 + n * 4);
+    o.z = (float*) (b4 + n * 8);
+    o.dist = (float*) (b4 + n * 12);
+    o.incl = (float*) (b4 + n * 16);
+    o.root_row = (int32_t*) (b4 + n * 20);
+    o.tpts = (uint32_t*) (b4 + n * 24);
+    o.width = (uint32_t*) (b4 + n * 28);
+    o.nchild = (uint32_t*) (b4 + n * 32);
+    o.visits = (int32_t*) (b4 + n * 36);
+    o.par_row = (int32_t*) (b4 + n * 40);
+    char* b1 = b4 + n * 44;
+    o.ground = (uint8_t*) b1;
+    o.debug = (uint8_t*) (b1 + n);
+    o.ignored = (uint8_t*) (b1 + 2 * n);
+    o.finished = (uint8_t*) (b1 + 3 * n);
+    if (bytes)
+        *bytes = (size_t) ((char*) o.finished + n - base);
+    return o;
+}
+
+constexpr int MV_COLS = 8; // columns a small call mirrors into pinned memory with its results (HostMirror::view)
+
 // what a small call on the host path hands back (cc_engine.hip: add_firings_small), written straight into pinned host memory by the last kernel of
 // the call instead of by three copy nodes of its graph: the stream's state, its first events, the early-stop counter
 struct HostMirror
@@ -20,6 +127,12 @@ struct HostMirror
     unsigned long long* seq;   // pinned: the number of mirrored calls so far, written LAST (the host spins on it instead of synchronising the stream)
     unsigned long long* d_seq; // device: [0] that number, [1] blocks of the current launch that are through
     unsigned long long* tail_req; // pinned (k_small_all): the number of the call whose serial fall-backs the host has to launch (k_small_tail), else 0
+    // round 6: the host views (cc_engine_read_columns' output) of the columns the call's events name — the columns it segmented and the columns it
+    // published, if they are at most MV_COLS together — ride along, so that a front-end that keeps a mirror of range_image_ (the drop-in class: one
+    // read per addFiring) needs no second kernel and no copy per call. view_hdr (pinned): [0] the call's number, [1] columns (-1: not mirrored),
+    // [2 ..] their global indices; `view`: planes of MV_COLS * rows cells in pinned memory (view_layout). nullptr: not wanted.
+    long long* view_hdr;
+    ViewOut view;
 };
 
 // cluster ids of the columns the batch published (cc.cpp:1035-1092: what publishing leaves in Point::id), columns by .. ny .. strided
@@ -45,14 +158,17 @@ __device__ __forceinline__ void publish_body(const Geometry& g, const Planes& P,
     }
 }
 
-// one wavefront: the call's results into pinned host memory, the sequence number last
-__device__ __forceinline__ void mirror_results(const Geometry& g, const Planes& P, const StreamState* states, const int s, const HostMirror& hm)
+// one wavefront: the call's results into pinned host memory (mirror_copy), then — behind a system-scope fence of every wavefront that wrote
+// something the host will read — the sequence number (mirror_commit). Returns the number the call gets.
+__device__ __forceinline__ unsigned long long mirror_copy(const Geometry& g, const Planes& P, const StreamState* states, const int s, const HostMirror& hm,
+                                                          const int n_view, const long long seg_b, const int n_seg, const long long pub_b)
 {
     const int lane = lane_id();
     const StreamState* s0 = &states[s];
     unsigned long long seq0 = 0ull; // (requested ahead of the copies: the last store of the call waits for nothing but the fence)
     if (lane == 0)
         seq0 = hm.d_seq[0];
+    seq0 = (unsigned long long) uniform_i64((long long) seq0);
     const unsigned* src = (const unsigned*) s0;
     unsigned* dst = (unsigned*) hm.state;
     for (int i = lane; i < (int) (sizeof(StreamState) / 4); i += 64)
@@ -64,14 +180,34 @@ __device__ __forceinline__ void mirror_results(const Geometry& g, const Planes& 
         ed[i] = es[i];
     if (lane == 0)
         *hm.remaining = *hm.d_remaining;
+    if (hm.view_hdr)
+    {
+        if (lane == 0)
+        {
+            hm.view_hdr[0] = (long long) (seq0 + 1ull);
+            hm.view_hdr[1] = n_view;
+        }
+        if (lane < n_view)
+            hm.view_hdr[2 + lane] = lane < n_seg ? seg_b + lane : pub_b + (lane - n_seg);
+    }
+    return seq0;
+}
+
+__device__ __forceinline__ void mirror_commit(const HostMirror& hm, const unsigned long long seq0)
+{
     __threadfence_system();
-    if (lane == 0)
+    if (lane_id() == 0)
     {
         hm.d_seq[1] = 0ull;
         const unsigned long long v = seq0 + 1ull;
         hm.d_seq[0] = v;
         __hip_atomic_store(hm.seq, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+__device__ __forceinline__ void mirror_results(const Geometry& g, const Planes& P, const StreamState* states, const int s, const HostMirror& hm)
+{
+    mirror_commit(hm, mirror_copy(g, P, states, s, hm, -1, 0, 0, 0));
 }
 
 __global__ __launch_bounds__(64) void k_publish(Geometry g, Planes P, const StreamState* states, int first_stream, int slot, HostMirror hm)
@@ -217,12 +353,34 @@ __device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config
             __hip_atomic_store(hm.tail_req, hm.d_seq[0] + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         return 1;
     }
-    // (the mirror only carries the stream's state and events, final since assocb_body: wavefront 0 sends it while the others write the cluster ids,
-    // which stay in HBM and are complete when the kernel ends — whatever reads them is ordered behind it on the stream)
+    // (the mirror carries the stream's state and events, final since assocb_body: wavefront 0 sends it while the others write the cluster ids,
+    // which stay in HBM and are complete when the kernel ends — whatever reads them is ordered behind it on the stream — and the host views of the
+    // columns the call's events name: what it segmented, what it published)
+    const long long seg_b = st->batch[slot].seg_begin, seg_e = st->batch[slot].seg_end, pub_b = st->batch[slot].pub_begin, pub_e = st->batch[slot].pub_end;
+    const int n_seg = uniform_i32(seg_b >= 0 && seg_e > seg_b ? (int) (seg_e - seg_b < 64 ? seg_e - seg_b : 64) : 0);
+    const int n_pub = uniform_i32(pub_b >= 0 && pub_e > pub_b ? (int) (pub_e - pub_b < 64 ? pub_e - pub_b : 64) : 0);
+    const int n_view = (hm.view_hdr && n_seg + n_pub <= MV_COLS && st->error == 0) ? n_seg + n_pub : -1;
+    unsigned long long seq0 = 0ull;
     if (wave == 0)
-        mirror_results(g, P, states, stream, hm);
+        seq0 = mirror_copy(g, P, states, stream, hm, n_view, seg_b, n_seg, pub_b);
     else
+    {
         publish_body(g, P, states, stream, slot, wave - 1, AB_WAVES);
+        if (n_view > 0)
+        {
+            const SP pv = stream_ptrs(P, g, stream);
+            // (newest column first: the wavefronts that finish the cluster ids early take the views)
+            for (int j = wave - 1; j < n_view; j += AB_WAVES)
+                view_column(g, pv, st, j < n_seg ? seg_b + j : pub_b + (j - n_seg), j, hm.view);
+        }
+    }
+    if (n_view > 0)
+    {
+        __threadfence_system(); // (the views are other wavefronts' stores: every one of them releases its own before wavefront 0 names the call)
+        __syncthreads();
+    }
+    if (wave == 0)
+        mirror_commit(hm, seq0);
 #ifdef CC_SF_STATS
     SA_MARK(6)
     if (threadIdx.x == 0)
@@ -490,22 +648,6 @@ __global__ __launch_bounds__(64) void k_gather_clusters(Geometry g, Planes P, co
 // k_view — host view of columns [from, from + ncols) of one stream (cc_engine_read_columns)
 // grid = ncols, block = 64
 // =====================================================================================================
-struct ViewOut
-{
-    float *x, *y, *z, *dist, *incl;
-    double* caz;
-    int64_t *gcol, *src, *root_gcol;
-    uint8_t *ground, *debug, *ignored;
-    uint64_t* id;
-    int32_t* root_row;
-    // the remaining clustering fields of Point (include/cc_hip.h), any of them may be null
-    double* fin;
-    uint32_t *tpts, *width, *nchild;
-    int32_t *visits, *par_row;
-    uint8_t* finished;
-    int64_t* par_gcol;
-};
-
 __global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamState* states, int s, long long from, ViewOut o, int max_back)
 {
     const StreamState* st = &states[s];
@@ -515,52 +657,7 @@ __global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamS
     const int lc = (int) (((gc % RC) + RC) % RC);
     const bool in_ring = st->ring_end >= 0 && gc >= 0 && gc >= st->clear_done && gc <= st->ring_end;
     const bool segmented = in_ring && st->first_column >= 0 && gc >= st->first_column && gc < st->first_unfinished;
-    const CazBase cb = caz_base_of_column(gc >= 0 ? gc : 0, g.num_columns);
-    const uint16_t tag = cell_tag((gc >= 0 ? gc : 0) / RC);
-    for (int row = lane_id(); row < R; row += 64)
-    {
-        const size_t ci = (size_t) lc * R + row;
-        const size_t oi = (size_t) blockIdx.x * R + row;
-        const float nanf_ = __builtin_nanf("");
-        const bool mine = p.gtag[ci] == tag; // the cell belongs to this pass over the ring (Point::global_column_index == gc)
-        const bool filled = in_ring && (segmented ? true : mine);
-        const bool has_point = filled && !(p.dist[ci] != p.dist[ci]) && mine;
-        const float4 rec = has_point ? p.sc_rec[ci] : make_float4(nanf_, nanf_, nanf_, nanf_);
-        o.x[oi] = rec.x;
-        o.y[oi] = rec.y;
-        o.z[oi] = rec.z;
-        o.dist[oi] = has_point ? p.dist[ci] : nanf_;
-        o.incl[oi] = (has_point || segmented) ? p.incl[ci] : nanf_;
-        // (a segmented cell without a return sits in the middle of its column, cc.cpp:371-372)
-        o.caz[oi] = has_point ? cell_caz(cb, p.incaz[ci]) : (segmented ? empty_cell_caz(gc, g.az_width) : __builtin_nan(""));
-        o.gcol[oi] = segmented ? gc : (has_point ? gc : -1);
-        // (the firing's sequence number, kept as its low 32 bits: it is one of the last 2^32 firings the stream consumed)
-        o.src[oi] = has_point ? (long long) (st->firings_consumed - (unsigned long long) (uint32_t) ((uint32_t) st->firings_consumed - p.src[ci])) : -1;
-        o.ground[oi] = segmented ? p.ground[ci] : (uint8_t) CC_GP_UNKNOWN;
-        o.debug[oi] = segmented ? p.debug[ci] : (uint8_t) CC_DBG_WHITE;
-        o.ignored[oi] = segmented ? p.ignored[ci] : 0;
-        const int r = segmented ? p.root[ci] : -1;
-        o.id[oi] = r >= 0 ? (uint64_t) p.t_cid[r] : 0ull;
-        o.root_gcol[oi] = r >= 0 ? p.colg[r / R] : -1;
-        o.root_row[oi] = r >= 0 ? r % R : 0;
-        // per-tree values live at the root cell (cc.cpp:666-671, 818-822, 933); everything else keeps its cleared value
-        const bool is_root = r >= 0 && (size_t) r == ci;
-        if (o.fin)
-            o.fin[oi] = is_root ? p.t_fin[ci] : 0.;
-        if (o.tpts)
-            o.tpts[oi] = is_root ? p.t_pts[ci] : 0u;
-        if (o.width)
-            o.width[oi] = is_root ? p.t_width[ci] : 0u;
-        if (o.finished)
-            o.finished[oi] = is_root ? p.t_finished[ci] : (uint8_t) 0;
-        if (o.visits)
-            o.visits[oi] = (segmented && g.mirror_fields) ? (int32_t) p.sc_visits[ci] : 0;
-        const int code = (segmented && r >= 0) ? (int) p.sc_parent[ci] : -1; // (columns back << 8) | row of the point whose child list holds this one
-        if (o.par_gcol)
-            o.par_gcol[oi] = code >= 0 ? gc - (code >> 8) : -1;
-        if (o.par_row)
-            o.par_row[oi] = code >= 0 ? (code & 0xff) : 0;
-    }
+    view_column(g, p, st, gc, (int) blockIdx.x, o);
     if (o.nchild)
     {
         // Point::child_points.size(): the points of this and the following columns whose parent is a cell of this column

@@ -323,8 +323,7 @@ void ContinuousClustering::reset(int num_rows)
     col_min_src_.assign(static_cast<size_t>(ring_buffer_max_columns), -1);
     mirror_stage_.assign(range_image_.size(), 0);
     tree_links_.clear();
-    v_from_ = 0;
-    v_to_ = -1;
+    v_ranges_.clear();
     reset_required_async_ = false;
     async_ = !config_.general.is_single_threaded; // cc.cpp:49-63
     if (async_)
@@ -515,35 +514,70 @@ int64_t ContinuousClustering::globalColumnOfLocal(int64_t local_column) const
     return end - (((end % rc) - local_column + rc) % rc);
 }
 
-// One read of the columns [from, to] into the v_* arrays (every field of cc_column_view).
-void ContinuousClustering::fetchColumns(int64_t from, int64_t to)
+// The columns of the given ranges into the v_* arrays (every field of cc_column_view): ranges merged where they touch, one engine read per merged
+// range (cut at 8 columns: what the engine serves from the views a small call mirrored with its results).
+void ContinuousClustering::fetchRanges(std::vector<std::pair<int64_t, int64_t>> want)
 {
-    v_from_ = from;
-    v_to_ = to;
-    if (to < from)
-        return;
-    const size_t n = static_cast<size_t>(to - from + 1) * static_cast<size_t>(num_rows_);
+    v_ranges_.clear();
+    std::sort(want.begin(), want.end());
+    std::vector<std::pair<int64_t, int64_t>> merged;
+    for (const auto& r : want)
+    {
+        if (r.second < r.first)
+            continue;
+        if (!merged.empty() && r.first <= merged.back().second + 1)
+            merged.back().second = std::max(merged.back().second, r.second);
+        else
+            merged.push_back(r);
+    }
+    if (!merged.empty())
+    {
+        // (never more than the ring holds: the oldest columns of an over-long range are gone)
+        const int64_t hi = merged.back().second;
+        for (auto& r : merged)
+            r.first = std::max(r.first, hi - ring_buffer_max_columns + 1);
+    }
+    size_t total = 0;
+    for (const auto& r : merged)
+        if (r.second >= r.first)
+        {
+            v_ranges_.push_back({r.first, r.second, total});
+            total += static_cast<size_t>(r.second - r.first + 1);
+        }
+    const size_t R = static_cast<size_t>(num_rows_);
+    const size_t n = total * R;
     v_x_.resize(n), v_y_.resize(n), v_z_.resize(n), v_d_.resize(n), v_i_.resize(n), v_caz_.resize(n), v_src_.resize(n);
     v_rootc_.resize(n), v_rootr_.resize(n), v_g_.resize(n), v_dbg_.resize(n), v_ign_.resize(n), v_id_.resize(n);
     v_fin_.resize(n), v_tpts_.resize(n), v_width_.resize(n), v_nchild_.resize(n), v_visits_.resize(n), v_parr_.resize(n);
     v_finished_.resize(n), v_parc_.resize(n);
-    const size_t R = static_cast<size_t>(num_rows_);
-    const int64_t step = 4096;
-    for (int64_t c0 = from; c0 <= to; c0 += step)
+    for (const ViewRange& vr : v_ranges_)
     {
-        const int64_t c1 = std::min(to, c0 + step - 1);
-        const size_t o = static_cast<size_t>(c0 - from) * R;
-        cc_column_view v{};
-        v.x = v_x_.data() + o, v.y = v_y_.data() + o, v.z = v_z_.data() + o, v.distance = v_d_.data() + o;
-        v.inclination_angle = v_i_.data() + o, v.continuous_azimuth_angle = v_caz_.data() + o, v.source_firing = v_src_.data() + o;
-        v.ground_point_label = v_g_.data() + o, v.debug_ground_point_label = v_dbg_.data() + o, v.is_ignored = v_ign_.data() + o;
-        v.id = v_id_.data() + o, v.tree_root_global_column = v_rootc_.data() + o, v.tree_root_row = v_rootr_.data() + o;
-        v.finished_at_continuous_azimuth_angle = v_fin_.data() + o, v.tree_num_points = v_tpts_.data() + o;
-        v.cluster_width = v_width_.data() + o, v.number_of_visited_neighbors = v_visits_.data() + o;
-        v.belongs_to_finished_cluster = v_finished_.data() + o, v.tree_parent_global_column = v_parc_.data() + o;
-        v.tree_parent_row = v_parr_.data() + o;
-        check(cc_engine_read_columns(engine_, 0, c0, c1, &v));
+        const int64_t step = (vr.to - vr.from + 1) <= 64 ? 8 : 4096; // (short ranges in pieces the engine's mirrored views can serve)
+        for (int64_t c0 = vr.from; c0 <= vr.to; c0 += step)
+        {
+            const int64_t c1 = std::min(vr.to, c0 + step - 1);
+            const size_t o = (vr.offset + static_cast<size_t>(c0 - vr.from)) * R;
+            cc_column_view v{};
+            v.x = v_x_.data() + o, v.y = v_y_.data() + o, v.z = v_z_.data() + o, v.distance = v_d_.data() + o;
+            v.inclination_angle = v_i_.data() + o, v.continuous_azimuth_angle = v_caz_.data() + o, v.source_firing = v_src_.data() + o;
+            v.ground_point_label = v_g_.data() + o, v.debug_ground_point_label = v_dbg_.data() + o, v.is_ignored = v_ign_.data() + o;
+            v.id = v_id_.data() + o, v.tree_root_global_column = v_rootc_.data() + o, v.tree_root_row = v_rootr_.data() + o;
+            v.finished_at_continuous_azimuth_angle = v_fin_.data() + o, v.tree_num_points = v_tpts_.data() + o;
+            v.cluster_width = v_width_.data() + o, v.number_of_visited_neighbors = v_visits_.data() + o;
+            v.belongs_to_finished_cluster = v_finished_.data() + o, v.tree_parent_global_column = v_parc_.data() + o;
+            v.tree_parent_row = v_parr_.data() + o;
+            check(cc_engine_read_columns(engine_, 0, c0, c1, &v));
+        }
     }
+}
+
+// index of global column g in the v_* arrays (in columns), -1: not fetched by the last call of fetchRanges
+int64_t ContinuousClustering::viewColumn(int64_t g) const
+{
+    for (const ViewRange& vr : v_ranges_)
+        if (g >= vr.from && g <= vr.to)
+            return static_cast<int64_t>(vr.offset) + (g - vr.from);
+    return -1;
 }
 
 // Bring the mirror cells of the columns [from, to] (inside the fetched range) to `stage`. STAGE_GROUND: range-image and ground
@@ -553,16 +587,17 @@ void ContinuousClustering::fetchColumns(int64_t from, int64_t to)
 // STAGE_FULL: cluster id and the per-tree values of root points.
 void ContinuousClustering::applyColumns(int64_t from, int64_t to, MirrorStage stage)
 {
-    from = std::max(from, v_from_);
-    to = std::min(to, v_to_);
     const size_t R = static_cast<size_t>(num_rows_);
     for (int64_t g = from; g <= to; g++)
     {
+        const int64_t vc = viewColumn(g);
+        if (vc < 0)
+            continue;
         const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
         int64_t min_src = -1;
         for (size_t r = 0; r < R; r++)
         {
-            const size_t i = static_cast<size_t>(g - v_from_) * R + r;
+            const size_t i = static_cast<size_t>(vc) * R + r;
             if (v_src_[i] >= 0 && (min_src < 0 || v_src_[i] < min_src))
                 min_src = v_src_[i];
             applyCell(g, static_cast<int>(r), stage);
@@ -573,11 +608,12 @@ void ContinuousClustering::applyColumns(int64_t from, int64_t to, MirrorStage st
 
 void ContinuousClustering::applyCell(int64_t g, int row, MirrorStage stage)
 {
-    if (g < v_from_ || g > v_to_)
+    const int64_t vc = viewColumn(g);
+    if (vc < 0)
         return;
     const size_t R = static_cast<size_t>(num_rows_), r = static_cast<size_t>(row);
     const size_t lc = static_cast<size_t>(g % ring_buffer_max_columns);
-    const size_t i = static_cast<size_t>(g - v_from_) * R + r;
+    const size_t i = static_cast<size_t>(vc) * R + r;
     const size_t ci = lc * R + r;
     Point& p = range_image_[ci];
     if (mirror_stage_[ci] < 1)
@@ -747,24 +783,19 @@ void ContinuousClustering::process()
         }
     }
 
-    // one read of every column an event of this call refers to; the mirror is then brought up to date in callback order
-    int64_t lo = std::numeric_limits<int64_t>::max(), hi = -1;
+    // the columns the events of this call refer to — and only those: the newest column (ground view) and the oldest ones (published) lie a lag of
+    // ~100 columns apart, and a call of a few firings gets both from what the engine mirrored with its results (no kernel, no copy: cc_hip.h,
+    // cc_engine_read_columns); the mirror is then brought up to date in callback order
+    std::vector<std::pair<int64_t, int64_t>> want;
     for (const cc_event& e : events_)
     {
         if (e.type == CC_EV_PUBLISH_COLUMNS && e.b < e.a)
             continue;
         if (e.type == CC_EV_CLUSTER && !(e.d > 20 && finished_cluster_callback_))
             continue;
-        lo = std::min(lo, e.a);
-        hi = std::max(hi, e.b);
+        want.emplace_back(e.a, e.b);
     }
-    if (hi >= 0)
-    {
-        lo = std::max(lo, hi - ring_buffer_max_columns + 1);
-        fetchColumns(lo, hi);
-    }
-    else
-        fetchColumns(0, -1);
+    fetchRanges(want);
 
     // member points of the clusters that get a callback: gathered and compacted on the device (cc_engine_gather_cluster_points)
     std::vector<uint32_t> g_cid, g_cnt;

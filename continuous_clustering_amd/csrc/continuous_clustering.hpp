@@ -315,14 +315,15 @@ class ContinuousClustering
     void waitIdle();
     void rethrowWorkerError();
     void check(int rc);
-    // mirror of range_image_: the columns a call touched are fetched once (fetchColumns) and applied in callback order, stage by stage
+    // mirror of range_image_: the columns a call's events name are fetched once (fetchRanges) and applied in callback order, stage by stage
     enum MirrorStage
     {
         STAGE_GROUND = 0, // what the reference's range image holds when the ground-view callback runs (cc.cpp:618-620)
         STAGE_ASSOC = 1,  // ... after associatePointsInColumn of the column (cc.cpp:773-835), which follows that callback directly
         STAGE_FULL = 2    // ... when the cluster-view callback publishes the column (cc.cpp:1087-1089)
     };
-    void fetchColumns(int64_t from, int64_t to);
+    void fetchRanges(std::vector<std::pair<int64_t, int64_t>> want);
+    int64_t viewColumn(int64_t g) const;
     void applyColumns(int64_t from, int64_t to, MirrorStage stage);
     void applyCell(int64_t global_column, int row, MirrorStage stage);
     void clearMirrorColumns(int64_t from, int64_t to);
@@ -366,7 +367,12 @@ class ContinuousClustering
     std::vector<int32_t> v_visits_, v_parr_;
     std::vector<uint8_t> v_finished_;
     std::vector<int64_t> v_parc_;
-    int64_t v_from_{0}, v_to_{-1}; // global columns held by the v_* arrays
+    struct ViewRange
+    {
+        int64_t from, to;
+        size_t offset; // first column of the range in the v_* arrays
+    };
+    std::vector<ViewRange> v_ranges_; // global columns held by the v_* arrays
     std::vector<uint8_t> mirror_stage_; // per ring cell: 0 cleared, 1 ground stage applied, 2 association stage, 3 full
     // Point::associated_trees of the unfinished trees, rebuilt from the engine's tree-link log: root (row, local column) -> linked roots
     std::map<RangeImageIndex, std::set<RangeImageIndex>> tree_links_;
