@@ -87,6 +87,7 @@ def load_library():
     L.cc_engine_drain_links.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
     L.cc_engine_stream_state.argtypes = [vp, i32, C.POINTER(capi.StreamState)]
     L.cc_engine_read_columns.argtypes = [vp, i32, i64, i64, C.POINTER(capi.ColumnView)]
+    L.cc_engine_read_column_ranges.argtypes = [vp, i32, i32, vp, vp, C.POINTER(capi.ColumnView)]
     L.cc_engine_output_planes.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(vp)]
     L.cc_engine_set_option.argtypes = [vp, C.c_char_p, i64]
     L.cc_engine_gather_cluster_points.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp]
@@ -96,6 +97,7 @@ def load_library():
     L.cc_engine_batch_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 2 + [C.POINTER(C.c_uint64 * 8)]
     L.cc_engine_gate_counters.argtypes = [vp] + [C.POINTER(C.c_uint64)] * 2
     L.cc_engine_resident_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L.cc_engine_view_counters.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.cc_engine_last_error.argtypes = [vp]
     L.cc_engine_last_error.restype = C.c_char_p
     _lib = L
@@ -226,6 +228,14 @@ class Engine:
         self._check(self.L.cc_engine_read_columns(self.h, stream, frm, to, C.byref(v)))
         return arrays
 
+    def read_column_ranges(self, ranges, stream: int = 0, fields=None) -> dict:
+        """Columns of up to 8 ranges [(from, to), ...] in one call; the arrays hold the ranges' columns one after the other."""
+        frm = np.ascontiguousarray([r[0] for r in ranges], dtype=np.int64)
+        to = np.ascontiguousarray([r[1] for r in ranges], dtype=np.int64)
+        v, arrays = capi.make_column_view(int((to - frm + 1).sum()), self.num_rows, fields)
+        self._check(self.L.cc_engine_read_column_ranges(self.h, stream, len(ranges), frm.ctypes.data, to.ctypes.data, C.byref(v)))
+        return arrays
+
     def gather_cluster_points(self, cluster_events: np.ndarray, stream: int = 0):
         """Member points of finished clusters (CC_EV_CLUSTER events drained from this stream), gathered on the device:
         returns (offsets[n + 1], global_column[total], row[total]); cluster i owns [offsets[i], offsets[i + 1])."""
@@ -275,6 +285,12 @@ class Engine:
         a, b, r = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
         self._check(self.L.cc_engine_resident_counters(self.h, C.byref(a), C.byref(b), C.byref(r)))
         return {"launches": int(a.value), "calls": int(b.value), "running": bool(r.value)}
+
+    def view_counters(self) -> dict:
+        """read_columns calls served from the views a small call mirrored with its results / by the view kernel."""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        self._check(self.L.cc_engine_view_counters(self.h, C.byref(a), C.byref(b)))
+        return {"mirror": int(a.value), "kernel": int(b.value)}
 
     def gate_counters(self) -> dict:
         v = [C.c_uint64(0) for _ in range(2)]

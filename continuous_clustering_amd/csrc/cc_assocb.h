@@ -219,6 +219,7 @@ struct AbShared
     int s_serial_cols;
     int s_reason;
     unsigned long long s_cols;
+    int s_view_done; // (k_small_all / k_resident, phase F: wavefronts that have written their share of the call's column views)
 };
 
 // what assocb_body needs of the stream's state before its first group: the persistent tree state (global planes indexed by root cell) -> LDS, list

@@ -2805,37 +2805,41 @@ int cc_engine_stream_state(cc_engine* e, int stream, cc_stream_state* out)
     return CC_OK;
 }
 
-int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, const cc_column_view* v)
+// the columns of up to 8 ranges [from[i], to[i]], one after the other in the caller's arrays: from the views the last small call mirrored, else ONE launch
+static int read_ranges(cc_engine* e, int stream, int nr, const int64_t* from, const int64_t* to, const cc_column_view* v)
 {
-    if (!e || stream < 0 || stream >= e->g.num_streams || !v || to < from || to - from >= e->g.ring_cols)
-        return CC_ERR_INVALID_ARGUMENT;
     (void) hipSetDevice(e->device);
     int rc = finish_batch(e);
     if (rc)
         return rc;
+    int64_t total = 0;
+    for (int i = 0; i < nr; i++)
+        total += to[i] - from[i] + 1;
+    const size_t R = (size_t) e->g.num_rows;
     // Served from what the last small call mirrored with its results (HostMirror::view: the columns it segmented and the columns it published), if
     // that covers the request: no kernel, no copy engine, no synchronisation — the per-firing read of a front-end that keeps a mirror of range_image_
-    if (e->small_view_ok && stream == e->small_view_stream && !v->number_of_child_points && to - from < cck::MV_COLS)
+    if (e->small_view_ok && stream == e->small_view_stream && !v->number_of_child_points && total <= cck::MV_COLS)
     {
         const long long* hdr = e->h_small_view_hdr;
         const int nv = (int) hdr[1];
-        const size_t R = (size_t) e->g.num_rows;
         int slot_of[cck::MV_COLS];
         bool all = nv > 0 && nv <= cck::MV_COLS;
-        for (int64_t gcx = from; all && gcx <= to; gcx++)
-        {
-            int j = 0;
-            while (j < nv && hdr[2 + j] != gcx)
-                j++;
-            all = j < nv;
-            slot_of[gcx - from] = j;
-        }
+        int k = 0;
+        for (int i = 0; all && i < nr; i++)
+            for (int64_t gcx = from[i]; all && gcx <= to[i]; gcx++)
+            {
+                int j = 0;
+                while (j < nv && hdr[2 + j] != gcx)
+                    j++;
+                all = j < nv;
+                slot_of[k++] = j;
+            }
         if (all)
         {
             const cck::ViewOut m = cck::view_layout(e->h_small_view, (size_t) cck::MV_COLS * R);
-            for (int64_t gcx = from; gcx <= to; gcx++)
+            for (int c = 0; c < k; c++)
             {
-                const size_t so = (size_t) slot_of[gcx - from] * R, dofs = (size_t) (gcx - from) * R;
+                const size_t so = (size_t) slot_of[c] * R, dofs = (size_t) c * R;
 #define VCOPY(dst, srcp, T)  \
     if (v->dst)              \
         memcpy(v->dst + dofs, (srcp) + so, R * sizeof(T));
@@ -2853,10 +2857,10 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
         }
     }
     e->view_misses++;
-    const size_t n = (size_t) (to - from + 1) * e->g.num_rows;
-    // one staging block: 5 float + 1 double + 3 int64 + 3 u8 + 1 u64 + 1 i32 planes, + 1 double + 1 int64 + 5 x 4-byte + 1 u8 of the
-    // remaining clustering fields
-    const size_t bytes = n * (5 * 4 + 8 + 3 * 8 + 3 + 8 + 4 + 8 + 8 + 5 * 4 + 1) + 256;
+    const size_t n = (size_t) total * R;
+    size_t used = 0;
+    (void) cck::view_layout(nullptr, n, &used);
+    const size_t bytes = used + 256;
     if (e->view_bytes < bytes)
     {
         void* p = nullptr;
@@ -2875,42 +2879,27 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
         e->h_view_bytes = bytes;
     }
     char* base = (char*) e->d_view;
-    cck::ViewOut o;
-    // 8-byte planes first to keep alignment
-    o.caz = (double*) base;
-    o.gcol = (int64_t*) (base + n * 8);
-    o.src = (int64_t*) (base + n * 16);
-    o.root_gcol = (int64_t*) (base + n * 24);
-    o.id = (uint64_t*) (base + n * 32);
-    o.fin = (double*) (base + n * 40);
-    o.par_gcol = (int64_t*) (base + n * 48);
-    char* b4 = base + n * 56;
-    o.x = (float*) b4;
-    o.y = (float*) (b4 + n * 4);
-    o.z = (float*) (b4 + n * 8);
-    o.dist = (float*) (b4 + n * 12);
-    o.incl = (float*) (b4 + n * 16);
-    o.root_row = (int32_t*) (b4 + n * 20);
-    o.tpts = (uint32_t*) (b4 + n * 24);
-    o.width = (uint32_t*) (b4 + n * 28);
-    o.nchild = (uint32_t*) (b4 + n * 32);
-    o.visits = (int32_t*) (b4 + n * 36);
-    o.par_row = (int32_t*) (b4 + n * 40);
-    char* b1 = b4 + n * 44;
-    o.ground = (uint8_t*) b1;
-    o.debug = (uint8_t*) (b1 + n);
-    o.ignored = (uint8_t*) (b1 + 2 * n);
-    o.finished = (uint8_t*) (b1 + 3 * n);
+    cck::ViewOut o = cck::view_layout(base, n);
+    char* const nchild_at = (char*) o.nchild;
     // the optional fields cost a child-count pass and extra copies: only when the caller asked for one of them
     if (!v->number_of_child_points)
         o.nchild = nullptr;
     int max_back = e->cfg.max_steps_in_row < e->g.ring_cols - 1 ? e->cfg.max_steps_in_row : e->g.ring_cols - 1;
     max_back = max_back < 0 ? 0 : (max_back > 255 ? 255 : max_back);
-    hipLaunchKernelGGL(cck::k_view, dim3((unsigned) (to - from + 1)), dim3(64), 0, query_stream(e), e->g, e->P, e->d_states, stream,
-                       (long long) from, o, max_back);
+    cck::ViewRanges vr;
+    vr.n = nr;
+    int acc = 0;
+    for (int i = 0; i < 8; i++)
+    {
+        vr.start[i] = acc;
+        vr.from[i] = i < nr ? (long long) from[i] : 0;
+        if (i < nr)
+            acc += (int) (to[i] - from[i] + 1);
+    }
+    vr.start[8] = acc;
+    hipLaunchKernelGGL(cck::k_view, dim3((unsigned) total), dim3(64), 0, query_stream(e), e->g, e->P, e->d_states, stream, vr, o, max_back);
     CC_HIP_CHECK(e, hipGetLastError());
     // one copy of the whole staging block (a call per field costs more than the bytes for the few columns a live mirror reads)
-    const size_t used = (size_t) ((char*) o.finished + n - base);
     CC_HIP_CHECK(e, hipMemcpyAsync(e->h_view, base, used, hipMemcpyDeviceToHost, query_stream(e)));
     CC_HIP_CHECK(e, hipStreamSynchronize(query_stream(e)));
 #define COPY(dst, srcp, T)                                                                        \
@@ -2924,9 +2913,34 @@ int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, c
     COPY(number_of_visited_neighbors, o.visits, int32_t) COPY(belongs_to_finished_cluster, o.finished, uint8_t);
     COPY(tree_parent_global_column, o.par_gcol, int64_t) COPY(tree_parent_row, o.par_row, int32_t);
     if (v->number_of_child_points)
-        memcpy(v->number_of_child_points, e->h_view + (b4 + n * 32 - base), n * sizeof(uint32_t));
+        memcpy(v->number_of_child_points, e->h_view + (nchild_at - base), n * sizeof(uint32_t));
 #undef COPY
     return CC_OK;
+}
+
+int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, const cc_column_view* v)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !v || to < from || to - from >= e->g.ring_cols)
+        return CC_ERR_INVALID_ARGUMENT;
+    return read_ranges(e, stream, 1, &from, &to, v);
+}
+
+int cc_engine_read_column_ranges(cc_engine* e, int stream, int n_ranges, const int64_t* from, const int64_t* to, const cc_column_view* v)
+{
+    if (!e || stream < 0 || stream >= e->g.num_streams || !v || n_ranges < 0 || n_ranges > 8 || (n_ranges > 0 && (!from || !to)))
+        return CC_ERR_INVALID_ARGUMENT;
+    int64_t total = 0;
+    for (int i = 0; i < n_ranges; i++)
+    {
+        if (to[i] < from[i])
+            return CC_ERR_INVALID_ARGUMENT;
+        total += to[i] - from[i] + 1;
+    }
+    if (total > e->g.ring_cols)
+        return CC_ERR_INVALID_ARGUMENT;
+    if (total == 0)
+        return CC_OK;
+    return read_ranges(e, stream, n_ranges, from, to, v);
 }
 
 int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const uint32_t* cluster_ids, const int64_t* col_from,
@@ -3357,6 +3371,17 @@ int cc_engine_scatter_apply(cc_engine* e, int stream, int64_t from, int64_t to, 
                        d_original_index, slots, d_is_ground, d_detection, (long long) max_points);
     CC_HIP_CHECK(e, hipGetLastError());
     return CC_OK; // (asynchronous on cc_engine_hip_stream(e): cc_eval_frame_device on the same stream, or cc_engine_sync, orders behind it)
+}
+
+int cc_engine_view_counters(cc_engine* e, uint64_t* served_from_mirror, uint64_t* served_by_kernel)
+{
+    if (!e)
+        return CC_ERR_INVALID_ARGUMENT;
+    if (served_from_mirror)
+        *served_from_mirror = e->view_hits;
+    if (served_by_kernel)
+        *served_by_kernel = e->view_misses;
+    return CC_OK;
 }
 
 int cc_engine_resident_counters(cc_engine* e, uint64_t* launches, uint64_t* calls, int* running)

@@ -276,6 +276,8 @@ __device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config
 #endif
     // what the association will start from, as far as it can be known before the insertion has run: the call's first finished column is the
     // stream's first unfinished one (insert2_body closes the batch descriptor with it); assocb_body checks the prediction
+    if (threadIdx.x == 0)
+        S.s_view_done = 0; // (phase F: view writers that are through; several block barriers lie between here and there)
     AbPreloaded pre;
     pre.col_begin = st->first_unfinished;
     pre.first_column = st->first_column;
@@ -360,27 +362,30 @@ __device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config
     const int n_seg = uniform_i32(seg_b >= 0 && seg_e > seg_b ? (int) (seg_e - seg_b < 64 ? seg_e - seg_b : 64) : 0);
     const int n_pub = uniform_i32(pub_b >= 0 && pub_e > pub_b ? (int) (pub_e - pub_b < 64 ? pub_e - pub_b : 64) : 0);
     const int n_view = (hm.view_hdr && n_seg + n_pub <= MV_COLS && st->error == 0) ? n_seg + n_pub : -1;
-    unsigned long long seq0 = 0ull;
+    // (wavefront 0 names the call as soon as ITS copies and the views are out: it waits for the view writers through an LDS counter, not for the
+    // wavefronts that are still writing cluster ids — a block barrier here put their time, and sixteen system-scope fences, on every call: + 10 us)
+    const int n_writers = n_view > 0 ? (n_view < 4 ? n_view : 4) : 0;
     if (wave == 0)
-        seq0 = mirror_copy(g, P, states, stream, hm, n_view, seg_b, n_seg, pub_b);
+    {
+        const unsigned long long seq0 = mirror_copy(g, P, states, stream, hm, n_view, seg_b, n_seg, pub_b);
+        if (n_writers > 0)
+            while (__hip_atomic_load(&S.s_view_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_writers)
+                __builtin_amdgcn_s_sleep(1);
+        mirror_commit(hm, seq0);
+    }
     else
     {
-        publish_body(g, P, states, stream, slot, wave - 1, AB_WAVES);
-        if (n_view > 0)
+        if (wave <= n_writers)
         {
             const SP pv = stream_ptrs(P, g, stream);
-            // (newest column first: the wavefronts that finish the cluster ids early take the views)
-            for (int j = wave - 1; j < n_view; j += AB_WAVES)
+            for (int j = wave - 1; j < n_view; j += n_writers)
                 view_column(g, pv, st, j < n_seg ? seg_b + j : pub_b + (j - n_seg), j, hm.view);
+            __threadfence_system(); // (this wavefront's stores to pinned memory are out before it says so)
+            if (lane_id() == 0)
+                __hip_atomic_fetch_add(&S.s_view_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        publish_body(g, P, states, stream, slot, wave - 1, AB_WAVES);
     }
-    if (n_view > 0)
-    {
-        __threadfence_system(); // (the views are other wavefronts' stores: every one of them releases its own before wavefront 0 names the call)
-        __syncthreads();
-    }
-    if (wave == 0)
-        mirror_commit(hm, seq0);
 #ifdef CC_SF_STATS
     SA_MARK(6)
     if (threadIdx.x == 0)
@@ -648,12 +653,23 @@ __global__ __launch_bounds__(64) void k_gather_clusters(Geometry g, Planes P, co
 // k_view — host view of columns [from, from + ncols) of one stream (cc_engine_read_columns)
 // grid = ncols, block = 64
 // =====================================================================================================
-__global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamState* states, int s, long long from, ViewOut o, int max_back)
+// (up to 8 ranges of columns per launch: block b views column from[r] + (b - start[r]) of the range r it falls into; the output holds the ranges one after the other)
+struct ViewRanges
+{
+    int n;
+    int start[9];
+    long long from[8];
+};
+
+__global__ __launch_bounds__(64) void k_view(Geometry g, Planes P, const StreamState* states, int s, ViewRanges vr, ViewOut o, int max_back)
 {
     const StreamState* st = &states[s];
     const SP p = stream_ptrs(P, g, s);
     const int R = g.num_rows, RC = g.ring_cols;
-    const long long gc = from + blockIdx.x;
+    int r = 0;
+    while (r + 1 < vr.n && (int) blockIdx.x >= vr.start[r + 1])
+        r++;
+    const long long gc = vr.from[r] + ((int) blockIdx.x - vr.start[r]);
     const int lc = (int) (((gc % RC) + RC) % RC);
     const bool in_ring = st->ring_end >= 0 && gc >= 0 && gc >= st->clear_done && gc <= st->ring_end;
     const bool segmented = in_ring && st->first_column >= 0 && gc >= st->first_column && gc < st->first_unfinished;

@@ -550,24 +550,32 @@ void ContinuousClustering::fetchRanges(std::vector<std::pair<int64_t, int64_t>> 
     v_rootc_.resize(n), v_rootr_.resize(n), v_g_.resize(n), v_dbg_.resize(n), v_ign_.resize(n), v_id_.resize(n);
     v_fin_.resize(n), v_tpts_.resize(n), v_width_.resize(n), v_nchild_.resize(n), v_visits_.resize(n), v_parr_.resize(n);
     v_finished_.resize(n), v_parc_.resize(n);
-    for (const ViewRange& vr : v_ranges_)
+    if (v_ranges_.empty())
+        return;
+    auto view_at = [&](size_t col_offset)
     {
-        const int64_t step = (vr.to - vr.from + 1) <= 64 ? 8 : 4096; // (short ranges in pieces the engine's mirrored views can serve)
-        for (int64_t c0 = vr.from; c0 <= vr.to; c0 += step)
-        {
-            const int64_t c1 = std::min(vr.to, c0 + step - 1);
-            const size_t o = (vr.offset + static_cast<size_t>(c0 - vr.from)) * R;
-            cc_column_view v{};
-            v.x = v_x_.data() + o, v.y = v_y_.data() + o, v.z = v_z_.data() + o, v.distance = v_d_.data() + o;
-            v.inclination_angle = v_i_.data() + o, v.continuous_azimuth_angle = v_caz_.data() + o, v.source_firing = v_src_.data() + o;
-            v.ground_point_label = v_g_.data() + o, v.debug_ground_point_label = v_dbg_.data() + o, v.is_ignored = v_ign_.data() + o;
-            v.id = v_id_.data() + o, v.tree_root_global_column = v_rootc_.data() + o, v.tree_root_row = v_rootr_.data() + o;
-            v.finished_at_continuous_azimuth_angle = v_fin_.data() + o, v.tree_num_points = v_tpts_.data() + o;
-            v.cluster_width = v_width_.data() + o, v.number_of_visited_neighbors = v_visits_.data() + o;
-            v.belongs_to_finished_cluster = v_finished_.data() + o, v.tree_parent_global_column = v_parc_.data() + o;
-            v.tree_parent_row = v_parr_.data() + o;
-            check(cc_engine_read_columns(engine_, 0, c0, c1, &v));
-        }
+        const size_t o = col_offset * R;
+        cc_column_view v{};
+        v.x = v_x_.data() + o, v.y = v_y_.data() + o, v.z = v_z_.data() + o, v.distance = v_d_.data() + o;
+        v.inclination_angle = v_i_.data() + o, v.continuous_azimuth_angle = v_caz_.data() + o, v.source_firing = v_src_.data() + o;
+        v.ground_point_label = v_g_.data() + o, v.debug_ground_point_label = v_dbg_.data() + o, v.is_ignored = v_ign_.data() + o;
+        v.id = v_id_.data() + o, v.tree_root_global_column = v_rootc_.data() + o, v.tree_root_row = v_rootr_.data() + o;
+        v.finished_at_continuous_azimuth_angle = v_fin_.data() + o, v.tree_num_points = v_tpts_.data() + o;
+        v.cluster_width = v_width_.data() + o, v.number_of_visited_neighbors = v_visits_.data() + o;
+        v.belongs_to_finished_cluster = v_finished_.data() + o, v.tree_parent_global_column = v_parc_.data() + o;
+        v.tree_parent_row = v_parr_.data() + o;
+        return v;
+    };
+    // ONE engine call for all ranges (cc_engine_read_column_ranges: the mirrored views of a small call, else one launch and one copy), eight ranges
+    // at a time
+    for (size_t k = 0; k < v_ranges_.size(); k += 8)
+    {
+        const int nr = static_cast<int>(std::min<size_t>(8, v_ranges_.size() - k));
+        int64_t fr[8], to[8];
+        for (int i = 0; i < nr; i++)
+            fr[i] = v_ranges_[k + i].from, to[i] = v_ranges_[k + i].to;
+        const cc_column_view v = view_at(v_ranges_[k].offset);
+        check(cc_engine_read_column_ranges(engine_, 0, nr, fr, to, &v));
     }
 }
 

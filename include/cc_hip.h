@@ -267,6 +267,11 @@ int cc_engine_pending_events(cc_engine* e, int stream, int64_t* n);
 int cc_engine_stream_state(cc_engine* e, int stream, cc_stream_state* out);
 /* Copy the columns [from, to] (global indices, inclusive, to - from < ring_buffer_max_columns) of `stream` to host. */
 int cc_engine_read_columns(cc_engine* e, int stream, int64_t from, int64_t to, const cc_column_view* view);
+/* The same for up to 8 ranges [from[i], to[i]] at once (the ranges' columns one after the other in the view's arrays, sum(to - from + 1) columns in
+ * all): what a front-end that keeps a mirror of range_image_ reads per call — the newest column (ground view) and the oldest ones (published) lie a
+ * lag of ~100 columns apart. One kernel launch and one copy whatever the number of ranges; none at all when the last call on the stream was a small
+ * one (< 64 firings) and the ranges only name columns it segmented or published (at most 8: option "mirror_views", cc_engine_view_counters). */
+int cc_engine_read_column_ranges(cc_engine* e, int stream, int n_ranges, const int64_t* from, const int64_t* to, const cc_column_view* view);
 
 /* Device pointers of the two per-cell OUTPUT planes of a stream's ring buffer (ground label u8,
  * cluster id u32), indexed [local_column * num_rows + row] — what the label-compare kernels and
@@ -348,6 +353,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *                                  pinned host memory
  *  "small_all"               (1)   ... as ONE launch, k_small_all, on a 64-row engine; the host launches the serial fall-back behind it when asked
  *  "small_direct"            (1)   calls of 9 .. 63 firings are one direct launch of k_small_all; up to 8 firings replay a captured one-node graph
+ *  "mirror_views"            (1)   a small call (k_small_all / the resident kernel) writes the host views of the columns its events name — what it
+ *                                  segmented, what it published, if at most 8 — into pinned memory with its results: cc_engine_read_columns for such
+ *                                  columns needs no kernel, no copy and no synchronisation (cc_engine_view_counters)
  *  "resident"                (0)   1: calls of 1 .. 63 firings on a 1-stream 64-row engine are handed to a RESIDENT kernel (k_resident: one block that
  *                                  stays on a compute unit) through a doorbell in pinned memory — no dispatch per call. Started by the first such
  *                                  call; read-only queries (cc_engine_read_columns, cc_engine_gather_cluster_points, the event drains) run beside
@@ -387,6 +395,9 @@ int cc_engine_batch_counters(cc_engine* e, uint64_t* batch_columns, uint64_t* ba
  * engine's stream right now (it leaves by itself after "resident_idle_ms" without a call, and whenever a call needs the host). The number of
  * calls of a launch that is still running is as of its last exit report (0 until then). Any pointer may be NULL. Never waits. */
 int cc_engine_resident_counters(cc_engine* e, uint64_t* launches, uint64_t* calls, int* running);
+/* cc_engine_read_columns calls served from the views a small call mirrored with its results (option "mirror_views": the columns the call
+ * segmented and published, at most 8; requests that name only such columns and do not ask for number_of_child_points) / by the view kernel. */
+int cc_engine_view_counters(cc_engine* e, uint64_t* served_from_mirror, uint64_t* served_by_kernel);
 
 /* The insertion gate of the pipelined mode (option "lazy_gate"): how many batches had their insertion enqueued before the host had read the
  * previous batch's insertion counters, and how many of those were launched a second time because the previous batch turned out to need the

@@ -127,3 +127,77 @@ def test_latency_of_a_one_firing_call_is_reported(oracle_lib):
         res[mode] = (float(np.percentile(v, 50)), float(np.percentile(v, 99)))
     print("one-firing call, engine only, us p50 / p99: launch per call", res[0], "resident", res[1])
     assert res[1][0] <= res[0][0] * 1.05, res
+
+
+def test_mirrored_views_equal_the_view_kernel(oracle_lib):
+    """A small call mirrors the host views of the columns its events name together with its results (HostMirror::view); cc_engine_read_columns then
+    serves them without a kernel. Every field must equal what k_view produces for the same column at the same moment: two engines, one with the
+    option off, fed the same firings one call at a time (calls of 1, 2, 3 and 7 firings), every column an event names read from both."""
+    stream, cfg, tf = cases.build_case("s64_turn")
+    from continuous_clustering_amd import IDENTITY_TF
+    a = Engine(cfg, 64, 1, 0, IDENTITY_TF if tf is None else tf)
+    b = Engine(cfg, 64, 1, 0, IDENTITY_TF if tf is None else tf)
+    b.set_option("mirror_views", 0)
+    fields = [k for k in capi.COLUMN_FIELDS if k != "number_of_child_points"]  # (the child counts need the view kernel's extra pass)
+    f, i, sizes, checked = 0, 0, [1, 1, 2, 1, 3, 1, 7], 0
+    while f < stream.n_firings:
+        m = min(sizes[i % len(sizes)], stream.n_firings - f)
+        for e in (a, b):
+            assert e.add_firings(stream.xyz[f:f + m], stream.intensity[f:f + m], stream.poses[f:f + m]) == 0, e.last_error()
+        f += m
+        i += 1
+        ea, eb = a.drain_events(), b.drain_events()
+        assert np.array_equal(ea, eb)
+        for ev in ea:
+            if ev["type"] == capi.EV_CLUSTER or ev["b"] < ev["a"]:
+                continue
+            lo, hi = int(ev["a"]), int(ev["b"])
+            for c0 in range(lo, hi + 1, 8):
+                c1 = min(hi, c0 + 7)
+                ca, cb = a.read_columns(c0, c1, fields=fields), b.read_columns(c0, c1, fields=fields)
+                for k in ca:
+                    x, y = ca[k], cb[k]
+                    if x.dtype.kind == "f":
+                        assert np.array_equal(x.view(np.uint32 if x.dtype == np.float32 else np.uint64), y.view(np.uint32 if y.dtype == np.float32 else np.uint64)), (k, c0)
+                    else:
+                        assert np.array_equal(x, y), (k, c0, c1)
+                checked += c1 - c0 + 1
+    assert checked > 2 * stream.n_firings // 2
+    va, vb = a.view_counters(), b.view_counters()
+    assert vb["mirror"] == 0 and va["mirror"] > 0.8 * (va["mirror"] + va["kernel"]), (va, vb)
+    a.close()
+    b.close()
+
+
+def test_read_column_ranges_equals_single_reads(oracle_lib):
+    """cc_engine_read_column_ranges (one launch — or the mirrored views — for up to 8 ranges) returns, range after range, what cc_engine_read_columns
+    returns for each range: after a large call (view kernel) and after a one-firing call (mirror), with and without the child counts."""
+    stream, cfg, tf = cases.build_case("s64_translate")
+    from continuous_clustering_amd import IDENTITY_TF
+    e = Engine(cfg, 64, 1, 0, IDENTITY_TF if tf is None else tf)
+    n = stream.n_firings
+    assert e.add_firings(stream.xyz[:n - 40], stream.intensity[:n - 40], stream.poses[:n - 40]) == 0
+    st = e.state()
+    hi = st["first_unfinished_global_column_index"] - 1
+    lo = max(st["ring_buffer_start_global_column_index"], 0)
+    ranges = [(lo + 3, lo + 3), (lo + 10, lo + 17), (hi - 5, hi), (lo + 40, lo + 41)]
+
+    def check(fields):
+        got = e.read_column_ranges(ranges, fields=fields)
+        off = 0
+        for a, b in ranges:
+            one = e.read_columns(a, b, fields=fields)
+            for k in one:
+                x, y = one[k], got[k][off:off + b - a + 1]
+                assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), (k, a, b)
+            off += b - a + 1
+    check(None)
+    check([k for k in capi.COLUMN_FIELDS if k != "number_of_child_points"])
+    for f in range(n - 40, n):
+        assert e.add_firings(stream.xyz[f:f + 1], stream.intensity[f:f + 1], stream.poses[f:f + 1]) == 0
+        ev = e.drain_events()
+        ranges = [(int(x["a"]), int(x["b"])) for x in ev if x["type"] != capi.EV_CLUSTER and x["b"] >= x["a"]][:8]
+        if ranges:
+            check([k for k in capi.COLUMN_FIELDS if k != "number_of_child_points"])
+    assert e.view_counters()["mirror"] > 0
+    e.close()
