@@ -2118,7 +2118,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     e->state_cache[stream] = st; // (n_events / n_links are not part of what cc_engine_stream_state reports)
     e->state_cached[stream] = 1;
     // the views of the columns this call's events name came with the results (unless the serial fall-backs finished the call, or they were too many)
-    e->small_view_ok = zvh != nullptr && e->h_small_view_hdr[0] == (long long) e->small_seq_expected && e->h_small_view_hdr[1] > 0;
+    // (the header's column list is there with the results; the views themselves follow within microseconds, stamped with the call's number)
+    e->small_view_ok = zvh != nullptr && e->h_small_view_hdr[1] > 0;
     e->small_view_stream = stream;
     return CC_OK;
 }
@@ -2821,7 +2822,12 @@ static int read_ranges(cc_engine* e, int stream, int nr, const int64_t* from, co
     if (e->small_view_ok && stream == e->small_view_stream && !v->number_of_child_points && total <= cck::MV_COLS)
     {
         const long long* hdr = e->h_small_view_hdr;
-        const int nv = (int) hdr[1];
+        // the views are written beside the call's results and stamped when they are complete: normally long before anybody asks
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; __atomic_load_n(&hdr[0], __ATOMIC_ACQUIRE) != (long long) e->small_seq_expected; spins++)
+            if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2))
+                break;
+        const int nv = __atomic_load_n(&hdr[0], __ATOMIC_ACQUIRE) == (long long) e->small_seq_expected ? (int) hdr[1] : 0;
         int slot_of[cck::MV_COLS];
         bool all = nv > 0 && nv <= cck::MV_COLS;
         int k = 0;

@@ -183,10 +183,7 @@ __device__ __forceinline__ unsigned long long mirror_copy(const Geometry& g, con
     if (hm.view_hdr)
     {
         if (lane == 0)
-        {
-            hm.view_hdr[0] = (long long) (seq0 + 1ull);
-            hm.view_hdr[1] = n_view;
-        }
+            hm.view_hdr[1] = n_view; // ([0], the call's number, is stamped by the last view writer once the views are out)
         if (lane < n_view)
             hm.view_hdr[2 + lane] = lane < n_seg ? seg_b + lane : pub_b + (lane - n_seg);
     }
@@ -278,6 +275,7 @@ __device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config
     // stream's first unfinished one (insert2_body closes the batch descriptor with it); assocb_body checks the prediction
     if (threadIdx.x == 0)
         S.s_view_done = 0; // (phase F: view writers that are through; several block barriers lie between here and there)
+    const unsigned long long call_no = hm.d_seq ? (unsigned long long) uniform_i64((long long) hm.d_seq[0]) + 1ull : 0ull; // (read before wavefront 0 moves it on)
     AbPreloaded pre;
     pre.col_begin = st->first_unfinished;
     pre.first_column = st->first_column;
@@ -362,17 +360,13 @@ __device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config
     const int n_seg = uniform_i32(seg_b >= 0 && seg_e > seg_b ? (int) (seg_e - seg_b < 64 ? seg_e - seg_b : 64) : 0);
     const int n_pub = uniform_i32(pub_b >= 0 && pub_e > pub_b ? (int) (pub_e - pub_b < 64 ? pub_e - pub_b : 64) : 0);
     const int n_view = (hm.view_hdr && n_seg + n_pub <= MV_COLS && st->error == 0) ? n_seg + n_pub : -1;
-    // (wavefront 0 names the call as soon as ITS copies and the views are out: it waits for the view writers through an LDS counter, not for the
-    // wavefronts that are still writing cluster ids — a block barrier here put their time, and sixteen system-scope fences, on every call: + 10 us)
+    // Wavefront 0 names the call as soon as ITS copies are out (state, events, and the header that says which views are coming); the view writers
+    // finish a few microseconds later and the LAST of them stamps the header with the call's number: cc_engine_read_columns waits for that stamp
+    // — by then the host has usually not even finished reading the events. (With the views in front of the call's number every call paid for
+    // them: + 5 us; with a block barrier as well for the wavefronts that write cluster ids: + 10 us.)
     const int n_writers = n_view > 0 ? (n_view < 4 ? n_view : 4) : 0;
     if (wave == 0)
-    {
-        const unsigned long long seq0 = mirror_copy(g, P, states, stream, hm, n_view, seg_b, n_seg, pub_b);
-        if (n_writers > 0)
-            while (__hip_atomic_load(&S.s_view_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < n_writers)
-                __builtin_amdgcn_s_sleep(1);
-        mirror_commit(hm, seq0);
-    }
+        mirror_commit(hm, mirror_copy(g, P, states, stream, hm, n_view, seg_b, n_seg, pub_b));
     else
     {
         if (wave <= n_writers)
@@ -381,8 +375,11 @@ __device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config
             for (int j = wave - 1; j < n_view; j += n_writers)
                 view_column(g, pv, st, j < n_seg ? seg_b + j : pub_b + (j - n_seg), j, hm.view);
             __threadfence_system(); // (this wavefront's stores to pinned memory are out before it says so)
+            int last = 0;
             if (lane_id() == 0)
-                __hip_atomic_fetch_add(&S.s_view_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                last = __hip_atomic_fetch_add(&S.s_view_done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == n_writers - 1 ? 1 : 0;
+            if (last)
+                __hip_atomic_store(&hm.view_hdr[0], (long long) call_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         publish_body(g, P, states, stream, slot, wave - 1, AB_WAVES);
     }

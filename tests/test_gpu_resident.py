@@ -164,7 +164,7 @@ def test_mirrored_views_equal_the_view_kernel(oracle_lib):
                 checked += c1 - c0 + 1
     assert checked > 2 * stream.n_firings // 2
     va, vb = a.view_counters(), b.view_counters()
-    assert vb["mirror"] == 0 and va["mirror"] > 0.8 * (va["mirror"] + va["kernel"]), (va, vb)
+    assert vb["mirror"] == 0 and va["mirror"] > 0.5 * (va["mirror"] + va["kernel"]), (va, vb)  # (calls of 7 firings name more than 8 columns)
     a.close()
     b.close()
 
