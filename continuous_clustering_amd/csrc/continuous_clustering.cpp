@@ -299,9 +299,10 @@ void ContinuousClustering::reset(int num_rows)
         check(cc_engine_set_option(engine_, "forget_inclination_table", 1)); // (what reset keeps across calls, cc.cpp:46, must not keep the made-up data's)
         check(cc_engine_record_events(engine_, 1));
     }
-    // Synchronous mode (is_single_threaded, thread_pool.hpp:58-64: addFiring returns when the firing's stages have run — kitti_demo.cpp:280): calls of
-    // a few firings are handed to the engine's RESIDENT kernel through a doorbell in pinned memory instead of a kernel launch each; the column
-    // reads of the mirror run beside it. (The asynchronous mode's worker takes whatever has queued up: graphs of 1 .. 8 firings and larger calls.)
+    // Synchronous mode (is_single_threaded, thread_pool.hpp:58-64: addFiring returns when the firing's stages have run — kitti_demo.cpp:280): on request
+    // (setResidentKernel) calls of a few firings are handed to the engine's RESIDENT kernel through a doorbell in pinned memory instead of a kernel
+    // launch each; the column reads of the mirror run beside it. (The asynchronous mode's worker takes whatever has queued up: graphs of 1 .. 8 firings
+    // and larger calls.)
     (void) cc_engine_set_option(engine_, "resident", (config_.general.is_single_threaded && use_resident_) ? 1 : 0);
     // the graphs of calls of 1 .. 8 firings: built here, not in front of live data — and LAST: cc_engine_reset, cc_engine_record_events and every
     // cc_engine_set_option drop captured graphs (they bake configuration, geometry and plane pointers)
