@@ -930,7 +930,7 @@ __device__ __forceinline__ void table_from_partials(const SP& p, const int R, co
         const int row = k * 64 + lane;
         carry[k] = (fused && row < R) ? p.curtab[row] : 0.f;
     }
-    constexpr int U = 8;
+    constexpr int U = 16; // (a rotation's 35 tiles in three rounds of loads instead of five: the kernel behind the insertion is a chain of round trips)
     for (int t0 = 0; t0 < touched; t0 += U)
     {
         unsigned long long v[U][RPL];
@@ -1034,6 +1034,10 @@ __device__ __forceinline__ void par_fin_body(const Geometry& g, const SP& p, Str
     if (done < upto)
         par_take_back<RPL>(p, R, RC, lc0, p.par_off[done], p.par_off[upto - 1], wave, nwaves, lane);
     const bool whole = done == (int) n && done > 0;
+    // (what par_close_stream will decide, known to every thread: the table does not wait for the state update — the two are chains of memory round
+    // trips of their own, on wavefront 1 and on thread 0; one behind the other they made this kernel 55 us of a 340 us step at 32 streams)
+    const bool fused_pred = left_over != nullptr && whole && fuse && ld_agent(&st->error) == 0;
+    const int off_upto = p.par_off[upto - 1], off_done = done > 0 ? p.par_off[done - 1] : 0;
     __syncthreads(); // (everybody has read the state thread 0 is about to replace)
     if (tid == 0)
     {
@@ -1042,11 +1046,10 @@ __device__ __forceinline__ void par_fin_body(const Geometry& g, const SP& p, Str
         st->dbg[6] += (unsigned long long) done;
         st->dbg[7] += 1;
 #endif
-        *s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0, done > 0 ? (long long) p.par_off[done - 1] : 0);
+        *s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0, (long long) off_done);
     }
-    __syncthreads();
-    if (fuse && wave == 0)
-        table_from_partials<RPL>(p, R, *s_fused != 0, (p.par_off[upto - 1] >> 6) + 1, *s_fused ? ((p.par_off[done - 1] + 63) >> 6) : 0, lane);
+    if (fuse && wave == (nwaves > 1 ? 1 : 0))
+        table_from_partials<RPL>(p, R, fused_pred, (off_upto >> 6) + 1, fused_pred ? ((off_done + 63) >> 6) : 0, lane);
 }
 
 // =====================================================================================================
@@ -1714,7 +1717,9 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
     if (done < upto)
         par_take_back<RPL>(p, R, RC, lc0, (int) s_off[done], (int) s_off[upto - 1], wave, W, lane);
     const bool whole = done == (int) n && done > 0;
-    __shared__ int s_fused;
+    // (the stream's state on thread 0, the table beside it on wavefront 1: two chains of memory round trips that do not wait for each other — what
+    // par_close_stream will decide is known to every thread; every wavefront's table partials reached Planes::tab_acc before the barrier above)
+    const bool fused_pred = left_over != nullptr && whole && fuse && ld_agent(&st->error) == 0;
     if (tid == 0)
     {
         st->clear_done = clear_done;
@@ -1722,12 +1727,12 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
         st->dbg[6] += (unsigned long long) done; // firings taken by this kernel / batches it saw (cc_engine_debug_counters)
         st->dbg[7] += 1;
 #endif
-        s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0,
-                                   done > 0 ? (long long) s_off[done - 1] : 0);
+        (void) par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0,
+                                done > 0 ? (long long) s_off[done - 1] : 0);
     }
-    __syncthreads(); // (also: every wavefront's table partials have reached Planes::tab_acc)
-    if (fuse && wave == 0 && upto > 0)
-        table_from_partials<RPL>(p, R, s_fused != 0, ((int) s_off[upto - 1] >> 6) + 1, s_fused ? (int) ((s_off[done - 1] + 63) >> 6) : 0, lane);
+    if (fuse && wave == 1 && upto > 0)
+        table_from_partials<RPL>(p, R, fused_pred, ((int) s_off[upto - 1] >> 6) + 1, fused_pred ? (int) ((s_off[done - 1] + 63) >> 6) : 0, lane);
+    __syncthreads();
     if (gt.ctr && tid == 0)
         par_gate_out(gt, left_over, (int) gridDim.x); // (the counters this stream contributes to the gate were added by thread 0, above)
 }

@@ -46,6 +46,11 @@ for n in (32, 64):
         out["few%%d" %% n] = thr(s64, cfg64, [1234 + j for j in range(n)], F, 20, 3)["value"]
     if "steady%%d" %% n in legs:
         out["steady%%d" %% n] = thr(s64, cfg64, [1234 + j for j in range(n)], F, 60, 3)["value"]
+for n in (32, 64, 128):
+    if "cluttered%%d" %% n in legs:
+        inputs = bench.gen_inputs(torch, dev, s64, [4321 + j for j in range(n)], F, 33, scene=synth.SceneModel.cluttered(0.1))
+        out["cluttered%%d" %% n] = thr(s64, cfg64, list(range(n)), F, 30, 3, inputs=inputs)["value"]
+        del inputs; torch.cuda.empty_cache()
 if "cluttered" in legs:
     inputs = bench.gen_inputs(torch, dev, s64, [4321 + j for j in range(256)], F, 15, scene=synth.SceneModel.cluttered(0.1))
     r = thr(s64, cfg64, list(range(256)), F, 12, 3, inputs=inputs)
