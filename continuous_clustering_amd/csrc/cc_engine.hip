@@ -1076,6 +1076,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         }
         CC_MARK(sc); // ev4: table + segment (start of the window scan)
         const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
+        bool use_split = false;
         if (small_front)
             ; // (k_small_front has scanned the call's columns)
         // (65 - 128 rows: packed by default. The lock-step form with two rows per lane — scan_packed = 0 — shortens the scan's own launch, 3.0 -> 2.35 ms at
@@ -1083,26 +1084,39 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         // (64 rows, end of round 4: with the insertion's uniform work on the scalar unit the step follows the vector-instruction count, and the packed
         // scan issues 0.65 x those of the lock-step one: + 3 % at 256 streams (same-box, 3 alternations: 16.22 -> 16.72 G points/s), - 1 ... - 2 % at
         // 32 - 128 streams where the GPU has room and the lock-step scan's shorter launch counts)
-        else if (e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192)))
+        else if ([&]() -> bool
+                 {
+                     // the long scans apart? scan_split 1: always (with the packed scan); 2 (default): while they are a large part of the scan's work. The
+                     // visits k_scan2_long makes per column (of 64 rows) say so: vegetation ~150, the 128-row bench scene ~15, the street scene ~4. Where they
+                     // are few the split costs chain time (two more launches whose blocks wait for wave slots, the longest single scan standing alone: street
+                     // scene - 8 % at 256 streams, the 128-row scene - 2 %), on vegetation it is + 60 .. + 70 %. Every 32nd batch is scanned packed and with
+                     // the split, which counts; the batches counted since the last look decide (on above 40 visits per column, off again below 20).
+                     // On vegetation the packed scan with the split also beats the lock-step scan from 48 streams per launch (64 streams + 14 %, 128 + 38 %;
+                     // 32 streams - 4 %), where the street scene wants the lock-step one up to 192.
+                     const bool packed_default = e->scan_packed == 1 || (e->scan_packed < 0 && (rpl > 1 || count > 192));
+                     use_split = false;
+                     if (g.mirror_fields || e->scan_split == 0)
+                         return packed_default;
+                     if (e->scan_split == 1 || !e->h_bail_count || e->capturing)
+                     {
+                         use_split = packed_default && e->scan_split == 1;
+                         return packed_default;
+                     }
+                     const unsigned vis = (unsigned) e->h_bail_count[1], cols = (unsigned) e->h_bail_count[2];
+                     const unsigned dc = cols - e->split_cols_seen, dv = vis - e->split_rec_seen;
+                     if (dc >= 1024u)
+                     {
+                         const double rate = (double) dv / ((double) dc * (double) rpl); // (per column of 64 rows)
+                         e->split_on = e->split_on ? rate > 20.0 : rate > 40.0;
+                         e->split_cols_seen = cols, e->split_rec_seen = vis;
+                     }
+                     const bool probe = (e->split_probe++ & 31u) == 0u;
+                     const bool promote = !packed_default && e->scan_packed < 0 && rpl == 1 && count >= 48; // (launches the lock-step scan would take)
+                     use_split = (e->split_on || probe) && (packed_default || promote);
+                     return packed_default || (promote && use_split);
+                 }())
         {
-            // the long scans apart? 1: always; 2 (default): while they are a large part of the scan's work. The visits k_scan2_long makes per column
-            // (of 64 rows) say so: vegetation ~150, the 128-row bench scene ~15, the street scene ~4. Where they are few the split costs chain time
-            // (two more launches whose blocks wait for wave slots, the longest single scan standing alone: street scene - 8 % at 256 streams, the
-            // 128-row scene - 2 %), on vegetation it is + 60 .. + 70 %. Every 32nd batch is scanned with the split, which counts; the batches
-            // counted since the last look decide (on above 40 visits per column, off again below 20).
-            bool split = !g.mirror_fields && e->scan_split != 0;
-            if (split && e->scan_split == 2 && e->h_bail_count && !e->capturing)
-            {
-                const unsigned vis = (unsigned) e->h_bail_count[1], cols = (unsigned) e->h_bail_count[2];
-                const unsigned dc = cols - e->split_cols_seen, dv = vis - e->split_rec_seen;
-                if (dc >= 1024u)
-                {
-                    const double rate = (double) dv / ((double) dc * (double) rpl); // (per column of 64 rows)
-                    e->split_on = e->split_on ? rate > 20.0 : rate > 40.0;
-                    e->split_cols_seen = cols, e->split_rec_seen = vis;
-                }
-                split = e->split_on || (e->split_probe++ & 31u) == 0u;
-            }
+            const bool split = use_split;
             if (split)
             {
                 // long scans apart (cc_k_scan.h): the packed scan hands points that are still scanning after SCAN_CAP visits to k_scan2_long, which
