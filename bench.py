@@ -353,7 +353,7 @@ def cpu_baseline_report(cfg, sensor, xyz, inten, poses, S, F, args, sweep_sizes=
 # ---------------------------------------------------------------------------------------------------------------------------
 def engine_options(eng):
     for env, opt in (("CC_SUB_BATCH", "sub_batch"), ("CC_TABLE_EARLY", "table_on_insert_chain"), ("CC_PIPELINE", "pipeline"),
-                     ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed"), ("CC_SCAN_SPLIT", "scan_split"), ("CC_SCAN_CAP", "scan_cap"), ("CC_EGO_OFF_CHAIN", "ego_off_chain"), ("CC_FIN_MERGE", "insert_fin_merge"),
+                     ("CC_PUBLISH_OFF_CHAIN", "publish_off_chain"), ("CC_PARALLEL_INSERT", "parallel_insert"), ("CC_SCAN_PACKED", "scan_packed"), ("CC_SCAN_SPLIT", "scan_split"), ("CC_SCAN_CAP", "scan_cap"), ("CC_EGO_OFF_CHAIN", "ego_off_chain"),
                      ("CC_SKIP_FALLBACKS", "skip_idle_fallbacks"), ("CC_ASSOC_ROUNDS", "assoc_rounds"), ("CC_ASSOC_BATCH", "assoc_batch"),
                      ("CC_EGO_EARLY", "ego_on_insert_chain"), ("CC_ASSOC_COOLDOWN", "assoc_cooldown"), ("CC_SWEEP_BLOCKS", "assoc_sweep_blocks"), ("CC_INSERT_WIDE", "insert_wide_max_streams"), ("CC_INSERT_SPLIT", "insert_split_blocks"), ("CC_DEBUG_NO_ASSOC_FALLBACK", "debug_no_assoc_fallback"), ("CC_FUSE_FRONT", "fuse_front"), ("CC_DEFER_TAIL", "defer_tail_max_streams"), ("CC_LAZY_GATE", "lazy_gate"), ("CC_LAZY_GATE_FROM", "lazy_gate_from"), ("CC_INSERT_LDS_PAD", "insert_lds_pad"), ("CC_INSERT_NARROW", "insert_narrow_blocks")):
         if os.environ.get(env) not in (None, ""):

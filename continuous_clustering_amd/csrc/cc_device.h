@@ -109,7 +109,7 @@ struct StreamState
     int64_t error_a;
     int64_t error_b;
     int32_t n_links;     // entries of the link log written in the current call
-    int32_t par_blocks;  // k_insert_par over several blocks: blocks of the stream that are through (the last one finishes the stream and clears it)
+    int32_t pad2;
     int64_t overrun_col; // lowest column found stale by the segmentation (CC_ERR_RING_OVERRUN), INT64_MAX = none
 };
 

@@ -65,8 +65,6 @@ struct cc_engine
     hipStream_t stream6{nullptr}; // k_publish of a pipelined batch: off the association chain, which is the longest of the three
     hipEvent_t ev_pubrdy[4]{};
     hipEvent_t ev_ego[4]{};       // k_ego of the slot's batch on the preparation stream (option "ego_off_chain")
-    bool insert_fin_merge{false}; // option "insert_fin_merge": k_insert_par's last blocks do k_insert_par_fin's and k_gate_out's work (measured, round 6: the
-                                  // agent-scope fences the hand-over between blocks needs write the XCD's whole L2 back — 32 / 64 streams - 22 %, 256 streams - 1 %)
     bool ego_off_chain{false};    // (measured, round 6: 32 streams - 8 % in the 20-step leg and - 12 % steady with it on — the cross-stream event costs more than the kernel's ~10 us on the chain —, 256 streams + 0)
     hipStream_t stream5{nullptr}; // k_prep of the *next* batch: independent of the engine state, so it runs ahead of the insertion chain
     hipEvent_t ev_ins[4]{}, ev_seg[4]{}, ev_assoc[4]{}, ev_segscan[4]{}, ev_prep[4]{};
@@ -777,12 +775,6 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             }
             if (gate && !gate_zeroed)
                 CC_HIP_CHECK(e, hipMemsetAsync(left, 0, 2 * sizeof(int), si));
-            // round 6: the stream's last block of k_insert_par finishes the stream (k_insert_par_fin's work) and the launch's last stream writes what the
-            // host reads at the gate into pinned memory (k_gate_out's work): up to two kernels less on the chain a step waits for
-            const bool in_kernel_gate = gate && e->insert_fin_merge && e->insert_narrow_blocks == 0;
-            const cck::ParGate gt = in_kernel_gate ? cck::ParGate{e->d_par_left + 8 + slot, (const int*) e->d_bail_count, (const int*) e->d_remaining, gate_h_left, e->h_bail_count,
-                                                                  with_remaining ? e->h_remaining : (int*) nullptr, 1}
-                                                   : cck::ParGate{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
             // few streams: the GPU is not full and the insertion chain is what a step waits for -> twice the wavefronts per block, and the firings of a
             // stream dealt to several blocks (k_insert_par_fin then finishes the stream's state)
             if (count <= e->insert_wide_max_streams)
@@ -797,8 +789,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 const int nb = e->insert_split_blocks > 0 ? e->insert_split_blocks
                                                           : (count <= 24 ? 8 : (count <= 32 ? 6 : (count <= 40 ? 4 : (count <= 64 ? 3 : (count <= 96 ? 2 : 1)))));
                 hipLaunchKernelGGL((cck::k_insert_par<1, 2 * cck::IP_WAVES>), dim3(count, nb), dim3(128 * cck::IP_WAVES), insert_lds_pad(e, count * nb, 20 * 1024), si, g, e->cfg, Pt, e->d_states,
-                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left, gt);
-                if (nb > 1 && !in_kernel_gate)
+                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
+                if (nb > 1)
                     hipLaunchKernelGGL(cck::k_insert_par_fin<1>, dim3(count), dim3(256), 0, si, g, Pt, e->d_states, first_stream, d_xyz, (long long) n,
                                        cur_ntotal, cur_f0, slot, left, fuse ? 1 : 0, prev_left);
             }
@@ -813,8 +805,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             }
             else
                 hipLaunchKernelGGL((cck::k_insert_par<1, cck::IP_WAVES>), dim3(count), dim3(64 * cck::IP_WAVES), insert_lds_pad(e, count, 20 * 1024), si, g, e->cfg, Pt, e->d_states,
-                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left, gt);
-            if (gate && !in_kernel_gate)
+                                   first_stream, d_xyz, d_int, d_pose, (long long) n, cur_ntotal, cur_f0, slot, left, ego_in, prev_left);
+            if (gate)
             {
                 // (the counter of k_assocb's stops rides along: as of whatever the association chain has finished by now — it only steers a heuristic;
                 // with the lazy gate also the early-stop counter the held-back chains would have copied)
@@ -1870,11 +1862,8 @@ int add_firings_small(cc_engine* e, int stream, int64_t n, const float* xyz, con
     auto with_views = [&](cck::HostMirror hm) -> cck::HostMirror
     {
         hm.view_hdr = zvh;
-        if (zvh)
-        {
-            hm.view = cck::view_layout(zvb, (size_t) cck::MV_COLS * R);
-            hm.view.nchild = nullptr;
-        }
+        hm.view = zvh ? zvb : nullptr;
+        hm.view_rows = R;
         return hm;
     };
     // option "resident": no launch per call at all — the call is handed to k_resident through a doorbell in pinned memory (cc_k_publish.h)
@@ -3233,8 +3222,6 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_batch = value != 0;
     else if (n == "assoc_rounds")
         e->assoc_rounds = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
-    else if (n == "insert_fin_merge")
-        e->insert_fin_merge = value != 0;
     else if (n == "ego_off_chain")
         e->ego_off_chain = value != 0;
     else if (n == "scan_split")

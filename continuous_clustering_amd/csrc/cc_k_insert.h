@@ -930,7 +930,7 @@ __device__ __forceinline__ void table_from_partials(const SP& p, const int R, co
         const int row = k * 64 + lane;
         carry[k] = (fused && row < R) ? p.curtab[row] : 0.f;
     }
-    constexpr int U = 16; // (a rotation's 35 tiles in three rounds of loads instead of five: the kernel behind the insertion is a chain of round trips)
+    constexpr int U = 8;
     for (int t0 = 0; t0 < touched; t0 += U)
     {
         unsigned long long v[U][RPL];
@@ -971,43 +971,6 @@ __device__ __forceinline__ void table_from_partials(const SP& p, const int R, co
                 p.curtab[row] = carry[k];
         }
     }
-}
-
-// what the host reads behind a batch's insertion (the gate), and where: the last block of the launch writes it into pinned memory itself
-// (round 6: k_gate_out was one more kernel on the chain a step waits for)
-struct ParGate
-{
-    int* ctr;               // device: blocks / streams of this launch that are through (reset by the last one); nullptr: no in-kernel gate
-    const int* bail_count;  // device: [0] stops of k_assocb, [1 .. 2] long-scan statistics
-    const int* remaining;   // device: the early-stop counter
-    int* h_left;            // pinned: left_over[0 .. 1]
-    int* h_bail_count;      // pinned
-    int* h_remaining;       // pinned (nullptr: not wanted)
-    int fin_in_kernel;      // several blocks per stream: the stream's last block does k_insert_par_fin's work
-};
-
-__device__ __forceinline__ void par_gate_out(const ParGate& gt, const int* left_over, const int n_streams)
-{
-    // (one thread per stream calls this, after everything it wrote for the stream)
-    __threadfence();
-    if (atomicAdd(gt.ctr, 1) != n_streams - 1)
-        return;
-    __threadfence();
-    *gt.ctr = 0;
-    if (gt.h_left && left_over)
-    {
-        gt.h_left[0] = __hip_atomic_load(&left_over[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gt.h_left[1] = __hip_atomic_load(&left_over[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (gt.h_bail_count)
-    {
-        gt.h_bail_count[0] = __hip_atomic_load(&gt.bail_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gt.h_bail_count[1] = __hip_atomic_load(&gt.bail_count[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gt.h_bail_count[2] = __hip_atomic_load(&gt.bail_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (gt.h_remaining)
-        *gt.h_remaining = __hip_atomic_load(gt.remaining, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __threadfence_system();
 }
 
 // what one block of k_insert_par does behind its phase D, for launches that dealt a stream's firings to several blocks: take back what lies behind
@@ -1092,7 +1055,7 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
                                                             const float* __restrict__ xyz, const uint8_t* __restrict__ inten,
                                                             const double* __restrict__ poses, long long n, long long n_total, long long fbase,
                                                             int slot, int* __restrict__ left_over, const double* __restrict__ ego,
-                                                            const int* __restrict__ prev_left = nullptr, ParGate gt = ParGate{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0})
+                                                            const int* __restrict__ prev_left = nullptr)
 {
     // prev_left (the engine's lazy gate, cc_engine.hip): the counters the PREVIOUS batch's insertion left behind. The host enqueues this batch's
     // insertion before it has read them; if they say that the previous batch needs the other insertion kernels (or k_table on this chain), this
@@ -1207,33 +1170,6 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
                 atomicAdd(left_over + 1, 1); // ... and k_table / k_seg_pre its segmentation
             }
             st->par_upto = -1;
-        }
-        if (gt.ctr)
-        {
-            // (the in-kernel gate: this stream is through as far as this kernel goes)
-            __shared__ int s_last0;
-            bool last = nby == 1;
-            if (nby > 1)
-            {
-                __threadfence();
-                __syncthreads();
-                if (tid == 0)
-                    s_last0 = atomicAdd(&st->par_blocks, 1) == nby - 1 ? 1 : 0;
-                __syncthreads();
-                last = s_last0 != 0;
-                if (last)
-                {
-                    __threadfence();
-                    if (tid == 0)
-                    {
-                        st->par_blocks = 0;
-                        if (gt.fin_in_kernel && st->par_clear_done >= 0)
-                            st->clear_done = st->par_clear_done; // (par_fin_body for a stream that is not steady)
-                    }
-                }
-            }
-            if (last && tid == 0)
-                par_gate_out(gt, left_over, (int) gridDim.x);
         }
         return;
     }
@@ -1691,35 +1627,13 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
                 }
             }
         }
-        if (gt.ctr && gt.fin_in_kernel)
-        {
-            // round 6: the stream's LAST block through does k_insert_par_fin's work itself (one kernel less on the chain a step waits for, and the
-            // streams that are through early finish beside the others' insertion), and the launch's last stream writes the host's gate
-            __shared__ int s_last1, s_fused1;
-            __threadfence(); // (release: this thread's cells, offsets, table partials)
-            __syncthreads();
-            if (tid == 0)
-                s_last1 = atomicAdd(&st->par_blocks, 1) == nby - 1 ? 1 : 0;
-            __syncthreads();
-            if (!s_last1)
-                return;
-            __threadfence(); // (acquire: what the stream's other blocks left — par_upto, par_bad, par_clear_done, par_off, the partials)
-            if (tid == 0)
-                st->par_blocks = 0;
-            par_fin_body<RPL>(g, p, st, n, slot, left_over, fuse ? 1 : 0, W, &s_fused1);
-            __syncthreads();
-            if (tid == 0)
-                par_gate_out(gt, left_over, (int) gridDim.x);
-        }
         return;
     }
     const int done = s_bad < upto ? s_bad : upto;
     if (done < upto)
         par_take_back<RPL>(p, R, RC, lc0, (int) s_off[done], (int) s_off[upto - 1], wave, W, lane);
     const bool whole = done == (int) n && done > 0;
-    // (the stream's state on thread 0, the table beside it on wavefront 1: two chains of memory round trips that do not wait for each other — what
-    // par_close_stream will decide is known to every thread; every wavefront's table partials reached Planes::tab_acc before the barrier above)
-    const bool fused_pred = left_over != nullptr && whole && fuse && ld_agent(&st->error) == 0;
+    __shared__ int s_fused;
     if (tid == 0)
     {
         st->clear_done = clear_done;
@@ -1727,18 +1641,18 @@ __global__ __launch_bounds__(64 * W, CC_IP_MIN_WAVES_PER_SIMD) void k_insert_par
         st->dbg[6] += (unsigned long long) done; // firings taken by this kernel / batches it saw (cc_engine_debug_counters)
         st->dbg[7] += 1;
 #endif
-        (void) par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0,
-                                done > 0 ? (long long) s_off[done - 1] : 0);
+        s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0,
+                                   done > 0 ? (long long) s_off[done - 1] : 0);
     }
-    if (fuse && wave == 1 && upto > 0)
-        table_from_partials<RPL>(p, R, fused_pred, ((int) s_off[upto - 1] >> 6) + 1, fused_pred ? (int) ((s_off[done - 1] + 63) >> 6) : 0, lane);
-    __syncthreads();
-    if (gt.ctr && tid == 0)
-        par_gate_out(gt, left_over, (int) gridDim.x); // (the counters this stream contributes to the gate were added by thread 0, above)
+    __syncthreads(); // (also: every wavefront's table partials have reached Planes::tab_acc)
+    if (fuse && wave == 0 && upto > 0)
+        table_from_partials<RPL>(p, R, s_fused != 0, ((int) s_off[upto - 1] >> 6) + 1, s_fused ? (int) ((s_off[done - 1] + 63) >> 6) : 0, lane);
 }
 
-// k_insert_par_fin — par_fin_body as a kernel of its own (option "insert_fin_merge" = 0; by default the stream's last block of k_insert_par does
-// it). grid = streams, block = 256.
+// k_insert_par_fin — par_fin_body as a kernel: a kernel boundary is what makes the blocks' writes visible to it for free. (Round 6 also built the
+// other way — the stream's last block through doing this work, the launch's last stream writing the host's gate counters: exact, but the agent-scope
+// fences the hand-over needs write the XCD's whole L2 back, - 22 % at 32 streams, and the gate's arguments doubled the kernel's scalar-register
+// spills; taken out again.) grid = streams, block = 256.
 template<int RPL>
 __global__ __launch_bounds__(256) void k_insert_par_fin(Geometry g, Planes P, StreamState* states, int first_stream, const float* __restrict__ xyz,
                                                         long long n, long long n_total, long long fbase, int slot, int* __restrict__ left_over, int fuse_on,

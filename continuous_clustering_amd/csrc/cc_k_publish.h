@@ -132,7 +132,8 @@ struct HostMirror
     // read per addFiring) needs no second kernel and no copy per call. view_hdr (pinned): [0] the call's number, [1] columns (-1: not mirrored),
     // [2 ..] their global indices; `view`: planes of MV_COLS * rows cells in pinned memory (view_layout). nullptr: not wanted.
     long long* view_hdr;
-    ViewOut view;
+    char* view; // (one pointer: the planes' places follow from it — twenty-two pointers as kernel arguments cost the small-call kernels 140 scalar spills)
+    int view_rows;
 };
 
 // cluster ids of the columns the batch published (cc.cpp:1035-1092: what publishing leaves in Point::id), columns by .. ny .. strided
@@ -372,8 +373,10 @@ __device__ __forceinline__ int small_all_body(const Geometry& g, const cc_config
         if (wave <= n_writers)
         {
             const SP pv = stream_ptrs(P, g, stream);
+            ViewOut vo = view_layout(hm.view, (size_t) MV_COLS * (size_t) hm.view_rows);
+            vo.nchild = nullptr;
             for (int j = wave - 1; j < n_view; j += n_writers)
-                view_column(g, pv, st, j < n_seg ? seg_b + j : pub_b + (j - n_seg), j, hm.view);
+                view_column(g, pv, st, j < n_seg ? seg_b + j : pub_b + (j - n_seg), j, vo);
             __threadfence_system(); // (this wavefront's stores to pinned memory are out before it says so)
             int last = 0;
             if (lane_id() == 0)

@@ -320,9 +320,6 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  "insert_wide_max_streams" (160) launches of at most that many streams run k_insert_par with 16 wavefronts per block ...
  *  "insert_split_blocks"     (0)   ... and deal a stream's firings to that many blocks; 0: 8 up to 24 streams, 6 up to 32, 4 up to 40, 3 up to 64,
  *                                  2 up to 96, else 1
- *  "insert_fin_merge"        (0)   experiment: the last block of k_insert_par that is through for a stream finishes the stream (k_insert_par_fin's work)
- *                                  and the launch's last stream writes the gate's counters into pinned memory (k_gate_out's work). Exact, but the
- *                                  agent-scope fences of the hand-over write the whole L2 back: - 22 % at 32 / 64 streams
  *  "insert_narrow_blocks"    (0)   experiment: that many 4-wavefront blocks per stream above insert_wide_max_streams
  *  "insert_lds_pad"          (0)   experiment: KB of unused dynamic LDS that keep a second insertion block off a compute unit
  *  -- segmentation, window scan ------------------------------------------------------------------------------------------------------------------
