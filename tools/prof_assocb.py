@@ -10,7 +10,8 @@ import bench
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 sensor = synth.SensorModel.s64(); cfg = capi.Config.kitti()
 F, NB = 2200, int(os.environ.get("AB_NB", "4"))
-xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [1234 + k for k in range(S)], F, NB)
+scene = synth.SceneModel.cluttered(0.1) if os.environ.get("AB_SCENE") == "cluttered" else None  # (AB_SCENE=cluttered: the bench's vegetation streams)
+xyz, inten, poses = bench.gen_inputs(torch, torch.device("cuda", 0), sensor, [(4321 if scene else 1234) + k for k in range(S)], F, NB, scene=scene)
 torch.cuda.synchronize()
 for pipe in (0,):
     e = Engine(cfg, 64, S); e.record_events(False); e.set_option("pipeline", pipe); e.enable_timing(True)
