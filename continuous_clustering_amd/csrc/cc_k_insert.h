@@ -973,6 +973,92 @@ __device__ __forceinline__ void table_from_partials(const SP& p, const int R, co
     }
 }
 
+// The same over the wavefronts of a block (k_insert_par_fin: the kernel behind the block-parallel insertion is on the chain a step of few streams
+// waits for, and one wavefront walking a rotation's 35 tiles eight loads at a time was 23 of its ~55 us — tools/fin_probe.py): wavefront w takes
+// the tiles [w C, (w + 1) C), finds the last valid entry of its chunk per row, the chunks' carries meet in LDS, every wavefront then writes its
+// tiles with the carry that enters its chunk. Same values in the same places as table_from_partials. Every thread of the block calls it.
+constexpr int TP_MAXC = 12; // tiles per wavefront this form takes (more: the serial form)
+template<int RPL>
+__device__ __forceinline__ void table_from_partials_waves(const SP& p, const int R, const bool fused, const int touched, const int ntiles, const int lane,
+                                                          const int wave, const int nwaves)
+{
+    __shared__ float s_last[4][RPL * 64];
+    __shared__ unsigned char s_has[4][RPL * 64];
+    const int C = (touched + nwaves - 1) / nwaves;
+    if (nwaves > 4 || C > TP_MAXC) // (wave-uniform: the arguments are)
+    {
+        if (wave == (nwaves > 1 ? 1 : 0))
+            table_from_partials<RPL>(p, R, fused, touched, ntiles, lane);
+        return;
+    }
+    const int t_lo = wave * C, t_hi = (t_lo + C < touched) ? t_lo + C : touched;
+    float carry[RPL];
+    unsigned long long v[TP_MAXC][RPL];
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        const int row = k * 64 + lane;
+        carry[k] = (fused && row < R) ? p.curtab[row] : 0.f; // (read by every wavefront in front of the barrier; rewritten behind it)
+    }
+#pragma unroll
+    for (int u = 0; u < TP_MAXC; u++)
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            v[u][k] = (row < R && t_lo + u < t_hi) ? p.tab_acc[(size_t) (t_lo + u) * R + row] : 0ull;
+        }
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+    {
+        float last = 0.f;
+        unsigned char has = 0;
+#pragma unroll
+        for (int u = 0; u < TP_MAXC; u++)
+            if (fused && t_lo + u < t_hi && t_lo + u < ntiles && (v[u][k] >> 32))
+            {
+                last = __uint_as_float((unsigned) v[u][k]);
+                has = 1;
+            }
+        s_last[wave][k * 64 + lane] = last;
+        s_has[wave][k * 64 + lane] = has;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RPL; k++)
+        for (int w = 0; w < wave; w++)
+            if (s_has[w][k * 64 + lane])
+                carry[k] = s_last[w][k * 64 + lane];
+#pragma unroll
+    for (int u = 0; u < TP_MAXC; u++)
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row < R && t_lo + u < t_hi)
+            {
+                if (v[u][k])
+                    p.tab_acc[(size_t) (t_lo + u) * R + row] = 0ull;
+                if (fused && t_lo + u < ntiles)
+                {
+                    p.tabc[(size_t) (t_lo + u) * R + row] = carry[k];
+                    if (v[u][k] >> 32)
+                        carry[k] = __uint_as_float((unsigned) v[u][k]);
+                }
+            }
+        }
+    if (fused && wave == nwaves - 1) // (the last chunk's carry-out is the table behind the batch; empty chunks pass their carry-in through)
+    {
+#pragma unroll
+        for (int k = 0; k < RPL; k++)
+        {
+            const int row = k * 64 + lane;
+            if (row < R)
+                p.curtab[row] = carry[k];
+        }
+    }
+}
+
 // what one block of k_insert_par does behind its phase D, for launches that dealt a stream's firings to several blocks: take back what lies behind
 // the first offending firing, then the stream state, the batch descriptor and (fused segmentation) the table. NW wavefronts, every thread of them.
 template<int RPL>
@@ -981,6 +1067,10 @@ __device__ __forceinline__ void par_fin_body(const Geometry& g, const SP& p, Str
 {
     const int lane = lane_id(), wave = uniform_i32((int) (threadIdx.x >> 6)), tid = threadIdx.x;
     const int R = g.num_rows, RC = g.ring_cols;
+#ifdef CC_FIN_STATS
+    // phase clocks (tools/fin_probe.py): entry | state read, barrier | thread 0: the stream's state | wavefront 1: the table
+    const unsigned long long fin_t0 = __builtin_amdgcn_s_memtime();
+#endif
     const int upto = st->par_upto;
     if (upto <= 0)
     {
@@ -1002,6 +1092,9 @@ __device__ __forceinline__ void par_fin_body(const Geometry& g, const SP& p, Str
     const bool fused_pred = left_over != nullptr && whole && fuse && ld_agent(&st->error) == 0;
     const int off_upto = p.par_off[upto - 1], off_done = done > 0 ? p.par_off[done - 1] : 0;
     __syncthreads(); // (everybody has read the state thread 0 is about to replace)
+#ifdef CC_FIN_STATS
+    const unsigned long long fin_t1 = __builtin_amdgcn_s_memtime();
+#endif
     if (tid == 0)
     {
         st->clear_done = st->par_clear_done;
@@ -1010,9 +1103,23 @@ __device__ __forceinline__ void par_fin_body(const Geometry& g, const SP& p, Str
         st->dbg[7] += 1;
 #endif
         *s_fused = par_close_stream(st, slot, left_over, fuse, whole, done, n, prev_rear0, first_unf0, ring_end0, seq0, (long long) off_done);
+#ifdef CC_FIN_STATS
+        __builtin_amdgcn_s_waitcnt(0);
+        const unsigned long long fin_t2 = __builtin_amdgcn_s_memtime();
+        st->dbg[8] += fin_t1 - fin_t0;
+        st->dbg[9] += fin_t2 - fin_t1;
+        st->dbg[12] += 1;
+#endif
     }
-    if (fuse && wave == (nwaves > 1 ? 1 : 0))
-        table_from_partials<RPL>(p, R, fused_pred, (off_upto >> 6) + 1, fused_pred ? ((off_done + 63) >> 6) : 0, lane);
+    if (fuse) // (every thread: the wavefronts share the tiles)
+    {
+        table_from_partials_waves<RPL>(p, R, fused_pred, (off_upto >> 6) + 1, fused_pred ? ((off_done + 63) >> 6) : 0, lane, wave, nwaves);
+#ifdef CC_FIN_STATS
+        __builtin_amdgcn_s_waitcnt(0);
+        if (tid == 64)
+            st->dbg[10] += __builtin_amdgcn_s_memtime() - fin_t1;
+#endif
+    }
 }
 
 // =====================================================================================================
