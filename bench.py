@@ -404,7 +404,11 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
     if rc != 0:
         raise SystemExit(f"engine error {rc}: {eng.last_error()}")
     before = eng.totals()
-    eng.enable_timing(True)
+    # per-kernel HIP events inside the timed region: on every 4th batch (three event records in a row on the association stream cost 15 - 25 us of
+    # that chain per batch — 3.5 - 5 % of a step at 32 - 64 streams, 1 % at 256, profiles/r06_ab_timing.txt); the engine scales the sampled sums to
+    # all batches. CC_BENCH_TIMING_EVERY=1 brackets every batch as the earlier rounds did, CC_BENCH_TIMING=0 none (tools/ab_legs.py experiments).
+    eng.set_option("timing_every", int(os.environ.get("CC_BENCH_TIMING_EVERY", "4")))
+    eng.enable_timing(os.environ.get("CC_BENCH_TIMING", "1") != "0")
 
     ctx.device_sync()
     ctx.barrier()
@@ -485,7 +489,7 @@ def run_throughput(ctx, sensor, cfg, seeds, F, steps, warmup, n_verify, inputs=N
         dom = max(KERNEL_OF, key=lambda k: per_kernel.get(k, 0.0))
     rocprof_ms = committed.get(dom)
     cells_per_launch = float(S * F * R) / launches_per_step
-    achieved = cells_per_launch * alg_bytes_per_cell / (per_kernel[dom] / launches_per_step * 1e-3) / 1e9
+    achieved = cells_per_launch * alg_bytes_per_cell / (max(per_kernel[dom], 1e-9) / launches_per_step * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json" if R == 64 else "traffic_s128.json")
     if os.path.exists(tpath):

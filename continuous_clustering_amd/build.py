@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "libcc_hip.so")
 SOURCES = ["cc_engine.hip", "cc_eval.hip", "cc_kitti.hip", "cc_gt_labels.hip"]
 DEPS = ["cc_engine.hip", "cc_eval.hip", "cc_kitti.hip", "cc_gt_labels.hip", os.path.join("..", "..", "include", "cc_kitti.h"), "cc_assoc_shared.h", "cc_assoc3.h", "cc_assocb.h", "cc_kernels.h", "cc_k_base.h", "cc_k_segcells.h", "cc_k_insert.h", "cc_k_segment.h", "cc_k_assoc_global.h", "cc_k_scan.h", "cc_k_assoc_lds.h", "cc_k_publish.h", "cc_device.h", "cc_math.h", os.path.join("..", "..", "include", "cc_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wall",
-               "-Wno-unused-variable", "-ldl"]
+               "-Wno-unused-variable", "-Wno-bitwise-instead-of-logical", "-ldl"]
 
 
 def hipcc() -> str:

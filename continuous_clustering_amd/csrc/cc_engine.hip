@@ -221,6 +221,10 @@ struct cc_engine
     bool batch_open{false};
     // optional per-kernel timing with HIP events on the engine's stream (bench.py roofline leg)
     bool timing{false};
+    int timing_every{1};       // option "timing_every": with timing on, the ten events bracket every n-th pass only (three event records in a row on the
+                               // association stream are 15 - 25 us of its chain: 3.5 - 5 % of a step at 32 - 64 streams, 1 % at 256)
+    uint64_t timing_pass{0};   // passes seen while timing was on (sampled or not)
+    double prep_ahead_ms{0};   // k_prep launches that ran ahead of their pass (own event pairs, never sampled)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used{0};
     double kernel_ms[7]{0, 0, 0, 0, 0, 0, 0}; // prep, insert+table, segment, scan, assoc_lds, assoc_global, publish
@@ -695,7 +699,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     dim3 seg_grid((unsigned) count, (unsigned) ((max_cols + 63) / 64));
     constexpr int NEV = 10;
     hipEvent_t ev[NEV] = {};
+    const bool mark = e->timing && (e->timing_every <= 1 || e->timing_pass % (uint64_t) e->timing_every == 0);
     if (e->timing)
+        e->timing_pass++;
+    if (mark)
     {
         int rct = take_timing_events(e, ev);
         if (rct)
@@ -703,7 +710,7 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
     }
     int k = 0;
 #define CC_MARK(st_) \
-    if (e->timing)   \
+    if (mark)        \
         CC_HIP_CHECK(e, hipEventRecord(ev[k++], st_));
     // ---- insertion chain -----------------------------------------------------------------------------------------
     // The head of the batch that has the single-column firing shape is inserted by all wavefronts of a block at once, straight from
@@ -1388,7 +1395,7 @@ int resolve_timing(cc_engine* e)
     {
         float ms = 0.f;
         CC_HIP_CHECK(e, hipEventElapsedTime(&ms, e->pev_pool[i], e->pev_pool[i + 1]));
-        e->kernel_ms[0] += ms;
+        e->prep_ahead_ms += ms;
     }
     e->pev_used = 0;
     e->ev_used = 0;
@@ -3150,6 +3157,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->debug_no_assoc_fallback = value != 0;
     else if (n == "publish_off_chain")
         e->publish_off_chain = value != 0;
+    else if (n == "timing_every")
+        e->timing_every = value < 1 ? 1 : (int) value;
     else if (n == "parallel_insert")
     {
         e->parallel_insert = value != 0;
@@ -3261,6 +3270,8 @@ int cc_engine_enable_timing(cc_engine* e, int enable)
     for (double& v : e->kernel_ms)
         v = 0;
     e->kernel_launches = 0;
+    e->timing_pass = 0;
+    e->prep_ahead_ms = 0;
     return CC_OK;
 }
 
@@ -3272,10 +3283,13 @@ int cc_engine_kernel_times(cc_engine* e, double ms[7], uint64_t* launches)
     int rc = finish_batch(e);
     if (rc)
         return rc;
+    // timing_every > 1: the sums of the sampled passes, scaled to all passes (average duration per launch x launches)
+    const bool sampled = e->timing_every > 1 && e->kernel_launches > 0 && e->timing_pass > e->kernel_launches;
+    const double scale = sampled ? (double) e->timing_pass / (double) e->kernel_launches : 1.0;
     for (int k = 0; k < 7; k++)
-        ms[k] = e->kernel_ms[k];
+        ms[k] = e->kernel_ms[k] * scale + (k == 0 ? e->prep_ahead_ms : 0.0);
     if (launches)
-        *launches = e->kernel_launches;
+        *launches = sampled ? e->timing_pass : e->kernel_launches;
     return CC_OK;
 }
 

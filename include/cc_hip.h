@@ -366,14 +366,17 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *  -- debugging --------------------------------------------------------------------------------------------------------------------------------------
  *  "debug_flags"             (0)   experiment switches
  *  "debug_no_assoc_fallback" (0)   1: do not launch the serial kernels behind k_assocb (tools only: shows what k_assocb alone covers)
+ *  "timing_every"            (1)   with cc_engine_enable_timing on: the ten HIP events bracket every n-th batch only; cc_engine_kernel_times returns
+ *                                  the sampled sums scaled to all batches (average launch duration x launches). The events cost 15 - 25 us of the
+ *                                  association chain per batch: 3.5 - 5 % of a step at 32 - 64 streams, 1 % at 256 (profiles/r06_ab_timing.txt)
  *  "check_input_lifetime"    (0)   1: checksum the inputs of every cc_engine_add_firings_device call at submission and again at release
  *                                  (cc_engine_inputs_released, cc_engine_sync ...): a caller that re-used a buffer too early gets
  *                                  CC_ERR_INVALID_ARGUMENT naming the call instead of a silent race; 2: released buffers are also filled with 0xFF */
 int cc_engine_set_option(cc_engine* e, const char* name, int64_t value);
 
-/* Per-kernel timing with HIP events recorded on the engine's stream around the three kernels of every
- * batch (prep, insert+table, segment, scan, assoc_lds, assoc_global, publish). enable resets the accumulators;
- * cc_engine_kernel_times returns the accumulated milliseconds and the number of batches measured. */
+/* Per-kernel timing with HIP events recorded on the engine's streams around the kernels of every batch (or every n-th: option
+ * "timing_every"): prep, insert+table, segment, scan, assoc_lds, assoc_global, publish. enable resets the accumulators;
+ * cc_engine_kernel_times returns the accumulated milliseconds and the number of batches they stand for. */
 int cc_engine_enable_timing(cc_engine* e, int enable);
 int cc_engine_kernel_times(cc_engine* e, double ms[7], uint64_t* launches);
 /* Sums over all streams (any pointer may be NULL). Implies sync. */

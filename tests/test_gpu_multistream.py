@@ -63,6 +63,43 @@ def test_multi_stream_device_path_equals_per_stream_oracle(oracle_lib):
             assert so[k] == se[k], (s, k)
 
 
+def test_kernel_times_sampled_every_nth_batch_stand_for_all_batches():
+    """option "timing_every": the HIP events of every 4th batch, scaled by the engine to all batches, tell the same story as events around
+    every batch (same number of batches, per-kernel sums within a factor of two on a quiet 8-stream engine) and change no result."""
+    import torch
+    from continuous_clustering_amd import Engine
+    sen = synth.SensorModel(num_rows=64, num_columns=720)
+    cfg = capi.Config.kitti()
+    cfg.num_columns = 720
+    S, F, NB = 8, 360, 13
+    streams = [synth.make_stream(F * NB, seed=300 + s, sensor=sen, motion=synth.Motion.translate()) for s in range(S)]
+    xyz, inten, poses = _device_batches(torch, streams, NB, F)
+    got = {}
+    for every in (1, 4):
+        e = Engine(cfg, 64, S)
+        e.record_events(False)
+        e.set_option("timing_every", every)
+        e.add_firings_device(F, xyz[0], inten[0], poses[0])
+        assert e.sync() == 0, e.last_error()
+        e.enable_timing(True)
+        for b in range(1, NB):
+            e.add_firings_device(F, xyz[b], inten[b], poses[b])
+        assert e.sync() == 0, e.last_error()
+        kt = e.kernel_times()
+        e.enable_timing(False)
+        got[every] = (kt, e.totals(), [e.state(s) for s in range(S)])
+        e.close()
+    k1, k4 = got[1][0], got[4][0]
+    assert k1["batches"] == k4["batches"] == NB - 1
+    for name in ("prep_ms", "segment_ms", "scan_ms", "assoc_lds_ms", "publish_ms"):
+        assert k1[name] > 0 and k4[name] > 0, name
+        assert 0.5 < k4[name] / k1[name] < 2.0, (name, k1[name], k4[name])
+    assert got[1][1] == got[4][1]
+    for a, b in zip(got[1][2], got[4][2]):
+        for k in util.STATE_FIELDS:
+            assert a[k] == b[k], k
+
+
 def test_full_size_properties_256_streams():
     """BASELINE.json configs[2] shape: 256 concurrent 64 x 2200 streams. Properties: every stream publishes, totals add
     up, replicated inputs give identical per-stream results (determinism across wavefronts), output planes carry only
