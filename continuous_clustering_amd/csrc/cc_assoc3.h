@@ -202,6 +202,7 @@ __device__ __forceinline__ void assoc3_stream(const Geometry& g, const cc_config
         double nx_fin[RPL];
         auto load_a = [&](long long gcx, int lcx)
         {
+            const CazBase cbx = caz_base_of_column(gcx, g.num_columns);
 #pragma unroll
             for (int k = 0; k < RPL; k++)
             {
@@ -214,7 +215,7 @@ __device__ __forceinline__ void assoc3_stream(const Geometry& g, const cc_config
                 if (row < R && gcx < col_end)
                 {
                     nx_par[k] = p.sc_parent[lcx * R + row];
-                    nx_fin[k] = p.sc_fin[lcx * R + row];
+                    nx_fin[k] = cell_fin(cfg, p, lcx * R + row, cbx);
                     nx_term[k] = p.sc_term[lcx * R + row];
                     if (!lwave)
                     {

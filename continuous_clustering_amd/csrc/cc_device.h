@@ -185,7 +185,8 @@ struct Planes
     uint16_t* col_act;   // per column: active points (cells the window scan ran for) of rows 0 - 63 | of rows 64 - 127 << 8 (k_assocb packs them into lanes)
     uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS
     unsigned long long* sc_links; // LINK_SLOTS x 16-bit candidate codes packed into one word per cell
-    double* sc_fin;      // continuous azimuth + max angle diff of the point (its contribution to finished_at)
+    // (a point's contribution to finished_at — continuous azimuth + max angle diff — is not stored per cell: the serial kernels recompute it,
+    // cc_k_base.h: cell_fin; the batch-parallel kernel gets it packed, pk_fin)
     uint16_t* sc_visits; // Point::number_of_visited_neighbors (cc.cpp:725), only with Geometry::mirror_fields
     int2* link_log;      // [stream][link_capacity] (root cell, root cell) of every tree link made in the current call (cc.cpp:693-694), only
                          // with Geometry::mirror_fields: the host rebuilds Point::associated_trees from it

@@ -372,7 +372,7 @@ int allocate(cc_engine* e)
     A(t_fin, C) A(t_width, C) A(t_pts, C) A(t_uf, C) A(t_cid, C) A(t_pos, C) A(t_finished, C);
     A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
     A(events, S * (size_t) g.event_capacity);
-    A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
+    A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C);
     A(sc_term, C) A(col_newfin, L) A(col_info, L) A(col_act, L) A(pk_meta, C) A(pk_fin, C) A(pk_lk, C);
     A(sg_x2, C) A(sg_uz, C) A(sg_w, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
@@ -1125,13 +1125,13 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 {
                     hipLaunchKernelGGL((cck::k_scan2<1, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
                     hipLaunchKernelGGL(cck::k_scan2_long<1>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
-                    hipLaunchKernelGGL(cck::k_scan2_epi<1>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot, e->d_bail_count);
+                    hipLaunchKernelGGL(cck::k_scan2_epi<1>, epi_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
                 else
                 {
                     hipLaunchKernelGGL((cck::k_scan2<2, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
                     hipLaunchKernelGGL(cck::k_scan2_long<2>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
-                    hipLaunchKernelGGL(cck::k_scan2_epi<2>, epi_grid, dim3(64), 0, sc, g, e->P, e->d_states, first_stream, slot, e->d_bail_count);
+                    hipLaunchKernelGGL(cck::k_scan2_epi<2>, epi_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
             }
             else if (rpl == 1 && !g.mirror_fields)

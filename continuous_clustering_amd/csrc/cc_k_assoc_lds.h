@@ -348,6 +348,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
     double nx_minaz = 0.;
     auto load_column = [&](long long gcx, int lcx)
     {
+        const CazBase cbx = caz_base_of_column(gcx, g.num_columns);
 #pragma unroll
         for (int k = 0; k < RPL; k++)
         {
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 const int ci = lcx * R + row;
                 nx_parent[k] = p.sc_parent[ci];
                 nx_nl[k] = p.sc_nlinks[ci];
-                nx_fin[k] = p.sc_fin[ci];
+                nx_fin[k] = cell_fin(cfg, p, ci, cbx);
                 nx_link[k] = p.sc_links[ci];
             }
         }

@@ -159,7 +159,6 @@ __device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cf
             {
                 p.sc_parent[ci] = (int16_t) parent[0];
                 p.sc_nlinks[ci] = (uint8_t) nlinks[0];
-                p.sc_fin[ci] = fin[0];
                 if (nlinks[0] > 0)
                     p.sc_links[ci] = packed[0];
                 if (MIRROR)
@@ -292,7 +291,6 @@ __device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cf
                     const int ci = lc * R + row;
                     p.sc_parent[ci] = (int16_t) parent[k];
                     p.sc_nlinks[ci] = (uint8_t) nlinks[k];
-                    p.sc_fin[ci] = fin[k];
                     if (nlinks[k] > 0)
                         p.sc_links[ci] = packed[k];
                     if (MIRROR)
@@ -718,7 +716,6 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
                 if (row < R)
                 {
                     const int ci = lc * R + row;
-                    p.sc_fin[ci] = fin[k];
                     if (!(later && parent[k] == -3)) // (a waiting point's parent and links are written by k_scan2_long)
                     {
                         p.sc_parent[ci] = (int16_t) parent[k];
@@ -833,7 +830,7 @@ __global__ __launch_bounds__(64) void k_scan2_long(Geometry g, cc_config cfg, Pl
 // k_scan2_epi — the column epilogue of the columns that waited for k_scan2_long: their per-cell scan results are complete in the planes now.
 // The last block through clears the stream's long-scan counters for the next batch. grid = (streams, SCAN_EPI_BLOCKS), block = 64.
 template<int RPL>
-__global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, Planes P, StreamState* states, int first_stream, int slot, int* __restrict__ stat)
+__global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, cc_config cfg, Planes P, StreamState* states, int first_stream, int slot, int* __restrict__ stat)
 {
     const int s = first_stream + blockIdx.x;
     int* const sl_ctl = P.sl_ctl + (size_t) s * 4;
@@ -855,6 +852,7 @@ __global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, Planes P, StreamSt
     for (int i = blockIdx.y; i < nd; i += gridDim.y)
     {
         const int lc = p.sl_cols[i];
+        const CazBase cb = caz_base_of_column(p.colg[lc], g.num_columns);
         int parent[RPL], nlinks[RPL];
         double fin[RPL];
         unsigned long long packed[RPL];
@@ -868,7 +866,7 @@ __global__ __launch_bounds__(64) void k_scan2_epi(Geometry g, Planes P, StreamSt
                 const int ci = lc * R + row;
                 parent[k] = p.sc_parent[ci];
                 nlinks[k] = p.sc_nlinks[ci];
-                fin[k] = p.sc_fin[ci];
+                fin[k] = cell_fin(cfg, p, ci, cb);
                 if (nlinks[k] > 0)
                     packed[k] = p.sc_links[ci];
             }
