@@ -215,7 +215,7 @@ __device__ __forceinline__ void assoc3_stream(const Geometry& g, const cc_config
                 if (row < R && gcx < col_end)
                 {
                     nx_par[k] = p.sc_parent[lcx * R + row];
-                    nx_fin[k] = cell_fin(cfg, p, lcx * R + row, cbx);
+                    nx_fin[k] = cell_fin_of(g, cfg, p, lcx * R + row, cbx);
                     nx_term[k] = p.sc_term[lcx * R + row];
                     if (!lwave)
                     {

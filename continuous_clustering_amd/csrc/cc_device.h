@@ -185,8 +185,9 @@ struct Planes
     uint16_t* col_act;   // per column: active points (cells the window scan ran for) of rows 0 - 63 | of rows 64 - 127 << 8 (k_assocb packs them into lanes)
     uint8_t* sc_nlinks;  // accepted candidates after the first one, 255 = more than LINK_SLOTS
     unsigned long long* sc_links; // LINK_SLOTS x 16-bit candidate codes packed into one word per cell
-    // (a point's contribution to finished_at — continuous azimuth + max angle diff — is not stored per cell: the serial kernels recompute it,
-    // cc_k_base.h: cell_fin; the batch-parallel kernel gets it packed, pk_fin)
+    double* sc_fin;      // continuous azimuth + max angle diff of the point (its contribution to finished_at): written by the window scan only for
+                         // batches whose launch has Geometry::scan_stores_fin set (the serial kernels are expected to associate); otherwise the
+                         // serial kernels recompute it (cc_k_base.h: cell_fin) and the batch-parallel kernel gets it packed (pk_fin)
     uint16_t* sc_visits; // Point::number_of_visited_neighbors (cc.cpp:725), only with Geometry::mirror_fields
     int2* link_log;      // [stream][link_capacity] (root cell, root cell) of every tree link made in the current call (cc.cpp:693-694), only
                          // with Geometry::mirror_fields: the host rebuilds Point::associated_trees from it
@@ -223,6 +224,8 @@ struct Geometry
     int32_t link_capacity;
     int32_t tab_tiles;       // tiles of 64 columns a batch can have: entries of Planes::tabc per stream and batch-descriptor slot
     int32_t scan_cap;        // visits a lane of the packed window scan spends on its point before it hands it to the long-scan list (option "scan_cap")
+    int32_t scan_stores_fin; // per LAUNCH (cc_engine.hip sets it in the copy it hands to a batch's window scan and serial association kernels, 0 elsewhere):
+                             // 1 = the scan writes Planes::sc_fin and the serial kernels read it, 0 = nobody writes it and they recompute (cell_fin)
     int32_t sl_cap;          // records of a stream's long-scan list the packed window scan may use (<= SL_CAP; option "scan_long_records": tests shrink it)
 };
 

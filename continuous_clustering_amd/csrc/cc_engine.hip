@@ -301,6 +301,7 @@ void fill_geometry(cc_engine* e, int num_rows)
         g.sl_cap = cck::SL_CAP;
     if (g.scan_cap <= 0)
         g.scan_cap = cck::SCAN_CAP;
+    g.scan_stores_fin = 0; // (set per launch: launch_batch)
 }
 
 int free_all(cc_engine* e)
@@ -372,7 +373,7 @@ int allocate(cc_engine* e)
     A(t_fin, C) A(t_width, C) A(t_pts, C) A(t_uf, C) A(t_cid, C) A(t_pos, C) A(t_finished, C);
     A(ulist, T) A(ucomp, T) A(agg_fin, T) A(agg_min, T) A(agg_max, T) A(agg_pts, T) A(agg_cid, T) A(agg_first, T) A(agg_flag, T);
     A(events, S * (size_t) g.event_capacity);
-    A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C);
+    A(sc_parent, C) A(sc_nlinks, C) A(sc_links, C) A(sc_fin, C);
     A(sc_term, C) A(col_newfin, L) A(col_info, L) A(col_act, L) A(pk_meta, C) A(pk_fin, C) A(pk_lk, C);
     A(sg_x2, C) A(sg_uz, C) A(sg_w, C) A(sg_flags, C) A(sc_rec, C);
     A(curtab, S * (size_t) g.num_rows);
@@ -1074,6 +1075,49 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
             CC_HIP_CHECK(e, hipStreamWaitEvent(sc, e->ev_segscan[slot], 0));
         }
         CC_MARK(sc); // ev4: table + segment (start of the window scan)
+        // ---- what the association chain of this batch will be (decided here: the window scan writes Planes::sc_fin only for the serial kernels) ----
+        bool batch_assoc = e->assoc_batch && e->cfg.cluster_point_trees_every_nth_column == 1;
+        // Streams on which k_assocb keeps stopping (vegetation: more trees born per group than it has lanes for) cost a batch more with it than
+        // without: every stop is a (batch-parallel, serial) round, and a launch lasts as long as its slowest stream — the one that went serial.
+        // While at least a quarter of a launch's streams stop per batch the serial kernels run alone; every ninth batch tries again.
+        if (batch_assoc && e->assoc_rounds == 0 && e->h_bail_count && !e->capturing && count >= 8)
+        {
+            const int seen_now = *e->h_bail_count;
+            if (e->chronic_skip > 0)
+            {
+                e->chronic_skip--;
+                e->bail_seen = seen_now;
+                batch_assoc = false;
+                // (the batches that try again must not meet the two sweeping blocks the serial kernel runs as behind an idle k_assocb)
+                if (e->chronic_skip == 0)
+                    e->bail_cooldown = e->bail_cooldown_batches > 2 ? e->bail_cooldown_batches : 2;
+            }
+            else if ((seen_now - e->chronic_seen) * 4 >= count && e->chronic_probe)
+                e->chronic_skip = 8;
+            e->chronic_probe = batch_assoc; // (the counter read behind the NEXT batch tells what this one did)
+            e->chronic_seen = seen_now;
+        }
+        int adaptive_rounds = 1;
+        if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
+        {
+            const int seen = *e->h_bail_count; // (as of some earlier batch: a heuristic, not a condition of correctness)
+            if (seen != e->bail_seen)
+            {
+                e->bail_seen = seen;
+                e->bail_cooldown = e->bail_cooldown_batches;
+            }
+            if (e->bail_cooldown > 0)
+            {
+                e->bail_cooldown--;
+                adaptive_rounds = 3;
+            }
+        }
+        // The serial kernels read a point's finished_at contribution from Planes::sc_fin or recompute it (cc_k_base.h: cell_fin_of). Behind the
+        // batch-parallel kernel they find nothing to do, and the scan saves the 8 bytes per cell; where they are expected to associate (the
+        // batch-parallel kernel off, pinned rounds, stops lately) the scan stores them. A small call's front kernel has scanned with the engine's
+        // geometry (never stored).
+        Geometry gs = g;
+        gs.scan_stores_fin = (!small_front && !(batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1)) ? 1 : 0;
         const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
         bool use_split = false;
         if (small_front)
@@ -1123,34 +1167,34 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 const dim3 long_grid((unsigned) count, cck::SCAN_LONG_BLOCKS), epi_grid((unsigned) count, cck::SCAN_EPI_BLOCKS);
                 if (rpl == 1)
                 {
-                    hipLaunchKernelGGL((cck::k_scan2<1, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL((cck::k_scan2<1, false, true>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
                     hipLaunchKernelGGL(cck::k_scan2_long<1>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                     hipLaunchKernelGGL(cck::k_scan2_epi<1>, epi_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
                 else
                 {
-                    hipLaunchKernelGGL((cck::k_scan2<2, false, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                    hipLaunchKernelGGL((cck::k_scan2<2, false, true>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
                     hipLaunchKernelGGL(cck::k_scan2_long<2>, long_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                     hipLaunchKernelGGL(cck::k_scan2_epi<2>, epi_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot, e->d_bail_count);
                 }
             }
             else if (rpl == 1 && !g.mirror_fields)
-                hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                hipLaunchKernelGGL((cck::k_scan2<1, false>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
             else if (rpl == 1)
-                hipLaunchKernelGGL((cck::k_scan2<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                hipLaunchKernelGGL((cck::k_scan2<1, true>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
             else if (!g.mirror_fields)
-                hipLaunchKernelGGL((cck::k_scan2<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                hipLaunchKernelGGL((cck::k_scan2<2, false>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
             else
-                hipLaunchKernelGGL((cck::k_scan2<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                hipLaunchKernelGGL((cck::k_scan2<2, true>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
         }
         else if (rpl == 1 && !g.mirror_fields)
-            hipLaunchKernelGGL((cck::k_scan<1, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL((cck::k_scan<1, false>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
         else if (rpl == 1)
-            hipLaunchKernelGGL((cck::k_scan<1, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL((cck::k_scan<1, true>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
         else if (!g.mirror_fields)
-            hipLaunchKernelGGL((cck::k_scan<2, false>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL((cck::k_scan<2, false>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
         else
-            hipLaunchKernelGGL((cck::k_scan<2, true>), scan_grid, dim3(64), 0, sc, g, e->cfg, e->P, e->d_states, first_stream, slot);
+            hipLaunchKernelGGL((cck::k_scan<2, true>), scan_grid, dim3(64), 0, sc, gs, e->cfg, e->P, e->d_states, first_stream, slot);
         CC_MARK(sc); // ev5: scan
         if (sc != sa)
         {
@@ -1163,27 +1207,6 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         // reference's sequential semantics (cc_assocb.h) and stops in front of the first group that might. With k_assoc3 behind it the pair runs
         // assoc_rounds times: a LIMITED launch of the serial kernel takes that one group, the batch-parallel kernel continues behind it; the last
         // serial launch takes whatever is left of the batch.
-        bool batch_assoc = e->assoc_batch && e->cfg.cluster_point_trees_every_nth_column == 1;
-        // Streams on which k_assocb keeps stopping (vegetation: more trees born per group than it has lanes for) cost a batch more with it than
-        // without: every stop is a (batch-parallel, serial) round, and a launch lasts as long as its slowest stream — the one that went serial.
-        // While at least a quarter of a launch's streams stop per batch the serial kernels run alone; every ninth batch tries again.
-        if (batch_assoc && e->assoc_rounds == 0 && e->h_bail_count && !e->capturing && count >= 8)
-        {
-            const int seen_now = *e->h_bail_count;
-            if (e->chronic_skip > 0)
-            {
-                e->chronic_skip--;
-                e->bail_seen = seen_now;
-                batch_assoc = false;
-                // (the batches that try again must not meet the two sweeping blocks the serial kernel runs as behind an idle k_assocb)
-                if (e->chronic_skip == 0)
-                    e->bail_cooldown = e->bail_cooldown_batches > 2 ? e->bail_cooldown_batches : 2;
-            }
-            else if ((seen_now - e->chronic_seen) * 4 >= count && e->chronic_probe)
-                e->chronic_skip = 8;
-            e->chronic_probe = batch_assoc; // (the counter read behind the NEXT batch tells what this one did)
-            e->chronic_seen = seen_now;
-        }
         auto launch_assocb = [&]()
         {
             if (rpl == 1)
@@ -1194,25 +1217,10 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                                    e->d_bail_count);
         };
         bool marked7 = false;
-        int adaptive_rounds = 1;
         bool global_done = false; // k_associate's work was done inside the last k_assoc3 launch
         // a lean small call (k_small_front in front, results mirrored): k_assocb, then ONE kernel for the serial fall-backs, the ids and the mirror
         const bool small_tail = small_front && e->capture_mirror.state != nullptr && batch_assoc && e->assoc_waves >= 2 && rpl == 1 &&
                                 e->cfg.cluster_point_trees_every_nth_column == 1 && !e->debug_no_assoc_fallback;
-        if (e->assoc_rounds == 0 && e->h_bail_count && !e->capturing)
-        {
-            const int seen = *e->h_bail_count; // (as of some earlier batch: a heuristic, not a condition of correctness)
-            if (seen != e->bail_seen)
-            {
-                e->bail_seen = seen;
-                e->bail_cooldown = e->bail_cooldown_batches;
-            }
-            if (e->bail_cooldown > 0)
-            {
-                e->bail_cooldown--;
-                adaptive_rounds = 3;
-            }
-        }
         if (small_tail)
         {
             launch_assocb();
@@ -1248,9 +1256,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 if (batch_assoc && e->debug_no_assoc_fallback)
                     continue;
                 if (rpl == 1)
-                    hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
+                    hipLaunchKernelGGL(cck::k_assoc3<1>, dim3(blocks), block, 0, sa, gs, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
                 else
-                    hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
+                    hipLaunchKernelGGL(cck::k_assoc3<2>, dim3(blocks), block, 0, sa, gs, e->cfg, e->P, e->d_states, first_stream, slot, limited, count, 1);
                 global_done = limited == 0; // (the last launch of k_assoc3 takes the streams that continue in global memory with it)
             }
         }
@@ -1263,9 +1271,9 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
                 marked7 = true;
             }
             if (rpl == 1)
-                hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                hipLaunchKernelGGL(cck::k_assoc_lds<1>, dim3(count), dim3(64), 0, sa, gs, e->cfg, e->P, e->d_states, first_stream, slot);
             else
-                hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, g, e->cfg, e->P, e->d_states, first_stream, slot);
+                hipLaunchKernelGGL(cck::k_assoc_lds<2>, dim3(count), dim3(64), 0, sa, gs, e->cfg, e->P, e->d_states, first_stream, slot);
         }
         if (!marked7)
             CC_MARK(sa); // ev7: assoc_lds (without the batch-parallel kernel: the serial LDS kernel)

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(64) void k_assoc_lds(Geometry g, cc_config cfg, Pla
                 const int ci = lcx * R + row;
                 nx_parent[k] = p.sc_parent[ci];
                 nx_nl[k] = p.sc_nlinks[ci];
-                nx_fin[k] = cell_fin(cfg, p, ci, cbx);
+                nx_fin[k] = cell_fin_of(g, cfg, p, ci, cbx);
                 nx_link[k] = p.sc_links[ci];
             }
         }

@@ -334,6 +334,7 @@ struct SP
     unsigned long long* pk_lk;
     uint8_t* sc_nlinks;
     unsigned long long* sc_links;
+    double* sc_fin;
     float *sg_x2, *sg_uz, *sg_w;
     uint8_t* sg_flags;
     float4* sc_rec;
@@ -393,6 +394,7 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
     p.pk_lk = P.pk_lk + co;
     p.sc_nlinks = P.sc_nlinks + co;
     p.sc_links = P.sc_links + co;
+    p.sc_fin = P.sc_fin + co;
     p.sg_x2 = P.sg_x2 + co;
     p.sg_uz = P.sg_uz + co;
     p.sg_w = P.sg_w + co;
@@ -408,10 +410,16 @@ __device__ __forceinline__ SP stream_ptrs(const Planes& P, const Geometry& g, in
 // distance; 0 for a cell the association ignores). The window scan computes it for the points it packs (pk_fin); the serial kernels, which run
 // for what the batch-parallel kernel left, recompute it from the cell's own planes with this — the same expression on the same operands, so the
 // same bits — instead of the scan writing a double per cell that is never read in steady state (8 of the 24 B per cell it wrote, round 6).
+// Launches in which the serial kernels are expected to associate a real share (the batch-parallel kernel switched off or stopping lately:
+// Geometry::scan_stores_fin) keep the stored form, Planes::sc_fin: recomputing costs the serial kernels 17 % on vegetation.
 __device__ __forceinline__ double cell_fin(const cc_config& cfg, const SP& p, const int ci, const CazBase& cb)
 {
     if (p.ignored[ci])
         return 0.;
     const float mad = ccm::asinf_exact(cfg.max_distance / p.dist[ci]);
     return cell_caz(cb, p.incaz[ci]) + (double) mad;
+}
+__device__ __forceinline__ double cell_fin_of(const Geometry& g, const cc_config& cfg, const SP& p, const int ci, const CazBase& cb)
+{
+    return g.scan_stores_fin ? p.sc_fin[ci] : cell_fin(cfg, p, ci, cb);
 }

@@ -159,6 +159,8 @@ __device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cf
             {
                 p.sc_parent[ci] = (int16_t) parent[0];
                 p.sc_nlinks[ci] = (uint8_t) nlinks[0];
+                if (g.scan_stores_fin)
+                    p.sc_fin[ci] = fin[0];
                 if (nlinks[0] > 0)
                     p.sc_links[ci] = packed[0];
                 if (MIRROR)
@@ -291,6 +293,8 @@ __device__ __forceinline__ void scan_body(const Geometry& g, const cc_config& cf
                     const int ci = lc * R + row;
                     p.sc_parent[ci] = (int16_t) parent[k];
                     p.sc_nlinks[ci] = (uint8_t) nlinks[k];
+                    if (g.scan_stores_fin)
+                        p.sc_fin[ci] = fin[k];
                     if (nlinks[k] > 0)
                         p.sc_links[ci] = packed[k];
                     if (MIRROR)
@@ -716,6 +720,8 @@ __global__ __launch_bounds__(64) void k_scan2(Geometry g, cc_config cfg, Planes 
                 if (row < R)
                 {
                     const int ci = lc * R + row;
+                    if (g.scan_stores_fin)
+                        p.sc_fin[ci] = fin[k];
                     if (!(later && parent[k] == -3)) // (a waiting point's parent and links are written by k_scan2_long)
                     {
                         p.sc_parent[ci] = (int16_t) parent[k];
