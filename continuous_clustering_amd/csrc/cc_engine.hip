@@ -146,6 +146,7 @@ struct cc_engine
     StreamState* h_small_state{nullptr}; // pinned
     cc_event* h_small_events{nullptr};   // pinned
     bool allow_graphs{true};            // option "graphs"
+    int scan_store_fin{-1};             // option "scan_store_fin": Planes::sc_fin written by the window scan and read by the serial kernels 1 always / 0 never (they recompute) / -1 per launch
     int scan_split{2};                  // option "scan_split": the packed window scan hands long scans to k_scan2_long (cc_k_scan.h); 2 = while there are many
     bool split_on{false};               // ... the automatic mode's current choice, from the counters k_scan2_epi leaves in d_bail_count[1 .. 2]
     unsigned split_cols_seen{0}, split_rec_seen{0}, split_probe{0};
@@ -1118,6 +1119,8 @@ int launch_batch(cc_engine* e, int first_stream, int count, int64_t n, const flo
         // geometry (never stored).
         Geometry gs = g;
         gs.scan_stores_fin = (!small_front && !(batch_assoc && e->assoc_rounds == 0 && adaptive_rounds == 1)) ? 1 : 0;
+        if (e->scan_store_fin >= 0 && !small_front)
+            gs.scan_stores_fin = e->scan_store_fin;
         const dim3 scan_grid((unsigned) count, cck::SCAN_BLOCKS);
         bool use_split = false;
         if (small_front)
@@ -3241,6 +3244,8 @@ int cc_engine_set_option(cc_engine* e, const char* name, int64_t value)
         e->assoc_rounds = (int) (value < 0 ? 0 : (value > 8 ? 8 : value));
     else if (n == "ego_off_chain")
         e->ego_off_chain = value != 0;
+    else if (n == "scan_store_fin")
+        e->scan_store_fin = value < 0 ? -1 : (value ? 1 : 0);
     else if (n == "scan_split")
         e->scan_split = (int) std::max<int64_t>(0, std::min<int64_t>(value, 2));
     else if (n == "scan_cap")

@@ -330,6 +330,9 @@ int cc_engine_gather_cluster_points(cc_engine* e, int stream, int64_t n, const u
  *                                  finishes its column. 1: always; 0: one pass; 2: while such scans are a large part of the work (every 32nd batch
  *                                  is scanned this way and counted: on above 40 visits of k_scan2_long per column of 64 rows, off again below 20)
  *  "scan_cap"                (6)   ... the number of visits after which a point is handed over
+ *  "scan_store_fin"          (-1)  a point's contribution to its tree's finished_at, for the serial association kernels: 1 the window scan stores it per
+ *                                  cell (8 B), 0 they recompute it, -1 per launch: stored where they are expected to associate (assoc_batch 0, pinned
+ *                                  rounds, a stop of k_assocb within the cool-down), not behind an undisturbed k_assocb, which gets the value packed
  *  "scan_long_records"       (8192) room of a stream's list of such points per batch (a lane that finds it full finishes its scan in place)
  *  -- association -----------------------------------------------------------------------------------------------------------------------------------
  *  "assoc_batch"             (1)   the batch-parallel kernel k_assocb runs in front of the serial one and takes every group of columns that cannot

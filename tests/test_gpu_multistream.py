@@ -213,8 +213,8 @@ def test_pipelined_throughput_path_matches_oracle(pipeline, sub_batch, oracle_li
         util.compare_columns(o.read_published(lo, hi), e.read_columns(lo, hi, stream=s), lo, mirror=False)
 
 
-@pytest.mark.parametrize("firings,rounds", [(240, 0), (97, 0), (240, 1), (720, 2)])
-def test_pipelined_path_with_streams_the_batch_parallel_association_stops_at(firings, rounds, oracle_lib):
+@pytest.mark.parametrize("firings,rounds,store_fin", [(240, 0, -1), (97, 0, -1), (240, 1, -1), (720, 2, -1), (240, 0, 0), (240, 0, 1), (720, 2, 0)])
+def test_pipelined_path_with_streams_the_batch_parallel_association_stops_at(firings, rounds, store_fin, oracle_lib):
     """Pipelined device path (events off: four chains of HIP streams, batches overlap) over streams made to make k_assocb stop (tests/cases.py
     EXCEPTION_CASES) next to ordinary ones: the hand-over to the serial kernel (adaptive number of rounds, or pinned) happens while the next batch is
     inserted, segmented and scanned. Every stream must end in the oracle's state with the oracle's published columns, and the exception path must
@@ -235,6 +235,7 @@ def test_pipelined_path_with_streams_the_batch_parallel_association_stops_at(fir
     e = Engine(cfg, 64, S)
     e.record_events(False)
     e.set_option("assoc_rounds", rounds)
+    e.set_option("scan_store_fin", store_fin)  # (the serial kernels read the points' finished_at contributions / recompute them / per launch)
     for b in range(NB):
         e.add_firings_device(F, xyz[b], inten[b], poses[b])
     assert e.sync() == 0, e.last_error()

@@ -125,7 +125,7 @@ def test_random_walk_over_engine_options(oracle_lib):
     choices = {"pipeline": [0, 1, 2], "lazy_gate": [0, 40], "lazy_gate_from": [0, 8, 80], "defer_tail_max_streams": [0, 96], "fuse_front": [0, 1],
                "skip_idle_fallbacks": [0, 1], "parallel_insert": [0, 1, 2], "insert_split_blocks": [0, 1, 3, 8], "insert_wide_max_streams": [0, 160],
                "assoc_batch": [0, 1], "assoc_rounds": [0, 1, 2], "assoc_sweep_blocks": [1, 2, 16], "assoc_waves": [0, 1, 3, 4], "scan_packed": [0, 1], "scan_split": [0, 1],
-               "scan_long_records": [1, 40, 8192],
+               "scan_long_records": [1, 40, 8192], "scan_store_fin": [-1, 0, 1],
                "publish_off_chain": [0, 1], "table_on_insert_chain": [0, 1, 2], "ego_on_insert_chain": [0, 1], "sub_batch": [0, 300], "limit_columns": [600, 1 << 20]}
     t0 = time.perf_counter()
     rounds = 0
