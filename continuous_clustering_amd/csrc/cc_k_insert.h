@@ -674,7 +674,6 @@ __device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config&
                 if (!too_far_behind)
                 {
                     const size_t ci = (size_t) lc * R + row;
-#ifndef CC_EXP_NOSTORE
                     p.sc_rec[ci] = make_float4(r_x[so], r_y[so], r_z[so], r_i[so]);
                     p.inten[ci] = (uint8_t) r_t[so];
                     p.src[ci] = (uint32_t) (seq0 + (f - cursor0));
@@ -682,7 +681,6 @@ __device__ __forceinline__ void insert2_body(const Geometry& g, const cc_config&
                     // rotation of the return = prev_rot + rot_off (cc.cpp:184-186) = that of its column gc = gcv (+ 1 if moved on), or one less
                     p.incaz[ci] = pack_incaz(r_a[so], cir[k] + (int) (gc - gcv[k]) >= NC);
                     p.gtag[ci] = cell_tag(pass);
-#endif
                     p.dist[ci] = d;
                     if (!NOWIN && gc >= wbase && gc < wbase + WINC)
                         w_dist[(int) (gc & (WINC - 1)) * R + row] = d;
